@@ -1,0 +1,102 @@
+/* libpxsht -- MI355X (gfx950) spherical-harmonic-transform and FFT kernels behind a C ABI.
+ *
+ * Drop-in boundary for the one hot path of simonsobs/pixell: the calls that
+ * pixell/curvedsky.py and pixell/fft.py make into the third-party ducc0 / pyfftw / numpy
+ * libraries.  The reference has no C ABI of its own for this path (its boundary is ducc0's
+ * Python keyword interface), so every entry point below cites the reference call site it
+ * replaces; INTEGRATION.md shows the ctypes binding a pixell maintainer would add.
+ *
+ * Conventions
+ *  - all data pointers are DEVICE pointers (hipMalloc / torch.cuda tensors) on the plan's
+ *    device; the caller owns them.  `stream` is a hipStream_t (NULL = default stream); calls
+ *    are asynchronous with respect to the host.
+ *  - plans own their device scratch and tables; a plan may be used by one call at a time.
+ *  - return value: 0 = OK, <0 = error (pxs_last_error() returns a thread-local message).
+ *    No C++ exception crosses the boundary.
+ *  - dtype codes: 0 = float32, 1 = float64, 2 = complex64, 3 = complex128.  All arithmetic is
+ *    float64 regardless of the I/O dtype.
+ *  - alm layout: element (l,m) of component c at alm[c*alm_cstride + mstart[m] + l*lstride]
+ *    (curvedsky.alm_info, curvedsky.py:409-447).
+ */
+#ifndef PXSHT_H
+#define PXSHT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pxs_plan pxs_plan;
+
+#define PXS_F32  0
+#define PXS_F64  1
+#define PXS_C64  2
+#define PXS_C128 3
+
+#define PXS_MODE_STANDARD 0
+#define PXS_MODE_DERIV1   1   /* curvedsky.py:917-920: spin-1 of sqrt(l(l+1)) a_lm -> (d_theta, d_phi/sin) */
+
+/* Plan for transforms on explicit iso-latitude rings.
+ * Replaces the geometry arguments of ducc0.sht.experimental.synthesis / adjoint_synthesis
+ * (curvedsky.py:936-960, 1068-1084; ring tables from get_ring_info, curvedsky.py:1170-1190).
+ * theta[nring] colatitudes, nphi[nring] pixels per ring (all equal in this version),
+ * phi0[nring] azimuth of pixel 0, ringstart[nring] index of pixel 0 of each ring in the flat map,
+ * pixstride: stride between pixels of a ring (+1 or -1). */
+int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64_t* nphi,
+                   const double* phi0, const uint64_t* ringstart, int64_t pixstride,
+                   int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device);
+
+/* Plan for a named full-sky equiangular grid ("CC","F1","MW","MWflip"), map[ntheta][nphi].
+ * Replaces the geometry arguments of ducc0.sht.experimental.{synthesis_2d, adjoint_synthesis_2d,
+ * analysis_2d, adjoint_analysis_2d} (curvedsky.py:907-924, 1032-1046).
+ * flip_y / flip_x fold curvedsky.map2buffer / buffer2map (curvedsky.py:1384-1411) into the kernels'
+ * addressing: with flip_y the map's row 0 is the SOUTHERN-most ring, with flip_x column 0 is the
+ * largest phi; phi0 is that of the flipped (ducc-orientation) map, i.e. analyse_geometry().phi0
+ * (curvedsky.py:1284). */
+int pxs_plan_grid2d(pxs_plan** plan, const char* geometry, int ntheta, int nphi, double phi0,
+                    int flip_y, int flip_x, int lmax, int mmax, const uint64_t* mstart,
+                    int64_t lstride, int device);
+
+void pxs_plan_destroy(pxs_plan* plan);
+
+/* alm -> map (adjoint = 0: synthesis[_2d]) or map -> alm (adjoint = 1: adjoint_synthesis[_2d]).
+ * spin 0: 1 alm component, 1 map component; spin > 0: 2 and 2; mode DERIV1: 1 and 2 (spin must be 1).
+ * alm_cstride / map_cstride: distance between components in elements of the respective dtype. */
+int pxs_synthesis(pxs_plan* plan, int spin, int mode, int adjoint,
+                  void* alm, int alm_dtype, int64_t alm_cstride,
+                  void* map, int map_dtype, int64_t map_cstride, void* stream);
+
+/* map -> alm (adjoint = 0: analysis_2d) or alm -> map (adjoint = 1: adjoint_analysis_2d).
+ * Only for grid2d plans: exact quadrature of the theta-interpolant (curvedsky.py:1018-1048). */
+int pxs_analysis(pxs_plan* plan, int spin, int adjoint,
+                 void* map, int map_dtype, int64_t map_cstride,
+                 void* alm, int alm_dtype, int64_t alm_cstride, void* stream);
+
+/* ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855): out[ntheta], sum = 4 pi. Host memory. */
+int pxs_gridweights(const char* geometry, int ntheta, double* out);
+
+/* largest lmax analysis_2d supports on the grid (curvedsky.get_ducc_maxlmax, curvedsky.py:1349-1353) */
+int pxs_grid_maxlmax(const char* geometry, int ntheta);
+
+/* number of Legendre rings the plan iterates (R_actual of SURVEY 8d) for synthesis / analysis */
+int pxs_plan_info(const pxs_plan* plan, int* nring_legendre_syn, int* nring_legendre_ana, int64_t* scratch_bytes);
+
+/* N-d FFT over `naxes` axes of a strided array: the engine behind fft.engines["hip"].FFTW(a,b,axes,
+ * direction) (pixell/fft.py:8-64,133-209) and enmap.fft/ifft (enmap.py:1307-1337).
+ * kind 0: c2c (in/out same shape), 1: r2c (out last transformed axis n//2+1), 2: c2r.
+ * shape[ndim] is the LOGICAL (real-space) shape; istride/ostride in elements of in/out dtype.
+ * forward: e^{-i...}; unnormalised, result multiplied by `scale`. */
+int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int64_t* ostride,
+               int naxes, const int* axes, int kind, int forward, double scale,
+               int in_dtype, int out_dtype, const void* in, void* out, int device, void* stream);
+
+/* 1 if the engine can transform this length (2,3,5-smooth or prime factors small enough) */
+int pxf_fft_supported(int64_t n);
+int64_t pxf_fft_good_size(int64_t n);
+
+const char* pxs_last_error(void);
+const char* pxs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,475 @@
+// Batched 1-D FFT engine for gfx950 (see fft.hpp).
+//
+// One workgroup (256 threads, 4 wave64) keeps T lines of n complex f64 points in LDS
+// (<= 64 KiB incl. the twiddle table => 2 workgroups per CU), performs decimation-in-time
+// mixed-radix passes in place after a digit-reversed scatter on load, and stores with the
+// thread->element map chosen so that the unit-stride direction of global memory is the
+// fast lane direction (coalesced 16-byte accesses).  Lines longer than FFT_NLOC_MAX use
+// the four-step split N = n1*n2 (pass A strided + twiddle, pass B contiguous), with the
+// intermediate kept below `temp_budget` bytes so that it stays in the 256 MiB Infinity
+// Cache between the two launches.
+#include "fft.hpp"
+#include <cmath>
+#include <algorithm>
+
+namespace pxs {
+
+#ifdef PXS_HOST_SIM
+static constexpr int FFT_THREADS  = 1;     // index logic only; see hostsim.hpp
+#else
+static constexpr int FFT_THREADS  = 256;
+#endif
+static constexpr int FFT_NLOC_MAX = 2048;   // longest line done in one LDS pass
+static constexpr int FFT_LDS_PTS  = 4096;   // complex points of LDS per workgroup (64 KiB)
+static constexpr int FFT_MAXFAC   = 16;
+
+struct PassDesc { int R; int L; int tws; FastDiv dL; FastDiv dnb; };
+
+struct KArgs {
+	int n, nfac, T, generic, mode, forward, n1, n2;
+	long N;
+	PassDesc pass[FFT_MAXFAC];
+	const int* perm; const double2* tw;
+	FastDiv dn, dT;
+	FftDims d; long i_base, i_count;
+	long ntile;
+	FftLoad ld; FftStore st;
+	double2* temp; const double2* bigtw;
+	int load_inner_fast, store_inner_fast, tile_i;
+};
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, FastDiv f) { return f.d <= 1 ? x : __umulhi(x, f.mul); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x+b.x, a.y+b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x-b.x, a.y-b.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 mulmi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+
+__device__ __forceinline__ double2 read_elem(const void* p, int dtype, long off) {
+	switch (dtype) {
+		case PX_F32:  return make_double2((double)((const float*)p)[off], 0.0);
+		case PX_F64:  return make_double2(((const double*)p)[off], 0.0);
+		case PX_C64:  { float2 v = ((const float2*)p)[off]; return make_double2(v.x, v.y); }
+		default:      return ((const double2*)p)[off];
+	}
+}
+__device__ __forceinline__ void write_elem(void* p, int dtype, long off, double2 v) {
+	switch (dtype) {
+		case PX_F32:  ((float*)p)[off] = (float)v.x; break;
+		case PX_F64:  ((double*)p)[off] = v.x; break;
+		case PX_C64:  ((float2*)p)[off] = make_float2((float)v.x, (float)v.y); break;
+		default:      ((double2*)p)[off] = v; break;
+	}
+}
+
+// value of input element e (0 <= e < N) of line (i,o1,o2)
+__device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1, long o2, long e) {
+	const FftLoad& ld = a.ld;
+	const long base = i*a.d.is_i + o1*a.d.is_o1 + o2*a.d.is_o2;
+	const long N = a.N;
+	switch (ld.mode) {
+	case LD_PLAIN: {
+		if (ld.ne >= 0 && e >= ld.ne) return make_double2(0, 0);
+		double2 v = read_elem(ld.ptr, ld.dtype, base + e*a.d.is_e);
+		if (ld.mul) v = cmul(v, ld.mul[e]);
+		return v; }
+	case LD_HERM: {
+		long m; bool cj;
+		if (e < ld.ne) { m = e; cj = false; }
+		else if (N - e < ld.ne) { m = N - e; cj = true; }
+		else return make_double2(0, 0);
+		double2 v = read_elem(ld.ptr, ld.dtype, base + m*a.d.is_e);
+		if (ld.mul) v = cmul(v, ld.mul[m]);
+		if (m == 0) v.y = 0;
+		return cj ? cconj(v) : v; }
+	case LD_MIRROR: {
+		long src = e; bool neg = false;
+		if (e >= ld.ne) { src = N - e - ld.mir_c; if (src < 0) src += N; neg = ((i + a.i_base + ld.par0) & 1) != 0; }
+		double2 v = read_elem(ld.ptr, ld.dtype, base + src*a.d.is_e);
+		if (ld.mul) v = cmul(v, ld.mul[src]);
+		return neg ? make_double2(-v.x, -v.y) : v; }
+	case LD_SPEC: {
+		const long Ns = ld.ne;
+		long k = (2*e <= N) ? e : e - N;
+		long ak = k < 0 ? -k : k;
+		if (ld.kmax >= 0 && ak > ld.kmax) return make_double2(0, 0);
+		if (2*ak > Ns) return make_double2(0, 0);
+		long si = k >= 0 ? k : Ns + k;
+		double2 v = read_elem(ld.ptr, ld.dtype, base + si*a.d.is_e);
+		if (2*ak == Ns && ld.nyq_half && N != Ns) { v.x *= 0.5; v.y *= 0.5; }
+		if (ld.mul) { double2 ph = ld.mul[ak]; if (k < 0) ph.y = -ph.y; v = cmul(v, ph); }
+		return v; }
+	default: { // LD_SPEC_ADJ: adjoint of LD_SPEC(Ns=N here -> larger): source is the larger spectrum of length ld.ne
+		const long Nb = ld.ne;
+		long k = (2*e <= N) ? e : e - N;
+		long ak = k < 0 ? -k : k;
+		if (ld.kmax >= 0 && ak > ld.kmax) return make_double2(0, 0);
+		double2 ph = ld.mul ? ld.mul[ak] : make_double2(1, 0);
+		if (2*ak == N && ld.nyq_half && N != Nb) {
+			double2 vp = read_elem(ld.ptr, ld.dtype, base + ak*a.d.is_e);
+			double2 vm = read_elem(ld.ptr, ld.dtype, base + (Nb-ak)*a.d.is_e);
+			double2 r = cadd(cmul(vp, cconj(ph)), cmul(vm, ph));
+			return make_double2(0.5*r.x, 0.5*r.y);
+		}
+		long si = k >= 0 ? k : Nb + k;
+		double2 v = read_elem(ld.ptr, ld.dtype, base + si*a.d.is_e);
+		if (k >= 0) ph.y = -ph.y;       // conj(ph(k)), ph(-k) = conj(ph(k))
+		return cmul(v, ph); }
+	}
+}
+
+__device__ __forceinline__ void store_functor(const KArgs& a, long i, long o1, long o2, long e, double2 v) {
+	const FftStore& st = a.st;
+	if (st.ne >= 0 && e >= st.ne) return;
+	if (st.two_sided_k >= 0 && e > st.two_sided_k && e < a.N - st.two_sided_k) return;
+	if (st.conj_out) v.y = -v.y;
+	if (st.mul) v = cmul(v, st.mul[e]);
+	v.x *= st.scale; v.y *= st.scale;
+	const long off = i*a.d.os_i + o1*a.d.os_o1 + o2*a.d.os_o2 + e*a.d.os_e;
+	write_elem(st.ptr, st.dtype, off, v);
+}
+
+template<int R> __device__ __forceinline__ void butterfly(double2* v);
+template<> __device__ __forceinline__ void butterfly<2>(double2* v) {
+	double2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b);
+}
+template<> __device__ __forceinline__ void butterfly<3>(double2* v) {
+	const double s = 0.86602540378443864676;
+	double2 t1 = cadd(v[1], v[2]);
+	double2 t2 = make_double2(v[0].x - 0.5*t1.x, v[0].y - 0.5*t1.y);
+	double2 d = csub(v[1], v[2]);
+	double2 t3 = make_double2(s*d.y, -s*d.x);   // -i*s*d
+	v[0] = cadd(v[0], t1); v[1] = cadd(t2, t3); v[2] = csub(t2, t3);
+}
+template<> __device__ __forceinline__ void butterfly<4>(double2* v) {
+	double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+	double2 t2 = cadd(v[1], v[3]), t3 = mulmi(csub(v[1], v[3]));
+	v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+}
+template<> __device__ __forceinline__ void butterfly<5>(double2* v) {
+	const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+	const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+	double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+	double2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+	double2 a = v[0];
+	double2 m1 = make_double2(a.x + c1*t1.x + c2*t2.x, a.y + c1*t1.y + c2*t2.y);
+	double2 m2 = make_double2(a.x + c2*t1.x + c1*t2.x, a.y + c2*t1.y + c1*t2.y);
+	double2 u1 = make_double2(s1*t3.x + s2*t4.x, s1*t3.y + s2*t4.y);
+	double2 u2 = make_double2(s2*t3.x - s1*t4.x, s2*t3.y - s1*t4.y);
+	double2 iu1 = mulmi(u1), iu2 = mulmi(u2);   // -i*u
+	v[0] = make_double2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
+	v[1] = cadd(m1, iu1); v[4] = csub(m1, iu1);
+	v[2] = cadd(m2, iu2); v[3] = csub(m2, iu2);
+}
+
+template<int R> __device__ __forceinline__ void radix_pass(double2* buf, const double2* tw, const KArgs& a, const PassDesc& ps) {
+	const int nb = a.n / R;
+	const int total = a.T*nb;
+	for (int b = threadIdx.x; b < total; b += FFT_THREADS) {
+		const uint32_t t = fdiv(b, ps.dnb);
+		const uint32_t bb = b - t*nb;
+		const uint32_t blk = fdiv(bb, ps.dL);
+		const uint32_t q = bb - blk*ps.L;
+		double2* p = buf + (size_t)t*a.n + blk*ps.L*R + q;
+		double2 v[R];
+#pragma unroll
+		for (int i = 0; i < R; i++) v[i] = p[i*ps.L];
+		if (ps.L > 1) {
+			const int step = q*ps.tws;
+#pragma unroll
+			for (int i = 1; i < R; i++) v[i] = cmul(v[i], tw[i*step]);
+		}
+		butterfly<R>(v);
+#pragma unroll
+		for (int i = 0; i < R; i++) p[i*ps.L] = v[i];
+	}
+}
+
+// generic radix: out of place src -> dst, one thread per output point
+__device__ __forceinline__ void generic_pass(const double2* src, double2* dst, const double2* tw, const KArgs& a, const PassDesc& ps) {
+	const int R = ps.R, n = a.n;
+	const int total = a.T*n;
+	const int wstep = n / R;
+	for (int idx = threadIdx.x; idx < total; idx += FFT_THREADS) {
+		const uint32_t t = fdiv(idx, a.dn);
+		const uint32_t j = idx - t*n;                 // output position within line
+		const uint32_t LR = ps.L*R;
+		const uint32_t blk = j / LR;
+		const uint32_t r = j - blk*LR;
+		const uint32_t ip = r / ps.L;                 // output digit i'
+		const uint32_t q = r - ip*ps.L;
+		const double2* p = src + (size_t)t*n + blk*LR + q;
+		double2 acc = make_double2(0, 0);
+		uint32_t widx = 0;                            // (i*ip) mod R
+		for (int i = 0; i < R; i++) {
+			double2 v = p[i*ps.L];
+			if (ps.L > 1) v = cmul(v, tw[i*q*ps.tws]);
+			acc = cadd(acc, cmul(v, tw[widx*wstep]));
+			widx += ip; if (widx >= (uint32_t)R) widx -= R;
+		}
+		dst[(size_t)t*n + j] = acc;
+	}
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
+{
+	PXS_SHARED(double2, lds);
+	const int n = a.n, T = a.T;
+	double2* tw = lds;                 // [n]
+	double2* bufA = lds + n;           // [T*n]
+	double2* bufB = bufA + (size_t)T*n; // only if generic
+
+	// decode block -> (tile, other, o1, o2).  mode 0: tile over lines i.  modes 1/2 (four-step):
+	// sub-lines are (i, s) with s = j2 (pass A) or k1 (pass B); tile_i selects which one is tiled.
+	long bx = blockIdx.x;
+	const long tile = bx % a.ntile; bx /= a.ntile;
+	const long slim = (a.mode == 1) ? a.n2 : a.n1;
+	long other = 0;
+	if (a.mode != 0) { const long no = a.tile_i ? slim : a.i_count; other = bx % no; bx /= no; }
+	const long o1 = bx % a.d.n_o1, o2 = bx / a.d.n_o1;
+	const long s0 = tile*T;
+	const long tlim = (a.mode == 0 || a.tile_i) ? a.i_count : slim;
+	const int nl = (int)min((long)T, tlim - s0);
+	const long lo = o2*a.d.n_o1 + o1;                  // outer line index (four-step scratch)
+
+	for (int k = threadIdx.x; k < n; k += FFT_THREADS) tw[k] = a.tw[k];
+
+	// ---- load ----
+	const int total = T*n;
+	for (int idx = threadIdx.x; idx < total; idx += FFT_THREADS) {
+		uint32_t t, j;
+		if (a.load_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
+		else                   { t = fdiv(idx, a.dn); j = idx - t*n; }
+		if ((int)t >= nl) continue;
+		const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
+		const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
+		double2 v;
+		if (a.mode == 0)      v = load_functor(a, il, o1, o2, j);
+		else if (a.mode == 1) v = load_functor(a, il, o1, o2, (long)j*a.n2 + sv);
+		else {
+			const long pos = sv*a.n2 + j;
+			v = a.temp[a.tile_i ? (lo*a.N + pos)*a.i_count + il : (lo*a.i_count + il)*a.N + pos];
+		}
+		if (!a.forward && a.mode != 2) v.y = -v.y;
+		bufA[(size_t)t*n + a.perm[j]] = v;
+	}
+	__syncthreads();
+
+	// ---- passes ----
+	double2* cur = bufA; double2* oth = bufB;
+	for (int p = 0; p < a.nfac; p++) {
+		const PassDesc& ps = a.pass[p];
+		switch (ps.R) {
+			case 2: radix_pass<2>(cur, tw, a, ps); break;
+			case 3: radix_pass<3>(cur, tw, a, ps); break;
+			case 4: radix_pass<4>(cur, tw, a, ps); break;
+			case 5: radix_pass<5>(cur, tw, a, ps); break;
+			default: generic_pass(cur, oth, tw, a, ps); { double2* x = cur; cur = oth; oth = x; } break;
+		}
+		__syncthreads();
+	}
+
+	// ---- store ----
+	for (int idx = threadIdx.x; idx < total; idx += FFT_THREADS) {
+		uint32_t t, j;
+		if (a.store_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
+		else                    { t = fdiv(idx, a.dn); j = idx - t*n; }
+		if ((int)t >= nl) continue;
+		const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
+		const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
+		double2 v = cur[(size_t)t*n + j];
+		if (a.mode == 1) {
+			v = cmul(v, a.bigtw[(long)j*sv]);
+			const long pos = (long)j*a.n2 + sv;
+			a.temp[a.tile_i ? (lo*a.N + pos)*a.i_count + il : (lo*a.i_count + il)*a.N + pos] = v;
+		} else {
+			if (!a.forward) v.y = -v.y;
+			if (a.mode == 0) store_functor(a, il, o1, o2, j, v);
+			else             store_functor(a, il, o1, o2, sv + (long)a.n1*j, v);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+struct FftSub {
+	int n; std::vector<int> fac; bool generic = false;
+	DevBuf perm, tw;
+	PassDesc pass[FFT_MAXFAC]; int nfac = 0;
+};
+
+static std::vector<int> factorize(long n) {
+	std::vector<int> f;
+	while (n % 4 == 0) { f.push_back(4); n /= 4; }
+	while (n % 2 == 0) { f.push_back(2); n /= 2; }
+	while (n % 3 == 0) { f.push_back(3); n /= 3; }
+	while (n % 5 == 0) { f.push_back(5); n /= 5; }
+	for (long p = 7; p*p <= n; p += 2) while (n % p == 0) { f.push_back((int)p); n /= p; }
+	if (n > 1) f.push_back((int)n);
+	return f;
+}
+
+static void twiddles(long n, std::vector<double2>& tw) {
+	tw.resize(n);
+	const long double tp = 6.283185307179586476925286766559L;
+	for (long k = 0; k < n; k++) {
+		// exploit octant symmetry for accuracy
+		long double ang = tp*(long double)k/(long double)n;
+		tw[k] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+	}
+}
+
+FftContext::FftContext(int device) : device_(device) {}
+FftContext::~FftContext() {}
+
+static bool split_two(long n, long& n1, long& n2) {
+	// choose n1*n2 = n, both <= FFT_NLOC_MAX, as balanced as possible
+	long best = -1;
+	for (long a = 1; a*a <= n; a++) if (n % a == 0) { long b = n/a; if (b <= FFT_NLOC_MAX) best = a; }
+	if (best < 0) return false;
+	n1 = best; n2 = n/best;
+	return n1 <= FFT_NLOC_MAX && n2 <= FFT_NLOC_MAX;
+}
+
+bool FftContext::supported(long n, std::string* why) {
+	if (n < 1) { if (why) *why = "length < 1"; return false; }
+	if (n <= FFT_NLOC_MAX) {
+		if ((int)factorize(n).size() > FFT_MAXFAC) { if (why) *why = "too many factors"; return false; }
+		return true;
+	}
+	long n1, n2;
+	if (!split_two(n, n1, n2)) {
+		if (why) *why = "FFT length " + std::to_string(n) + " has no factorisation n1*n2 with both factors <= " +
+			std::to_string(FFT_NLOC_MAX) + " (large prime factor; Bluestein not implemented)";
+		return false;
+	}
+	return true;
+}
+
+long FftContext::good_size(long n) {
+	for (long m = std::max<long>(n, 1);; m++) {
+		long r = m;
+		while (r % 2 == 0) r /= 2; while (r % 3 == 0) r /= 3; while (r % 5 == 0) r /= 5;
+		if (r == 1 && supported(m)) return m;
+	}
+}
+
+std::shared_ptr<FftSub> FftContext::sub(long n) {
+	std::lock_guard<std::mutex> g(mu_);
+	auto it = subs_.find(n);
+	if (it != subs_.end()) return it->second;
+	auto s = std::make_shared<FftSub>();
+	s->n = (int)n; s->fac = factorize(n);
+	PXS_REQUIRE((int)s->fac.size() <= FFT_MAXFAC, "FFT: too many factors");
+	int L = 1; s->nfac = (int)s->fac.size();
+	std::vector<int> Ls(s->nfac+1); Ls[0] = 1;
+	for (int p = 0; p < s->nfac; p++) {
+		int R = s->fac[p];
+		if (R != 2 && R != 3 && R != 4 && R != 5) s->generic = true;
+		PassDesc& ps = s->pass[p];
+		ps.R = R; ps.L = L; ps.tws = (int)(n/((long)L*R));
+		ps.dL = make_fastdiv(L); ps.dnb = make_fastdiv((uint32_t)(n/R));
+		L *= R; Ls[p+1] = L;
+	}
+	std::vector<int> perm(n);
+	for (long j = 0; j < n; j++) {
+		long t = j, pos = 0;
+		for (int p = s->nfac-1; p >= 0; p--) { long i = t % s->fac[p]; t /= s->fac[p]; pos += i*Ls[p]; }
+		perm[j] = (int)pos;
+	}
+	std::vector<double2> tw; twiddles(n, tw);
+	s->perm = upload(perm); s->tw = upload(tw);
+	subs_[n] = s;
+	return s;
+}
+
+const double2* FftContext::bigtw(long n) {
+	std::lock_guard<std::mutex> g(mu_);
+	auto it = bigtw_.find(n);
+	if (it != bigtw_.end()) return it->second.as<double2>();
+	std::vector<double2> tw; twiddles(n, tw);
+	bigtw_[n] = upload(tw);
+	return bigtw_[n].as<double2>();
+}
+
+static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
+	k.n = s.n; k.nfac = s.nfac; k.generic = s.generic;
+	for (int p = 0; p < s.nfac; p++) k.pass[p] = s.pass[p];
+	k.perm = s.perm.as<int>(); k.tw = s.tw.as<double2>();
+	int bufs = s.generic ? 2 : 1;
+	long T = (FFT_LDS_PTS - s.n)/((long)bufs*s.n);
+	if (T < 1) T = 1;
+	if (T > maxlines) T = maxlines;
+	if (T > 64) T = 64;
+	k.T = (int)T;
+	k.dn = make_fastdiv(s.n); k.dT = make_fastdiv((uint32_t)T);
+}
+
+static size_t lds_bytes(const KArgs& k) { return sizeof(double2)*((size_t)k.n + (size_t)k.T*k.n*(k.generic ? 2 : 1)); }
+
+void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, const FftLoad& ld, const FftStore& stf) {
+	std::string why;
+	if (!supported(n, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
+	if (d.n_i <= 0 || d.n_o1 <= 0 || d.n_o2 <= 0) return;
+	static std::once_flag once;
+	std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)fft_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); });
+	KArgs k; memset(&k, 0, sizeof(k));
+	k.N = n; k.forward = forward ? 1 : 0; k.d = d; k.ld = ld; k.st = stf; k.i_base = 0; k.i_count = d.n_i;
+	if (n <= FFT_NLOC_MAX) {
+		auto s = sub(n);
+		fill_sub(k, *s, d.n_i);
+		k.mode = 0; k.n1 = (int)n; k.n2 = 1;
+		k.ntile = (d.n_i + k.T - 1)/k.T;
+		// lines adjacent in memory (|stride| of the line index smaller than the element stride) => line index fastest
+		k.load_inner_fast  = (std::abs(d.is_i) < std::abs(d.is_e)) ? 1 : 0;
+		k.store_inner_fast = (std::abs(d.os_i) < std::abs(d.os_e)) ? 1 : 0;
+		long nblk = k.ntile*d.n_o1*d.n_o2;
+		size_t sh = lds_bytes(k);
+		hipLaunchKernelGGL(fft_lds_kernel, dim3((unsigned)nblk), dim3(FFT_THREADS), sh, st, k);
+		PXS_HIP(hipGetLastError());
+		return;
+	}
+	long n1, n2; split_two(n, n1, n2);
+	auto s1 = sub(n1); auto s2 = sub(n2);
+	const double2* btw = bigtw(n);
+	// chunk lines so that the scratch stays below temp_budget
+	long lines_budget = std::max<long>(1, (long)(temp_budget/(sizeof(double2)*n)));
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		size_t want = sizeof(double2)*n*std::min<long>(lines_budget, d.n_i*d.n_o1*d.n_o2);
+		temp_.ensure(want);
+	}
+	// iterate over o2, o1 chunks, i chunks
+	long o1_per = 1, i_per = d.n_i;
+	if (d.n_i <= lines_budget) { o1_per = std::min<long>(d.n_o1, std::max<long>(1, lines_budget/d.n_i)); }
+	else i_per = lines_budget;
+	for (long o2 = 0; o2 < d.n_o2; o2++)
+	for (long o1 = 0; o1 < d.n_o1; o1 += o1_per)
+	for (long i0 = 0; i0 < d.n_i; i0 += i_per) {
+		long no1 = std::min(o1_per, d.n_o1 - o1), ni = std::min(i_per, d.n_i - i0);
+		KArgs a = k;
+		a.d.n_o1 = no1; a.d.n_o2 = 1; a.i_base = i0; a.i_count = ni;
+		// shift base pointers
+		auto esz = [](int dt) { return dt == PX_F32 ? 4 : dt == PX_F64 ? 8 : dt == PX_C64 ? 8 : 16; };
+		a.ld.ptr = (const char*)ld.ptr + esz(ld.dtype)*(o2*d.is_o2 + o1*d.is_o1 + i0*d.is_i);
+		a.st.ptr = (char*)stf.ptr + esz(stf.dtype)*(o2*d.os_o2 + o1*d.os_o1 + i0*d.os_i);
+		a.temp = temp_.as<double2>(); a.bigtw = btw; a.n1 = (int)n1; a.n2 = (int)n2;
+		const int tile_i = (std::abs(d.is_i) < std::abs(d.is_e)) ? 1 : 0;
+		// pass A: n1-point FFTs over j1 for each (i, j2); tile over j2 (lines contiguous) or over i (lines adjacent)
+		KArgs pa = a; fill_sub(pa, *s1, tile_i ? ni : n2); pa.mode = 1; pa.tile_i = tile_i;
+		pa.ntile = ((tile_i ? ni : n2) + pa.T - 1)/pa.T;
+		pa.load_inner_fast = 1; pa.store_inner_fast = 1;
+		long nblkA = pa.ntile*(tile_i ? n2 : ni)*no1;
+		hipLaunchKernelGGL(fft_lds_kernel, dim3((unsigned)nblkA), dim3(FFT_THREADS), lds_bytes(pa), st, pa);
+		// pass B: n2-point FFTs over j2 for each (i, k1)
+		KArgs pb = a; fill_sub(pb, *s2, tile_i ? ni : n1); pb.mode = 2; pb.tile_i = tile_i;
+		pb.ntile = ((tile_i ? ni : n1) + pb.T - 1)/pb.T;
+		pb.load_inner_fast = tile_i ? 1 : 0; pb.store_inner_fast = 1;
+		long nblkB = pb.ntile*(tile_i ? n1 : ni)*no1;
+		hipLaunchKernelGGL(fft_lds_kernel, dim3((unsigned)nblkB), dim3(FFT_THREADS), lds_bytes(pb), st, pb);
+		PXS_HIP(hipGetLastError());
+	}
+}
+
+} // namespace pxs

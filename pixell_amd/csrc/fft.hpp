@@ -1,0 +1,65 @@
+// Batched 1-D FFT engine for gfx950: LDS-resident mixed-radix passes (2,3,4,5 + generic
+// odd radix), four-step decomposition for long lines, load/store functors that fuse the
+// index remaps the SHT needs (Hermitian expansion, parity mirror extension, spectrum
+// resize with Nyquist rule, pruned / scaled / table-multiplied stores).
+// Replaces ducc0.fft.c2c/r2c/c2r as called from pixell/fft.py:45-64 and the ring / theta
+// FFTs inside ducc0's SHT (not in the reference tree).
+#pragma once
+#include "common.hpp"
+#include <map>
+#include <memory>
+#include <mutex>
+
+namespace pxs {
+
+enum LoadMode : int { LD_PLAIN = 0, LD_HERM = 1, LD_MIRROR = 2, LD_SPEC = 3, LD_SPEC_ADJ = 4 };
+
+// Line index space: a transform "line" is addressed by (i, o1, o2); element e along it.
+struct FftDims {
+	long n_i = 1, n_o1 = 1, n_o2 = 1;
+	long is_i = 0, is_o1 = 0, is_o2 = 0, is_e = 1;   // input strides (in elements of the input dtype)
+	long os_i = 0, os_o1 = 0, os_o2 = 0, os_e = 1;   // output strides
+};
+
+struct FftLoad {
+	const void* ptr = nullptr; int dtype = PX_C128; int mode = LD_PLAIN;
+	long ne = -1;               // PLAIN: elements >= ne read as zero (-1: all n); HERM: half-spectrum length (mmax+1);
+	                            // MIRROR: number of real rings; SPEC*: source spectrum length Ns
+	const double2* mul = nullptr; // PLAIN: multiplier indexed by e. SPEC: phase indexed by |k| (conjugated for k<0)
+	int mir_c = 0, par0 = 0;    // MIRROR: src index for e>=ne is (-e-c) mod n, sign -1 if ((i+par0)&1)
+	long kmax = -1;             // SPEC: keep |k| <= kmax (-1: all representable)
+	int nyq_half = 0;           // SPEC: source Nyquist bin (Ns even) is split 1/2,1/2 onto +-Ns/2
+	int mul_by_line = 0;        // PLAIN: 0 = mul indexed by e
+};
+
+struct FftStore {
+	void* ptr = nullptr; int dtype = PX_C128;
+	long ne = -1;               // store only e < ne (-1: all)
+	long two_sided_k = -1;      // if >= 0: store only e <= k or e >= n-k
+	const double2* mul = nullptr; // multiplier indexed by e
+	double scale = 1.0;
+	int conj_out = 0;           // conjugate the result before mul/scale
+};
+
+struct FftSub;   // per-length tables
+
+class FftContext {
+public:
+	explicit FftContext(int device);
+	~FftContext();
+	// out = FFT_n(in) along e for every line; forward: e^{-2 pi i jk/n}; unnormalised.
+	void exec(hipStream_t st, long n, bool forward, const FftDims& d, const FftLoad& ld, const FftStore& stf);
+	static long good_size(long n);          // smallest 2^a 3^b 5^c >= n that the engine can factor
+	static bool supported(long n, std::string* why = nullptr);
+	size_t temp_budget = size_t(192) << 20; // bytes of four-step scratch kept cache resident
+private:
+	int device_;
+	std::mutex mu_;
+	std::map<long, std::shared_ptr<FftSub>> subs_;
+	std::map<long, DevBuf> bigtw_;
+	DevBuf temp_;
+	std::shared_ptr<FftSub> sub(long n);
+	const double2* bigtw(long n);
+};
+
+} // namespace pxs

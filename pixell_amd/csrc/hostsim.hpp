@@ -1,0 +1,125 @@
+// TEST-ONLY host simulator of the tiny subset of HIP the kernels in this directory use.
+// Compiling the *same* .hip sources with g++ -DPXS_HOST_SIM gives libpxsht_hostsim.so, in which
+// every workgroup is executed by one OS thread per lane (barriers and wave shuffles are real
+// rendezvous).  It exists so that the index arithmetic of the kernels can be unit-tested in
+// the GPU-less container (tests/ -m "not gpu"); it is never built by __graft_entry__.build(),
+// never loaded by the product loader, and is orders of magnitude too slow to be a fallback.
+#pragma once
+#ifdef PXS_HOST_SIM
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <thread>
+#include <vector>
+#include <mutex>
+#include <condition_variable>
+#include <algorithm>
+
+struct double2 { double x, y; };
+struct float2 { float x, y; };
+static inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint3_ { unsigned x, y, z; };
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
+template<class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { std::free(p); return 0; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memmove(d, s, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memmove(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return 0; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+
+namespace pxsim {
+struct Barrier {
+	std::mutex m; std::condition_variable cv; int n, count = 0; unsigned gen = 0;
+	explicit Barrier(int n_) : n(n_) {}
+	void wait() { std::unique_lock<std::mutex> l(m); unsigned g = gen; if (++count == n) { count = 0; gen++; cv.notify_all(); } else cv.wait(l, [&] { return g != gen; }); }
+};
+struct BlockCtx {
+	char* shared; Barrier* bar; std::vector<Barrier*> wbar; std::vector<uint64_t>* wslot; int nthreads;
+};
+extern thread_local uint3_ t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local BlockCtx* t_ctx;
+template<class F> void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
+	const int nt = block.x*block.y*block.z;
+	const int nw = (nt + 63)/64;
+	std::vector<char> sh(shmem + 64);
+	for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+		Barrier bar(nt);
+		std::vector<Barrier*> wb; for (int w = 0; w < nw; w++) wb.push_back(new Barrier(std::min(64, nt - 64*w)));
+		std::vector<uint64_t> slots((size_t)nw*64*2);
+		BlockCtx ctx{sh.data(), &bar, wb, &slots, nt};
+		if (nt == 1) {
+			t_threadIdx = {0, 0, 0}; t_blockIdx = {bx, by, bz}; t_blockDim = {block.x, block.y, block.z}; t_gridDim = {grid.x, grid.y, grid.z};
+			t_ctx = &ctx; body();
+		} else {
+			std::vector<std::thread> th;
+			for (int t = 0; t < nt; t++) th.emplace_back([&, t] {
+				t_threadIdx = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x*block.y))};
+				t_blockIdx = {bx, by, bz}; t_blockDim = {block.x, block.y, block.z}; t_gridDim = {grid.x, grid.y, grid.z};
+				t_ctx = &ctx; body();
+			});
+			for (auto& x : th) x.join();
+		}
+		for (auto b : wb) delete b;
+	}
+}
+static inline int lane_id() { return (t_threadIdx.x + t_threadIdx.y*t_blockDim.x) & 63; }
+static inline int wave_id() { return (t_threadIdx.x + t_threadIdx.y*t_blockDim.x) >> 6; }
+static inline uint64_t xchg(uint64_t v, int src_lane) {
+	BlockCtx* c = t_ctx; int w = wave_id(), l = lane_id();
+	uint64_t* s = c->wslot->data() + (size_t)w*128;
+	s[l] = v; c->wbar[w]->wait();
+	uint64_t r = s[src_lane & 63]; c->wbar[w]->wait();
+	return r;
+}
+}
+#define threadIdx pxsim::t_threadIdx
+#define blockIdx  pxsim::t_blockIdx
+#define blockDim  pxsim::t_blockDim
+#define gridDim   pxsim::t_gridDim
+static inline void __syncthreads() { if (pxsim::t_ctx->nthreads > 1) pxsim::t_ctx->bar->wait(); }
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a*b) >> 32); }
+static inline double __shfl_xor(double v, int mask) { uint64_t u; std::memcpy(&u, &v, 8); u = pxsim::xchg(u, pxsim::lane_id() ^ mask); std::memcpy(&v, &u, 8); return v; }
+static inline double __shfl(double v, int src) { uint64_t u; std::memcpy(&u, &v, 8); u = pxsim::xchg(u, src); std::memcpy(&v, &u, 8); return v; }
+static inline int __shfl(int v, int src) { return (int)pxsim::xchg((uint64_t)(uint32_t)v, src); }
+static inline unsigned long long __ballot(int pred) {
+	pxsim::BlockCtx* c = pxsim::t_ctx; int w = pxsim::wave_id(), l = pxsim::lane_id();
+	uint64_t* s = c->wslot->data() + (size_t)w*128 + 64;
+	s[l] = pred ? 1 : 0; c->wbar[w]->wait();
+	unsigned long long r = 0; int nl = std::min(64, c->nthreads - 64*w);
+	for (int i = 0; i < nl; i++) r |= (unsigned long long)(s[i] & 1) << i;
+	c->wbar[w]->wait();
+	return r;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+static inline int __all(int pred) { pxsim::BlockCtx* c = pxsim::t_ctx; int w = pxsim::wave_id(); int nl = std::min(64, c->nthreads - 64*w);
+	unsigned long long full = nl == 64 ? ~0ull : ((1ull << nl) - 1); return __ballot(pred) == full; }
+using std::min; using std::max;
+#define PXS_SHARED(type, name) type* name = reinterpret_cast<type*>(pxsim::t_ctx->shared)
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) pxsim::launch((grid), (block), (shmem), [&] { kern(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+#define PXS_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
