@@ -1,0 +1,65 @@
+"""ctypes loader of libpxsht.so (the HIP kernels behind include/pxsht.h).
+
+The product path has NO CPU fallback: if the library is missing or cannot be loaded this
+module raises.  The only alternative library it will load is the test-only host simulator
+(tests/hostsim), and only when a test sets PIXELL_AMD_HOSTSIM=1 explicitly."""
+import ctypes, os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_is_hostsim = False
+
+class PxsError(RuntimeError):
+	def __init__(self, code, msg):
+		RuntimeError.__init__(self, "libpxsht error %d: %s" % (code, msg))
+		self.code = code
+
+def _declare(lib):
+	c = ctypes
+	vp, i32, i64, dbl = c.c_void_p, c.c_int, c.c_int64, c.c_double
+	lib.pxs_last_error.restype = c.c_char_p
+	lib.pxs_version.restype = c.c_char_p
+	lib.pxs_plan_rings.argtypes = [c.POINTER(vp), i32, vp, vp, vp, vp, i64, i32, i32, vp, i64, i32]
+	lib.pxs_plan_grid2d.argtypes = [c.POINTER(vp), c.c_char_p, i32, i32, dbl, i32, i32, i32, i32, vp, i64, i32]
+	lib.pxs_plan_destroy.argtypes = [vp]; lib.pxs_plan_destroy.restype = None
+	lib.pxs_synthesis.argtypes = [vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp]
+	lib.pxs_analysis.argtypes = [vp, i32, i32, vp, i32, i64, vp, i32, i64, vp]
+	lib.pxs_gridweights.argtypes = [c.c_char_p, i32, vp]
+	lib.pxs_grid_maxlmax.argtypes = [c.c_char_p, i32]
+	lib.pxs_plan_info.argtypes = [vp, c.POINTER(i32), c.POINTER(i32), c.POINTER(i64)]
+	lib.pxf_fft_nd.argtypes = [i32, vp, vp, vp, i32, vp, i32, i32, dbl, i32, i32, vp, vp, i32, vp]
+	lib.pxf_fft_supported.argtypes = [i64]
+	lib.pxf_fft_good_size.argtypes = [i64]; lib.pxf_fft_good_size.restype = i64
+	for name in ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_synthesis", "pxs_analysis", "pxs_gridweights",
+			"pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported"]:
+		getattr(lib, name).restype = i32
+	return lib
+
+EXPORTS = ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_plan_destroy", "pxs_synthesis", "pxs_analysis",
+	"pxs_gridweights", "pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported",
+	"pxf_fft_good_size", "pxs_last_error", "pxs_version"]
+
+def lib_path():
+	return os.path.join(HERE, "libpxsht.so")
+
+def load():
+	"""Return the loaded library, loading it on first use.  Raises if it is absent."""
+	global _lib, _is_hostsim
+	if _lib is not None: return _lib
+	if os.environ.get("PIXELL_AMD_HOSTSIM") == "1":
+		path = os.path.join(HERE, "..", "tests", "hostsim", "libpxsht_hostsim.so")
+		_is_hostsim = True
+	else:
+		path = lib_path()
+	if not os.path.exists(path):
+		raise ImportError("pixell_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+			"(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+	_lib = _declare(ctypes.CDLL(path))
+	return _lib
+
+def is_hostsim():
+	load(); return _is_hostsim
+
+def check(code):
+	if code != 0:
+		raise PxsError(code, load().pxs_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,727 @@
+// Legendre stage of the SHT for gfx950: alm <-> leg[comp][m][ring].
+//
+// Replaces ducc0's alm2leg / leg2alm (inside ducc0.sht.experimental.*; not in the reference
+// tree) as reached from pixell/curvedsky.py:907-960, 1032-1084.
+//
+// Design (MI355X-first, plain FP64 FMA -- the contraction is 1-4 right-hand sides wide, too
+// narrow for the 16x16x4 f64 MFMA):
+//  * one wave64 per workgroup; a lane owns K ring PAIRS (theta, pi-theta) => K independent
+//    recurrence chains of ILP per lane, north/south sharing one recurrence;
+//  * spin 0: Ishioka-type two-step recurrence in x^2, p_{k+1} = (a_k x^2 + b_k) p_k + p_{k-1},
+//    p_k ~ lambda_{m+2k+1,m}/x: 2 FMA of recurrence serve TWO degrees l, 4 FMA accumulate;
+//    spin s: scaled three-term recurrence for (s)lambda and (-s)lambda, 4 FMA + 8 FMA per l;
+//  * per-step coefficients (a,b) and the pre-scaled alm are wave-uniform: they are fetched with
+//    scalar loads and fed to v_fma_f64 as SGPR operands, the recurrence state and the
+//    accumulators stay in VGPRs for the whole l loop;
+//  * extended exponent: lambda_mm ~ sin^m(theta) underflows for large m, so a chain starts as
+//    (mantissa, scale) with value = mantissa * 2^(800*scale), is advanced without accumulating
+//    until some lane of the wave reaches scale 0, then advanced with gated accumulation until all
+//    lanes have, then runs the branch-free fast loop;
+//  * analysis needs sum over rings (lanes) for every l: partial sums of 4 k-steps are transposed
+//    through a 16x66 LDS tile (conflict free) and reduced by 16 lanes each, one 128-byte store of
+//    partial moments per wave per 4 steps; a second tiny kernel sums the waves.
+#include "legendre.hpp"
+#include <cmath>
+#include <algorithm>
+
+namespace pxs {
+
+static constexpr double SC_BIG   = 0x1p+400;
+static constexpr double SC_SMALL = 0x1p-800;
+static constexpr int    SC_STEP  = 800;
+static constexpr int    LEG_K0   = 4;    // ring pairs per lane, spin 0
+static constexpr int    LEG_KS   = 2;    // ring pairs per lane, spin s
+
+struct LegK {
+	int lmax, mmax, spin, nm, npairs, nring, nwave;
+	long nrows;
+	const long* row; const double2* coef; const double* alpha;
+	const int* ring_n; const int* ring_s; const double* cth; const double* sth; const double* sh2; const double* ch2;
+	double* almt; double* part; double* mom;
+	double2* leg;
+	double ofs;
+};
+
+// ---------------------------------------------------------------------------------
+// scaled powers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void frexp_norm(double& m, int& e) { int d; m = frexp(m, &d); e += d; }
+
+// x^n as mant * 2^e, mant in [0.5,1) (or 0)
+__device__ __forceinline__ void pow_scaled(double x, int n, double& mant, int& e) {
+	double rm = 0.5; int re = 1;
+	int be = 0; double bm = frexp(x, &be);
+	while (n) {
+		if (n & 1) { rm *= bm; re += be; frexp_norm(rm, re); }
+		bm *= bm; be *= 2; frexp_norm(bm, be);
+		n >>= 1;
+	}
+	mant = rm; e = re;
+}
+// value = mant*2^e  ->  v*2^(800*scale), scale <= 0, |v| <= 2^400
+__device__ __forceinline__ void to_scaled(double mant, int e, double& v, int& scale) {
+	if (mant == 0.0) { v = 0.0; scale = 0; return; }
+	int s = (e >= 0) ? (e + SC_STEP/2)/SC_STEP : -((-e + SC_STEP/2)/SC_STEP);
+	if (s > 0) s = 0;
+	v = ldexp(mant, e - SC_STEP*s); scale = s;
+}
+
+// ---------------------------------------------------------------------------------
+// alm pre / post transforms
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double2 ld_alm(const void* alm, int dtype, long idx) {
+	if (dtype == PX_C64) { float2 v = ((const float2*)alm)[idx]; return make_double2(v.x, v.y); }
+	return ((const double2*)alm)[idx];
+}
+__device__ __forceinline__ void st_alm(void* alm, int dtype, long idx, double2 v) {
+	if (dtype == PX_C64) ((float2*)alm)[idx] = make_float2((float)v.x, (float)v.y);
+	else ((double2*)alm)[idx] = v;
+}
+__device__ __forceinline__ double eps_lm(int l, int m) {
+	if (l <= m) return 0.0;
+	double L = l, M = m;
+	return sqrt((L*L - M*M)/(4.0*L*L - 1.0));
+}
+
+struct AlmK {
+	int lmax, mmax, spin, deriv1, dtype;
+	long nrows, cstride, lstride;
+	const long* row; const double* alpha; const uint64_t* mstart;
+	void* alm; double* almt; const double* mom;
+};
+
+// spin 0: almt[row(m)+k] = alpha_k * ( eps_{l+1} a_l + eps_{l+2} a_{l+2},  a_{l+1} ),  l = m+2k
+__global__ __launch_bounds__(256) void alm_pre_s0(AlmK a) {
+	const int m = blockIdx.y;
+	const int nk = (a.lmax - m)/2 + 1;
+	const int k = blockIdx.x*blockDim.x + threadIdx.x;
+	if (k >= nk) return;
+	const int l = m + 2*k;
+	const long base = (long)a.mstart[m];
+	double2 a0 = ld_alm(a.alm, a.dtype, base + (long)l*a.lstride);
+	double2 a1 = (l+1 <= a.lmax) ? ld_alm(a.alm, a.dtype, base + (long)(l+1)*a.lstride) : make_double2(0, 0);
+	double2 a2 = (l+2 <= a.lmax) ? ld_alm(a.alm, a.dtype, base + (long)(l+2)*a.lstride) : make_double2(0, 0);
+	const double al = a.alpha[a.row[m] + k];
+	const double e1 = eps_lm(l+1, m), e2 = eps_lm(l+2, m);
+	double* o = a.almt + 4*(a.row[m] + k);
+	o[0] = al*(e1*a0.x + e2*a2.x); o[1] = al*(e1*a0.y + e2*a2.y);
+	o[2] = al*a1.x;                o[3] = al*a1.y;
+}
+// a_{m+2k} = eps_{l+1} alpha_k M1_k + eps_l alpha_{k-1} M1_{k-1};  a_{m+2k+1} = alpha_k M2_k
+__global__ __launch_bounds__(256) void alm_post_s0(AlmK a) {
+	const int m = blockIdx.y;
+	const int nk = (a.lmax - m)/2 + 1;
+	const int k = blockIdx.x*blockDim.x + threadIdx.x;
+	if (k >= nk) return;
+	const int l = m + 2*k;
+	const long r = a.row[m] + k;
+	const double* M = a.mom + 4*r;
+	const double al = a.alpha[r];
+	const double e1 = eps_lm(l+1, m), e0 = eps_lm(l, m);
+	double2 v = make_double2(e1*al*M[0], e1*al*M[1]);
+	if (k > 0) { const double alp = a.alpha[r-1]; v.x += e0*alp*M[-4]; v.y += e0*alp*M[-3]; }
+	const long base = (long)a.mstart[m];
+	st_alm(a.alm, a.dtype, base + (long)l*a.lstride, v);
+	if (l+1 <= a.lmax) st_alm(a.alm, a.dtype, base + (long)(l+1)*a.lstride, make_double2(al*M[2], al*M[3]));
+}
+// spin s: rows l = l0..lmax; almt = beta_l * ( a+ = -(E+iB),  a- = -(-1)^s (E-iB) )
+__global__ __launch_bounds__(256) void alm_pre_spin(AlmK a) {
+	const int m = blockIdx.y;
+	const int l0 = max(m, a.spin);
+	const int l = l0 + blockIdx.x*blockDim.x + threadIdx.x;
+	if (l > a.lmax) return;
+	const long idx = (long)a.mstart[m] + (long)l*a.lstride;
+	double2 E = ld_alm(a.alm, a.dtype, idx), B;
+	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); E.x *= f; E.y *= f; B = make_double2(0, 0); }
+	else B = ld_alm(a.alm, a.dtype, idx + a.cstride);
+	const long r = a.row[m] + (l - l0);
+	const double be = a.alpha[r];
+	const double sg = (a.spin & 1) ? -1.0 : 1.0;
+	double* o = a.almt + 4*r;
+	o[0] = -be*(E.x - B.y); o[1] = -be*(E.y + B.x);
+	o[2] = -sg*be*(E.x + B.y); o[3] = -sg*be*(E.y - B.x);
+}
+// E = -1/2 beta (mu+ + sg mu-),  B = i/2 beta (mu+ - sg mu-)
+__global__ __launch_bounds__(256) void alm_post_spin(AlmK a) {
+	const int m = blockIdx.y;
+	const int l0 = max(m, a.spin);
+	const int l = blockIdx.x*blockDim.x + threadIdx.x + min(m, l0);   // also zero-fill m <= l < l0
+	if (l > a.lmax) return;
+	const long idx = (long)a.mstart[m] + (long)l*a.lstride;
+	double2 E = make_double2(0, 0), B = make_double2(0, 0);
+	if (l >= l0) {
+		const long r = a.row[m] + (l - l0);
+		const double* M = a.mom + 4*r;
+		const double be = a.alpha[r];
+		const double sg = (a.spin & 1) ? -1.0 : 1.0;
+		E = make_double2(-0.5*be*(M[0] + sg*M[2]), -0.5*be*(M[1] + sg*M[3]));
+		B = make_double2(-0.5*be*(M[1] - sg*M[3]),  0.5*be*(M[0] - sg*M[2]));
+	}
+	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); st_alm(a.alm, a.dtype, idx, make_double2(f*E.x, f*E.y)); }
+	else { st_alm(a.alm, a.dtype, idx, E); st_alm(a.alm, a.dtype, idx + a.cstride, B); }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials(const double* part, double* mom, long n4, int nwave) {
+	const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= n4) return;
+	double s = 0;
+	for (int w = 0; w < nwave; w++) s += part[(long)w*n4 + i];
+	mom[i] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// spin-0 kernels
+// ---------------------------------------------------------------------------------
+#define LEG_RED_STRIDE 66
+
+template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
+{
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const long row0 = a.row[m];
+	const int nk = (a.lmax - m)/2 + 1;
+	const double2* __restrict__ coef = a.coef + row0;
+	const double* __restrict__ at = a.almt + 4*row0;
+	double x[K], csq[K], lam1[K], lam2[K], p1r[K], p1i[K], p2r[K], p2i[K];
+	int sc[K], rn[K], rs[K];
+	bool alive_any = false;
+#pragma unroll
+	for (int s = 0; s < K; s++) {
+		const int p = (wv*K + s)*64 + lane;
+		const bool valid = p < a.npairs;
+		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
+		x[s] = valid ? a.cth[p] : 0.0; csq[s] = x[s]*x[s];
+		const double sth = valid ? a.sth[p] : 0.0;
+		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
+		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
+		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
+		p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0;
+		alive_any |= alive;
+	}
+	int k = 0;
+	if (__any(alive_any)) {
+		// phase A: nobody at scale 0 yet -> recurrence only
+		while (k < nk) {
+			bool act = false;
+#pragma unroll
+			for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
+			if (__any(act)) break;
+			const double2 ab = coef[k];
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+				lam1[s] = lam2[s]; lam2[s] = t;
+				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
+			}
+			k++;
+		}
+		// phase B: gated accumulation until every lane is at scale 0
+		while (k < nk) {
+			bool pend = false;
+#pragma unroll
+			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
+			if (!__any(pend)) break;
+			const double2 ab = coef[k];
+			const double er = at[4*k], ei = at[4*k+1], orr = at[4*k+2], oi = at[4*k+3];
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				const double g = (sc[s] == 0) ? lam2[s] : 0.0;
+				p1r[s] = fma(g, er, p1r[s]); p1i[s] = fma(g, ei, p1i[s]);
+				p2r[s] = fma(g, orr, p2r[s]); p2i[s] = fma(g, oi, p2i[s]);
+				const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+				lam1[s] = lam2[s]; lam2[s] = t;
+				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
+			}
+			k++;
+		}
+		// phase C: fast loop
+		for (; k < nk; k++) {
+			const double2 ab = coef[k];
+			const double er = at[4*k], ei = at[4*k+1], orr = at[4*k+2], oi = at[4*k+3];
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				p1r[s] = fma(lam2[s], er, p1r[s]); p1i[s] = fma(lam2[s], ei, p1i[s]);
+				p2r[s] = fma(lam2[s], orr, p2r[s]); p2i[s] = fma(lam2[s], oi, p2i[s]);
+				const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+				lam1[s] = lam2[s]; lam2[s] = t;
+			}
+		}
+	}
+	double2* __restrict__ out = a.leg + (long)m*a.nring;
+#pragma unroll
+	for (int s = 0; s < K; s++) {
+		if (rn[s] >= 0) out[rn[s]] = make_double2(p1r[s] + x[s]*p2r[s], p1i[s] + x[s]*p2i[s]);
+		if (rs[s] >= 0) out[rs[s]] = make_double2(p1r[s] - x[s]*p2r[s], p1i[s] - x[s]*p2i[s]);
+	}
+}
+
+// flush nrow4 (<=4) k-steps of per-lane partial sums held in the LDS tile
+__device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk) {
+	__syncthreads();
+	const int rowi = lane >> 2, part = lane & 3;
+	double sum = 0;
+	if (rowi < 4*nkk) {
+#pragma unroll
+		for (int i = 0; i < 16; i++) sum += red[rowi*LEG_RED_STRIDE + i*4 + part];
+	}
+	sum += __shfl_xor(sum, 1);
+	sum += __shfl_xor(sum, 2);
+	if (part == 0 && rowi < 4*nkk) dst[rowi] = sum;
+	__syncthreads();
+}
+
+template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
+{
+	PXS_SHARED(double, red);
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const long row0 = a.row[m];
+	const int nk = (a.lmax - m)/2 + 1;
+	const double2* __restrict__ coef = a.coef + row0;
+	double* __restrict__ pout = a.part + ((long)wv*a.nrows + row0)*4;
+	const double2* __restrict__ in = a.leg + (long)m*a.nring;
+	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
+	int sc[K];
+	bool alive_any = false;
+#pragma unroll
+	for (int s = 0; s < K; s++) {
+		const int p = (wv*K + s)*64 + lane;
+		const bool valid = p < a.npairs;
+		const int rn = valid ? a.ring_n[p] : -1, rs = valid ? a.ring_s[p] : -1;
+		const double x = valid ? a.cth[p] : 0.0; csq[s] = x*x;
+		const double sth = valid ? a.sth[p] : 0.0;
+		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
+		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
+		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
+		double2 vn = (alive && rn >= 0) ? in[rn] : make_double2(0, 0);
+		double2 vs = (alive && rs >= 0) ? in[rs] : make_double2(0, 0);
+		d1r[s] = vn.x + vs.x; d1i[s] = vn.y + vs.y;
+		d2r[s] = (vn.x - vs.x)*x; d2i[s] = (vn.y - vs.y)*x;
+		alive_any |= alive;
+	}
+	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
+	int k = 0;
+	while (k < nk) {
+		bool act = false;
+#pragma unroll
+		for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
+		if (__any(act)) break;
+		const double2 ab = coef[k];
+#pragma unroll
+		for (int s = 0; s < K; s++) {
+			const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+			lam1[s] = lam2[s]; lam2[s] = t;
+			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
+		}
+		k++;
+	}
+	int kk = 0, kbase = k;
+	while (k < nk) {
+		bool pend = false;
+#pragma unroll
+		for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
+		if (!__any(pend)) break;
+		const double2 ab = coef[k];
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+		for (int s = 0; s < K; s++) {
+			const double g = (sc[s] == 0) ? lam2[s] : 0.0;
+			t0 = fma(g, d1r[s], t0); t1 = fma(g, d1i[s], t1); t2 = fma(g, d2r[s], t2); t3 = fma(g, d2i[s], t3);
+			const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+			lam1[s] = lam2[s]; lam2[s] = t;
+			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
+		}
+		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
+		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
+		k++; kk++;
+		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k; }
+	}
+	for (; k < nk; k++) {
+		const double2 ab = coef[k];
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+		for (int s = 0; s < K; s++) {
+			t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3);
+			const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+			lam1[s] = lam2[s]; lam2[s] = t;
+		}
+		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
+		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
+		kk++;
+		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+1; }
+	}
+	if (kk > 0) leg_flush(red, pout + 4*kbase, lane, kk);
+}
+
+// ---------------------------------------------------------------------------------
+// spin-s kernels.  rows l = l0..lmax.  chains G+ (spin +s) and G- (spin -s) of the NORTH ring;
+// south ring: F+_S = (-1)^(l+m) F-_N, F-_S = (-1)^(l+m) F+_N.
+// ---------------------------------------------------------------------------------
+template<int K> struct SpinState {
+	double x[K], gp1[K], gp2[K], gm1[K], gm2[K];
+	int scp[K], scm[K];
+};
+
+template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv, int lane, int m, SpinState<K>& S, int* rn, int* rs) {
+	const int s_ = a.spin;
+	bool alive_any = false;
+#pragma unroll
+	for (int s = 0; s < K; s++) {
+		const int p = (wv*K + s)*64 + lane;
+		const bool valid = p < a.npairs;
+		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
+		S.x[s] = valid ? a.cth[p] : 0.0;
+		const double sth = valid ? a.sth[p] : 0.0;
+		// libsharp's m-limit generalised to spin: rings with m beyond it carry nothing up to lmax
+		const double t1 = a.lmax*sth + a.ofs;
+		const double b = -2.0*s_*fabs(S.x[s]);
+		const double c = (double)s_*s_ - t1*t1;
+		const double discr = b*b - 4*c;
+		const double mlim = discr <= 0 ? a.lmax : fmin((double)a.lmax, 0.5*(-b + sqrt(discr)));
+		const bool alive = valid && ((double)m <= mlim + 0.5);
+		S.gp1[s] = S.gm1[s] = 0; S.gp2[s] = S.gm2[s] = 0; S.scp[s] = S.scm[s] = 0;
+		if (alive) {
+			const double sh = a.sh2[p], ch = a.ch2[p];
+			double m1, m2; int e1, e2;
+			if (m >= s_) {
+				pow_scaled(sh, m + s_, m1, e1); pow_scaled(ch, m - s_, m2, e2);
+				double mt = m1*m2; int e = e1 + e2 + m; frexp_norm(mt, e); to_scaled(mt, e, S.gp2[s], S.scp[s]);
+				pow_scaled(sh, m - s_, m1, e1); pow_scaled(ch, m + s_, m2, e2);
+				mt = m1*m2; e = e1 + e2 + m; frexp_norm(mt, e); to_scaled(mt, e, S.gm2[s], S.scm[s]);
+			} else {
+				pow_scaled(sh, s_ + m, m1, e1); pow_scaled(ch, s_ - m, m2, e2);
+				double mt = m1*m2; int e = e1 + e2; frexp_norm(mt, e); to_scaled(mt, e, S.gp2[s], S.scp[s]);
+				pow_scaled(sh, s_ - m, m1, e1); pow_scaled(ch, s_ + m, m2, e2);
+				mt = m1*m2; e = e1 + e2; frexp_norm(mt, e); to_scaled(mt, e, S.gm2[s], S.scm[s]);
+				if ((s_ - m) & 1) S.gm2[s] = -S.gm2[s];
+			}
+		}
+		alive_any |= alive;
+	}
+	return alive_any;
+}
+
+template<int K> __device__ __forceinline__ void spin_step(SpinState<K>& S, int s, double ca, double cb, bool rescale) {
+	const double tp = fma(ca, S.x[s], cb), tm = fma(ca, S.x[s], -cb);
+	const double np_ = fma(tp, S.gp2[s], -S.gp1[s]), nm_ = fma(tm, S.gm2[s], -S.gm1[s]);
+	S.gp1[s] = S.gp2[s]; S.gp2[s] = np_; S.gm1[s] = S.gm2[s]; S.gm2[s] = nm_;
+	if (rescale) {
+		if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
+		if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
+	}
+}
+
+template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
+{
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const int l0 = max(m, a.spin);
+	const int nl = a.lmax - l0 + 1;
+	double2* __restrict__ outq = a.leg + (long)m*a.nring;
+	double2* __restrict__ outu = a.leg + ((long)a.nm + m)*a.nring;
+	SpinState<K> S; int rn[K], rs[K];
+	double pnr[K], pni[K], mnr[K], mni[K], psr[K], psi[K], msr[K], msi[K];
+#pragma unroll
+	for (int s = 0; s < K; s++) pnr[s] = pni[s] = mnr[s] = mni[s] = psr[s] = psi[s] = msr[s] = msi[s] = 0;
+	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs);
+	if (nl > 0 && __any(alive_any)) {
+		const long row0 = a.row[m];
+		const double2* __restrict__ coef = a.coef + row0;
+		const double* __restrict__ at = a.almt + 4*row0;
+		double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m)
+		int j = 0;
+		while (j < nl) {
+			bool act = false;
+#pragma unroll
+			for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
+			if (__any(act)) break;
+			const double2 ab = coef[j];
+#pragma unroll
+			for (int s = 0; s < K; s++) spin_step<K>(S, s, ab.x, ab.y, true);
+			j++; sgn = -sgn;
+		}
+		while (j < nl) {
+			bool pend = false;
+#pragma unroll
+			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
+			if (!__any(pend)) break;
+			const double2 ab = coef[j];
+			const double apr = at[4*j], api = at[4*j+1], amr = at[4*j+2], ami = at[4*j+3];
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				const double gp = (S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (S.scm[s] == 0) ? S.gm2[s] : 0.0;
+				pnr[s] = fma(gp, apr, pnr[s]); pni[s] = fma(gp, api, pni[s]);
+				mnr[s] = fma(gm, amr, mnr[s]); mni[s] = fma(gm, ami, mni[s]);
+				psr[s] = fma(gm, sgn*apr, psr[s]); psi[s] = fma(gm, sgn*api, psi[s]);
+				msr[s] = fma(gp, sgn*amr, msr[s]); msi[s] = fma(gp, sgn*ami, msi[s]);
+				spin_step<K>(S, s, ab.x, ab.y, true);
+			}
+			j++; sgn = -sgn;
+		}
+		for (; j < nl; j++) {
+			const double2 ab = coef[j];
+			const double apr = at[4*j], api = at[4*j+1], amr = at[4*j+2], ami = at[4*j+3];
+			const double sapr = sgn*apr, sapi = sgn*api, samr = sgn*amr, sami = sgn*ami;
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				const double gp = S.gp2[s], gm = S.gm2[s];
+				pnr[s] = fma(gp, apr, pnr[s]); pni[s] = fma(gp, api, pni[s]);
+				mnr[s] = fma(gm, amr, mnr[s]); mni[s] = fma(gm, ami, mni[s]);
+				psr[s] = fma(gm, sapr, psr[s]); psi[s] = fma(gm, sapi, psi[s]);
+				msr[s] = fma(gp, samr, msr[s]); msi[s] = fma(gp, sami, msi[s]);
+				spin_step<K>(S, s, ab.x, ab.y, false);
+			}
+			sgn = -sgn;
+		}
+	}
+	// Q = (P+M)/2, U = -i (P-M)/2
+#pragma unroll
+	for (int s = 0; s < K; s++) {
+		if (rn[s] >= 0) {
+			outq[rn[s]] = make_double2(0.5*(pnr[s] + mnr[s]), 0.5*(pni[s] + mni[s]));
+			outu[rn[s]] = make_double2(0.5*(pni[s] - mni[s]), -0.5*(pnr[s] - mnr[s]));
+		}
+		if (rs[s] >= 0) {
+			outq[rs[s]] = make_double2(0.5*(psr[s] + msr[s]), 0.5*(psi[s] + msi[s]));
+			outu[rs[s]] = make_double2(0.5*(psi[s] - msi[s]), -0.5*(psr[s] - msr[s]));
+		}
+	}
+}
+
+template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
+{
+	PXS_SHARED(double, red);
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const int l0 = max(m, a.spin);
+	const int nl = a.lmax - l0 + 1;
+	if (nl <= 0) return;
+	const long row0 = a.row[m];
+	const double2* __restrict__ coef = a.coef + row0;
+	double* __restrict__ pout = a.part + ((long)wv*a.nrows + row0)*4;
+	const double2* __restrict__ inq = a.leg + (long)m*a.nring;
+	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.nring;
+	SpinState<K> S; int rn[K], rs[K];
+	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs);
+	if (!__any(alive_any)) return;
+	// T+ = Q + iU, T- = Q - iU for north and south rings
+	double tpnr[K], tpni[K], tmnr[K], tmni[K], tpsr[K], tpsi[K], tmsr[K], tmsi[K];
+#pragma unroll
+	for (int s = 0; s < K; s++) {
+		double2 q = rn[s] >= 0 ? inq[rn[s]] : make_double2(0, 0), u = rn[s] >= 0 ? inu[rn[s]] : make_double2(0, 0);
+		tpnr[s] = q.x - u.y; tpni[s] = q.y + u.x; tmnr[s] = q.x + u.y; tmni[s] = q.y - u.x;
+		q = rs[s] >= 0 ? inq[rs[s]] : make_double2(0, 0); u = rs[s] >= 0 ? inu[rs[s]] : make_double2(0, 0);
+		tpsr[s] = q.x - u.y; tpsi[s] = q.y + u.x; tmsr[s] = q.x + u.y; tmsi[s] = q.y - u.x;
+	}
+	double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;
+	int j = 0;
+	while (j < nl) {
+		bool act = false;
+#pragma unroll
+		for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
+		if (__any(act)) break;
+		const double2 ab = coef[j];
+#pragma unroll
+		for (int s = 0; s < K; s++) spin_step<K>(S, s, ab.x, ab.y, true);
+		j++; sgn = -sgn;
+	}
+	int kk = 0, jbase = j;
+	bool fast = false;
+	for (; j < nl; j++) {
+		if (!fast) {
+			bool pend = false;
+#pragma unroll
+			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
+			fast = !__any(pend);
+		}
+		const double2 ab = coef[j];
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+		for (int s = 0; s < K; s++) {
+			const double gp = (fast || S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (fast || S.scm[s] == 0) ? S.gm2[s] : 0.0;
+			const double sgp = sgn*gp, sgm = sgn*gm;
+			// mu+ = G+ T+_N + sgn G- T+_S ;  mu- = G- T-_N + sgn G+ T-_S
+			t0 = fma(gp, tpnr[s], t0); t0 = fma(sgm, tpsr[s], t0);
+			t1 = fma(gp, tpni[s], t1); t1 = fma(sgm, tpsi[s], t1);
+			t2 = fma(gm, tmnr[s], t2); t2 = fma(sgp, tmsr[s], t2);
+			t3 = fma(gm, tmni[s], t3); t3 = fma(sgp, tmsi[s], t3);
+			spin_step<K>(S, s, ab.x, ab.y, !fast);
+		}
+		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
+		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
+		kk++; sgn = -sgn;
+		if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+1; }
+	}
+	if (kk > 0) leg_flush(red, pout + 4*jbase, lane, kk);
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+void RingSet::build(const std::vector<long double>& theta) {
+	const long double PIl = 3.141592653589793238462643383279502884L;
+	nring = (int)theta.size();
+	std::vector<char> used(nring, 0);
+	ring_n.clear(); ring_s.clear(); cth.clear(); sth.clear(); sh2.clear(); ch2.clear();
+	// order pairs by colatitude of the northern member (pole first)
+	std::vector<int> order(nring);
+	for (int i = 0; i < nring; i++) order[i] = i;
+	std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+		long double a = std::min(theta[x], PIl - theta[x]), b = std::min(theta[y], PIl - theta[y]); return a < b; });
+	// fast path for symmetric ascending grids: partner of i is nring-1-i
+	for (int oi = 0; oi < nring; oi++) {
+		int i = order[oi];
+		if (used[i]) continue;
+		used[i] = 1;
+		int partner = -1;
+		int cand = nring-1-i;
+		const long double tol = 1e-12L;
+		if (cand != i && cand >= 0 && !used[cand] && fabsl(theta[cand] - (PIl - theta[i])) < tol) partner = cand;
+		else {
+			for (int j = 0; j < nring; j++) if (!used[j] && j != i && fabsl(theta[j] - (PIl - theta[i])) < tol) { partner = j; break; }
+		}
+		int in_ = i, is_ = partner;
+		if (partner >= 0) { used[partner] = 1; if (theta[partner] < theta[i]) { in_ = partner; is_ = i; } }
+		long double th = theta[in_];
+		bool flipped = false;
+		if (partner < 0 && th > PIl/2) { th = PIl - th; flipped = true; }   // lone southern ring: treat via its mirror
+		if (flipped) { ring_n.push_back(-1); ring_s.push_back(in_); }
+		else { ring_n.push_back(in_); ring_s.push_back(is_); }
+		cth.push_back((double)cosl(th)); sth.push_back((double)sinl(th));
+		sh2.push_back((double)sinl(th/2)); ch2.push_back((double)cosl(th/2));
+	}
+	npairs = (int)ring_n.size();
+}
+void RingSet::upload_all() {
+	d_ring_n = upload(ring_n); d_ring_s = upload(ring_s); d_cth = upload(cth); d_sth = upload(sth);
+	d_sh2 = upload(sh2); d_ch2 = upload(ch2);
+}
+
+void LegTables::build(int lmax_, int mmax_, int spin_) {
+	lmax = lmax_; mmax = mmax_; spin = spin_;
+	row.assign(mmax+2, 0);
+	for (int m = 0; m <= mmax; m++) {
+		long n = spin == 0 ? (lmax - m)/2 + 1 : std::max(0, lmax - std::max(m, spin) + 1);
+		row[m+1] = row[m] + n;
+	}
+	nrows = row[mmax+1];
+	std::vector<double2> coef(std::max<long>(nrows, 1)); std::vector<double> alpha(std::max<long>(nrows, 1));
+	typedef long double LDb;
+	const LDb PIl = 3.141592653589793238462643383279502884L;
+	if (spin == 0) {
+		LDb cm = 1/sqrtl(4*PIl);
+		for (int m = 0; m <= mmax; m++) {
+			if (m > 0) cm = -cm*sqrtl((LDb)(2*m+1)/(LDb)(2*m));
+			auto eps = [&](int l) -> LDb { if (l <= m) return 0; LDb L = l, M = m; return sqrtl((L*L-M*M)/(4*L*L-1)); };
+			const int nk = (lmax - m)/2 + 1;
+			LDb a_prev = 0, a_cur = sqrtl((LDb)(2*m+3))*cm;   // alpha_{k-1}, alpha_k
+			for (int k = 0; k < nk; k++) {
+				const int lp = m + 2*k + 1;
+				const LDb e2 = eps(lp+1)*eps(lp+1) + eps(lp)*eps(lp), f = eps(lp)*eps(lp-1), d = eps(lp+1)*eps(lp+2);
+				const LDb a_next = (k == 0) ? a_cur/d : -f*a_prev/d;
+				const LDb ak = a_cur/(a_next*d);
+				coef[row[m]+k] = make_double2((double)ak, (double)(-ak*e2));
+				alpha[row[m]+k] = (double)a_cur;
+				a_prev = a_cur; a_cur = a_next;
+			}
+		}
+	} else {
+		const int s = spin;
+		// m < s: h(m) = (2s+1)(2s)!/((s+m)!(s-m)!) ; m >= s: c'_m^2 = g(m)/(4 pi 4^m)
+		std::vector<LDb> nrm(mmax+1);
+		{
+			LDb h = 2*s+1; for (int i = 1; i <= s; i++) h = h*(LDb)(s+i)/(LDb)i;
+			for (int m = 0; m < std::min(s, mmax+1); m++) { if (m > 0) h = h*(LDb)(s-m+1)/(LDb)(s+m); nrm[m] = sqrtl(h/(4*PIl)); }
+			if (s <= mmax) {
+				LDb c2 = (LDb)(2*s+1)/(4*PIl*powl(4.0L, s));
+				nrm[s] = sqrtl(c2);
+				for (int m = s+1; m <= mmax; m++) { c2 = c2*(LDb)(2*m+1)*(LDb)(2*m)/(4*(LDb)(m+s)*(LDb)(m-s)); nrm[m] = sqrtl(c2); }
+			}
+		}
+		for (int m = 0; m <= mmax; m++) {
+			const int l0 = std::max(m, s);
+			const int nl = lmax - l0 + 1;
+			if (nl <= 0) continue;
+			auto Sf = [&](int l) -> LDb { LDb L = l, M = m, Sp = s; return sqrtl((L*L-M*M)*(L*L-Sp*Sp)); };
+			LDb b_prev = 0, b_cur = ((m & 1) ? -1 : 1)*nrm[m];
+			for (int l = l0; l <= lmax; l++) {
+				const LDb L = l;
+				const LDb q = sqrtl((2*L+3)/(2*L+1))*(2*L+1);
+				const LDb A = q*(L+1)/Sf(l+1);
+				const LDb B = q*(LDb)m*(LDb)s/(L*Sf(l+1));
+				const LDb C = (l > l0) ? sqrtl((2*L+3)/(2*L-1))*(L+1)*Sf(l)/(L*Sf(l+1)) : 0;
+				const LDb b_next = (l == l0) ? A*b_cur : C*b_prev;
+				coef[row[m]+(l-l0)] = make_double2((double)(A*b_cur/b_next), (double)(B*b_cur/b_next));
+				alpha[row[m]+(l-l0)] = (double)b_cur;
+				b_prev = b_cur; b_cur = b_next;
+			}
+		}
+	}
+	d_row = upload(row); d_coef = upload(coef); d_alpha = upload(alpha);
+}
+
+int leg_waves_per_m(const RingSet& rs) { return 0; }
+
+static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, double2* leg, int K) {
+	LegK a; memset(&a, 0, sizeof(a));
+	a.lmax = tb.lmax; a.mmax = tb.mmax; a.spin = tb.spin; a.nm = tb.mmax+1; a.npairs = rs.npairs; a.nring = rs.nring;
+	a.nwave = (rs.npairs + 64*K - 1)/(64*K);
+	a.nrows = tb.nrows; a.row = tb.d_row.as<long>(); a.coef = tb.d_coef.as<double2>(); a.alpha = tb.d_alpha.as<double>();
+	a.ring_n = rs.d_ring_n.as<int>(); a.ring_s = rs.d_ring_s.as<int>(); a.cth = rs.d_cth.as<double>(); a.sth = rs.d_sth.as<double>();
+	a.sh2 = rs.d_sh2.as<double>(); a.ch2 = rs.d_ch2.as<double>();
+	a.almt = wk.almt.as<double>(); a.part = wk.part.as<double>(); a.mom = wk.mom.as<double>();
+	a.leg = leg;
+	a.ofs = std::max(100.0, 0.01*tb.lmax);
+	return a;
+}
+
+static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dtype, long cstride, const uint64_t* d_mstart, long lstride, int deriv1) {
+	AlmK k; memset(&k, 0, sizeof(k));
+	k.lmax = tb.lmax; k.mmax = tb.mmax; k.spin = tb.spin; k.deriv1 = deriv1; k.dtype = dtype;
+	k.nrows = tb.nrows; k.cstride = cstride; k.lstride = lstride; k.row = tb.d_row.as<long>(); k.alpha = tb.d_alpha.as<double>();
+	k.mstart = d_mstart; k.alm = const_cast<void*>(alm); k.almt = wk.almt.as<double>(); k.mom = wk.mom.as<double>();
+	return k;
+}
+
+void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
+                   const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
+                   double2* leg, int deriv1)
+{
+	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
+	wk.almt.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
+	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
+	const int nm = tb.mmax+1;
+	if (tb.spin == 0) {
+		const int nkmax = tb.lmax/2 + 1;
+		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
+		LegK a = make_legk(rs, tb, wk, leg, LEG_K0);
+		hipLaunchKernelGGL(leg_syn_s0<LEG_K0>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+	} else {
+		const int nlmax = tb.lmax + 1;
+		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
+		LegK a = make_legk(rs, tb, wk, leg, LEG_KS);
+		hipLaunchKernelGGL(leg_syn_spin<LEG_KS>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+	}
+	PXS_HIP(hipGetLastError());
+}
+
+void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
+                  const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
+                  int deriv1)
+{
+	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
+	const int K = tb.spin == 0 ? LEG_K0 : LEG_KS;
+	const int nm = tb.mmax+1;
+	LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
+	const long n4 = 4*std::max<long>(tb.nrows, 1);
+	wk.part.ensure(sizeof(double)*n4*a.nwave);
+	wk.mom.ensure(sizeof(double)*n4);
+	a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
+	PXS_HIP(hipMemsetAsync(wk.part.p, 0, sizeof(double)*n4*a.nwave, st));
+	const size_t sh = sizeof(double)*16*LEG_RED_STRIDE;
+	if (tb.spin == 0) hipLaunchKernelGGL(leg_ana_s0<LEG_K0>, dim3(a.nwave, nm), dim3(64), sh, st, a);
+	else              hipLaunchKernelGGL(leg_ana_spin<LEG_KS>, dim3(a.nwave, nm), dim3(64), sh, st, a);
+	hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((n4+255)/256)), dim3(256), 0, st, (const double*)wk.part.p, (double*)wk.mom.p, n4, a.nwave);
+	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
+	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm), dim3(256), 0, st, ak);
+	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm), dim3(256), 0, st, ak);
+	PXS_HIP(hipGetLastError());
+}
+
+} // namespace pxs

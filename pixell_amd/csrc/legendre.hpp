@@ -1,0 +1,44 @@
+// Legendre stage of the SHT on gfx950 (alm <-> leg[m][ring]); see legendre.hip.
+#pragma once
+#include "common.hpp"
+
+namespace pxs {
+
+// Ring set the Legendre kernels iterate: north/south mirror pairs share one recurrence.
+struct RingSet {
+	int nring = 0;               // rings in leg[m][ring]
+	int npairs = 0;
+	std::vector<int> ring_n, ring_s;        // leg ring index of the northern / southern member (-1: none)
+	std::vector<double> cth, sth, sh2, ch2; // of the northern member: cos, sin, sin(theta/2), cos(theta/2)
+	DevBuf d_ring_n, d_ring_s, d_cth, d_sth, d_sh2, d_ch2;
+	void build(const std::vector<long double>& theta);   // pairs rings theta <-> pi-theta
+	void upload_all();
+};
+
+// Per-(lmax,mmax,spin) recurrence tables (host long double -> device double)
+struct LegTables {
+	int lmax = 0, mmax = 0, spin = 0;
+	std::vector<long> row;      // row[m]: first row of m; rows = k-steps (spin 0: two l per row) or l-steps (spin s)
+	long nrows = 0;
+	DevBuf d_row, d_coef, d_alpha;   // coef[row] = (a,b); alpha[row] = scaling folded into the alm
+	void build(int lmax, int mmax, int spin);
+};
+
+struct LegWork {     // scratch owned by the SHT plan
+	DevBuf almt;     // [nrows][4] doubles
+	DevBuf part;     // [nwave][nrows][4] doubles (analysis partial moments)
+	DevBuf mom;      // [nrows][4] reduced moments
+};
+
+int leg_waves_per_m(const RingSet& rs);
+
+// alm[(c) * alm_cstride + mstart[m] + l*lstride] -> leg[(c*nm + m)*nring + ring]  (c = 0 or 0,1)
+void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
+                   const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
+                   double2* leg, int deriv1);
+// transpose of leg_synthesis (no weights)
+void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
+                  const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
+                  int deriv1);
+
+} // namespace pxs

@@ -1,0 +1,399 @@
+// SHT plans and pipelines (C-ABI pxs_* of include/pxsht.h) for gfx950.
+//
+//   synthesis        alm --Legendre--> leg[m][ring] --transpose*phase--> h[ring][m] --c2r ring FFT--> map
+//   adjoint synth.   map --r2c ring FFT (pruned to m<=mmax)--> h[ring][m] --transpose*phase--> leg --Legendre^T--> alm
+//   analysis_2d      map --ring FFT--> leg on the map's rings --theta resampling--> leg on a minimal
+//                    Clenshaw-Curtis grid (lmax+2.. rings) incl. exact |sin| quadrature --Legendre^T--> alm
+//   adj. analysis    the exact transpose of the above
+//
+// The theta resampling integrates the trigonometric interpolant exactly: mirror-extend each m
+// column to the full circle with parity (-1)^(m+s), FFT, resize the spectrum onto a fine grid
+// of M > N + 2 lmax points, multiply by the truncated Fourier series of |sin theta| there, FFT
+// back, keep |k| <= lmax and evaluate on the CC grid.  All index remaps are fused into the FFT
+// load/store functors (fft.hpp).
+// flip_y / flip_x (curvedsky.map2buffer, curvedsky.py:1384-1411) are negative strides here.
+#include "../../include/pxsht.h"
+#include "fft.hpp"
+#include "legendre.hpp"
+#include <map>
+#include <memory>
+#include <cmath>
+#include <algorithm>
+
+namespace pxs {
+
+FftContext& fft_context(int device);
+const char* get_last_error();
+
+typedef long double LDb;
+static const LDb PIl = 3.141592653589793238462643383279502884L;
+
+struct GridInfo { long N; int c; bool ok; };
+static GridInfo grid_info(const std::string& g, int n) {
+	if (g == "CC")     return {2L*n-2, 0, true};
+	if (g == "F1")     return {2L*n,   1, true};
+	if (g == "MW")     return {2L*n-1, 1, true};
+	if (g == "MWflip") return {2L*n-1, 0, true};
+	return {0, 0, false};
+}
+static int grid_maxlmax(const std::string& g, int n) {
+	if (g == "CC") return n-2;
+	if (g == "DH") return (n-2)/2;
+	if (g == "F2") return (n-1)/2;
+	return n-1;
+}
+static std::vector<LDb> grid_theta(const std::string& g, int n) {
+	GridInfo gi = grid_info(g, n);
+	std::vector<LDb> th(n);
+	for (int j = 0; j < n; j++) th[j] = (LDb)gi.c*PIl/gi.N + 2*PIl*j/gi.N;
+	return th;
+}
+// Fourier coefficients of |sin|: s_q = -(2/pi)/(q^2-1) (q even), 0 (q odd)
+static double abs_sin_coef(long q) { if (q & 1) return 0.0; LDb Q = q; return (double)(-(2/PIl)/(Q*Q-1)); }
+
+// ---- glue kernels ----------------------------------------------------------------------
+// out[b][c][r] = in[b][r][c] * tab[c] (optionally conj(tab)); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_mul(const double2* __restrict__ in, double2* __restrict__ out,
+		int nr, int nc, long in_bstride, long out_bstride, const double2* __restrict__ tab, int conj_tab, double scale)
+{
+	PXS_SHARED(double2, tile);   // [32][33]
+	const int b = blockIdx.z;
+	const int r0 = blockIdx.y*32, c0 = blockIdx.x*32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+	in += (long)b*in_bstride; out += (long)b*out_bstride;
+	for (int j = ty; j < 32; j += 8) {
+		const int r = r0 + j, c = c0 + tx;
+		if (r < nr && c < nc) tile[j*33 + tx] = in[(long)r*nc + c];
+	}
+	__syncthreads();
+	for (int j = ty; j < 32; j += 8) {
+		const int c = c0 + j, r = r0 + tx;
+		if (r < nr && c < nc) {
+			double2 v = tile[tx*33 + j];
+			if (tab) { double2 t = tab[c]; if (conj_tab) t.y = -t.y; v = make_double2(v.x*t.x - v.y*t.y, v.x*t.y + v.y*t.x); }
+			v.x *= scale; v.y *= scale;
+			out[(long)c*nr + r] = v;
+		}
+	}
+}
+// out[b][r][c] = in[b][c][r] * tab[c]: same kernel with roles swapped is enough (tab indexed by the OUTPUT column)
+__global__ __launch_bounds__(256) void transpose_mul_outcol(const double2* __restrict__ in, double2* __restrict__ out,
+		int nr, int nc, long in_bstride, long out_bstride, const double2* __restrict__ tab, int conj_tab, double scale)
+{
+	// in[b][c][r] (nc rows of length nr) -> out[b][r][c]
+	PXS_SHARED(double2, tile);
+	const int b = blockIdx.z;
+	const int r0 = blockIdx.y*32, c0 = blockIdx.x*32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	in += (long)b*in_bstride; out += (long)b*out_bstride;
+	for (int j = ty; j < 32; j += 8) {
+		const int c = c0 + j, r = r0 + tx;
+		if (r < nr && c < nc) tile[j*33 + tx] = in[(long)c*nr + r];
+	}
+	__syncthreads();
+	for (int j = ty; j < 32; j += 8) {
+		const int r = r0 + j, c = c0 + tx;
+		if (r < nr && c < nc) {
+			double2 v = tile[tx*33 + j];
+			if (tab) { double2 t = tab[c]; if (conj_tab) t.y = -t.y; v = make_double2(v.x*t.x - v.y*t.y, v.x*t.y + v.y*t.x); }
+			v.x *= scale; v.y *= scale;
+			out[(long)r*nc + c] = v;
+		}
+	}
+}
+
+} // namespace pxs
+
+using namespace pxs;
+
+struct pxs_plan {
+	int device = 0;
+	bool is_grid = false;
+	std::string geometry;
+	int nring = 0, nphi = 0;
+	double phi0 = 0;
+	long ring_off0 = 0, ring_stride = 0, pix_stride = 1;   // user-map offset of (ring r, pixel x) = ring_off0 + r*ring_stride + x*pix_stride
+	int lmax = 0, mmax = 0; long lstride = 1;
+	DevBuf d_mstart;
+	RingSet rs_map, rs_cc;
+	std::map<int, std::unique_ptr<LegTables>> tables;
+	LegWork wk;
+	DevBuf leg, leg2, hbuf, phase;
+	// analysis resampling (grid plans)
+	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
+	DevBuf ph_shift, sigma, wcc, b1, b2;
+	FftContext* fc = nullptr;
+
+	LegTables& table(int spin) {
+		auto& p = tables[spin];
+		if (!p) { p.reset(new LegTables()); p->build(lmax, mmax, spin); }
+		return *p;
+	}
+};
+
+namespace {
+
+void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device) {
+	PXS_REQUIRE(lmax >= 0 && mmax >= 0 && mmax <= lmax, "need 0 <= mmax <= lmax");
+	PXS_REQUIRE(mstart != nullptr, "mstart is required");
+	PXS_REQUIRE(2L*mmax < p->nphi, "mmax >= nphi/2 would alias on the rings (not supported)");
+	PXS_HIP(hipSetDevice(device));
+	p->device = device; p->lmax = lmax; p->mmax = mmax; p->lstride = lstride;
+	std::vector<uint64_t> ms(mstart, mstart+mmax+1);
+	p->d_mstart = upload(ms);
+	p->fc = &fft_context(device);
+	std::string why;
+	if (!FftContext::supported(p->nphi, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
+	// e^{-i m phi0}
+	std::vector<double2> ph(mmax+1);
+	for (int m = 0; m <= mmax; m++) { LDb a = (LDb)m*(LDb)p->phi0; ph[m] = make_double2((double)cosl(a), (double)(-sinl(a))); }
+	p->phase = upload(ph);
+}
+
+void setup_resampling(pxs_plan* p) {
+	GridInfo gi = grid_info(p->geometry, p->nring);
+	p->N = gi.N; p->mir_c = gi.c;
+	const int lmax = p->lmax;
+	p->Ncc = FftContext::good_size(std::max<long>(2L*lmax + 2, 4));
+	if (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
+	while (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
+	p->ncc = (int)(p->Ncc/2 + 1);
+	p->M = FftContext::good_size(p->N + 2L*lmax + 2);
+	std::string why;
+	if (!FftContext::supported(p->N, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
+	// CC ring set
+	std::vector<LDb> th(p->ncc);
+	for (int j = 0; j < p->ncc; j++) th[j] = 2*PIl*j/p->Ncc;
+	th[p->ncc-1] = PIl;
+	p->rs_cc.build(th); p->rs_cc.upload_all();
+	// shift phases e^{-i k theta0}, k = 0..N/2
+	const LDb th0 = (LDb)gi.c*PIl/gi.N;
+	std::vector<double2> ps(p->N/2 + 1);
+	for (long k = 0; k <= p->N/2; k++) { LDb a = (LDb)k*th0; ps[k] = make_double2((double)cosl(a), (double)(-sinl(a))); }
+	p->ph_shift = upload(ps);
+	// sigma_i = sum_{|q|<=Ks} s_q e^{i q theta_i} on the M grid, via one device FFT
+	const long Ks = lmax + p->N/2;
+	PXS_REQUIRE(2*Ks < p->M, "internal: fine grid too small");
+	std::vector<double2> spec(p->M, make_double2(0, 0));
+	for (long q = 0; q <= Ks; q++) { double s = abs_sin_coef(q); spec[q].x = s; if (q > 0) spec[p->M - q].x = s; }
+	DevBuf dspec = upload(spec);
+	p->sigma.alloc(sizeof(double2)*p->M);
+	FftDims d; d.n_i = 1; d.is_e = 1; d.os_e = 1;
+	FftLoad ld; ld.ptr = dspec.p; FftStore st; st.ptr = p->sigma.p;
+	p->fc->exec(nullptr, p->M, false, d, ld, st);
+	PXS_HIP(hipStreamSynchronize(nullptr));
+	// CC weights incl. all FFT normalisations: (pi/nphi)(2pi/Ncc) eps_j / (N M)
+	std::vector<double2> w(p->ncc);
+	for (int j = 0; j < p->ncc; j++) {
+		LDb e = (j == 0 || j == p->ncc-1) ? 1 : 2;
+		w[j] = make_double2((double)((PIl/p->nphi)*(2*PIl/p->Ncc)*e/((LDb)p->N*(LDb)p->M)), 0.0);
+	}
+	p->wcc = upload(w);
+}
+
+int ncomp_of(int spin, int mode, bool alm_side) {
+	if (mode == PXS_MODE_DERIV1) return alm_side ? 1 : 2;
+	return spin == 0 ? 1 : 2;
+}
+
+// ring FFT: user map -> hbuf[c][ring][m] -> leg[c][m][ring] * e^{-i m phi0} * scale
+void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale) {
+	const int nm = p->mmax+1, nr = p->nring;
+	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
+	FftDims d; d.n_i = nr; d.is_i = p->ring_stride; d.os_i = nm; d.n_o1 = nc; d.is_o1 = map_cstride; d.os_o1 = (long)nr*nm;
+	d.is_e = p->pix_stride; d.os_e = 1;
+	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
+	FftLoad ld; ld.ptr = (const char*)map + esz(map_dtype)*p->ring_off0; ld.dtype = map_dtype;
+	FftStore sf; sf.ptr = p->hbuf.p; sf.ne = nm;
+	p->fc->exec(st, p->nphi, true, d, ld, sf);
+	dim3 grid((nm+31)/32, (nr+31)/32, nc);
+	hipLaunchKernelGGL(transpose_mul, grid, dim3(256), sizeof(double2)*32*33, st, (const double2*)p->hbuf.p, leg, nr, nm,
+		(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 0, scale);
+	PXS_HIP(hipGetLastError());
+}
+
+// leg[c][m][ring] * e^{+i m phi0} -> hbuf[c][ring][m] -> c2r ring FFT -> user map
+void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map_dtype, long map_cstride, int nc) {
+	const int nm = p->mmax+1, nr = p->nring;
+	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
+	dim3 grid((nm+31)/32, (nr+31)/32, nc);
+	hipLaunchKernelGGL(transpose_mul_outcol, grid, dim3(256), sizeof(double2)*32*33, st, leg, (double2*)p->hbuf.p, nr, nm,
+		(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 1, 1.0);
+	FftDims d; d.n_i = nr; d.is_i = nm; d.os_i = p->ring_stride; d.n_o1 = nc; d.is_o1 = (long)nr*nm; d.os_o1 = map_cstride;
+	d.is_e = 1; d.os_e = p->pix_stride;
+	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
+	FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM; ld.ne = nm;
+	FftStore sf; sf.ptr = (char*)map + esz(map_dtype)*p->ring_off0; sf.dtype = map_dtype;
+	p->fc->exec(st, p->nphi, false, d, ld, sf);
+	PXS_HIP(hipGetLastError());
+}
+
+// leg on the map's rings [c][m][nring] -> weighted leg on the CC grid [c][m][ncc]
+void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2* leg_cc, int nc, int spin) {
+	const int nm = p->mmax+1, nr = p->nring;
+	p->b1.ensure(sizeof(double2)*(size_t)nm*p->N);
+	p->b2.ensure(sizeof(double2)*(size_t)nm*p->M);
+	for (int c = 0; c < nc; c++) {
+		{	// (a) mirror-extend, forward FFT_N
+			FftDims d; d.n_i = nm; d.is_i = nr; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = leg_in + (size_t)c*nm*nr; ld.mode = LD_MIRROR; ld.ne = nr; ld.mir_c = p->mir_c; ld.par0 = spin & 1;
+			FftStore sf; sf.ptr = p->b1.p;
+			p->fc->exec(st, p->N, true, d, ld, sf);
+		}
+		{	// (b) shift to theta0 = 0, pad to M, backward FFT_M, multiply by the |sin| series
+			FftDims d; d.n_i = nm; d.is_i = p->N; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->N; ld.nyq_half = 1; ld.mul = p->ph_shift.as<double2>();
+			FftStore sf; sf.ptr = p->b2.p; sf.mul = p->sigma.as<double2>();
+			p->fc->exec(st, p->M, false, d, ld, sf);
+		}
+		{	// (c) forward FFT_M in place; only |k| <= lmax are needed
+			FftDims d; d.n_i = nm; d.is_i = p->M; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b2.p;
+			FftStore sf; sf.ptr = p->b2.p; sf.two_sided_k = p->lmax;
+			p->fc->exec(st, p->M, true, d, ld, sf);
+		}
+		{	// (d) truncate to |k| <= lmax, backward FFT_Ncc, keep rings 0..ncc-1, apply weights
+			FftDims d; d.n_i = nm; d.is_i = p->M; d.os_i = p->ncc; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b2.p; ld.mode = LD_SPEC; ld.ne = p->M; ld.kmax = p->lmax;
+			FftStore sf; sf.ptr = leg_cc + (size_t)c*nm*p->ncc; sf.ne = p->ncc; sf.mul = p->wcc.as<double2>();
+			p->fc->exec(st, p->Ncc, false, d, ld, sf);
+		}
+	}
+}
+
+} // namespace
+
+#define PXS_TRY try {
+#define PXS_CATCH } catch (const pxs::Error& e) { pxs::set_last_error(e.what()); return e.code; } \
+	catch (const std::exception& e) { pxs::set_last_error(e.what()); return pxs::PXS_ERR_ARG; } return 0;
+
+extern "C" {
+
+int pxs_grid_maxlmax(const char* geometry, int ntheta) { return grid_maxlmax(geometry ? geometry : "", ntheta); }
+
+int pxs_gridweights(const char* geometry, int ntheta, double* out) {
+	PXS_TRY
+	PXS_REQUIRE(geometry && out && ntheta > 0, "pxs_gridweights: bad arguments");
+	GridInfo gi = grid_info(geometry, ntheta);
+	if (!gi.ok) throw Error(PXS_ERR_UNSUPPORTED, std::string("gridweights: unsupported geometry '") + geometry + "' (CC, F1, MW, MWflip)");
+	const long N = gi.N; const int n = ntheta;
+	const LDb th0 = (LDb)gi.c*PIl/N;
+	std::vector<LDb> v(N);
+	const long K = (N-1)/2;
+	for (long j = 0; j < N; j++) {
+		LDb th = th0 + 2*PIl*j/N, s = (LDb)abs_sin_coef(0);
+		for (long k = 2; k <= K; k += 2) s += 2*(-(2/PIl)/((LDb)k*k-1))*cosl(k*th);
+		if (N % 2 == 0 && ((N/2) % 2) == 0) s += (-(2/PIl)/((LDb)(N/2)*(N/2)-1))*cosl((N/2)*(th-th0))*cosl((N/2)*th0);
+		v[j] = s*PIl/N;
+	}
+	for (int j = 0; j < n; j++) out[j] = 0;
+	for (long jp = 0; jp < N; jp++) { long r = jp < n ? jp : ((-jp - gi.c) % N + N) % N; out[r] += (double)(v[jp]*2*PIl); }
+	PXS_CATCH
+}
+
+int pxs_plan_grid2d(pxs_plan** plan, const char* geometry, int ntheta, int nphi, double phi0,
+                    int flip_y, int flip_x, int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device)
+{
+	PXS_TRY
+	PXS_REQUIRE(plan && geometry && ntheta > 0 && nphi > 0, "pxs_plan_grid2d: bad arguments");
+	GridInfo gi = grid_info(geometry, ntheta);
+	if (!gi.ok) throw Error(PXS_ERR_UNSUPPORTED, std::string("unsupported 2d geometry '") + geometry + "' (supported: CC, F1, MW, MWflip)");
+	std::unique_ptr<pxs_plan> p(new pxs_plan());
+	p->is_grid = true; p->geometry = geometry; p->nring = ntheta; p->nphi = nphi; p->phi0 = phi0;
+	p->ring_stride = flip_y ? -(long)nphi : (long)nphi;
+	p->pix_stride = flip_x ? -1 : 1;
+	p->ring_off0 = (flip_y ? (long)(ntheta-1)*nphi : 0) + (flip_x ? (long)nphi-1 : 0);
+	plan_common(p.get(), lmax, mmax, mstart, lstride, device);
+	p->rs_map.build(grid_theta(geometry, ntheta)); p->rs_map.upload_all();
+	if (lmax <= grid_maxlmax(geometry, ntheta)) setup_resampling(p.get());
+	*plan = p.release();
+	PXS_CATCH
+}
+
+int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64_t* nphi,
+                   const double* phi0, const uint64_t* ringstart, int64_t pixstride,
+                   int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device)
+{
+	PXS_TRY
+	PXS_REQUIRE(plan && nring > 0 && theta && nphi && phi0 && ringstart, "pxs_plan_rings: bad arguments");
+	std::unique_ptr<pxs_plan> p(new pxs_plan());
+	p->is_grid = false; p->nring = nring; p->nphi = (int)nphi[0]; p->phi0 = phi0[0];
+	for (int r = 0; r < nring; r++) {
+		if ((long)nphi[r] != p->nphi) throw Error(PXS_ERR_UNSUPPORTED, "rings with varying nphi (e.g. healpix) are not supported yet");
+		if (std::fabs(phi0[r] - phi0[0]) > 1e-13) throw Error(PXS_ERR_UNSUPPORTED, "rings with varying phi0 are not supported yet");
+	}
+	p->ring_off0 = (long)ringstart[0];
+	p->ring_stride = nring > 1 ? (long)ringstart[1] - (long)ringstart[0] : (long)nphi[0];
+	for (int r = 0; r < nring; r++)
+		if ((long)ringstart[r] != p->ring_off0 + r*p->ring_stride) throw Error(PXS_ERR_UNSUPPORTED, "ringstart must be an arithmetic progression");
+	p->pix_stride = pixstride;
+	plan_common(p.get(), lmax, mmax, mstart, lstride, device);
+	std::vector<LDb> th(nring);
+	for (int r = 0; r < nring; r++) th[r] = theta[r];
+	p->rs_map.build(th); p->rs_map.upload_all();
+	*plan = p.release();
+	PXS_CATCH
+}
+
+void pxs_plan_destroy(pxs_plan* plan) { delete plan; }
+
+int pxs_plan_info(const pxs_plan* p, int* nsyn, int* nana, int64_t* scratch) {
+	if (!p) return PXS_ERR_ARG;
+	if (nsyn) *nsyn = p->nring;
+	if (nana) *nana = p->ncc > 0 ? p->ncc : p->nring;
+	if (scratch) *scratch = (int64_t)(p->leg.bytes + p->leg2.bytes + p->hbuf.bytes + p->b1.bytes + p->b2.bytes + p->wk.almt.bytes + p->wk.part.bytes + p->wk.mom.bytes);
+	return 0;
+}
+
+int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
+                  void* alm, int alm_dtype, int64_t alm_cstride,
+                  void* map, int map_dtype, int64_t map_cstride, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(p && alm && map, "pxs_synthesis: null argument");
+	PXS_REQUIRE(spin >= 0 && spin <= p->lmax + 1, "pxs_synthesis: bad spin");
+	PXS_REQUIRE(mode == PXS_MODE_STANDARD || (mode == PXS_MODE_DERIV1 && spin == 1), "DERIV1 needs spin 1");
+	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
+	PXS_HIP(hipSetDevice(p->device));
+	hipStream_t st = (hipStream_t)stream;
+	const int ncm = ncomp_of(spin, mode, false);
+	const int nm = p->mmax+1;
+	LegTables& tb = p->table(spin);
+	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*p->nring);
+	if (!adjoint) {
+		leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1);
+		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm);
+	} else {
+		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0);
+		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1);
+	}
+	PXS_CATCH
+}
+
+int pxs_analysis(pxs_plan* p, int spin, int adjoint,
+                 void* map, int map_dtype, int64_t map_cstride,
+                 void* alm, int alm_dtype, int64_t alm_cstride, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(p && alm && map, "pxs_analysis: null argument");
+	PXS_REQUIRE(p->is_grid, "pxs_analysis needs a grid2d plan");
+	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
+	if (p->lmax > grid_maxlmax(p->geometry, p->nring)) throw Error(PXS_ERR_ARG, "too few rings for analysis up to requested lmax");
+	PXS_HIP(hipSetDevice(p->device));
+	hipStream_t st = (hipStream_t)stream;
+	const int nc = spin == 0 ? 1 : 2;
+	const int nm = p->mmax+1;
+	LegTables& tb = p->table(spin);
+	p->leg.ensure(sizeof(double2)*(size_t)nc*nm*p->nring);
+	p->leg2.ensure(sizeof(double2)*(size_t)nc*nm*p->ncc);
+	if (!adjoint) {
+		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0);
+		resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
+		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0);
+	} else {
+		throw Error(PXS_ERR_UNSUPPORTED, "adjoint_analysis_2d: not implemented yet");
+	}
+	PXS_CATCH
+}
+
+} // extern "C"

@@ -1,0 +1,201 @@
+"""`ducc0.sht.experimental`-shaped entry points backed by the HIP kernels (include/pxsht.h).
+
+Same keyword interface as the calls pixell/curvedsky.py makes (curvedsky.py:907-924, 936-960,
+1032-1046, 1068-1084, 501): arrays may be numpy (staged through device memory) or torch CUDA
+tensors (used in place, no copies).  Output arrays are mutated in place and returned, as ducc does.
+Extra keyword `flip=(flip_y, flip_x)` (ours): the map is given in its native pixel order and the
+flips of curvedsky.map2buffer/buffer2map (curvedsky.py:1384-1411) are folded into kernel
+addressing; phi0 is still that of the flipped map (analyse_geometry().phi0).
+"""
+import ctypes
+import numpy as np
+from . import _lib
+
+_DT = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.complex64): 2, np.dtype(np.complex128): 3}
+
+def _torch():
+	import torch
+	return torch
+
+def _is_tensor(x):
+	return type(x).__module__.startswith("torch")
+
+def _np_dtype(x):
+	if _is_tensor(x):
+		torch = _torch()
+		return np.dtype({torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64, torch.complex128: np.complex128}[x.dtype])
+	return np.dtype(x.dtype)
+
+def device_index():
+	if _lib.is_hostsim(): return 0
+	torch = _torch()
+	if not torch.cuda.is_available():
+		raise RuntimeError("pixell_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+	return torch.cuda.current_device()
+
+def current_stream():
+	if _lib.is_hostsim(): return None
+	return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+class _Buf:
+	"""device view of a numpy array or torch tensor (contiguous), with optional write-back"""
+	def __init__(self, arr, writeback=False):
+		self.arr = arr; self.writeback = writeback; self.tmp = None; self.keep = None
+		if _is_tensor(arr):
+			if not arr.is_cuda and not _lib.is_hostsim(): raise ValueError("torch tensors passed to pixell_amd must live on the GPU")
+			if not arr.is_contiguous():
+				if writeback: raise ValueError("output tensors must be contiguous")
+				arr = arr.contiguous()
+			self.keep = arr; self.ptr = arr.data_ptr()
+		else:
+			if _lib.is_hostsim():
+				if arr.flags.c_contiguous and arr.dtype.isnative: self.keep = arr
+				else: self.keep = np.ascontiguousarray(arr); self.tmp = self.keep
+				self.ptr = self.keep.ctypes.data
+			else:
+				torch = _torch()
+				self.tmp = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+				self.ptr = self.tmp.data_ptr()
+	def finish(self):
+		if not self.writeback or self.tmp is None: return
+		if _lib.is_hostsim(): self.arr[...] = self.tmp
+		else: self.arr[...] = self.tmp.cpu().numpy()
+
+class Plan:
+	"""RAII wrapper of pxs_plan"""
+	def __init__(self, handle): self.handle = handle
+	def __del__(self):
+		try:
+			if self.handle: _lib.load().pxs_plan_destroy(self.handle); self.handle = None
+		except Exception: pass
+	def info(self):
+		a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+		return dict(nring_syn=a.value, nring_ana=b.value, scratch_bytes=c.value)
+
+_plans = {}
+def clear_plans(): _plans.clear()
+
+def tri_mstart(lmax, mmax=None):
+	if mmax is None: mmax = lmax
+	m = np.arange(mmax+1, dtype=np.int64)
+	return (m*(2*lmax+1-m)//2).astype(np.uint64)
+
+def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1):
+	ms = np.ascontiguousarray(np.asarray(mstart)[:mmax+1], dtype=np.uint64)
+	key = ("g", geometry, int(ntheta), int(nphi), float(phi0), bool(flip[0]), bool(flip[1]), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index())
+	p = _plans.get(key)
+	if p is None:
+		h = ctypes.c_void_p()
+		_lib.check(_lib.load().pxs_plan_grid2d(ctypes.byref(h), geometry.encode(), int(ntheta), int(nphi), float(phi0),
+			int(bool(flip[0])), int(bool(flip[1])), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
+		p = _plans[key] = Plan(h)
+	return p
+
+def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
+	th = np.ascontiguousarray(theta, dtype=np.float64); nph = np.ascontiguousarray(nphi, dtype=np.uint64)
+	p0 = np.ascontiguousarray(phi0, dtype=np.float64); rs = np.ascontiguousarray(ringstart, dtype=np.uint64)
+	ms = np.ascontiguousarray(np.asarray(mstart)[:mmax+1], dtype=np.uint64)
+	key = ("r", th.tobytes(), nph.tobytes(), p0.tobytes(), rs.tobytes(), int(pixstride), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index())
+	p = _plans.get(key)
+	if p is None:
+		h = ctypes.c_void_p()
+		_lib.check(_lib.load().pxs_plan_rings(ctypes.byref(h), len(th), th.ctypes.data, nph.ctypes.data, p0.ctypes.data, rs.ctypes.data,
+			int(pixstride), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
+		p = _plans[key] = Plan(h)
+	return p
+
+def _ncomp(spin, mode):
+	if mode == "DERIV1": return 1, 2
+	return (1, 1) if spin == 0 else (2, 2)
+
+def _check_pair(alm, map, spin, mode, pixdims):
+	nca, ncm = _ncomp(spin, mode)
+	if mode not in ("STANDARD", "DERIV1"): raise ValueError("unknown mode '%s'" % str(mode))
+	if alm.ndim != 2 or alm.shape[0] != nca: raise ValueError("alm must have shape [%d,nelem] for spin %d mode %s" % (nca, spin, mode))
+	if map.ndim != 1+pixdims or map.shape[0] != ncm: raise ValueError("map must have %d components" % ncm)
+	ad, md = _np_dtype(alm), _np_dtype(map)
+	if ad not in (np.complex64, np.complex128) or md not in (np.float32, np.float64): raise TypeError("alm must be complex, map real")
+	return ad, md
+
+def _run_syn(plan, alm, map, spin, mode, adjoint):
+	ad, md = _np_dtype(alm), _np_dtype(map)
+	ab = _Buf(alm, writeback=bool(adjoint)); mb = _Buf(map, writeback=not adjoint)
+	acs = alm.shape[-1]; mcs = int(np.prod(map.shape[1:]))
+	_lib.check(_lib.load().pxs_synthesis(plan.handle, int(spin), 1 if mode == "DERIV1" else 0, int(bool(adjoint)),
+		ab.ptr, _DT[ad], acs, mb.ptr, _DT[md], mcs, current_stream()))
+	ab.finish(); mb.finish()
+
+def _run_ana(plan, map, alm, spin, adjoint):
+	ad, md = _np_dtype(alm), _np_dtype(map)
+	ab = _Buf(alm, writeback=not adjoint); mb = _Buf(map, writeback=bool(adjoint))
+	acs = alm.shape[-1]; mcs = int(np.prod(map.shape[1:]))
+	_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), mb.ptr, _DT[md], mcs, ab.ptr, _DT[ad], acs, current_stream()))
+	ab.finish(); mb.finish()
+
+def _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip):
+	_check_pair(alm, map, spin, mode, 2)
+	if mmax is None: mmax = lmax
+	if mstart is None: mstart = tri_mstart(lmax, mmax)
+	nt, nph = map.shape[-2:]
+	return grid_plan(geometry, nt, nph, phi0, flip, lmax, mmax, mstart, lstride)
+
+def synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False)):
+	"""ducc0.sht.experimental.synthesis_2d as called at curvedsky.py:907-924"""
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip)
+	_run_syn(plan, alm, map, spin, mode, False)
+	return map
+
+def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False)):
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip)
+	_run_syn(plan, alm, map, spin, mode, True)
+	return alm
+
+def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False)):
+	"""ducc0.sht.experimental.analysis_2d as called at curvedsky.py:1032-1046"""
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
+	_run_ana(plan, map, alm, spin, False)
+	return alm
+
+def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False)):
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
+	_run_ana(plan, map, alm, spin, True)
+	return map
+
+def _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode):
+	if mmax is None: mmax = lmax
+	if mstart is None: mstart = tri_mstart(lmax, mmax)
+	return ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride, pixstride), mmax, mstart
+
+def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, map=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD"):
+	"""ducc0.sht.experimental.synthesis as called at curvedsky.py:936-960 (map[nc, npix])"""
+	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
+	nca, ncm = _ncomp(spin, mode)
+	if map is None:
+		npix = int(np.max(np.asarray(ringstart).astype(np.int64)+(np.asarray(nphi).astype(np.int64)-1)*pixstride)+1)
+		rdt = np.float32 if _np_dtype(alm) == np.complex64 else np.float64
+		map = _torch().zeros((ncm, npix), dtype=getattr(_torch(), np.dtype(rdt).name), device=alm.device) if _is_tensor(alm) else np.zeros((ncm, npix), rdt)
+	_check_pair(alm, map, spin, mode, 1)
+	_run_syn(plan, alm, map, spin, mode, False)
+	return map
+
+def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, alm=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD"):
+	"""ducc0.sht.experimental.adjoint_synthesis as called at curvedsky.py:1068-1084"""
+	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
+	nca, ncm = _ncomp(spin, mode)
+	if alm is None:
+		nelem = int(np.max(np.asarray(mstart).astype(np.int64))+lmax*lstride+1)
+		cdt = np.complex64 if _np_dtype(map) == np.float32 else np.complex128
+		alm = _torch().zeros((nca, nelem), dtype=getattr(_torch(), np.dtype(cdt).name), device=map.device) if _is_tensor(map) else np.zeros((nca, nelem), cdt)
+	_check_pair(alm, map, spin, mode, 1)
+	_run_syn(plan, alm, map, spin, mode, True)
+	return alm
+
+def get_gridweights(geometry, ntheta):
+	"""ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855); sum = 4 pi"""
+	out = np.zeros(int(ntheta), np.float64)
+	_lib.check(_lib.load().pxs_gridweights(geometry.encode(), int(ntheta), out.ctypes.data))
+	return out
+
+def grid_maxlmax(geometry, ntheta):
+	return int(_lib.load().pxs_grid_maxlmax(geometry.encode(), int(ntheta)))
