@@ -24,8 +24,8 @@ libsharp conventions, which docs/usage.rst:401-402 of the reference asserts):
             map[0] +- i map[1] = sum_lm (+-s a_lm) (+-s Y_lm)   (Goldberg sYlm).
   DERIV1  : spin-1 transform of E = sqrt(l(l+1)) a_lm, B = 0  -> (d_theta f, d_phi f / sin theta).
   adjoint_synthesis  = exact transpose of synthesis (a_lm = sum_pix map Y*_lm, no weights).
-  analysis_2d        = exact integration of the trigonometric interpolant (in theta) of
-                       the ring-FFT of the map against Y*_lm: the left inverse of
+  analysis_2d        = exact integration over the full theta circle, against |sin theta| Y*_lm,
+                       of the trigonometric interpolant of the parity-extended ring-FFT of the map: the left inverse of
                        synthesis_2d for band-limited maps whenever the grid carries
                        enough rings (curvedsky.py:1349-1353 get_ducc_maxlmax).
   adjoint_analysis_2d= exact transpose of analysis_2d.
@@ -455,14 +455,18 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	N = grid_info(geometry, nt)["N"]
 	nq = (N//2 + lmax)//2 + 2
 	thq, wq = _gl(nq)
-	M = _interp_matrix(geometry, nt, thq)                           # [nq, N]
+	Ma = _interp_matrix(geometry, nt, thq)                          # [nq, N]  at theta_q
+	Mb = _interp_matrix(geometry, nt, 2*np.pi-thq)                  # at the mirror points 2pi - theta_q
 	ring, mirrored = _extension(geometry, nt, None)
 	par = ((np.arange(mmax+1)+spin) % 2)
 	sign = np.where(mirrored[:, None] & (par[None, :] == 1), -1.0, 1.0)   # [N, nm]
+	psgn = np.where(par == 1, -1.0, 1.0)
 	legq = np.zeros((nc, nq, mmax+1), np.complex128)
 	for c in range(nc):
 		ext = leg[c, ring, :]*sign
-		legq[c] = M @ ext
+		# the integral runs over the full circle against |sin|: only the (-1)^(m+s)-parity part of
+		# the interpolant survives (pole samples of the wrong parity are projected out)
+		legq[c] = 0.5*(Ma @ ext + (Mb @ ext)*psgn[None, :])
 	legq *= (wq*2*np.pi/nph)[None, :, None]
 	res = leg2alm(legq, spin, lmax, mmax, mstart, thq.astype(LD), alm.shape[-1], lstride)
 	alm[...] = res.astype(alm.dtype)
@@ -484,15 +488,17 @@ def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=Non
 	N = grid_info(geometry, nt)["N"]
 	nq = (N//2 + lmax)//2 + 2
 	thq, wq = _gl(nq)
-	M = _interp_matrix(geometry, nt, thq)
+	Ma = _interp_matrix(geometry, nt, thq)
+	Mb = _interp_matrix(geometry, nt, 2*np.pi-thq)
 	ring, mirrored = _extension(geometry, nt, None)
 	par = ((np.arange(mmax+1)+spin) % 2)
 	sign = np.where(mirrored[:, None] & (par[None, :] == 1), -1.0, 1.0)
+	psgn = np.where(par == 1, -1.0, 1.0)
 	legq = alm2leg(np.atleast_2d(alm), spin, lmax, mmax, mstart, thq.astype(LD), lstride)
 	legq = legq*(wq*2*np.pi/nph)[None, :, None]
 	leg = np.zeros((nc, nt, mmax+1), np.complex128)
 	for c in range(nc):
-		ext = (M.T @ legq[c])*sign
+		ext = 0.5*(Ma.T @ legq[c] + Mb.T @ (legq[c]*psgn[None, :]))*sign
 		np.add.at(leg[c], ring, ext)
 	res = leg2map(leg, nphi, p0, rs, nt*nph)
 	map[...] = res.reshape(map.shape).astype(map.dtype)

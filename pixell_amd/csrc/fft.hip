@@ -83,8 +83,12 @@ __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1,
 		if (m == 0) v.y = 0;
 		return cj ? cconj(v) : v; }
 	case LD_MIRROR: {
-		long src = e; bool neg = false;
-		if (e >= ld.ne) { src = N - e - ld.mir_c; if (src < 0) src += N; neg = ((i + a.i_base + ld.par0) & 1) != 0; }
+		long src = e;
+		const bool odd = ((i + a.i_base + ld.par0) & 1) != 0;
+		bool neg = false;
+		if (e >= ld.ne) { src = N - e - ld.mir_c; if (src < 0) src += N; neg = odd; }
+		// a sample that is its own mirror image (a pole ring) cannot carry odd parity: project it out
+		if (odd && (2*e + ld.mir_c) % N == 0) return make_double2(0, 0);
 		double2 v = read_elem(ld.ptr, ld.dtype, base + src*a.d.is_e);
 		if (ld.mul) v = cmul(v, ld.mul[src]);
 		return neg ? make_double2(-v.x, -v.y) : v; }

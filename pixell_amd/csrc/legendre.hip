@@ -32,10 +32,12 @@ static constexpr int    SC_STEP  = 800;
 static constexpr int    LEG_K0   = 4;    // ring pairs per lane, spin 0
 static constexpr int    LEG_KS   = 2;    // ring pairs per lane, spin s
 
+struct double4_t { double a, b, c, d; };
+
 struct LegK {
 	int lmax, mmax, spin, nm, npairs, nring, nwave;
 	long nrows;
-	const long* row; const double2* coef; const double* alpha;
+	const long* row; const double4_t* coef; const double* alpha;
 	const int* ring_n; const int* ring_s; const double* cth; const double* sth; const double* sh2; const double* ch2;
 	double* almt; double* part; double* mom;
 	double2* leg;
@@ -169,6 +171,15 @@ __global__ __launch_bounds__(256) void reduce_partials(const double* part, doubl
 	mom[i] = s;
 }
 
+// a slot (64 consecutive ring pairs of a wave) is 'polar' when all its rings have cos^2 > 1/2: it then runs the recurrences in the
+// variable -sin^2(theta) (resp. -2 sin^2(theta/2)), which keeps full relative precision near the poles
+__device__ __forceinline__ bool leg_slot_polar(const LegK& a, int wv, int K, int s) {
+	const int last = min((wv*K + s + 1)*64, a.npairs) - 1;   // most equatorial pair of the slot (wave-uniform)
+	if (last < (wv*K + s)*64) return false;
+	const double c = a.cth[last];
+	return c*c > 0.5;
+}
+
 // ---------------------------------------------------------------------------------
 // spin-0 kernels
 // ---------------------------------------------------------------------------------
@@ -179,18 +190,21 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
-	const double2* __restrict__ coef = a.coef + row0;
+	const double4_t* __restrict__ coef = a.coef + row0;
 	const double* __restrict__ at = a.almt + 4*row0;
 	double x[K], csq[K], lam1[K], lam2[K], p1r[K], p1i[K], p2r[K], p2i[K];
 	int sc[K], rn[K], rs[K];
 	bool alive_any = false;
+	bool polar[K];
 #pragma unroll
 	for (int s = 0; s < K; s++) {
+		polar[s] = leg_slot_polar(a, wv, K, s);
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
 		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
-		x[s] = valid ? a.cth[p] : 0.0; csq[s] = x[s]*x[s];
+		x[s] = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
+		csq[s] = polar[s] ? -sth*sth : x[s]*x[s];
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
 		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
@@ -205,10 +219,10 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
 			if (__any(act)) break;
-			const double2 ab = coef[k];
+			const double4_t cf = coef[k];
 #pragma unroll
 			for (int s = 0; s < K; s++) {
-				const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+				const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
 				lam1[s] = lam2[s]; lam2[s] = t;
 				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
 			}
@@ -220,14 +234,14 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 			if (!__any(pend)) break;
-			const double2 ab = coef[k];
+			const double4_t cf = coef[k];
 			const double er = at[4*k], ei = at[4*k+1], orr = at[4*k+2], oi = at[4*k+3];
 #pragma unroll
 			for (int s = 0; s < K; s++) {
 				const double g = (sc[s] == 0) ? lam2[s] : 0.0;
 				p1r[s] = fma(g, er, p1r[s]); p1i[s] = fma(g, ei, p1i[s]);
 				p2r[s] = fma(g, orr, p2r[s]); p2i[s] = fma(g, oi, p2i[s]);
-				const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+				const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
 				lam1[s] = lam2[s]; lam2[s] = t;
 				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
 			}
@@ -235,13 +249,13 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 		}
 		// phase C: fast loop
 		for (; k < nk; k++) {
-			const double2 ab = coef[k];
+			const double4_t cf = coef[k];
 			const double er = at[4*k], ei = at[4*k+1], orr = at[4*k+2], oi = at[4*k+3];
 #pragma unroll
 			for (int s = 0; s < K; s++) {
 				p1r[s] = fma(lam2[s], er, p1r[s]); p1i[s] = fma(lam2[s], ei, p1i[s]);
 				p2r[s] = fma(lam2[s], orr, p2r[s]); p2i[s] = fma(lam2[s], oi, p2i[s]);
-				const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+				const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
 				lam1[s] = lam2[s]; lam2[s] = t;
 			}
 		}
@@ -275,19 +289,22 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
-	const double2* __restrict__ coef = a.coef + row0;
+	const double4_t* __restrict__ coef = a.coef + row0;
 	double* __restrict__ pout = a.part + ((long)wv*a.nrows + row0)*4;
 	const double2* __restrict__ in = a.leg + (long)m*a.nring;
 	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
 	int sc[K];
 	bool alive_any = false;
+	bool polar[K];
 #pragma unroll
 	for (int s = 0; s < K; s++) {
+		polar[s] = leg_slot_polar(a, wv, K, s);
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
 		const int rn = valid ? a.ring_n[p] : -1, rs = valid ? a.ring_s[p] : -1;
-		const double x = valid ? a.cth[p] : 0.0; csq[s] = x*x;
+		const double x = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
+		csq[s] = polar[s] ? -sth*sth : x*x;
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
 		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
@@ -304,10 +321,10 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 #pragma unroll
 		for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
 		if (__any(act)) break;
-		const double2 ab = coef[k];
+		const double4_t cf = coef[k];
 #pragma unroll
 		for (int s = 0; s < K; s++) {
-			const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+			const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
 			lam1[s] = lam2[s]; lam2[s] = t;
 			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
 		}
@@ -319,13 +336,13 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 #pragma unroll
 		for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 		if (!__any(pend)) break;
-		const double2 ab = coef[k];
+		const double4_t cf = coef[k];
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
 		for (int s = 0; s < K; s++) {
 			const double g = (sc[s] == 0) ? lam2[s] : 0.0;
 			t0 = fma(g, d1r[s], t0); t1 = fma(g, d1i[s], t1); t2 = fma(g, d2r[s], t2); t3 = fma(g, d2i[s], t3);
-			const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+			const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
 			lam1[s] = lam2[s]; lam2[s] = t;
 			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
 		}
@@ -335,12 +352,12 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k; }
 	}
 	for (; k < nk; k++) {
-		const double2 ab = coef[k];
+		const double4_t cf = coef[k];
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
 		for (int s = 0; s < K; s++) {
 			t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3);
-			const double t = fma(fma(ab.x, csq[s], ab.y), lam2[s], lam1[s]);
+			const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
 			lam1[s] = lam2[s]; lam2[s] = t;
 		}
 		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
@@ -360,19 +377,22 @@ template<int K> struct SpinState {
 	int scp[K], scm[K];
 };
 
-template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv, int lane, int m, SpinState<K>& S, int* rn, int* rs) {
+template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv, int lane, int m, SpinState<K>& S, int* rn, int* rs, bool* polar) {
 	const int s_ = a.spin;
 	bool alive_any = false;
 #pragma unroll
 	for (int s = 0; s < K; s++) {
+		polar[s] = leg_slot_polar(a, wv, K, s);
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
 		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
-		S.x[s] = valid ? a.cth[p] : 0.0;
+		const double cth = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
+		const double shh = valid ? a.sh2[p] : 0.0;
+		S.x[s] = polar[s] ? -2.0*shh*shh : cth;
 		// libsharp's m-limit generalised to spin: rings with m beyond it carry nothing up to lmax
 		const double t1 = a.lmax*sth + a.ofs;
-		const double b = -2.0*s_*fabs(S.x[s]);
+		const double b = -2.0*s_*fabs(cth);
 		const double c = (double)s_*s_ - t1*t1;
 		const double discr = b*b - 4*c;
 		const double mlim = discr <= 0 ? a.lmax : fmin((double)a.lmax, 0.5*(-b + sqrt(discr)));
@@ -399,8 +419,8 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 	return alive_any;
 }
 
-template<int K> __device__ __forceinline__ void spin_step(SpinState<K>& S, int s, double ca, double cb, bool rescale) {
-	const double tp = fma(ca, S.x[s], cb), tm = fma(ca, S.x[s], -cb);
+template<int K> __device__ __forceinline__ void spin_step(SpinState<K>& S, int s, double ca, double c1, double c2, bool rescale) {
+	const double tp = fma(ca, S.x[s], c1), tm = fma(ca, S.x[s], c2);
 	const double np_ = fma(tp, S.gp2[s], -S.gp1[s]), nm_ = fma(tm, S.gm2[s], -S.gm1[s]);
 	S.gp1[s] = S.gp2[s]; S.gp2[s] = np_; S.gm1[s] = S.gm2[s]; S.gm2[s] = nm_;
 	if (rescale) {
@@ -420,10 +440,11 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	double pnr[K], pni[K], mnr[K], mni[K], psr[K], psi[K], msr[K], msi[K];
 #pragma unroll
 	for (int s = 0; s < K; s++) pnr[s] = pni[s] = mnr[s] = mni[s] = psr[s] = psi[s] = msr[s] = msi[s] = 0;
-	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs);
+	bool polar[K];
+	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
 	if (nl > 0 && __any(alive_any)) {
 		const long row0 = a.row[m];
-		const double2* __restrict__ coef = a.coef + row0;
+		const double4_t* __restrict__ coef = a.coef + row0;
 		const double* __restrict__ at = a.almt + 4*row0;
 		double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m)
 		int j = 0;
@@ -432,9 +453,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
 			if (__any(act)) break;
-			const double2 ab = coef[j];
+			const double4_t cf = coef[j];
 #pragma unroll
-			for (int s = 0; s < K; s++) spin_step<K>(S, s, ab.x, ab.y, true);
+			for (int s = 0; s < K; s++) spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, true);
 			j++; sgn = -sgn;
 		}
 		while (j < nl) {
@@ -442,7 +463,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 			if (!__any(pend)) break;
-			const double2 ab = coef[j];
+			const double4_t cf = coef[j];
 			const double apr = at[4*j], api = at[4*j+1], amr = at[4*j+2], ami = at[4*j+3];
 #pragma unroll
 			for (int s = 0; s < K; s++) {
@@ -451,12 +472,12 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 				mnr[s] = fma(gm, amr, mnr[s]); mni[s] = fma(gm, ami, mni[s]);
 				psr[s] = fma(gm, sgn*apr, psr[s]); psi[s] = fma(gm, sgn*api, psi[s]);
 				msr[s] = fma(gp, sgn*amr, msr[s]); msi[s] = fma(gp, sgn*ami, msi[s]);
-				spin_step<K>(S, s, ab.x, ab.y, true);
+				spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, true);
 			}
 			j++; sgn = -sgn;
 		}
 		for (; j < nl; j++) {
-			const double2 ab = coef[j];
+			const double4_t cf = coef[j];
 			const double apr = at[4*j], api = at[4*j+1], amr = at[4*j+2], ami = at[4*j+3];
 			const double sapr = sgn*apr, sapi = sgn*api, samr = sgn*amr, sami = sgn*ami;
 #pragma unroll
@@ -466,7 +487,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 				mnr[s] = fma(gm, amr, mnr[s]); mni[s] = fma(gm, ami, mni[s]);
 				psr[s] = fma(gm, sapr, psr[s]); psi[s] = fma(gm, sapi, psi[s]);
 				msr[s] = fma(gp, samr, msr[s]); msi[s] = fma(gp, sami, msi[s]);
-				spin_step<K>(S, s, ab.x, ab.y, false);
+				spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, false);
 			}
 			sgn = -sgn;
 		}
@@ -493,12 +514,13 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	const int nl = a.lmax - l0 + 1;
 	if (nl <= 0) return;
 	const long row0 = a.row[m];
-	const double2* __restrict__ coef = a.coef + row0;
+	const double4_t* __restrict__ coef = a.coef + row0;
 	double* __restrict__ pout = a.part + ((long)wv*a.nrows + row0)*4;
 	const double2* __restrict__ inq = a.leg + (long)m*a.nring;
 	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.nring;
 	SpinState<K> S; int rn[K], rs[K];
-	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs);
+	bool polar[K];
+	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
 	if (!__any(alive_any)) return;
 	// T+ = Q + iU, T- = Q - iU for north and south rings
 	double tpnr[K], tpni[K], tmnr[K], tmni[K], tpsr[K], tpsi[K], tmsr[K], tmsi[K];
@@ -516,9 +538,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 #pragma unroll
 		for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
 		if (__any(act)) break;
-		const double2 ab = coef[j];
+		const double4_t cf = coef[j];
 #pragma unroll
-		for (int s = 0; s < K; s++) spin_step<K>(S, s, ab.x, ab.y, true);
+		for (int s = 0; s < K; s++) spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, true);
 		j++; sgn = -sgn;
 	}
 	int kk = 0, jbase = j;
@@ -530,7 +552,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 			fast = !__any(pend);
 		}
-		const double2 ab = coef[j];
+		const double4_t cf = coef[j];
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
 		for (int s = 0; s < K; s++) {
@@ -541,7 +563,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 			t1 = fma(gp, tpni[s], t1); t1 = fma(sgm, tpsi[s], t1);
 			t2 = fma(gm, tmnr[s], t2); t2 = fma(sgp, tmsr[s], t2);
 			t3 = fma(gm, tmni[s], t3); t3 = fma(sgp, tmsi[s], t3);
-			spin_step<K>(S, s, ab.x, ab.y, !fast);
+			spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, !fast);
 		}
 		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
 		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
@@ -601,7 +623,7 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 		row[m+1] = row[m] + n;
 	}
 	nrows = row[mmax+1];
-	std::vector<double2> coef(std::max<long>(nrows, 1)); std::vector<double> alpha(std::max<long>(nrows, 1));
+	std::vector<double4_t> coef(std::max<long>(nrows, 1)); std::vector<double> alpha(std::max<long>(nrows, 1));
 	typedef long double LDb;
 	const LDb PIl = 3.141592653589793238462643383279502884L;
 	if (spin == 0) {
@@ -616,7 +638,7 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 				const LDb e2 = eps(lp+1)*eps(lp+1) + eps(lp)*eps(lp), f = eps(lp)*eps(lp-1), d = eps(lp+1)*eps(lp+2);
 				const LDb a_next = (k == 0) ? a_cur/d : -f*a_prev/d;
 				const LDb ak = a_cur/(a_next*d);
-				coef[row[m]+k] = make_double2((double)ak, (double)(-ak*e2));
+				coef[row[m]+k] = double4_t{(double)ak, (double)(-ak*e2), (double)(ak - ak*e2), 0.0};
 				alpha[row[m]+k] = (double)a_cur;
 				a_prev = a_cur; a_cur = a_next;
 			}
@@ -647,7 +669,7 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 				const LDb B = q*(LDb)m*(LDb)s/(L*Sf(l+1));
 				const LDb C = (l > l0) ? sqrtl((2*L+3)/(2*L-1))*(L+1)*Sf(l)/(L*Sf(l+1)) : 0;
 				const LDb b_next = (l == l0) ? A*b_cur : C*b_prev;
-				coef[row[m]+(l-l0)] = make_double2((double)(A*b_cur/b_next), (double)(B*b_cur/b_next));
+				{ const LDb ca = A*b_cur/b_next, cb = B*b_cur/b_next; coef[row[m]+(l-l0)] = double4_t{(double)ca, (double)cb, (double)(ca+cb), (double)(ca-cb)}; }
 				alpha[row[m]+(l-l0)] = (double)b_cur;
 				b_prev = b_cur; b_cur = b_next;
 			}
@@ -662,7 +684,7 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	LegK a; memset(&a, 0, sizeof(a));
 	a.lmax = tb.lmax; a.mmax = tb.mmax; a.spin = tb.spin; a.nm = tb.mmax+1; a.npairs = rs.npairs; a.nring = rs.nring;
 	a.nwave = (rs.npairs + 64*K - 1)/(64*K);
-	a.nrows = tb.nrows; a.row = tb.d_row.as<long>(); a.coef = tb.d_coef.as<double2>(); a.alpha = tb.d_alpha.as<double>();
+	a.nrows = tb.nrows; a.row = tb.d_row.as<long>(); a.coef = tb.d_coef.as<double4_t>(); a.alpha = tb.d_alpha.as<double>();
 	a.ring_n = rs.d_ring_n.as<int>(); a.ring_s = rs.d_ring_s.as<int>(); a.cth = rs.d_cth.as<double>(); a.sth = rs.d_sth.as<double>();
 	a.sh2 = rs.d_sh2.as<double>(); a.ch2 = rs.d_ch2.as<double>();
 	a.almt = wk.almt.as<double>(); a.part = wk.part.as<double>(); a.mom = wk.mom.as<double>();
