@@ -85,7 +85,7 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 	PXS_TRY
 	PXS_REQUIRE(ndim >= 1 && ndim <= 16 && naxes >= 1 && naxes <= ndim, "pxf_fft_nd: bad ndim/naxes");
 	PXS_REQUIRE(kind >= 0 && kind <= 2, "pxf_fft_nd: kind must be 0 (c2c), 1 (r2c) or 2 (c2r)");
-	if (kind == 0) PXS_REQUIRE(in_dtype >= PX_C64 && out_dtype >= PX_C64, "c2c needs complex in/out");
+	if (kind == 0) PXS_REQUIRE(out_dtype >= PX_C64, "c2c needs complex output (real input is read with zero imaginary part)");
 	if (kind == 1) PXS_REQUIRE(in_dtype <= PX_F64 && out_dtype >= PX_C64, "r2c needs real in, complex out");
 	if (kind == 2) PXS_REQUIRE(in_dtype >= PX_C64 && out_dtype <= PX_F64, "c2r needs complex in, real out");
 	std::vector<int> axes(axes_in, axes_in+naxes);

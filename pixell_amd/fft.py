@@ -1,0 +1,130 @@
+"""pixell.fft-shaped front end of the HIP FFT engine (pxf_fft_nd).
+
+Mirrors pixell/fft.py: fft (fft.py:133-156), ifft (:158-184), rfft (:186-195), irfft (:197-209)
+and the engine protocol `engines[name].FFTW(a, b, axes, direction, threads, flags)()` /
+`.empty_aligned` (fft.py:8-31, 78-82).  The transform kind is inferred from the shapes and
+dtypes of input and output exactly as the reference's numpy engine does.  Arrays may be numpy
+(staged through the GPU) or torch CUDA tensors (in place, no copies).
+`register()` installs the engine into an imported `pixell.fft` as engines["hip"]."""
+import ctypes
+import numpy as np
+from . import _lib
+from .sht import _Buf, _np_dtype, _is_tensor, _torch, _DT, current_stream, device_index
+
+def astuple(x):
+	try: return tuple(x)
+	except TypeError: return (x,)
+
+def _empty_like(shape, dtype, like):
+	if _is_tensor(like):
+		torch = _torch()
+		return torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device=like.device)
+	return np.empty(shape, dtype)
+
+def _strides(x):
+	if _is_tensor(x): return list(x.stride())
+	return [s//x.itemsize for s in x.strides]
+
+def _exec(a, b, axes, forward, scale):
+	"""a -> b along axes; kind from shapes/dtypes (fft.py:14-31)"""
+	ad, bd = _np_dtype(a), _np_dtype(b)
+	nd = a.ndim
+	axes = [ax % nd for ax in astuple(axes)]
+	ashape, bshape = tuple(a.shape), tuple(b.shape)
+	half = lambda shp: tuple(n//2+1 if i == axes[-1] else n for i, n in enumerate(shp))
+	if bd.kind == "c" and ashape == bshape:
+		kind, shape = 0, ashape
+	elif bd.kind == "c":
+		if ad.kind == "c" or bshape != half(ashape): raise ValueError("r2c: output shape %s does not match input %s" % (str(bshape), str(ashape)))
+		kind, shape = 1, ashape
+	else:
+		if ad.kind != "c" or ashape != half(bshape): raise ValueError("c2r: input shape %s does not match output %s" % (str(ashape), str(bshape)))
+		kind, shape = 2, bshape
+	# numpy inputs are staged contiguously; tensors are used with their own strides
+	ab = _Buf(a) if not _is_tensor(a) else None
+	bb = _Buf(b, writeback=True) if not _is_tensor(b) else None
+	def cstr(shp):
+		st = [1]*len(shp)
+		for i in range(len(shp)-2, -1, -1): st[i] = st[i+1]*shp[i+1]
+		return st
+	ist = cstr(ashape) if ab is not None else _strides(a)
+	ost = cstr(bshape) if bb is not None else _strides(b)
+	aptr = ab.ptr if ab is not None else a.data_ptr()
+	bptr = bb.ptr if bb is not None else b.data_ptr()
+	I64 = ctypes.c_int64
+	sh = (I64*nd)(*shape); isa = (I64*nd)(*ist); osa = (I64*nd)(*ost); ax = (ctypes.c_int*len(axes))(*axes)
+	_lib.check(_lib.load().pxf_fft_nd(nd, sh, isa, osa, len(axes), ax, kind, int(bool(forward)), float(scale),
+		_DT[ad], _DT[bd], aptr, bptr, device_index(), current_stream()))
+	if bb is not None: bb.finish()
+	return b
+
+def fft(tod, ft=None, nthread=0, axes=[-1], flags=None, _direction="FFTW_FORWARD", engine="auto", _scale=1.0):
+	"""pixell.fft.fft: unnormalised forward transform of tod into ft (complex of tod.shape if omitted)"""
+	axes = astuple(-1 if axes is None else axes)
+	if int(np.prod(tod.shape)) == 0: return
+	if ft is None:
+		ft = _empty_like(tod.shape, np.result_type(_np_dtype(tod), 0j), tod)
+	return _exec(tod, ft, axes, _direction == "FFTW_FORWARD", _scale)
+
+def ifft(ft, tod=None, nthread=0, normalize=False, axes=[-1], flags=None, engine="auto", _scale=1.0):
+	"""pixell.fft.ifft: unnormalised backward transform unless normalize=True"""
+	axes = astuple(-1 if axes is None else axes)
+	if int(np.prod(ft.shape)) == 0: return
+	if tod is None: tod = _empty_like(ft.shape, _np_dtype(ft), ft)
+	scale = _scale
+	if normalize: scale = scale/np.prod([tod.shape[i] for i in axes])
+	return _exec(ft, tod, axes, False, scale)
+
+def rfft_shape(shape, axes=[-1]):
+	s = list(shape); s[astuple(axes)[-1]] = s[astuple(axes)[-1]]//2+1
+	return tuple(s)
+def irfft_shape(shape, axes=[-1], n=None):
+	s = list(shape); ax = astuple(axes)[-1]
+	s[ax] = n if n is not None else (s[ax]-1)*2
+	return tuple(s)
+
+def rfft(tod, ft=None, nthread=0, axes=[-1], flags=None, engine="auto"):
+	axes = astuple(-1 if axes is None else axes)
+	if ft is None: ft = _empty_like(rfft_shape(tod.shape, axes), np.result_type(_np_dtype(tod), 0j), tod)
+	return fft(tod, ft, nthread, axes, flags=flags)
+
+def irfft(ft, tod=None, n=None, nthread=0, normalize=False, axes=[-1], flags=None, engine="auto"):
+	axes = astuple(-1 if axes is None else axes)
+	if tod is None: tod = _empty_like(irfft_shape(ft.shape, axes, n), np.zeros([], _np_dtype(ft)).real.dtype, ft)
+	return ifft(ft, tod, nthread, normalize, axes, flags=flags)
+
+def fft_len(n, direction="below", factors=None):
+	"""nearest length the engine handles well (2,3,5-smooth), cf. pixell.fft.fft_len (fft.py:319)"""
+	n = int(n)
+	if direction == "above": return int(_lib.load().pxf_fft_good_size(n))
+	m = n
+	while m > 1 and int(_lib.load().pxf_fft_good_size(m)) != m: m -= 1
+	return m
+
+class HipFFTW:
+	"""engine protocol object: plan = engines["hip"].FFTW(a, b, axes=..., direction=...); plan()"""
+	def __init__(self, a, b, axes=(-1,), direction="FFTW_FORWARD", threads=1, flags=None, *args, **kwargs):
+		self.a, self.b, self.axes, self.direction = a, b, astuple(axes), direction
+		if not isinstance(direction, str): raise NotImplementedError("r2r (DCT/DST) transforms are outside the accelerated path")
+	def __call__(self, normalise_idft=False):
+		fwd = self.direction == "FFTW_FORWARD"
+		scale = 1.0
+		if not fwd and normalise_idft:
+			shp = self.a.shape if tuple(self.a.shape) == tuple(self.b.shape) or _np_dtype(self.b).kind == "c" else self.b.shape
+			scale = 1.0/np.prod([shp[i] for i in self.axes])
+		_exec(self.a, self.b, self.axes, fwd, scale)
+		return self.b
+
+def empty_aligned(shape, dtype, n=None):
+	return np.empty(shape, dtype)
+
+class HipEngine: pass
+hip_engine = HipEngine()
+hip_engine.FFTW = HipFFTW
+hip_engine.empty_aligned = empty_aligned
+
+def register(pixell_fft_module, make_default=True):
+	"""pixell.fft.engines["hip"] = this engine (pixell/fft.py:5, 78-131)"""
+	pixell_fft_module.engines["hip"] = hip_engine
+	if make_default: pixell_fft_module.set_engine("hip")
+	return hip_engine

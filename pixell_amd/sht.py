@@ -172,7 +172,8 @@ def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None
 	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
 	nca, ncm = _ncomp(spin, mode)
 	if map is None:
-		npix = int(np.max(np.asarray(ringstart).astype(np.int64)+(np.asarray(nphi).astype(np.int64)-1)*pixstride)+1)
+		rs_ = np.asarray(ringstart).astype(np.int64); last_ = rs_+(np.asarray(nphi).astype(np.int64)-1)*pixstride
+		npix = int(max(rs_.max(), last_.max())+1)
 		rdt = np.float32 if _np_dtype(alm) == np.complex64 else np.float64
 		map = _torch().zeros((ncm, npix), dtype=getattr(_torch(), np.dtype(rdt).name), device=alm.device) if _is_tensor(alm) else np.zeros((ncm, npix), rdt)
 	_check_pair(alm, map, spin, mode, 1)

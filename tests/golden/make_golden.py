@@ -184,7 +184,7 @@ def main():
 	fx["enmap_fft"] = np.asarray(enmap.fft(im)); fx["enmap_fft_phys"] = np.asarray(enmap.fft(im, normalize="phys"))
 	fx["enmap_ifft_of_fft"] = np.asarray(enmap.ifft(enmap.fft(im)))
 	fx["enmap_pixsize"] = np.array(float(im.pixsize()))
-	fx["enmap_cdelt"] = np.array(w.wcs.cdelt)
+	fx["enmap_cdelt"] = np.array(w.wcs.cdelt); fx["enmap_crval"] = np.array(w.wcs.crval); fx["enmap_crpix"] = np.array(w.wcs.crpix)
 	np.savez_compressed(os.path.join(HERE, "fft_golden.npz"), **fx)
 
 	# ---- 5. alm helper fixtures (cmisc) -------------------------------------------------

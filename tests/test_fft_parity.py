@@ -1,0 +1,100 @@
+"""Parity of the HIP FFT path (pixell_amd.fft / enmap.fft -> pxf_fft_nd) with the reference's numpy
+engine (pixell/fft.py:8-31): golden vectors generated from the reference (tests/golden/fft_golden.npz),
+the reference's known-answer shape tests (tests/test_pixell.py:373-486) and numpy.fft itself."""
+import os
+import numpy as np
+import pytest
+from pixell_amd import fft as pfft, enmap
+from pixell_amd.wcs import CarWCS
+
+def rel(a, b): return np.max(np.abs(a-b))/max(np.max(np.abs(b)), 1e-300)
+TOL = 1e-13
+
+def check_golden(golden_dir):
+	g = np.load(os.path.join(golden_dir, "fft_golden.npz"))
+	a = g["r_3x12x20"]; c = g["c_2x9x61"]
+	assert rel(pfft.fft(a, axes=[-2, -1]), g["fft_r_3x12x20_axes-2-1"]) < TOL
+	assert rel(pfft.fft(a, axes=[-1]), g["fft_r_3x12x20_axes-1"]) < TOL
+	assert rel(pfft.rfft(a, axes=[-1]), g["rfft_r_3x12x20_axes-1"]) < TOL
+	assert rel(pfft.fft(c, axes=[-2, -1]), g["fft_c_2x9x61_axes-2-1"]) < TOL
+	assert rel(pfft.ifft(c, axes=[-2, -1]), g["ifft_c_2x9x61_axes-2-1"]) < TOL
+	assert rel(pfft.ifft(c, axes=[-2, -1], normalize=True), g["ifft_c_2x9x61_axes-2-1_norm"]) < TOL
+	h = pfft.rfft(a, axes=[-1])
+	assert rel(pfft.irfft(h, n=20, axes=[-1], normalize=True), g["irfft_of_rfft"]) < TOL
+	# enmap.fft / ifft incl. "phys" normalisation (enmap.py:1307-1337); geometry from the fixture
+	im = g["enmap_in"]; cd = g["enmap_cdelt"]
+	wcs = CarWCS(cdelt=cd, crval=g["enmap_crval"], crpix=g["enmap_crpix"])
+	m = enmap.ndmap(im, wcs)
+	assert abs(m.pixsize()/float(g["enmap_pixsize"])-1) < 1e-6
+	f = enmap.fft(m)
+	assert rel(np.asarray(f), g["enmap_fft"]) < TOL
+	assert rel(np.asarray(enmap.ifft(f)).real, im) < TOL            # reference test_fft (tests/test_pixell.py:373-378)
+	fp = enmap.fft(m, normalize="phys")
+	assert rel(np.asarray(fp)/m.pixsize()**0.5, g["enmap_fft_phys"]/float(g["enmap_pixsize"])**0.5) < TOL
+	assert rel(np.asarray(enmap.ifft(fp, normalize="phys")).real, im) < TOL
+
+def check_known_answers():
+	"""constant inputs -> DC-only outputs over last / middle / non-contiguous axes, output written
+	into a caller-supplied view (reference tests/test_pixell.py:380-486)"""
+	signal = np.ones((1, 2, 5, 10))
+	out = pfft.fft(signal, axes=[-1])
+	exp = np.zeros((1, 2, 5, 10), complex); exp[..., 0] = 10
+	assert np.allclose(out, exp)
+	out = pfft.fft(signal, axes=[-2, -1]); exp[:] = 0; exp[..., 0, 0] = 50
+	assert np.allclose(out, exp)
+	out = pfft.fft(signal, axes=[-3, -2, -1]); exp[:] = 0; exp[..., 0, 0, 0] = 100
+	assert np.allclose(out, exp)
+	# middle axis, non-contiguous input view, output into a view of a bigger array
+	big = np.ones((1, 2, 5, 20))[..., ::2]
+	out = pfft.fft(big, axes=[-2]); exp = np.zeros((1, 2, 5, 10), complex); exp[..., 0, :] = 5
+	assert np.allclose(out, exp)
+	obig = np.zeros((1, 2, 5, 20), complex); ov = obig[..., ::2]
+	res = pfft.fft(signal, ov, axes=[-2, -1])
+	assert np.shares_memory(res, obig) and np.allclose(ov[..., 0, 0], 50) and np.allclose(obig[..., 1::2], 0)
+	sig = np.zeros((1, 2, 5, 10), complex); sig[..., 0, 0] = 50
+	out = pfft.ifft(sig, axes=[-2, -1], normalize=True)
+	assert np.allclose(out, 1)
+	out = pfft.ifft(sig, axes=[-2, -1])
+	assert np.allclose(out, 50)
+
+def check_lengths(lengths, batch=3):
+	rng = np.random.default_rng(5)
+	for n in lengths:
+		a = rng.standard_normal((batch, n))+1j*rng.standard_normal((batch, n))
+		assert rel(pfft.fft(a), np.fft.fft(a, axis=-1)) < 5e-13, n
+		assert rel(pfft.ifft(a), np.fft.ifft(a, axis=-1)*n) < 5e-13, n
+		r = a.real.copy()
+		assert rel(pfft.rfft(r), np.fft.rfft(r, axis=-1)) < 5e-13, n
+		assert rel(pfft.irfft(np.fft.rfft(r, axis=-1), n=n, normalize=True), r) < 5e-13, n
+
+@pytest.mark.hostsim
+def test_fft_golden_hostsim(golden_dir): check_golden(golden_dir)
+@pytest.mark.hostsim
+def test_fft_known_answers_hostsim(): check_known_answers()
+@pytest.mark.hostsim
+def test_fft_lengths_hostsim(): check_lengths([1, 2, 3, 4, 5, 7, 8, 12, 61, 100, 122, 216, 1000, 2048, 2304, 4320, 10800])
+
+@pytest.mark.gpu
+def test_fft_golden_gpu(golden_dir): check_golden(golden_dir)
+@pytest.mark.gpu
+def test_fft_known_answers_gpu(): check_known_answers()
+@pytest.mark.gpu
+def test_fft_lengths_gpu():
+	check_lengths([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 25, 27, 49, 61, 64, 100, 121, 122, 125, 216, 243, 360, 1000, 1024, 2048,
+		2304, 4096, 4320, 8100, 10800, 19200, 20250, 21600, 43200, 64000], batch=5)
+
+@pytest.mark.gpu
+def test_fft_2d_large_gpu():
+	"""2-D c2c / r2c over the last two axes at map-like sizes incl. four-step columns"""
+	rng = np.random.default_rng(6)
+	a = rng.standard_normal((2, 2700, 5400))
+	assert rel(pfft.fft(a, axes=[-2, -1]), np.fft.fftn(a, axes=(-2, -1))) < 1e-12
+	h = pfft.rfft(a, axes=[-2, -1])
+	assert rel(h, np.fft.rfftn(a, axes=(-2, -1))) < 1e-12
+	assert rel(pfft.irfft(h, n=5400, axes=[-2, -1], normalize=True), a) < 1e-12
+
+def test_unsupported_length_raises():
+	from pixell_amd._lib import PxsError
+	with pytest.raises(PxsError):
+		pfft.fft(np.zeros((1, 2*4099), complex))      # prime factor > 2048: no Bluestein yet
+	assert pfft.fft_len(4099, "above") == 4320 or pfft.fft_len(4099, "above") >= 4099

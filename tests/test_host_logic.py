@@ -1,0 +1,80 @@
+"""CPU: host-side mirror of the reference's geometry / layout bookkeeping against fixtures generated
+from the reference itself (tests/golden/make_golden.py)."""
+import os, json
+import numpy as np
+import pytest
+from pixell_amd import curvedsky, enmap
+from pixell_amd.wcs import CarWCS
+
+@pytest.fixture(scope="module")
+def geo(golden_dir):
+	return json.load(open(os.path.join(golden_dir, "geometry.json")))
+
+KEYS = ["c1_1024x2048", "c2_5400x10800", "c3_21600x43200", "c5_10800x21600", "rt_32x61", "ref_bench_900x1800",
+	"cc_181x360", "f1_6x12", "cc_7x12", "patch_cc", "patch_gen_cyl", "band_30deg"]
+
+@pytest.mark.parametrize("key", KEYS)
+def test_analyse_geometry_matches_reference(geo, key):
+	"""curvedsky.analyse_geometry / get_ducc_geo / get_method (curvedsky.py:1252-1353, 478-488)"""
+	d = geo[key]
+	wcs = CarWCS(d["cdelt"], d["crval"], d["crpix"])
+	mi = curvedsky.analyse_geometry(tuple(d["shape"]), wcs)
+	assert mi.case == d["case"]
+	assert [bool(f) for f in mi.flip] == d["flip"]
+	assert abs(mi.phi0-d["phi0"]) < 1e-12
+	assert [int(v) for v in mi.ypad] == d["ypad"] and [int(v) for v in mi.xpad] == d["xpad"]
+	assert curvedsky.get_method(tuple(d["shape"]), wcs) == d["method"]
+	if "name" in d:
+		g = mi.ducc_geo
+		assert (g.name, int(g.ny), int(g.nx), int(g.yoff), int(g.lmax)) == (d["name"], d["ny"], d["nx"], d["yoff"], d["lmax"])
+	else:
+		assert mi.ducc_geo is None
+	if "theta_first" in d:
+		ri = curvedsky.get_ring_info(tuple(d["shape"]), wcs)
+		assert abs(ri.theta[0]-d["theta_first"]) < 1e-12 and abs(ri.theta[-1]-d["theta_last"]) < 1e-12
+		assert abs(np.exp(1j*ri.phi0[0])-np.exp(1j*d["ring_phi0"])) < 1e-12   # equal modulo 2 pi (the reference unwinds RA)
+
+def test_fullsky_geometry_matches_reference(geo):
+	"""enmap.fullsky_geometry (enmap.py:1713-1740); reference test tests/test_pixell.py:560-566"""
+	shape, wcs = enmap.fullsky_geometry(res=np.deg2rad(0.5/60))
+	assert list(shape) == geo["fullsky_0.5arcmin_shape"] == [21600, 43200]
+	assert abs(enmap.area(shape, wcs)-4*np.pi) < 1e-6
+	for key in ["c1_1024x2048", "rt_32x61"]:
+		d = geo[key]
+		shape, wcs = enmap.fullsky_geometry(shape=tuple(d["shape"]))
+		assert np.allclose(wcs.wcs.cdelt, d["cdelt"], rtol=0, atol=1e-13) and np.allclose(wcs.wcs.crval, d["crval"], rtol=0, atol=1e-13)
+		assert np.allclose(wcs.wcs.crpix, d["crpix"], rtol=0, atol=1e-13)
+	shape, wcs = enmap.fullsky_geometry(res=np.deg2rad(1.0), variant="CC")
+	assert tuple(shape) == (181, 360) and np.allclose(wcs.wcs.crpix, geo["cc_181x360"]["crpix"])
+	shape, wcs = enmap.band_geometry(np.deg2rad(30), res=np.deg2rad(0.5))
+	assert list(shape) == geo["band_30deg"]["shape"] and np.allclose(wcs.wcs.crpix, geo["band_30deg"]["crpix"])
+
+def test_alm_info_layouts(geo):
+	"""curvedsky.alm_info (curvedsky.py:409-447); reference test tests/test_pixell.py:760-824"""
+	ai = curvedsky.alm_info(lmax=10, mmax=7)
+	assert ai.nelem == geo["alm_info_10_7"]["nelem"] and [int(v) for v in ai.mstart] == geo["alm_info_10_7"]["mstart"]
+	ai = curvedsky.alm_info(lmax=6, layout="rect")
+	assert ai.nelem == geo["alm_info_rect_6"]["nelem"] and [int(v) for v in ai.mstart] == geo["alm_info_rect_6"]["mstart"]
+	ai = curvedsky.alm_info(nalm=66)
+	assert ai.lmax == 10 and ai.mstart.dtype == np.uint64 and ai.lm2ind(3, 2) == int(ai.mstart[2])+3
+	with pytest.raises(AssertionError):
+		curvedsky.alm_info(lmax=10, mmax=7, nalm=66)
+
+def test_spin_helper(geo):
+	"""enmap.spin_helper (enmap.py:3378-3388)"""
+	assert [[int(a), int(b), int(c)] for a, b, c in enmap.spin_helper([0, 2], 3)] == geo["spin_helper_02_3"]
+	assert [[int(a), int(b), int(c)] for a, b, c in enmap.spin_helper([0, 1, 2], 5)] == geo["spin_helper_012_5"]
+	assert [[int(a), int(b), int(c)] for a, b, c in enmap.spin_helper(1, 6)] == geo["spin_helper_1_6"]
+	with pytest.raises(IndexError):
+		list(enmap.spin_helper([0, 2], 2))
+
+def test_prepare_alm_errors():
+	"""curvedsky.prepare_alm (curvedsky.py:1413-1427)"""
+	with pytest.raises(ValueError):
+		curvedsky.prepare_alm()
+	alm, ai = curvedsky.prepare_alm(lmax=5, pre=(3,), dtype=np.float32)
+	assert alm.shape == (3, 21) and alm.dtype == np.complex64 and ai.lmax == 5
+	with pytest.raises(ValueError):
+		curvedsky.prepare_alm(alm=np.zeros(21, np.complex64), dtype=np.float64)
+	alm, ai = curvedsky.prepare_alm(alm=np.zeros(21, np.complex64), dtype=np.float64, convert=True)
+	assert alm.dtype == np.complex128
