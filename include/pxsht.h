@@ -80,6 +80,16 @@ int pxs_grid_maxlmax(const char* geometry, int ntheta);
 /* number of Legendre rings the plan iterates (R_actual of SURVEY 8d) for synthesis / analysis */
 int pxs_plan_info(const pxs_plan* plan, int* nring_legendre_syn, int* nring_legendre_ana, int64_t* scratch_bytes);
 
+/* Optional device-side stage timers (hipEvents recorded on the launch stream around each stage):
+ * used by bench.py to time the dominant kernel live.  ms[PXS_NSTAGE], counts[PXS_NSTAGE]. */
+#define PXS_STAGE_LEG_SYN  0   /* Legendre synthesis kernel (alm2leg) */
+#define PXS_STAGE_LEG_ANA  1   /* Legendre analysis kernel (leg2alm) */
+#define PXS_STAGE_RING_FFT 2   /* ring FFTs + transposes (map2leg / leg2map) */
+#define PXS_STAGE_RESAMPLE 3   /* theta resampling FFT chain */
+#define PXS_NSTAGE 4
+int pxs_profile(pxs_plan* plan, int enable);
+int pxs_profile_read(pxs_plan* plan, double* ms, int* counts, int reset);
+
 /* N-d FFT over `naxes` axes of a strided array: the engine behind fft.engines["hip"].FFTW(a,b,axes,
  * direction) (pixell/fft.py:8-64,133-209) and enmap.fft/ifft (enmap.py:1307-1337).
  * kind 0: c2c (in/out same shape), 1: r2c (out last transformed axis n//2+1), 2: c2r.

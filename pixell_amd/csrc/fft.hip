@@ -74,14 +74,21 @@ __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1,
 		if (ld.mul) v = cmul(v, ld.mul[e]);
 		return v; }
 	case LD_HERM: {
-		long m; bool cj;
-		if (e < ld.ne) { m = e; cj = false; }
-		else if (N - e < ld.ne) { m = N - e; cj = true; }
-		else return make_double2(0, 0);
-		double2 v = read_elem(ld.ptr, ld.dtype, base + m*a.d.is_e);
-		if (ld.mul) v = cmul(v, ld.mul[m]);
-		if (m == 0) v.y = 0;
-		return cj ? cconj(v) : v; }
+		// X[e] = sum_{m = e (mod N)} h[m] + sum_{m = -e (mod N), m > 0} conj(h[m]); only Re h[0] counts.
+		// Without aliasing (2*ne <= N) at most one term exists; with mmax >= N/2 the sums fold m onto the ring.
+		double2 acc = make_double2(0, 0);
+		for (long m = e; m < ld.ne; m += N) {
+			double2 v = read_elem(ld.ptr, ld.dtype, base + m*a.d.is_e);
+			if (ld.mul) v = cmul(v, ld.mul[m]);
+			if (m == 0) v.y = 0;
+			acc = cadd(acc, v);
+		}
+		for (long m = N - e; m < ld.ne; m += N) {
+			double2 v = read_elem(ld.ptr, ld.dtype, base + m*a.d.is_e);
+			if (ld.mul) v = cmul(v, ld.mul[m]);
+			acc = cadd(acc, cconj(v));
+		}
+		return acc; }
 	case LD_MIRROR: {
 		long src = e;
 		const bool odd = ((i + a.i_base + ld.par0) & 1) != 0;

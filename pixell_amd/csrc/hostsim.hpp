@@ -42,6 +42,12 @@ static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 
 #define __global__
 #define __device__

@@ -42,6 +42,7 @@ struct LegK {
 	double* almt; double* part; double* mom;
 	double2* leg;
 	double ofs;
+	int m0; long rowbase, rows_chunk;   // analysis processes m in chunks to bound the partial-moment scratch
 };
 
 // ---------------------------------------------------------------------------------
@@ -187,7 +188,7 @@ __device__ __forceinline__ bool leg_slot_polar(const LegK& a, int wv, int K, int
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 {
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
@@ -286,11 +287,11 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
 	PXS_SHARED(double, red);
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
-	double* __restrict__ pout = a.part + ((long)wv*a.nrows + row0)*4;
+	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
 	const double2* __restrict__ in = a.leg + (long)m*a.nring;
 	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
 	int sc[K];
@@ -431,7 +432,7 @@ template<int K> __device__ __forceinline__ void spin_step(SpinState<K>& S, int s
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	double2* __restrict__ outq = a.leg + (long)m*a.nring;
@@ -509,13 +510,13 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 {
 	PXS_SHARED(double, red);
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y;
+	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	if (nl <= 0) return;
 	const long row0 = a.row[m];
 	const double4_t* __restrict__ coef = a.coef + row0;
-	double* __restrict__ pout = a.part + ((long)wv*a.nrows + row0)*4;
+	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
 	const double2* __restrict__ inq = a.leg + (long)m*a.nring;
 	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.nring;
 	SpinState<K> S; int rn[K], rs[K];
@@ -576,6 +577,26 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
+void LegProfile::begin(hipStream_t st, int stage) {
+	if (!enabled) return;
+	hipEvent_t e; PXS_HIP(hipEventCreate(&e)); PXS_HIP(hipEventRecord(e, st)); open_.push_back(e);
+}
+void LegProfile::end(hipStream_t st, int stage) {
+	if (!enabled || open_.empty()) return;
+	hipEvent_t e; PXS_HIP(hipEventCreate(&e)); PXS_HIP(hipEventRecord(e, st));
+	recs.push_back(Rec{open_.back(), e, stage}); open_.pop_back();
+}
+void LegProfile::read(double* ms, int* counts, int nstage, bool reset) {
+	for (int i = 0; i < nstage; i++) { ms[i] = 0; counts[i] = 0; }
+	for (auto& r : recs) {
+		PXS_HIP(hipEventSynchronize(r.b));
+		float t = 0; PXS_HIP(hipEventElapsedTime(&t, r.a, r.b));
+		if (r.stage >= 0 && r.stage < nstage) { ms[r.stage] += t; counts[r.stage]++; }
+	}
+	if (reset) { for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } recs.clear(); }
+}
+LegProfile::~LegProfile() { for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } for (auto e : open_) (void)hipEventDestroy(e); }
+
 void RingSet::build(const std::vector<long double>& theta) {
 	const long double PIl = 3.141592653589793238462643383279502884L;
 	nring = (int)theta.size();
@@ -678,7 +699,6 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 	d_row = upload(row); d_coef = upload(coef); d_alpha = upload(alpha);
 }
 
-int leg_waves_per_m(const RingSet& rs) { return 0; }
 
 static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, double2* leg, int K) {
 	LegK a; memset(&a, 0, sizeof(a));
@@ -703,7 +723,7 @@ static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dty
 
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                   double2* leg, int deriv1)
+                   double2* leg, int deriv1, LegProfile* prof)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	wk.almt.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
@@ -713,33 +733,56 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		const int nkmax = tb.lmax/2 + 1;
 		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
 		LegK a = make_legk(rs, tb, wk, leg, LEG_K0);
+		if (prof) prof->begin(st, 0);
 		hipLaunchKernelGGL(leg_syn_s0<LEG_K0>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		if (prof) prof->end(st, 0);
 	} else {
 		const int nlmax = tb.lmax + 1;
 		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
 		LegK a = make_legk(rs, tb, wk, leg, LEG_KS);
+		if (prof) prof->begin(st, 0);
 		hipLaunchKernelGGL(leg_syn_spin<LEG_KS>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		if (prof) prof->end(st, 0);
 	}
 	PXS_HIP(hipGetLastError());
 }
 
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                  int deriv1)
+                  int deriv1, LegProfile* prof)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	const int K = tb.spin == 0 ? LEG_K0 : LEG_KS;
 	const int nm = tb.mmax+1;
-	LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
+	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = 4*std::max<long>(tb.nrows, 1);
-	wk.part.ensure(sizeof(double)*n4*a.nwave);
 	wk.mom.ensure(sizeof(double)*n4);
-	a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
-	PXS_HIP(hipMemsetAsync(wk.part.p, 0, sizeof(double)*n4*a.nwave, st));
+	// chunk m so that the per-wave partial moments stay below part_budget bytes
+	const size_t budget = wk.part_budget;
+	std::vector<int> cuts; cuts.push_back(0);
+	for (int m = 0; m < nm;) {
+		int m1 = m+1;
+		while (m1 < nm && (size_t)(tb.row[m1+1]-tb.row[m])*32*nwave <= budget) m1++;
+		cuts.push_back(m1); m = m1;
+	}
+	size_t maxrows = 1;
+	for (size_t c = 0; c+1 < cuts.size(); c++) maxrows = std::max<size_t>(maxrows, (size_t)(tb.row[cuts[c+1]]-tb.row[cuts[c]]));
+	wk.part.ensure(sizeof(double)*4*maxrows*nwave);
 	const size_t sh = sizeof(double)*16*LEG_RED_STRIDE;
-	if (tb.spin == 0) hipLaunchKernelGGL(leg_ana_s0<LEG_K0>, dim3(a.nwave, nm), dim3(64), sh, st, a);
-	else              hipLaunchKernelGGL(leg_ana_spin<LEG_KS>, dim3(a.nwave, nm), dim3(64), sh, st, a);
-	hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((n4+255)/256)), dim3(256), 0, st, (const double*)wk.part.p, (double*)wk.mom.p, n4, a.nwave);
+	for (size_t c = 0; c+1 < cuts.size(); c++) {
+		const int m0 = cuts[c], m1 = cuts[c+1];
+		const long rows = tb.row[m1]-tb.row[m0];
+		if (rows <= 0) continue;
+		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
+		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows;
+		PXS_HIP(hipMemsetAsync(wk.part.p, 0, sizeof(double)*4*rows*nwave, st));
+		if (prof) prof->begin(st, 1);
+		if (tb.spin == 0) hipLaunchKernelGGL(leg_ana_s0<LEG_K0>, dim3(a.nwave, m1-m0), dim3(64), sh, st, a);
+		else              hipLaunchKernelGGL(leg_ana_spin<LEG_KS>, dim3(a.nwave, m1-m0), dim3(64), sh, st, a);
+		if (prof) prof->end(st, 1);
+		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*rows+255)/256)), dim3(256), 0, st, (const double*)wk.part.p,
+			(double*)wk.mom.p + 4*tb.row[m0], 4*rows, a.nwave);
+	}
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm), dim3(256), 0, st, ak);

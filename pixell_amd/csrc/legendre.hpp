@@ -24,21 +24,32 @@ struct LegTables {
 	void build(int lmax, int mmax, int spin);
 };
 
+// optional per-stage device timers (hipEvents on the launch stream); stage ids: see pxsht.h PXS_STAGE_*
+struct LegProfile {
+	struct Rec { hipEvent_t a, b; int stage; };
+	std::vector<Rec> recs; std::vector<hipEvent_t> open_;
+	bool enabled = false;
+	void begin(hipStream_t st, int stage);
+	void end(hipStream_t st, int stage);
+	void read(double* ms, int* counts, int nstage, bool reset);
+	~LegProfile();
+};
+
 struct LegWork {     // scratch owned by the SHT plan
+	size_t part_budget = size_t(1) << 30;
 	DevBuf almt;     // [nrows][4] doubles
 	DevBuf part;     // [nwave][nrows][4] doubles (analysis partial moments)
 	DevBuf mom;      // [nrows][4] reduced moments
 };
 
-int leg_waves_per_m(const RingSet& rs);
 
 // alm[(c) * alm_cstride + mstart[m] + l*lstride] -> leg[(c*nm + m)*nring + ring]  (c = 0 or 0,1)
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                   double2* leg, int deriv1);
+                   double2* leg, int deriv1, LegProfile* prof = nullptr);
 // transpose of leg_synthesis (no weights)
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                  int deriv1);
+                  int deriv1, LegProfile* prof = nullptr);
 
 } // namespace pxs

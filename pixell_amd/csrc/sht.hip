@@ -102,6 +102,20 @@ __global__ __launch_bounds__(256) void transpose_mul_outcol(const double2* __res
 	}
 }
 
+// aliased rings (mmax >= nphi): leg[b][m][r] = h[b][r][m mod nphi] * tab[m]   (rare; simple gather)
+__global__ __launch_bounds__(256) void gather_alias(const double2* __restrict__ in, double2* __restrict__ out,
+		int nr, int nm, int ncin, int nphi, long in_bstride, long out_bstride, const double2* __restrict__ tab, double scale)
+{
+	const long idx = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	const int b = blockIdx.y;
+	if (idx >= (long)nr*nm) return;
+	const int m = (int)(idx / nr), r = (int)(idx - (long)m*nr);
+	double2 v = in[(long)b*in_bstride + (long)r*ncin + (m % nphi)];
+	const double2 t = tab[m];
+	v = make_double2((v.x*t.x - v.y*t.y)*scale, (v.x*t.y + v.y*t.x)*scale);
+	out[(long)b*out_bstride + idx] = v;
+}
+
 } // namespace pxs
 
 using namespace pxs;
@@ -123,6 +137,7 @@ struct pxs_plan {
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
 	DevBuf ph_shift, sigma, wcc, b1, b2;
 	FftContext* fc = nullptr;
+	LegProfile prof;
 
 	LegTables& table(int spin) {
 		auto& p = tables[spin];
@@ -136,7 +151,6 @@ namespace {
 void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device) {
 	PXS_REQUIRE(lmax >= 0 && mmax >= 0 && mmax <= lmax, "need 0 <= mmax <= lmax");
 	PXS_REQUIRE(mstart != nullptr, "mstart is required");
-	PXS_REQUIRE(2L*mmax < p->nphi, "mmax >= nphi/2 would alias on the rings (not supported)");
 	PXS_HIP(hipSetDevice(device));
 	p->device = device; p->lmax = lmax; p->mmax = mmax; p->lstride = lstride;
 	std::vector<uint64_t> ms(mstart, mstart+mmax+1);
@@ -198,22 +212,32 @@ int ncomp_of(int spin, int mode, bool alm_side) {
 
 // ring FFT: user map -> hbuf[c][ring][m] -> leg[c][m][ring] * e^{-i m phi0} * scale
 void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale) {
+	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
+	const int ncin = std::min(nm, p->nphi);           // distinct FFT bins needed (m >= nphi alias onto m mod nphi)
 	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
-	FftDims d; d.n_i = nr; d.is_i = p->ring_stride; d.os_i = nm; d.n_o1 = nc; d.is_o1 = map_cstride; d.os_o1 = (long)nr*nm;
+	FftDims d; d.n_i = nr; d.is_i = p->ring_stride; d.os_i = ncin; d.n_o1 = nc; d.is_o1 = map_cstride; d.os_o1 = (long)nr*ncin;
 	d.is_e = p->pix_stride; d.os_e = 1;
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	FftLoad ld; ld.ptr = (const char*)map + esz(map_dtype)*p->ring_off0; ld.dtype = map_dtype;
-	FftStore sf; sf.ptr = p->hbuf.p; sf.ne = nm;
+	FftStore sf; sf.ptr = p->hbuf.p; sf.ne = ncin;
 	p->fc->exec(st, p->nphi, true, d, ld, sf);
-	dim3 grid((nm+31)/32, (nr+31)/32, nc);
-	hipLaunchKernelGGL(transpose_mul, grid, dim3(256), sizeof(double2)*32*33, st, (const double2*)p->hbuf.p, leg, nr, nm,
-		(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 0, scale);
+	if (ncin == nm) {
+		dim3 grid((nm+31)/32, (nr+31)/32, nc);
+		hipLaunchKernelGGL(transpose_mul, grid, dim3(256), sizeof(double2)*32*33, st, (const double2*)p->hbuf.p, leg, nr, nm,
+			(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 0, scale);
+	} else {
+		dim3 grid((unsigned)(((long)nr*nm + 255)/256), nc);
+		hipLaunchKernelGGL(gather_alias, grid, dim3(256), 0, st, (const double2*)p->hbuf.p, leg, nr, nm, ncin, p->nphi,
+			(long)nr*ncin, (long)nr*nm, (const double2*)p->phase.p, scale);
+	}
+	p->prof.end(st, PXS_STAGE_RING_FFT);
 	PXS_HIP(hipGetLastError());
 }
 
 // leg[c][m][ring] * e^{+i m phi0} -> hbuf[c][ring][m] -> c2r ring FFT -> user map
 void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map_dtype, long map_cstride, int nc) {
+	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
 	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
 	dim3 grid((nm+31)/32, (nr+31)/32, nc);
@@ -225,6 +249,7 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map
 	FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM; ld.ne = nm;
 	FftStore sf; sf.ptr = (char*)map + esz(map_dtype)*p->ring_off0; sf.dtype = map_dtype;
 	p->fc->exec(st, p->nphi, false, d, ld, sf);
+	p->prof.end(st, PXS_STAGE_RING_FFT);
 	PXS_HIP(hipGetLastError());
 }
 
@@ -233,6 +258,7 @@ void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2*
 	const int nm = p->mmax+1, nr = p->nring;
 	p->b1.ensure(sizeof(double2)*(size_t)nm*p->N);
 	p->b2.ensure(sizeof(double2)*(size_t)nm*p->M);
+	p->prof.begin(st, PXS_STAGE_RESAMPLE);
 	for (int c = 0; c < nc; c++) {
 		{	// (a) mirror-extend, forward FFT_N
 			FftDims d; d.n_i = nm; d.is_i = nr; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
@@ -259,6 +285,7 @@ void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2*
 			p->fc->exec(st, p->Ncc, false, d, ld, sf);
 		}
 	}
+	p->prof.end(st, PXS_STAGE_RESAMPLE);
 }
 
 } // namespace
@@ -345,6 +372,15 @@ int pxs_plan_info(const pxs_plan* p, int* nsyn, int* nana, int64_t* scratch) {
 	return 0;
 }
 
+int pxs_profile(pxs_plan* p, int enable) { if (!p) return PXS_ERR_ARG; p->prof.enabled = enable != 0; return 0; }
+
+int pxs_profile_read(pxs_plan* p, double* ms, int* counts, int reset) {
+	PXS_TRY
+	PXS_REQUIRE(p && ms && counts, "pxs_profile_read: null argument");
+	p->prof.read(ms, counts, PXS_NSTAGE, reset != 0);
+	PXS_CATCH
+}
+
 int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
                   void* alm, int alm_dtype, int64_t alm_cstride,
                   void* map, int map_dtype, int64_t map_cstride, void* stream)
@@ -361,11 +397,11 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 	LegTables& tb = p->table(spin);
 	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*p->nring);
 	if (!adjoint) {
-		leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1);
+		leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
 		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm);
 	} else {
 		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0);
-		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1);
+		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1, &p->prof);
 	}
 	PXS_CATCH
 }
@@ -389,7 +425,7 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint,
 	if (!adjoint) {
 		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0);
 		resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
-		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0);
+		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof);
 	} else {
 		throw Error(PXS_ERR_UNSUPPORTED, "adjoint_analysis_2d: not implemented yet");
 	}

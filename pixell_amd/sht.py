@@ -68,6 +68,14 @@ class Plan:
 		try:
 			if self.handle: _lib.load().pxs_plan_destroy(self.handle); self.handle = None
 		except Exception: pass
+	def profile(self, enable=True):
+		_lib.check(_lib.load().pxs_profile(self.handle, int(bool(enable))))
+	def profile_read(self, reset=True):
+		"""{stage: (total ms, launches)} from the hipEvent stage timers (pxsht.h PXS_STAGE_*)"""
+		ms = (ctypes.c_double*4)(); cnt = (ctypes.c_int*4)()
+		_lib.check(_lib.load().pxs_profile_read(self.handle, ms, cnt, int(bool(reset))))
+		names = ["leg_syn", "leg_ana", "ring_fft", "resample"]
+		return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 	def info(self):
 		a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
 		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))

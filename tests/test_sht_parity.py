@@ -35,14 +35,15 @@ def check_grid(geometry, nt, nph, lmax, spin, phi0=0.3, seed=3, random_map=True,
 		oa = np.zeros_like(alm); sht.analysis_2d(alm=oa, map=ref, **kw)
 		sel = np.zeros(alm.shape[1], bool)
 		for m in range(mmax+1): sel[int(ms[m])+m:int(ms[m])+lmax+1] = True
-		if mmax == lmax: assert relrms(oa[:, sel], alm[:, sel]) < TOL, "round trip"
+		if mmax == lmax and 2*mmax < nph: assert relrms(oa[:, sel], alm[:, sel]) < TOL, "round trip"   # (no exact inverse when m aliases)
 		if random_map:
 			ra = np.zeros_like(alm); so.analysis_2d(alm=ra, map=pix, **kw)
 			oa = np.zeros_like(alm); sht.analysis_2d(alm=oa, map=pix, **kw)
 			assert relrms(oa, ra) < TOL, "analysis_2d on a non-band-limited map"
 
 SMALL = [("F1", 20, 41, 19, 0), ("F1", 20, 41, 19, 2), ("F1", 32, 61, 30, 1), ("CC", 21, 40, 19, 0), ("CC", 21, 48, 19, 2),
-	("MW", 16, 33, 15, 0), ("MWflip", 16, 33, 15, 2), ("F1", 24, 64, 12, 0), ("F1", 24, 64, 12, 3)]
+	("MW", 16, 33, 15, 0), ("MWflip", 16, 33, 15, 2), ("F1", 24, 64, 12, 0), ("F1", 24, 64, 12, 3),
+	("CC", 20, 12, 18, 0), ("F1", 20, 38, 19, 2)]   # the last two alias m onto the rings (mmax >= nphi/2), as the golden CC 181x360 lmax=400 case does
 
 @pytest.mark.hostsim
 @pytest.mark.parametrize("geometry,nt,nph,lmax,spin", SMALL)
@@ -135,8 +136,6 @@ def test_errors():
 	lmax = 20; ms = so._tri_mstart(lmax, lmax); n = so.nalm(lmax)
 	with pytest.raises(PxsError):
 		sht.analysis_2d(alm=np.zeros((1, n), complex), map=np.zeros((1, 10, 64)), spin=0, lmax=lmax, mstart=ms, geometry="F1")
-	with pytest.raises(PxsError):
-		sht.synthesis_2d(alm=np.zeros((1, n), complex), map=np.zeros((1, 30, 32)), spin=0, lmax=lmax, mstart=ms, geometry="F1")
 	with pytest.raises(PxsError):
 		sht.synthesis_2d(alm=np.zeros((1, n), complex), map=np.zeros((1, 30, 64)), spin=0, lmax=lmax, mstart=ms, geometry="GL")
 	with pytest.raises(ValueError):
