@@ -1,0 +1,117 @@
+"""Python driver of oracle/sht_port.c -- TEST / BASELINE INFRASTRUCTURE ONLY.
+
+build()        gcc -O3 -march=native -fopenmp -> oracle/libsht_port.so (git-ignored, travels with gpurun)
+leg_s0/leg_spin  thin ctypes wrappers (used by tests/test_oracle_port.py to pin the port to the oracle)
+time_sample()  bench.py's cpu_baseline leg: times the port on a bounded sample of the benchmark
+               workload on the host cores and extrapolates to one full map2alm+alm2map round trip.
+"""
+import ctypes, os, subprocess, time
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsht_port.so")
+_lib = None
+
+def build(force=False):
+	src = os.path.join(HERE, "sht_port.c")
+	if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+		subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-ffast-math", "-fno-finite-math-only", "-shared", "-fPIC", src, "-o", LIB, "-lm"])
+	return LIB
+
+def lib():
+	global _lib
+	if _lib is None:
+		_lib = ctypes.CDLL(build())
+		vp, i = ctypes.c_void_p, ctypes.c_int
+		_lib.sht_port_leg_s0.argtypes = [i, i, vp, i, vp, vp, vp, vp, vp, vp, i]
+		_lib.sht_port_leg_spin.argtypes = [i, i, i, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i]
+		_lib.sht_port_threads.restype = i
+	return _lib
+
+def pairs_from_theta(theta):
+	"""north/south pairing of an ascending symmetric ring list -> (idx_n, idx_s(-1), cth, sth, sh2, ch2)"""
+	th = np.asarray(theta, np.longdouble); n = len(th)
+	idx_n, idx_s = [], []
+	for i in range((n+1)//2):
+		j = n-1-i
+		if j != i and abs(th[j]-(np.pi-th[i])) < 1e-12: idx_n.append(i); idx_s.append(j)
+		else: idx_n.append(i); idx_s.append(-1)
+		if j != i and idx_s[-1] == -1: idx_n.append(j); idx_s.append(-1)
+	idx_n = np.array(idx_n, np.int32); idx_s = np.array(idx_s, np.int32)
+	t = th[idx_n]
+	return idx_n, idx_s, np.cos(t).astype(float), np.sin(t).astype(float), np.sin(t/2).astype(float), np.cos(t/2).astype(float)
+
+def _p(a): return a.ctypes.data
+
+def leg(spin, lmax, msel, theta, alm=None, leg=None):
+	"""alm[nmsel, nc, lmax+1] <-> leg[nmsel, nc, nring] for the listed m (synthesis if leg is None, else adjoint).
+	Only rings with theta <= pi/2 or paired rings are supported (all grids used here)."""
+	msel = np.ascontiguousarray(msel, np.int32); nms = len(msel)
+	idx_n, idx_s, cth, sth, sh2, ch2 = pairs_from_theta(theta); np_ = len(idx_n); nr = len(theta)
+	has_s = np.ascontiguousarray(idx_s >= 0, np.int32)
+	nc = 1 if spin == 0 else 2
+	direction = 0 if leg is None else 1
+	if direction == 0:
+		A = np.ascontiguousarray(alm, np.complex128).reshape(nms, nc, lmax+1).copy()
+		ln = np.zeros((nms, nc, np_), np.complex128); ls = np.zeros((nms, nc, np_), np.complex128)
+	else:
+		A = np.zeros((nms, nc, lmax+1), np.complex128)
+		L = np.asarray(leg, np.complex128).reshape(nms, nc, nr)
+		ln = np.ascontiguousarray(L[:, :, idx_n]); ls = np.ascontiguousarray(L[:, :, np.maximum(idx_s, 0)])
+	if spin == 0: lib().sht_port_leg_s0(lmax, nms, _p(msel), np_, _p(cth), _p(sth), _p(has_s), _p(A), _p(ln), _p(ls), direction)
+	else: lib().sht_port_leg_spin(spin, lmax, nms, _p(msel), np_, _p(cth), _p(sth), _p(sh2), _p(ch2), _p(has_s), _p(A), _p(ln), _p(ls), direction)
+	if direction == 1: return A
+	out = np.zeros((nms, nc, nr), np.complex128)
+	out[:, :, idx_n] = ln
+	sel = idx_s >= 0
+	out[:, :, idx_s[sel]] = ls[:, :, sel]
+	return out
+
+def time_sample(cfg, budget_s=20.0):
+	"""Time the port on a bounded sample and extrapolate to one full round trip of `cfg`
+	(dict with shape, lmax, spin, ncomp as in bench.py).  Legendre on the minimal CC grid
+	(lmax+2 rings, the same ring count the GPU path iterates) for a subset of m, all host threads;
+	ring FFTs with numpy.fft (the reference's numpy engine) on a subset of rings, 1 thread, credited
+	with ideal scaling over the cores."""
+	L = lib(); ncores = L.sht_port_threads()
+	lmax = cfg["lmax"]; ny, nx = cfg["shape"]
+	R = min(ny, lmax+2)
+	theta = np.arange(R)*np.pi/(R-1)
+	rng = np.random.default_rng(0)
+	def run(spin, msel):
+		nc = 1 if spin == 0 else 2
+		alm = rng.standard_normal((len(msel), nc, lmax+1))+1j*rng.standard_normal((len(msel), nc, lmax+1))
+		t0 = time.perf_counter()
+		lg = leg(spin, lmax, msel, theta, alm=alm)
+		leg(spin, lmax, msel, theta, leg=lg)
+		return time.perf_counter()-t0
+	def weight(ms, spin): return float(np.sum(lmax-np.maximum(np.asarray(ms), spin)+1))
+	allm = np.arange(lmax+1)
+	spins = list(cfg["spin"])
+	t_leg = 0.0; nsel_used = {}
+	for spin in spins:
+		n0 = min(lmax+1, max(2*ncores, 8))
+		msel = np.unique(np.linspace(0, lmax, n0).astype(int))
+		t = run(spin, msel)                                   # calibration (also warms the threads)
+		share = budget_s*0.8/len(spins)
+		n1 = int(min(lmax+1, max(n0, n0*share/max(t, 1e-3))))
+		msel = np.unique(np.linspace(0, lmax, n1).astype(int))
+		t = run(spin, msel)
+		t_leg += t*weight(allm, spin)/weight(msel, spin)
+		nsel_used[spin] = len(msel)
+	# ring FFTs
+	nr = max(4, min(ny, int(2e7/nx)))
+	x = rng.standard_normal((nr, nx))
+	t0 = time.perf_counter(); h = np.fft.rfft(x, axis=1); np.fft.irfft(h, n=nx, axis=1); t_fft = time.perf_counter()-t0
+	t_fft_full = t_fft*(cfg["ncomp"]*ny/nr)/ncores
+	total = t_leg+t_fft_full
+	return dict(value=round(1.0/total, 6), unit="round-trips/s", cores=ncores, kind="port",
+		seconds_per_round_trip=round(total, 3), legendre_s=round(t_leg, 3), ring_fft_s_ideal_scaling=round(t_fft_full, 3),
+		sample="oracle/sht_port.c (C, f64, OpenMP x%d): Legendre synthesis+adjoint on the CC grid of %d rings for %s of %d m values "
+			"(extrapolated by sum(lmax-m+1)); numpy rfft+irfft on %d of %d rings (1 thread, credited ideal %d-core scaling); "
+			"theta resampling not included. NOT ducc0 (absent from this image)." % (ncores, R, str(nsel_used), lmax+1, nr, cfg["ncomp"]*ny, ncores))
+
+if __name__ == "__main__":
+	import json, sys
+	cfg = dict(shape=(5400, 10800), lmax=4000, spin=[0, 2], ncomp=3)
+	print(json.dumps(time_sample(cfg, float(sys.argv[1]) if len(sys.argv) > 1 else 10.0), indent=1))

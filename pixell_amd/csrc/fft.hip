@@ -74,6 +74,13 @@ __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1,
 		if (ld.mul) v = cmul(v, ld.mul[e]);
 		return v; }
 	case LD_HERM: {
+		if (!ld.herm_fold) {
+			// plain c2r (numpy.fft.irfft semantics): X[e] = h[e] for e < nh, conj(h[N-e]) otherwise
+			if (e < ld.ne) return read_elem(ld.ptr, ld.dtype, base + e*a.d.is_e);
+			if (N - e < ld.ne) return cconj(read_elem(ld.ptr, ld.dtype, base + (N-e)*a.d.is_e));
+			return make_double2(0, 0);
+		}
+		// SHT ring synthesis: ring(x) = Re h[0] + 2 Re sum_{m>=1} h[m] e^{i m phi_x}, i.e.
 		// X[e] = sum_{m = e (mod N)} h[m] + sum_{m = -e (mod N), m > 0} conj(h[m]); only Re h[0] counts.
 		// Without aliasing (2*ne <= N) at most one term exists; with mmax >= N/2 the sums fold m onto the ring.
 		double2 acc = make_double2(0, 0);

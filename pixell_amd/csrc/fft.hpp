@@ -29,7 +29,7 @@ struct FftLoad {
 	int mir_c = 0, par0 = 0;    // MIRROR: src index for e>=ne is (-e-c) mod n, sign -1 if ((i+par0)&1)
 	long kmax = -1;             // SPEC: keep |k| <= kmax (-1: all representable)
 	int nyq_half = 0;           // SPEC: source Nyquist bin (Ns even) is split 1/2,1/2 onto +-Ns/2
-	int mul_by_line = 0;        // PLAIN: 0 = mul indexed by e
+	int herm_fold = 0;          // HERM: 1 = SHT ring semantics (2 Re sum over m, with aliasing folds), 0 = plain c2r
 };
 
 struct FftStore {

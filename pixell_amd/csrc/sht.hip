@@ -246,7 +246,7 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map
 	FftDims d; d.n_i = nr; d.is_i = nm; d.os_i = p->ring_stride; d.n_o1 = nc; d.is_o1 = (long)nr*nm; d.os_o1 = map_cstride;
 	d.is_e = 1; d.os_e = p->pix_stride;
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
-	FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM; ld.ne = nm;
+	FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM; ld.ne = nm; ld.herm_fold = 1;
 	FftStore sf; sf.ptr = (char*)map + esz(map_dtype)*p->ring_off0; sf.dtype = map_dtype;
 	p->fc->exec(st, p->nphi, false, d, ld, sf);
 	p->prof.end(st, PXS_STAGE_RING_FFT);
