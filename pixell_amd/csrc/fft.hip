@@ -252,24 +252,32 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 
 	for (int k = threadIdx.x; k < n; k += FFT_THREADS) tw[k] = a.tw[k];
 
-	// ---- load ----
+	// ---- load ---- (4 independent global loads in flight per thread before the LDS scatter)
 	const int total = T*n;
-	for (int idx = threadIdx.x; idx < total; idx += FFT_THREADS) {
-		uint32_t t, j;
-		if (a.load_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
-		else                   { t = fdiv(idx, a.dn); j = idx - t*n; }
-		if ((int)t >= nl) continue;
-		const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
-		const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
-		double2 v;
-		if (a.mode == 0)      v = load_functor(a, il, o1, o2, j);
-		else if (a.mode == 1) v = load_functor(a, il, o1, o2, (long)j*a.n2 + sv);
-		else {
-			const long pos = sv*a.n2 + j;
-			v = a.temp[a.tile_i ? (lo*a.N + pos)*a.i_count + il : (lo*a.i_count + il)*a.N + pos];
+	for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4*FFT_THREADS) {
+		double2 v[4]; int pos[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int idx = idx0 + u*FFT_THREADS;
+			pos[u] = -1;
+			if (idx >= total) continue;
+			uint32_t t, j;
+			if (a.load_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
+			else                   { t = fdiv(idx, a.dn); j = idx - t*n; }
+			if ((int)t >= nl) continue;
+			const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
+			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
+			if (a.mode == 0)      v[u] = load_functor(a, il, o1, o2, j);
+			else if (a.mode == 1) v[u] = load_functor(a, il, o1, o2, (long)j*a.n2 + sv);
+			else {
+				const long p2 = sv*a.n2 + j;
+				v[u] = a.temp[a.tile_i ? (lo*a.N + p2)*a.i_count + il : (lo*a.i_count + il)*a.N + p2];
+			}
+			if (!a.forward && a.mode != 2) v[u].y = -v[u].y;
+			pos[u] = (int)(t*n) + a.perm[j];
 		}
-		if (!a.forward && a.mode != 2) v.y = -v.y;
-		bufA[(size_t)t*n + a.perm[j]] = v;
+#pragma unroll
+		for (int u = 0; u < 4; u++) if (pos[u] >= 0) bufA[pos[u]] = v[u];
 	}
 	__syncthreads();
 
@@ -288,22 +296,27 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 	}
 
 	// ---- store ----
-	for (int idx = threadIdx.x; idx < total; idx += FFT_THREADS) {
-		uint32_t t, j;
-		if (a.store_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
-		else                    { t = fdiv(idx, a.dn); j = idx - t*n; }
-		if ((int)t >= nl) continue;
-		const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
-		const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
-		double2 v = cur[(size_t)t*n + j];
-		if (a.mode == 1) {
-			v = cmul(v, a.bigtw[(long)j*sv]);
-			const long pos = (long)j*a.n2 + sv;
-			a.temp[a.tile_i ? (lo*a.N + pos)*a.i_count + il : (lo*a.i_count + il)*a.N + pos] = v;
-		} else {
-			if (!a.forward) v.y = -v.y;
-			if (a.mode == 0) store_functor(a, il, o1, o2, j, v);
-			else             store_functor(a, il, o1, o2, sv + (long)a.n1*j, v);
+	for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4*FFT_THREADS) {
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const int idx = idx0 + u*FFT_THREADS;
+			if (idx >= total) continue;
+			uint32_t t, j;
+			if (a.store_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
+			else                    { t = fdiv(idx, a.dn); j = idx - t*n; }
+			if ((int)t >= nl) continue;
+			const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
+			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
+			double2 v = cur[(size_t)t*n + j];
+			if (a.mode == 1) {
+				v = cmul(v, a.bigtw[(long)j*sv]);
+				const long p2 = (long)j*a.n2 + sv;
+				a.temp[a.tile_i ? (lo*a.N + p2)*a.i_count + il : (lo*a.i_count + il)*a.N + p2] = v;
+			} else {
+				if (!a.forward) v.y = -v.y;
+				if (a.mode == 0) store_functor(a, il, o1, o2, j, v);
+				else             store_functor(a, il, o1, o2, sv + (long)a.n1*j, v);
+			}
 		}
 	}
 }
@@ -416,7 +429,8 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	for (int p = 0; p < s.nfac; p++) k.pass[p] = s.pass[p];
 	k.perm = s.perm.as<int>(); k.tw = s.tw.as<double2>();
 	int bufs = s.generic ? 2 : 1;
-	long T = (FFT_LDS_PTS - s.n)/((long)bufs*s.n);
+	const long pts = s.n <= 1024 ? FFT_LDS_PTS/2 : FFT_LDS_PTS;    // 32 KiB tiles for short lines: 4-5 workgroups per CU
+	long T = (pts - s.n)/((long)bufs*s.n);
 	if (T < 1) T = 1;
 	if (T > maxlines) T = maxlines;
 	if (T > 64) T = 64;

@@ -29,8 +29,16 @@ namespace pxs {
 static constexpr double SC_BIG   = 0x1p+400;
 static constexpr double SC_SMALL = 0x1p-800;
 static constexpr int    SC_STEP  = 800;
-static constexpr int    LEG_K0   = 4;    // ring pairs per lane, spin 0
-static constexpr int    LEG_KS   = 2;    // ring pairs per lane, spin s
+// ring pairs per lane (K): defaults chosen by measurement on MI355X; PXS_K_SYN0/PXS_K_ANA0 (4|8) and
+// PXS_K_SYNS/PXS_K_ANAS (2|3|4) override them for tuning runs
+static int env_k(const char* name, int def, int lo, int hi) {
+	const char* v = getenv(name); if (!v) return def;
+	int k = atoi(v); return (k >= lo && k <= hi) ? k : def;
+}
+static int k_syn0() { static int k = env_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_ana0() { static int k = env_k("PXS_K_ANA0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_syns() { static int k = env_k("PXS_K_SYNS", 2, 2, 4); return k; }
+static int k_anas() { static int k = env_k("PXS_K_ANAS", 2, 2, 4); return k; }
 
 struct double4_t { double a, b, c, d; };
 
@@ -172,19 +180,33 @@ __global__ __launch_bounds__(256) void reduce_partials(const double* part, doubl
 	mom[i] = s;
 }
 
-// a slot (64 consecutive ring pairs of a wave) is 'polar' when all its rings have cos^2 > 1/2: it then runs the recurrences in the
-// variable -sin^2(theta) (resp. -2 sin^2(theta/2)), which keeps full relative precision near the poles
-__device__ __forceinline__ bool leg_slot_polar(const LegK& a, int wv, int K, int s) {
-	const int last = min((wv*K + s + 1)*64, a.npairs) - 1;   // most equatorial pair of the slot (wave-uniform)
-	if (last < (wv*K + s)*64) return false;
+// A wave is 'polar' when all its rings have cos^2 > 1/2: it then runs the recurrences in the variable
+// -sin^2(theta) (spin 0) resp. -2 sin^2(theta/2) (spin s), with the constant term of the step
+// coefficient adjusted accordingly (table columns c,d).  This keeps full relative precision near the
+// poles, where x = cos(theta) rounds away the information about theta.
+__device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
+	const int last = min((wv+1)*K*64, a.npairs) - 1;   // most equatorial pair of the wave (wave-uniform)
 	const double c = a.cth[last];
 	return c*c > 0.5;
 }
 
-// ---------------------------------------------------------------------------------
-// spin-0 kernels
-// ---------------------------------------------------------------------------------
+// make a VGPR copy of a wave-uniform value once, so that v_fma_f64 can take it as the addend next to
+// an SGPR multiplicand (gfx950 allows one scalar source per VALU op; without this the compiler
+// re-materialises the constant for every use with two v_mov_b32)
+#ifdef PXS_HOST_SIM
+#define PXS_VCOPY(dst, src) double dst = (src)
+#else
+#define PXS_VCOPY(dst, src) double dst; asm("v_mov_b64 %0, %1" : "=v"(dst) : "s"(src))
+#endif
+
 #define LEG_RED_STRIDE 66
+
+// one recurrence step with rescaling (ramp phases)
+#define S0_STEP_RESCALE(cfa, cfb) \
+	_Pragma("unroll") for (int s = 0; s < K; s++) { \
+		const double t = fma(fma(cfa, csq[s], cfb), lam2[s], lam1[s]); \
+		lam1[s] = lam2[s]; lam2[s] = t; \
+		if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; } }
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 {
@@ -192,20 +214,19 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
-	const double* __restrict__ at = a.almt + 4*row0;
+	const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
 	double x[K], csq[K], lam1[K], lam2[K], p1r[K], p1i[K], p2r[K], p2i[K];
 	int sc[K], rn[K], rs[K];
 	bool alive_any = false;
-	bool polar[K];
+	const bool polar = leg_wave_polar(a, wv, K);
 #pragma unroll
 	for (int s = 0; s < K; s++) {
-		polar[s] = leg_slot_polar(a, wv, K, s);
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
 		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
 		x[s] = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
-		csq[s] = polar[s] ? -sth*sth : x[s]*x[s];
+		csq[s] = polar ? -sth*sth : x[s]*x[s];
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
 		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
@@ -220,13 +241,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
 			if (__any(act)) break;
-			const double4_t cf = coef[k];
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
-				lam1[s] = lam2[s]; lam2[s] = t;
-				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
-			}
+			const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
+			S0_STEP_RESCALE(cf.a, cb)
 			k++;
 		}
 		// phase B: gated accumulation until every lane is at scale 0
@@ -235,29 +251,43 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 			if (!__any(pend)) break;
-			const double4_t cf = coef[k];
-			const double er = at[4*k], ei = at[4*k+1], orr = at[4*k+2], oi = at[4*k+3];
+			const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
+			const double4_t al = at[k];
 #pragma unroll
 			for (int s = 0; s < K; s++) {
 				const double g = (sc[s] == 0) ? lam2[s] : 0.0;
-				p1r[s] = fma(g, er, p1r[s]); p1i[s] = fma(g, ei, p1i[s]);
-				p2r[s] = fma(g, orr, p2r[s]); p2i[s] = fma(g, oi, p2i[s]);
-				const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
-				lam1[s] = lam2[s]; lam2[s] = t;
-				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
+				p1r[s] = fma(g, al.a, p1r[s]); p1i[s] = fma(g, al.b, p1i[s]);
+				p2r[s] = fma(g, al.c, p2r[s]); p2i[s] = fma(g, al.d, p2i[s]);
 			}
+			S0_STEP_RESCALE(cf.a, cb)
 			k++;
 		}
-		// phase C: fast loop
-		for (; k < nk; k++) {
-			const double4_t cf = coef[k];
-			const double er = at[4*k], ei = at[4*k+1], orr = at[4*k+2], oi = at[4*k+3];
+		// phase C: fast loop, two steps per iteration (lam1/lam2 swap roles, no register moves),
+		// coefficients of the next iteration prefetched with scalar loads (tables are padded by 2 rows)
+		double4_t c0 = coef[k], c1 = coef[k+1], a0 = at[k], a1 = at[k+1];
+		for (; k + 1 < nk; k += 2) {
+			const double4_t n0 = coef[k+2], n1 = coef[k+3], m0 = at[k+2], m1 = at[k+3];
+			PXS_VCOPY(vb0, polar ? c0.c : c0.b);
+			PXS_VCOPY(vb1, polar ? c1.c : c1.b);
 #pragma unroll
 			for (int s = 0; s < K; s++) {
-				p1r[s] = fma(lam2[s], er, p1r[s]); p1i[s] = fma(lam2[s], ei, p1i[s]);
-				p2r[s] = fma(lam2[s], orr, p2r[s]); p2i[s] = fma(lam2[s], oi, p2i[s]);
-				const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
-				lam1[s] = lam2[s]; lam2[s] = t;
+				p1r[s] = fma(lam2[s], a0.a, p1r[s]); p1i[s] = fma(lam2[s], a0.b, p1i[s]);
+				p2r[s] = fma(lam2[s], a0.c, p2r[s]); p2i[s] = fma(lam2[s], a0.d, p2i[s]);
+				lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]);
+			}
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				p1r[s] = fma(lam1[s], a1.a, p1r[s]); p1i[s] = fma(lam1[s], a1.b, p1i[s]);
+				p2r[s] = fma(lam1[s], a1.c, p2r[s]); p2i[s] = fma(lam1[s], a1.d, p2i[s]);
+				lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]);
+			}
+			c0 = n0; c1 = n1; a0 = m0; a1 = m1;
+		}
+		if (k < nk) {
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				p1r[s] = fma(lam2[s], a0.a, p1r[s]); p1i[s] = fma(lam2[s], a0.b, p1i[s]);
+				p2r[s] = fma(lam2[s], a0.c, p2r[s]); p2i[s] = fma(lam2[s], a0.d, p2i[s]);
 			}
 		}
 	}
@@ -269,20 +299,77 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 	}
 }
 
-// flush nrow4 (<=4) k-steps of per-lane partial sums held in the LDS tile
+// Workgroups are ONE wave: lanes run in lockstep and a wave's LDS operations execute in order, so
+// cross-lane visibility of the LDS tile only needs the LDS counter drained -- not an s_barrier, whose
+// compiler-inserted s_waitcnt vmcnt(0) would also wait for the (slow, fire-and-forget) global store
+// of the previous flush.
+#ifdef PXS_HOST_SIM
+#define PXS_WAVE_LDS_SYNC() __syncthreads()
+#else
+#define PXS_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+#ifdef PXS_HOST_SIM
+// simulator path: transpose the per-lane partial sums through a 16x66 LDS tile
 __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk) {
-	__syncthreads();
+	PXS_WAVE_LDS_SYNC();
 	const int rowi = lane >> 2, part = lane & 3;
+	double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+	if (rowi < 4*nkk) {
+		const double* r = red + rowi*LEG_RED_STRIDE + part;
+		for (int i = 0; i < 16; i += 4) { s0 += r[i*4]; s1 += r[(i+1)*4]; s2 += r[(i+2)*4]; s3 += r[(i+3)*4]; }
+	}
+	double sum = (s0 + s1) + (s2 + s3);
+	sum += __shfl_xor(sum, 1);
+	sum += __shfl_xor(sum, 2);
+	if (part == 0 && rowi < 4*nkk) dst[rowi] = sum;
+	PXS_WAVE_LDS_SYNC();
+}
+#define LEG_RED_PUT(kk, t0, t1, t2, t3) \
+	red[((kk)*4+0)*LEG_RED_STRIDE + lane] = t0; red[((kk)*4+1)*LEG_RED_STRIDE + lane] = t1; \
+	red[((kk)*4+2)*LEG_RED_STRIDE + lane] = t2; red[((kk)*4+3)*LEG_RED_STRIDE + lane] = t3;
+#else
+// MI355X path: reduce-scatter across lanes with the gfx950 lane-swap instructions.  Stage 1
+// (v_permlane32_swap on the pairs (t0,t1), (t2,t3)) leaves sum(t0|t2) in lanes 0-31 and sum(t1|t3) in
+// lanes 32-63; stage 2 (v_permlane16_swap) leaves ONE value per lane, already summed over the 4 lanes
+// {l, l+16, l+32, l+48}: rows 0..3 of the wave hold t0, t2, t1, t3.  One ds_write_b64 per step (4x fewer
+// LDS bytes than transposing all partial sums; the LDS write port was the limiter), and every 4 steps
+// 4 lanes per output add the remaining 16 partials.  (Tried and rejected: v_mfma_f64_4x4x4 with B = 1 as
+// a lane adder -- layout in tools/mfma_probe.hip -- correct, but 8 dependent f64 MFMAs per step made the
+// kernel matrix-pipe bound.)
+__device__ __forceinline__ void leg_swap32(double& a, double& b) {
+	const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+	const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+	const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+	a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ void leg_swap16(double& a, double& b) {
+	const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+	const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+	const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+	a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk) {
+	PXS_WAVE_LDS_SYNC();
+	const int rowi = lane >> 2, part = lane & 3;
+	const int kk = rowi >> 2, c = rowi & 3;
+	const int block = (c == 1) ? 2 : (c == 2) ? 1 : c;          // wave rows hold t0, t2, t1, t3
 	double sum = 0;
 	if (rowi < 4*nkk) {
-#pragma unroll
-		for (int i = 0; i < 16; i++) sum += red[rowi*LEG_RED_STRIDE + i*4 + part];
+		const double* r = red + kk*64 + block*16 + part*4;
+		sum = (r[0] + r[1]) + (r[2] + r[3]);
 	}
 	sum += __shfl_xor(sum, 1);
 	sum += __shfl_xor(sum, 2);
 	if (part == 0 && rowi < 4*nkk) dst[rowi] = sum;
-	__syncthreads();
+	PXS_WAVE_LDS_SYNC();
 }
+#define LEG_RED_PUT(kk, t0, t1, t2, t3) { \
+	double a_ = t0, b_ = t1, c_ = t2, d_ = t3; \
+	leg_swap32(a_, b_); leg_swap32(c_, d_); \
+	double u_ = a_ + b_, v_ = c_ + d_; \
+	leg_swap16(u_, v_); \
+	red[(kk)*64 + lane] = u_ + v_; }
+#endif
 
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
@@ -296,16 +383,15 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
 	int sc[K];
 	bool alive_any = false;
-	bool polar[K];
+	const bool polar = leg_wave_polar(a, wv, K);
 #pragma unroll
 	for (int s = 0; s < K; s++) {
-		polar[s] = leg_slot_polar(a, wv, K, s);
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
 		const int rn = valid ? a.ring_n[p] : -1, rs = valid ? a.ring_s[p] : -1;
 		const double x = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
-		csq[s] = polar[s] ? -sth*sth : x*x;
+		csq[s] = polar ? -sth*sth : x*x;
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
 		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
@@ -322,13 +408,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 #pragma unroll
 		for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
 		if (__any(act)) break;
-		const double4_t cf = coef[k];
-#pragma unroll
-		for (int s = 0; s < K; s++) {
-			const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
-			lam1[s] = lam2[s]; lam2[s] = t;
-			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
-		}
+		const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
+		S0_STEP_RESCALE(cf.a, cb)
 		k++;
 	}
 	int kk = 0, kbase = k;
@@ -337,34 +418,54 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 #pragma unroll
 		for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 		if (!__any(pend)) break;
-		const double4_t cf = coef[k];
+		const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
 		for (int s = 0; s < K; s++) {
 			const double g = (sc[s] == 0) ? lam2[s] : 0.0;
 			t0 = fma(g, d1r[s], t0); t1 = fma(g, d1i[s], t1); t2 = fma(g, d2r[s], t2); t3 = fma(g, d2i[s], t3);
-			const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
-			lam1[s] = lam2[s]; lam2[s] = t;
-			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; }
 		}
-		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
-		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
+		S0_STEP_RESCALE(cf.a, cb)
+		LEG_RED_PUT(kk, t0, t1, t2, t3)
 		k++; kk++;
 		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k; }
 	}
-	for (; k < nk; k++) {
-		const double4_t cf = coef[k];
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+	// align to a flush boundary with single steps, then run 4 steps per flush (two unrolled pairs)
+	double4_t c0 = coef[k], c1 = coef[k+1];
+	for (; k + 1 < nk; k += 2) {
+		const double4_t n0 = coef[k+2], n1 = coef[k+3];
+		PXS_VCOPY(vb0, polar ? c0.c : c0.b);
+		PXS_VCOPY(vb1, polar ? c1.c : c1.b);
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
 #pragma unroll
 		for (int s = 0; s < K; s++) {
 			t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3);
-			const double t = fma(fma(cf.a, csq[s], polar[s] ? cf.c : cf.b), lam2[s], lam1[s]);
-			lam1[s] = lam2[s]; lam2[s] = t;
+			lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]);
 		}
-		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
-		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
+#pragma unroll
+		for (int s = 0; s < K; s++) {
+			u0 = fma(lam1[s], d1r[s], u0); u1 = fma(lam1[s], d1i[s], u1); u2 = fma(lam1[s], d2r[s], u2); u3 = fma(lam1[s], d2i[s], u3);
+			lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]);
+		}
+		c0 = n0; c1 = n1;
+		if (kk == 3) {   // keep pairs within one flush group
+			LEG_RED_PUT(3, t0, t1, t2, t3)
+			leg_flush(red, pout + 4*kbase, lane, 4); kbase = k+1;
+			LEG_RED_PUT(0, u0, u1, u2, u3)
+			kk = 1;
+		} else {
+			LEG_RED_PUT(kk, t0, t1, t2, t3)
+			LEG_RED_PUT(kk+1, u0, u1, u2, u3)
+			kk += 2;
+			if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+2; }
+		}
+	}
+	if (k < nk) {
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+		for (int s = 0; s < K; s++) { t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3); }
+		LEG_RED_PUT(kk, t0, t1, t2, t3)
 		kk++;
-		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+1; }
 	}
 	if (kk > 0) leg_flush(red, pout + 4*kbase, lane, kk);
 }
@@ -372,25 +473,25 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 // ---------------------------------------------------------------------------------
 // spin-s kernels.  rows l = l0..lmax.  chains G+ (spin +s) and G- (spin -s) of the NORTH ring;
 // south ring: F+_S = (-1)^(l+m) F-_N, F-_S = (-1)^(l+m) F+_N.
+// G_{l+1} = (a x +- b) G_l - G_{l-1}; in polar waves x -> u = -2 sin^2(theta/2), +-b -> a +- b.
 // ---------------------------------------------------------------------------------
 template<int K> struct SpinState {
 	double x[K], gp1[K], gp2[K], gm1[K], gm2[K];
 	int scp[K], scm[K];
 };
 
-template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv, int lane, int m, SpinState<K>& S, int* rn, int* rs, bool* polar) {
+template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv, int lane, int m, SpinState<K>& S, int* rn, int* rs, bool polar) {
 	const int s_ = a.spin;
 	bool alive_any = false;
 #pragma unroll
 	for (int s = 0; s < K; s++) {
-		polar[s] = leg_slot_polar(a, wv, K, s);
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
 		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
 		const double cth = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
 		const double shh = valid ? a.sh2[p] : 0.0;
-		S.x[s] = polar[s] ? -2.0*shh*shh : cth;
+		S.x[s] = polar ? -2.0*shh*shh : cth;
 		// libsharp's m-limit generalised to spin: rings with m beyond it carry nothing up to lmax
 		const double t1 = a.lmax*sth + a.ofs;
 		const double b = -2.0*s_*fabs(cth);
@@ -400,7 +501,7 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 		const bool alive = valid && ((double)m <= mlim + 0.5);
 		S.gp1[s] = S.gm1[s] = 0; S.gp2[s] = S.gm2[s] = 0; S.scp[s] = S.scm[s] = 0;
 		if (alive) {
-			const double sh = a.sh2[p], ch = a.ch2[p];
+			const double sh = shh, ch = a.ch2[p];
 			double m1, m2; int e1, e2;
 			if (m >= s_) {
 				pow_scaled(sh, m + s_, m1, e1); pow_scaled(ch, m - s_, m2, e2);
@@ -420,15 +521,15 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 	return alive_any;
 }
 
-template<int K> __device__ __forceinline__ void spin_step(SpinState<K>& S, int s, double ca, double c1, double c2, bool rescale) {
-	const double tp = fma(ca, S.x[s], c1), tm = fma(ca, S.x[s], c2);
-	const double np_ = fma(tp, S.gp2[s], -S.gp1[s]), nm_ = fma(tm, S.gm2[s], -S.gm1[s]);
+// ramp-phase step with rescaling
+template<int K> __device__ __forceinline__ void spin_step_rescale(SpinState<K>& S, int s, double ca, double c1, double c2) {
+	const double ax = ca*S.x[s];
+	const double np_ = fma(ax + c1, S.gp2[s], -S.gp1[s]), nm_ = fma(ax + c2, S.gm2[s], -S.gm1[s]);
 	S.gp1[s] = S.gp2[s]; S.gp2[s] = np_; S.gm1[s] = S.gm2[s]; S.gm2[s] = nm_;
-	if (rescale) {
-		if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
-		if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
-	}
+	if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
+	if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
 }
+#define SPIN_COEF(cf) const double ca = cf.a, c1 = polar ? cf.c : cf.b, c2 = polar ? cf.d : -cf.b
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
@@ -441,12 +542,12 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	double pnr[K], pni[K], mnr[K], mni[K], psr[K], psi[K], msr[K], msi[K];
 #pragma unroll
 	for (int s = 0; s < K; s++) pnr[s] = pni[s] = mnr[s] = mni[s] = psr[s] = psi[s] = msr[s] = msi[s] = 0;
-	bool polar[K];
+	const bool polar = leg_wave_polar(a, wv, K);
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
 	if (nl > 0 && __any(alive_any)) {
 		const long row0 = a.row[m];
 		const double4_t* __restrict__ coef = a.coef + row0;
-		const double* __restrict__ at = a.almt + 4*row0;
+		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
 		double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m)
 		int j = 0;
 		while (j < nl) {
@@ -454,9 +555,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
 			if (__any(act)) break;
-			const double4_t cf = coef[j];
+			const double4_t cf = coef[j]; SPIN_COEF(cf);
 #pragma unroll
-			for (int s = 0; s < K; s++) spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, true);
+			for (int s = 0; s < K; s++) spin_step_rescale<K>(S, s, ca, c1, c2);
 			j++; sgn = -sgn;
 		}
 		while (j < nl) {
@@ -464,34 +565,68 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 #pragma unroll
 			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 			if (!__any(pend)) break;
-			const double4_t cf = coef[j];
-			const double apr = at[4*j], api = at[4*j+1], amr = at[4*j+2], ami = at[4*j+3];
+			const double4_t cf = coef[j]; SPIN_COEF(cf);
+			const double4_t al = at[j];
 #pragma unroll
 			for (int s = 0; s < K; s++) {
 				const double gp = (S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (S.scm[s] == 0) ? S.gm2[s] : 0.0;
-				pnr[s] = fma(gp, apr, pnr[s]); pni[s] = fma(gp, api, pni[s]);
-				mnr[s] = fma(gm, amr, mnr[s]); mni[s] = fma(gm, ami, mni[s]);
-				psr[s] = fma(gm, sgn*apr, psr[s]); psi[s] = fma(gm, sgn*api, psi[s]);
-				msr[s] = fma(gp, sgn*amr, msr[s]); msi[s] = fma(gp, sgn*ami, msi[s]);
-				spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, true);
+				pnr[s] = fma(gp, al.a, pnr[s]); pni[s] = fma(gp, al.b, pni[s]);
+				mnr[s] = fma(gm, al.c, mnr[s]); mni[s] = fma(gm, al.d, mni[s]);
+				psr[s] = fma(gm, sgn*al.a, psr[s]); psi[s] = fma(gm, sgn*al.b, psi[s]);
+				msr[s] = fma(gp, sgn*al.c, msr[s]); msi[s] = fma(gp, sgn*al.d, msi[s]);
+				spin_step_rescale<K>(S, s, ca, c1, c2);
 			}
 			j++; sgn = -sgn;
 		}
-		for (; j < nl; j++) {
-			const double4_t cf = coef[j];
-			const double apr = at[4*j], api = at[4*j+1], amr = at[4*j+2], ami = at[4*j+3];
-			const double sapr = sgn*apr, sapi = sgn*api, samr = sgn*amr, sami = sgn*ami;
+		// fast loop: two l per iteration (signs explicit, G1/G2 swap roles), next coefficients prefetched.
+		// The south-ring accumulators take sgn * a: fold the overall sign of the pair into the final result.
+		const double sg0 = sgn;            // sign of the first (even-offset) step; the second has -sg0
+		double qsr[K], qsi[K], nsr[K], nsi[K];   // accumulate with sign +1 on even steps, -1 on odd steps, multiply by sg0 at the end
+#pragma unroll
+		for (int s = 0; s < K; s++) qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
+		double4_t f0 = coef[j], f1 = coef[j+1], a0 = at[j], a1 = at[j+1];
+		for (; j + 1 < nl; j += 2) {
+			const double4_t n0 = coef[j+2], n1 = coef[j+3], m0 = at[j+2], m1 = at[j+3];
+			{
+				const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b;
+#pragma unroll
+				for (int s = 0; s < K; s++) {
+					const double gp = S.gp2[s], gm = S.gm2[s];
+					pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]);
+					mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]);
+					qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]);
+					nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]);
+					const double ax = ca*S.x[s];
+					S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]);
+				}
+			}
+			{
+				const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b;
+#pragma unroll
+				for (int s = 0; s < K; s++) {
+					const double gp = S.gp1[s], gm = S.gm1[s];
+					pnr[s] = fma(gp, a1.a, pnr[s]); pni[s] = fma(gp, a1.b, pni[s]);
+					mnr[s] = fma(gm, a1.c, mnr[s]); mni[s] = fma(gm, a1.d, mni[s]);
+					qsr[s] = fma(-gm, a1.a, qsr[s]); qsi[s] = fma(-gm, a1.b, qsi[s]);
+					nsr[s] = fma(-gp, a1.c, nsr[s]); nsi[s] = fma(-gp, a1.d, nsi[s]);
+					const double ax = ca*S.x[s];
+					S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]);
+				}
+			}
+			f0 = n0; f1 = n1; a0 = m0; a1 = m1;
+		}
+		if (j < nl) {
 #pragma unroll
 			for (int s = 0; s < K; s++) {
 				const double gp = S.gp2[s], gm = S.gm2[s];
-				pnr[s] = fma(gp, apr, pnr[s]); pni[s] = fma(gp, api, pni[s]);
-				mnr[s] = fma(gm, amr, mnr[s]); mni[s] = fma(gm, ami, mni[s]);
-				psr[s] = fma(gm, sapr, psr[s]); psi[s] = fma(gm, sapi, psi[s]);
-				msr[s] = fma(gp, samr, msr[s]); msi[s] = fma(gp, sami, msi[s]);
-				spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, false);
+				pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]);
+				mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]);
+				qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]);
+				nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]);
 			}
-			sgn = -sgn;
 		}
+#pragma unroll
+		for (int s = 0; s < K; s++) { psr[s] = fma(sg0, qsr[s], psr[s]); psi[s] = fma(sg0, qsi[s], psi[s]); msr[s] = fma(sg0, nsr[s], msr[s]); msi[s] = fma(sg0, nsi[s], msi[s]); }
 	}
 	// Q = (P+M)/2, U = -i (P-M)/2
 #pragma unroll
@@ -520,7 +655,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	const double2* __restrict__ inq = a.leg + (long)m*a.nring;
 	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.nring;
 	SpinState<K> S; int rn[K], rs[K];
-	bool polar[K];
+	const bool polar = leg_wave_polar(a, wv, K);
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
 	if (!__any(alive_any)) return;
 	// T+ = Q + iU, T- = Q - iU for north and south rings
@@ -539,37 +674,94 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 #pragma unroll
 		for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
 		if (__any(act)) break;
-		const double4_t cf = coef[j];
+		const double4_t cf = coef[j]; SPIN_COEF(cf);
 #pragma unroll
-		for (int s = 0; s < K; s++) spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, true);
+		for (int s = 0; s < K; s++) spin_step_rescale<K>(S, s, ca, c1, c2);
 		j++; sgn = -sgn;
 	}
 	int kk = 0, jbase = j;
-	bool fast = false;
-	for (; j < nl; j++) {
-		if (!fast) {
-			bool pend = false;
+	while (j < nl) {
+		bool pend = false;
 #pragma unroll
-			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
-			fast = !__any(pend);
-		}
-		const double4_t cf = coef[j];
+		for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
+		if (!__any(pend)) break;
+		const double4_t cf = coef[j]; SPIN_COEF(cf);
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
 		for (int s = 0; s < K; s++) {
-			const double gp = (fast || S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (fast || S.scm[s] == 0) ? S.gm2[s] : 0.0;
+			const double gp = (S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (S.scm[s] == 0) ? S.gm2[s] : 0.0;
 			const double sgp = sgn*gp, sgm = sgn*gm;
 			// mu+ = G+ T+_N + sgn G- T+_S ;  mu- = G- T-_N + sgn G+ T-_S
 			t0 = fma(gp, tpnr[s], t0); t0 = fma(sgm, tpsr[s], t0);
 			t1 = fma(gp, tpni[s], t1); t1 = fma(sgm, tpsi[s], t1);
 			t2 = fma(gm, tmnr[s], t2); t2 = fma(sgp, tmsr[s], t2);
 			t3 = fma(gm, tmni[s], t3); t3 = fma(sgp, tmsi[s], t3);
-			spin_step<K>(S, s, cf.a, polar[s] ? cf.c : cf.b, polar[s] ? cf.d : -cf.b, !fast);
+			spin_step_rescale<K>(S, s, ca, c1, c2);
 		}
-		red[(kk*4+0)*LEG_RED_STRIDE + lane] = t0; red[(kk*4+1)*LEG_RED_STRIDE + lane] = t1;
-		red[(kk*4+2)*LEG_RED_STRIDE + lane] = t2; red[(kk*4+3)*LEG_RED_STRIDE + lane] = t3;
-		kk++; sgn = -sgn;
-		if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+1; }
+		LEG_RED_PUT(kk, t0, t1, t2, t3)
+		kk++; j++; sgn = -sgn;
+		if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j; }
+	}
+	// fast loop: fold the sign of the south rings into the data once (even steps +sg0, odd steps -sg0)
+	if (sgn < 0) {
+#pragma unroll
+		for (int s = 0; s < K; s++) { tpsr[s] = -tpsr[s]; tpsi[s] = -tpsi[s]; tmsr[s] = -tmsr[s]; tmsi[s] = -tmsi[s]; }
+	}
+	double4_t f0 = coef[j], f1 = coef[j+1];
+	for (; j + 1 < nl; j += 2) {
+		const double4_t n0 = coef[j+2], n1 = coef[j+3];
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+		{
+			const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b;
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				const double gp = S.gp2[s], gm = S.gm2[s];
+				t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0);
+				t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1);
+				t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2);
+				t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3);
+				const double ax = ca*S.x[s];
+				S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]);
+			}
+		}
+		{
+			const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b;
+#pragma unroll
+			for (int s = 0; s < K; s++) {
+				const double gp = S.gp1[s], gm = S.gm1[s];
+				u0 = fma(gp, tpnr[s], u0); u0 = fma(-gm, tpsr[s], u0);
+				u1 = fma(gp, tpni[s], u1); u1 = fma(-gm, tpsi[s], u1);
+				u2 = fma(gm, tmnr[s], u2); u2 = fma(-gp, tmsr[s], u2);
+				u3 = fma(gm, tmni[s], u3); u3 = fma(-gp, tmsi[s], u3);
+				const double ax = ca*S.x[s];
+				S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]);
+			}
+		}
+		f0 = n0; f1 = n1;
+		if (kk == 3) {
+			LEG_RED_PUT(3, t0, t1, t2, t3)
+			leg_flush(red, pout + 4*jbase, lane, 4); jbase = j+1;
+			LEG_RED_PUT(0, u0, u1, u2, u3)
+			kk = 1;
+		} else {
+			LEG_RED_PUT(kk, t0, t1, t2, t3)
+			LEG_RED_PUT(kk+1, u0, u1, u2, u3)
+			kk += 2;
+			if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+2; }
+		}
+	}
+	if (j < nl) {
+		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+		for (int s = 0; s < K; s++) {
+			const double gp = S.gp2[s], gm = S.gm2[s];
+			t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0);
+			t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1);
+			t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2);
+			t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3);
+		}
+		LEG_RED_PUT(kk, t0, t1, t2, t3)
+		kk++;
 	}
 	if (kk > 0) leg_flush(red, pout + 4*jbase, lane, kk);
 }
@@ -644,7 +836,7 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 		row[m+1] = row[m] + n;
 	}
 	nrows = row[mmax+1];
-	std::vector<double4_t> coef(std::max<long>(nrows, 1)); std::vector<double> alpha(std::max<long>(nrows, 1));
+	std::vector<double4_t> coef(nrows + 4, double4_t{0, 0, 0, 0}); std::vector<double> alpha(nrows + 4, 0.0);   // +4: the fast loops prefetch up to 3 rows ahead
 	typedef long double LDb;
 	const LDb PIl = 3.141592653589793238462643383279502884L;
 	if (spin == 0) {
@@ -726,22 +918,27 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
                    double2* leg, int deriv1, LegProfile* prof)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
-	wk.almt.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
+	wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
 	const int nm = tb.mmax+1;
 	if (tb.spin == 0) {
 		const int nkmax = tb.lmax/2 + 1;
 		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
-		LegK a = make_legk(rs, tb, wk, leg, LEG_K0);
+		const int K = k_syn0();
+		LegK a = make_legk(rs, tb, wk, leg, K);
 		if (prof) prof->begin(st, 0);
-		hipLaunchKernelGGL(leg_syn_s0<LEG_K0>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		else        hipLaunchKernelGGL(leg_syn_s0<4>, dim3(a.nwave, nm), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
 	} else {
 		const int nlmax = tb.lmax + 1;
 		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
-		LegK a = make_legk(rs, tb, wk, leg, LEG_KS);
+		const int K = k_syns();
+		LegK a = make_legk(rs, tb, wk, leg, K);
 		if (prof) prof->begin(st, 0);
-		hipLaunchKernelGGL(leg_syn_spin<LEG_KS>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		else             hipLaunchKernelGGL(leg_syn_spin<2>, dim3(a.nwave, nm), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
 	}
 	PXS_HIP(hipGetLastError());
@@ -752,7 +949,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
                   int deriv1, LegProfile* prof)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
-	const int K = tb.spin == 0 ? LEG_K0 : LEG_KS;
+	const int K = tb.spin == 0 ? k_ana0() : k_anas();
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = 4*std::max<long>(tb.nrows, 1);
@@ -777,8 +974,15 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows;
 		PXS_HIP(hipMemsetAsync(wk.part.p, 0, sizeof(double)*4*rows*nwave, st));
 		if (prof) prof->begin(st, 1);
-		if (tb.spin == 0) hipLaunchKernelGGL(leg_ana_s0<LEG_K0>, dim3(a.nwave, m1-m0), dim3(64), sh, st, a);
-		else              hipLaunchKernelGGL(leg_ana_spin<LEG_KS>, dim3(a.nwave, m1-m0), dim3(64), sh, st, a);
+		const dim3 grid(a.nwave, m1-m0);
+		if (tb.spin == 0) {
+			if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
+			else        hipLaunchKernelGGL(leg_ana_s0<4>, grid, dim3(64), sh, st, a);
+		} else {
+			if (K == 4)      hipLaunchKernelGGL(leg_ana_spin<4>, grid, dim3(64), sh, st, a);
+			else if (K == 3) hipLaunchKernelGGL(leg_ana_spin<3>, grid, dim3(64), sh, st, a);
+			else             hipLaunchKernelGGL(leg_ana_spin<2>, grid, dim3(64), sh, st, a);
+		}
 		if (prof) prof->end(st, 1);
 		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*rows+255)/256)), dim3(256), 0, st, (const double*)wk.part.p,
 			(double*)wk.mom.p + 4*tb.row[m0], 4*rows, a.nwave);

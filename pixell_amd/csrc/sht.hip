@@ -135,7 +135,8 @@ struct pxs_plan {
 	DevBuf leg, leg2, hbuf, phase;
 	// analysis resampling (grid plans)
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
-	DevBuf ph_shift, sigma, wcc, b1, b2;
+	DevBuf ph_shift, ph_up, sigma, wcc, b1, b2;
+	bool syn_via_cc = false;
 	FftContext* fc = nullptr;
 	LegProfile prof;
 
@@ -185,6 +186,9 @@ void setup_resampling(pxs_plan* p) {
 	std::vector<double2> ps(p->N/2 + 1);
 	for (long k = 0; k <= p->N/2; k++) { LDb a = (LDb)k*th0; ps[k] = make_double2((double)cosl(a), (double)(-sinl(a))); }
 	p->ph_shift = upload(ps);
+	{ std::vector<double2> pu(ps.size()); for (size_t k = 0; k < ps.size(); k++) pu[k] = make_double2(ps[k].x, -ps[k].y); p->ph_up = upload(pu); }
+	// synthesis: Legendre on the minimal CC grid + exact Fourier upsampling in theta pays once the map has clearly more rings
+	{ const char* e = getenv("PXS_SYN_VIA_CC"); p->syn_via_cc = e ? atoi(e) != 0 : (p->nring > p->ncc + p->ncc/4); }
 	// sigma_i = sum_{|q|<=Ks} s_q e^{i q theta_i} on the M grid, via one device FFT
 	const long Ks = lmax + p->N/2;
 	PXS_REQUIRE(2*Ks < p->M, "internal: fine grid too small");
@@ -288,6 +292,28 @@ void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2*
 	p->prof.end(st, PXS_STAGE_RESAMPLE);
 }
 
+// band-limited leg on the CC grid [c][m][ncc] -> leg on the map's rings [c][m][nring] (exact for degree <= lmax)
+void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double2* leg_out, int nc, int spin) {
+	const int nm = p->mmax+1, nr = p->nring;
+	p->b1.ensure(sizeof(double2)*(size_t)nm*std::max(p->N, p->Ncc));
+	p->prof.begin(st, PXS_STAGE_RESAMPLE);
+	for (int c = 0; c < nc; c++) {
+		{	// mirror-extend the CC rings to the full circle, forward FFT_Ncc
+			FftDims d; d.n_i = nm; d.is_i = p->ncc; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = leg_cc + (size_t)c*nm*p->ncc; ld.mode = LD_MIRROR; ld.ne = p->ncc; ld.mir_c = 0; ld.par0 = spin & 1;
+			FftStore sf; sf.ptr = p->b1.p;
+			p->fc->exec(st, p->Ncc, true, d, ld, sf);
+		}
+		{	// keep |k| <= lmax, shift to the target grid's theta0, backward FFT_N, keep the real rings
+			FftDims d; d.n_i = nm; d.is_i = p->Ncc; d.os_i = nr; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->Ncc; ld.kmax = p->lmax; ld.mul = p->ph_up.as<double2>();
+			FftStore sf; sf.ptr = leg_out + (size_t)c*nm*nr; sf.ne = nr; sf.scale = 1.0/(double)p->Ncc;
+			p->fc->exec(st, p->N, false, d, ld, sf);
+		}
+	}
+	p->prof.end(st, PXS_STAGE_RESAMPLE);
+}
+
 } // namespace
 
 #define PXS_TRY try {
@@ -366,7 +392,7 @@ void pxs_plan_destroy(pxs_plan* plan) { delete plan; }
 
 int pxs_plan_info(const pxs_plan* p, int* nsyn, int* nana, int64_t* scratch) {
 	if (!p) return PXS_ERR_ARG;
-	if (nsyn) *nsyn = p->nring;
+	if (nsyn) *nsyn = (p->syn_via_cc && p->ncc > 0) ? p->ncc : p->nring;
 	if (nana) *nana = p->ncc > 0 ? p->ncc : p->nring;
 	if (scratch) *scratch = (int64_t)(p->leg.bytes + p->leg2.bytes + p->hbuf.bytes + p->b1.bytes + p->b2.bytes + p->wk.almt.bytes + p->wk.part.bytes + p->wk.mom.bytes);
 	return 0;
@@ -397,7 +423,13 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 	LegTables& tb = p->table(spin);
 	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*p->nring);
 	if (!adjoint) {
-		leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
+			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*p->ncc);
+			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+			resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin);
+		} else {
+			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+		}
 		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm);
 	} else {
 		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0);

@@ -1,0 +1,44 @@
+"""Multi-GPU use of the path: independent maps shard across ranks (one process per GPU), each rank
+runs the single-GPU transforms on its slice, and the resulting alm are all-gathered once over RCCL
+(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).  No collective sits on the
+data path of a transform."""
+import numpy as np
+
+def shard_range(n, rank, world):
+	"""contiguous slice [i0, i1) of n independent maps owned by `rank`; sizes differ by at most one"""
+	base, rem = divmod(n, world)
+	i0 = rank*base+min(rank, rem)
+	return i0, i0+base+(1 if rank < rem else 0)
+
+def shard_sizes(n, world):
+	return [shard_range(n, r, world)[1]-shard_range(n, r, world)[0] for r in range(world)]
+
+def allgather_alm(local_alm, nmaps, group=None, async_op=False):
+	"""local_alm: tensor [n_local, ncomp, nelem] (complex) on this rank -> [nmaps, ncomp, nelem] on every rank.
+	Uneven shards are padded to the largest shard so that ONE all_gather_into_tensor moves everything."""
+	import torch, torch.distributed as dist
+	world = dist.get_world_size(group); rank = dist.get_rank(group)
+	sizes = shard_sizes(nmaps, world); nmax = max(sizes)
+	assert local_alm.shape[0] == sizes[rank], "local shard has %d maps, expected %d" % (local_alm.shape[0], sizes[rank])
+	real = torch.view_as_real(local_alm.contiguous())                    # RCCL has no complex dtype
+	if sizes[rank] < nmax:
+		pad = torch.zeros((nmax-sizes[rank],)+tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+		real = torch.cat([real, pad], 0)
+	out = torch.empty((world*nmax,)+tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+	work = dist.all_gather_into_tensor(out, real.contiguous(), group=group, async_op=async_op)
+	def finish():
+		if work is not None: work.wait()
+		parts = [out[r*nmax:r*nmax+sizes[r]] for r in range(world)]
+		return torch.view_as_complex(torch.cat(parts, 0).contiguous())
+	return finish if async_op else finish()
+
+def map2alm_sharded(maps, wcs, lmax, spin, transform, group=None):
+	"""maps: the FULL list/array of nmaps independent maps (host or device; only this rank's slice is touched).
+	transform(map_i) -> alm tensor [ncomp, nelem] for one map (e.g. a closure over curvedsky.map2alm)."""
+	import torch, torch.distributed as dist
+	world = dist.get_world_size(group); rank = dist.get_rank(group)
+	i0, i1 = shard_range(len(maps), rank, world)
+	local = [transform(maps[i]) for i in range(i0, i1)]
+	local = torch.stack(local, 0) if local else None
+	if local is None: raise ValueError("more ranks than maps")
+	return allgather_alm(local, len(maps), group=group)
