@@ -38,6 +38,9 @@ struct KArgs {
 	int load_inner_fast, store_inner_fast, tile_i;
 };
 
+// LDS line buffer addressing hook (see below)
+#define LPAD(i) (i)   /* padding ((i)+((i)>>4)) measured neutral-to-slower on MI355X: global latency, not LDS banks, bounds this kernel */
+
 __device__ __forceinline__ uint32_t fdiv(uint32_t x, FastDiv f) { return f.d <= 1 ? x : __umulhi(x, f.mul); }
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x+b.x, a.y+b.y); }
@@ -188,10 +191,10 @@ template<int R> __device__ __forceinline__ void radix_pass(double2* buf, const d
 		const uint32_t bb = b - t*nb;
 		const uint32_t blk = fdiv(bb, ps.dL);
 		const uint32_t q = bb - blk*ps.L;
-		double2* p = buf + (size_t)t*a.n + blk*ps.L*R + q;
+		const uint32_t p0 = t*a.n + blk*ps.L*R + q;
 		double2 v[R];
 #pragma unroll
-		for (int i = 0; i < R; i++) v[i] = p[i*ps.L];
+		for (int i = 0; i < R; i++) v[i] = buf[LPAD(p0 + i*ps.L)];
 		if (ps.L > 1) {
 			const int step = q*ps.tws;
 #pragma unroll
@@ -199,7 +202,7 @@ template<int R> __device__ __forceinline__ void radix_pass(double2* buf, const d
 		}
 		butterfly<R>(v);
 #pragma unroll
-		for (int i = 0; i < R; i++) p[i*ps.L] = v[i];
+		for (int i = 0; i < R; i++) buf[LPAD(p0 + i*ps.L)] = v[i];
 	}
 }
 
@@ -216,16 +219,16 @@ __device__ __forceinline__ void generic_pass(const double2* src, double2* dst, c
 		const uint32_t r = j - blk*LR;
 		const uint32_t ip = r / ps.L;                 // output digit i'
 		const uint32_t q = r - ip*ps.L;
-		const double2* p = src + (size_t)t*n + blk*LR + q;
+		const uint32_t p0 = t*n + blk*LR + q;
 		double2 acc = make_double2(0, 0);
 		uint32_t widx = 0;                            // (i*ip) mod R
 		for (int i = 0; i < R; i++) {
-			double2 v = p[i*ps.L];
+			double2 v = src[LPAD(p0 + i*ps.L)];
 			if (ps.L > 1) v = cmul(v, tw[i*q*ps.tws]);
 			acc = cadd(acc, cmul(v, tw[widx*wstep]));
 			widx += ip; if (widx >= (uint32_t)R) widx -= R;
 		}
-		dst[(size_t)t*n + j] = acc;
+		dst[LPAD(t*n + j)] = acc;
 	}
 }
 
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 	const int n = a.n, T = a.T;
 	double2* tw = lds;                 // [n]
 	double2* bufA = lds + n;           // [T*n]
-	double2* bufB = bufA + (size_t)T*n; // only if generic
+	double2* bufB = bufA + LPAD((size_t)T*n) + 1; // only if generic
 
 	// decode block -> (tile, other, o1, o2).  mode 0: tile over lines i.  modes 1/2 (four-step):
 	// sub-lines are (i, s) with s = j2 (pass A) or k1 (pass B); tile_i selects which one is tiled.
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 			pos[u] = (int)(t*n) + a.perm[j];
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++) if (pos[u] >= 0) bufA[pos[u]] = v[u];
+		for (int u = 0; u < 4; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
 	}
 	__syncthreads();
 
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 			if ((int)t >= nl) continue;
 			const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
 			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
-			double2 v = cur[(size_t)t*n + j];
+			double2 v = cur[LPAD(t*n + j)];
 			if (a.mode == 1) {
 				v = cmul(v, a.bigtw[(long)j*sv]);
 				const long p2 = (long)j*a.n2 + sv;
@@ -438,7 +441,7 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	k.dn = make_fastdiv(s.n); k.dT = make_fastdiv((uint32_t)T);
 }
 
-static size_t lds_bytes(const KArgs& k) { return sizeof(double2)*((size_t)k.n + (size_t)k.T*k.n*(k.generic ? 2 : 1)); }
+static size_t lds_bytes(const KArgs& k) { const size_t pts = (size_t)k.T*k.n; const size_t padded = pts + (pts >> 4) + 2; return sizeof(double2)*((size_t)k.n + padded*(k.generic ? 2 : 1)); }
 
 void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, const FftLoad& ld, const FftStore& stf) {
 	std::string why;

@@ -35,10 +35,10 @@ static int env_k(const char* name, int def, int lo, int hi) {
 	const char* v = getenv(name); if (!v) return def;
 	int k = atoi(v); return (k >= lo && k <= hi) ? k : def;
 }
-static int k_syn0() { static int k = env_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
-static int k_ana0() { static int k = env_k("PXS_K_ANA0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
-static int k_syns() { static int k = env_k("PXS_K_SYNS", 2, 2, 4); return k; }
-static int k_anas() { static int k = env_k("PXS_K_ANAS", 2, 2, 4); return k; }
+static int k_syn0() { static int k = env_k("PXS_K_SYN0", 8, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_ana0() { static int k = env_k("PXS_K_ANA0", 8, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_syns() { static int k = env_k("PXS_K_SYNS", 3, 2, 4); return k; }
+static int k_anas() { static int k = env_k("PXS_K_ANAS", 3, 2, 4); return k; }
 
 struct double4_t { double a, b, c, d; };
 
@@ -201,6 +201,30 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 
 #define LEG_RED_STRIDE 66
 
+// (An L2 prefetch of the coefficient streams via global_load_lds into an LDS sink was tried to hide SMEM
+// miss latency and measured SLOWER on MI355X: leg_syn 10.8 -> 12.4 ms at config 2; removed.)
+
+// Phase A of the spin-0 kernels: no lane of the wave has reached scale 0 yet, so nothing is
+// accumulated.  Four recurrence steps per iteration with the four coefficient rows fetched together;
+// the rescale / activity test runs once per 4 steps (a chain grows by < 2^60 in 4 steps, far from
+// overflow at 2^1024, and entering the accumulating phases a few steps late only drops terms < 2^-340).
+#define S0_PHASE_A \
+	while (k + 4 <= nk) { \
+		bool act = false; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0); \
+		if (__any(act)) break; \
+		const double4_t q0 = coef[k], q1 = coef[k+1], q2 = coef[k+2], q3 = coef[k+3]; \
+		const double b0 = polar ? q0.c : q0.b, b1 = polar ? q1.c : q1.b, b2 = polar ? q2.c : q2.b, b3 = polar ? q3.c : q3.b; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			lam1[s] = fma(fma(q0.a, csq[s], b0), lam2[s], lam1[s]); \
+			lam2[s] = fma(fma(q1.a, csq[s], b1), lam1[s], lam2[s]); \
+			lam1[s] = fma(fma(q2.a, csq[s], b2), lam2[s], lam1[s]); \
+			lam2[s] = fma(fma(q3.a, csq[s], b3), lam1[s], lam2[s]); \
+			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; } \
+		} \
+		k += 4; \
+	}
+
 // one recurrence step with rescaling (ramp phases)
 #define S0_STEP_RESCALE(cfa, cfb) \
 	_Pragma("unroll") for (int s = 0; s < K; s++) { \
@@ -235,16 +259,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 	}
 	int k = 0;
 	if (__any(alive_any)) {
-		// phase A: nobody at scale 0 yet -> recurrence only
-		while (k < nk) {
-			bool act = false;
-#pragma unroll
-			for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
-			if (__any(act)) break;
-			const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
-			S0_STEP_RESCALE(cf.a, cb)
-			k++;
-		}
+		// phase A: nobody at scale 0 yet -> recurrence only, 4 steps per check (S0_PHASE_A)
+		S0_PHASE_A
 		// phase B: gated accumulation until every lane is at scale 0
 		while (k < nk) {
 			bool pend = false;
@@ -403,15 +419,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	}
 	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
 	int k = 0;
-	while (k < nk) {
-		bool act = false;
-#pragma unroll
-		for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0);
-		if (__any(act)) break;
-		const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
-		S0_STEP_RESCALE(cf.a, cb)
-		k++;
-	}
+	S0_PHASE_A
 	int kk = 0, kbase = k;
 	while (k < nk) {
 		bool pend = false;
@@ -530,6 +538,24 @@ template<int K> __device__ __forceinline__ void spin_step_rescale(SpinState<K>& 
 	if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
 }
 #define SPIN_COEF(cf) const double ca = cf.a, c1 = polar ? cf.c : cf.b, c2 = polar ? cf.d : -cf.b
+// phase A of the spin kernels (see S0_PHASE_A): 4 steps per rescale / activity test; sgn is unchanged by 4 steps
+#define SPIN_PHASE_A \
+	while (j + 4 <= nl) { \
+		bool act = false; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0); \
+		if (__any(act)) break; \
+		const double4_t q0 = coef[j], q1 = coef[j+1], q2 = coef[j+2], q3 = coef[j+3]; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			double ax; \
+			ax = q0.a*S.x[s]; S.gp1[s] = fma(ax + (polar ? q0.c : q0.b), S.gp2[s], -S.gp1[s]); S.gm1[s] = fma(ax + (polar ? q0.d : -q0.b), S.gm2[s], -S.gm1[s]); \
+			ax = q1.a*S.x[s]; S.gp2[s] = fma(ax + (polar ? q1.c : q1.b), S.gp1[s], -S.gp2[s]); S.gm2[s] = fma(ax + (polar ? q1.d : -q1.b), S.gm1[s], -S.gm2[s]); \
+			ax = q2.a*S.x[s]; S.gp1[s] = fma(ax + (polar ? q2.c : q2.b), S.gp2[s], -S.gp1[s]); S.gm1[s] = fma(ax + (polar ? q2.d : -q2.b), S.gm2[s], -S.gm1[s]); \
+			ax = q3.a*S.x[s]; S.gp2[s] = fma(ax + (polar ? q3.c : q3.b), S.gp1[s], -S.gp2[s]); S.gm2[s] = fma(ax + (polar ? q3.d : -q3.b), S.gm1[s], -S.gm2[s]); \
+			if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; } \
+			if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; } \
+		} \
+		j += 4; \
+	}
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
@@ -550,16 +576,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
 		double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m)
 		int j = 0;
-		while (j < nl) {
-			bool act = false;
-#pragma unroll
-			for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
-			if (__any(act)) break;
-			const double4_t cf = coef[j]; SPIN_COEF(cf);
-#pragma unroll
-			for (int s = 0; s < K; s++) spin_step_rescale<K>(S, s, ca, c1, c2);
-			j++; sgn = -sgn;
-		}
+		SPIN_PHASE_A
 		while (j < nl) {
 			bool pend = false;
 #pragma unroll
@@ -669,16 +686,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	}
 	double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;
 	int j = 0;
-	while (j < nl) {
-		bool act = false;
-#pragma unroll
-		for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0);
-		if (__any(act)) break;
-		const double4_t cf = coef[j]; SPIN_COEF(cf);
-#pragma unroll
-		for (int s = 0; s < K; s++) spin_step_rescale<K>(S, s, ca, c1, c2);
-		j++; sgn = -sgn;
-	}
+	SPIN_PHASE_A
 	int kk = 0, jbase = j;
 	while (j < nl) {
 		bool pend = false;

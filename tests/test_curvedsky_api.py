@@ -130,7 +130,7 @@ def test_roundtrip_hostsim(): roundtrip_body(12)
 @pytest.mark.hostsim
 def test_alm_conversion_hostsim(): alm_conversion_body()
 @pytest.mark.hostsim
-def test_adjointness_hostsim(): adjointness_body(variants=("fejer1",), ncomps=(1,), do_analysis=False)
+def test_adjointness_hostsim(): adjointness_body(variants=("fejer1",), ncomps=(1,), do_analysis=True)
 @pytest.mark.hostsim
 def test_cyl_hostsim(): cyl_body()
 
@@ -139,7 +139,7 @@ def test_roundtrip_gpu(): roundtrip_body(30)
 @pytest.mark.gpu
 def test_alm_conversion_gpu(): alm_conversion_body()
 @pytest.mark.gpu
-def test_adjointness_gpu(): adjointness_body(do_analysis=False)
+def test_adjointness_gpu(): adjointness_body(do_analysis=True, dtypes=(np.float64, np.float32))
 @pytest.mark.gpu
 def test_golden_unlensed_gpu(golden_dir): golden_body(golden_dir)
 @pytest.mark.gpu

@@ -36,6 +36,10 @@ def check_grid(geometry, nt, nph, lmax, spin, phi0=0.3, seed=3, random_map=True,
 		sel = np.zeros(alm.shape[1], bool)
 		for m in range(mmax+1): sel[int(ms[m])+m:int(ms[m])+lmax+1] = True
 		if mmax == lmax and 2*mmax < nph: assert relrms(oa[:, sel], alm[:, sel]) < TOL, "round trip"   # (no exact inverse when m aliases)
+		ref2 = np.zeros((nc, nt, nph)); out2 = np.zeros((nc, nt, nph))
+		if nt <= 64:
+			so.adjoint_analysis_2d(alm=alm, map=ref2, **kw); sht.adjoint_analysis_2d(alm=alm, map=out2, **kw)
+			assert rel(out2, ref2) < TOL, "adjoint_analysis_2d"
 		if random_map:
 			ra = np.zeros_like(alm); so.analysis_2d(alm=ra, map=pix, **kw)
 			oa = np.zeros_like(alm); sht.analysis_2d(alm=oa, map=pix, **kw)
