@@ -109,6 +109,22 @@ __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1,
 		double2 v = read_elem(ld.ptr, ld.dtype, base + src*a.d.is_e);
 		if (ld.mul) v = cmul(v, ld.mul[src]);
 		return neg ? make_double2(-v.x, -v.y) : v; }
+	case LD_MIRROR_PAIR: {
+		// two source lines of opposite parity share one transform: z = ext(even line) + ext(odd line).
+		// direct samples: a + b; mirrored samples: (+a_even - b_odd); self-mirrored samples keep only the even line.
+		const long la = 2*(i + a.i_base), lb = la + 1;
+		const bool a_odd = (ld.par0 & 1) != 0;            // parity of line 2i (lines alternate parity)
+		long src = e; bool mir = false;
+		if (e >= ld.ne) { src = N - e - ld.mir_c; if (src < 0) src += N; mir = true; }
+		const bool selfm = ((2*e + ld.mir_c) % N) == 0;
+		const long ba = (2*i)*a.d.is_i + o1*a.d.is_o1 + o2*a.d.is_o2;
+		double2 va = read_elem(ld.ptr, ld.dtype, ba + src*a.d.is_e);
+		double2 vb = (lb < ld.pair_lines) ? read_elem(ld.ptr, ld.dtype, ba + a.d.is_i + src*a.d.is_e) : make_double2(0, 0);
+		// odd-parity line: sign flip on mirrored samples, zero on self-mirrored ones
+		double2& vo = a_odd ? va : vb;
+		if (selfm) vo = make_double2(0, 0);
+		else if (mir) { vo.x = -vo.x; vo.y = -vo.y; }
+		return cadd(va, vb); }
 	case LD_SPEC: {
 		const long Ns = ld.ne;
 		long k = (2*e <= N) ? e : e - N;

@@ -12,7 +12,7 @@
 
 namespace pxs {
 
-enum LoadMode : int { LD_PLAIN = 0, LD_HERM = 1, LD_MIRROR = 2, LD_SPEC = 3, LD_SPEC_ADJ = 4 };
+enum LoadMode : int { LD_PLAIN = 0, LD_HERM = 1, LD_MIRROR = 2, LD_SPEC = 3, LD_SPEC_ADJ = 4, LD_MIRROR_PAIR = 5 };
 
 // Line index space: a transform "line" is addressed by (i, o1, o2); element e along it.
 struct FftDims {
@@ -29,6 +29,7 @@ struct FftLoad {
 	int mir_c = 0, par0 = 0;    // MIRROR: src index for e>=ne is (-e-c) mod n, sign -1 if ((i+par0)&1)
 	long kmax = -1;             // SPEC: keep |k| <= kmax (-1: all representable)
 	int nyq_half = 0;           // SPEC: source Nyquist bin (Ns even) is split 1/2,1/2 onto +-Ns/2
+	long pair_lines = 0;        // MIRROR_PAIR: number of source lines (line i packs source lines 2i [parity par0] and 2i+1 [opposite parity])
 	int herm_fold = 0;          // HERM: 1 = SHT ring semantics (2 Re sum over m, with aliasing folds), 0 = plain c2r
 };
 

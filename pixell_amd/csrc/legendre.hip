@@ -35,10 +35,10 @@ static int env_k(const char* name, int def, int lo, int hi) {
 	const char* v = getenv(name); if (!v) return def;
 	int k = atoi(v); return (k >= lo && k <= hi) ? k : def;
 }
-static int k_syn0() { static int k = env_k("PXS_K_SYN0", 8, 4, 8) >= 8 ? 8 : 4; return k; }
-static int k_ana0() { static int k = env_k("PXS_K_ANA0", 8, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_syn0() { static int k = env_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_ana0() { static int k0 = env_k("PXS_K_ANA0", 8, 4, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : 4); return k; }
 static int k_syns() { static int k = env_k("PXS_K_SYNS", 3, 2, 4); return k; }
-static int k_anas() { static int k = env_k("PXS_K_ANAS", 3, 2, 4); return k; }
+static int k_anas() { static int k = env_k("PXS_K_ANAS", 6, 2, 6); return k; }
 
 struct double4_t { double a, b, c, d; };
 
@@ -984,10 +984,13 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		if (prof) prof->begin(st, 1);
 		const dim3 grid(a.nwave, m1-m0);
 		if (tb.spin == 0) {
-			if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
-			else        hipLaunchKernelGGL(leg_ana_s0<4>, grid, dim3(64), sh, st, a);
+			if (K == 12)     hipLaunchKernelGGL(leg_ana_s0<12>, grid, dim3(64), sh, st, a);
+			else if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
+			else             hipLaunchKernelGGL(leg_ana_s0<4>, grid, dim3(64), sh, st, a);
 		} else {
-			if (K == 4)      hipLaunchKernelGGL(leg_ana_spin<4>, grid, dim3(64), sh, st, a);
+			if (K >= 6)      hipLaunchKernelGGL(leg_ana_spin<6>, grid, dim3(64), sh, st, a);
+			else if (K == 5) hipLaunchKernelGGL(leg_ana_spin<5>, grid, dim3(64), sh, st, a);
+			else if (K == 4) hipLaunchKernelGGL(leg_ana_spin<4>, grid, dim3(64), sh, st, a);
 			else if (K == 3) hipLaunchKernelGGL(leg_ana_spin<3>, grid, dim3(64), sh, st, a);
 			else             hipLaunchKernelGGL(leg_ana_spin<2>, grid, dim3(64), sh, st, a);
 		}

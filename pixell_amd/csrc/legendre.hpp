@@ -36,7 +36,7 @@ struct LegProfile {
 };
 
 struct LegWork {     // scratch owned by the SHT plan
-	size_t part_budget = size_t(1) << 30;
+	size_t part_budget = size_t(8) << 30;   // bytes of per-wave partial moments per launch (PXS_PART_GB overrides)
 	DevBuf almt;     // [nrows][4] doubles
 	DevBuf part;     // [nwave][nrows][4] doubles (analysis partial moments)
 	DevBuf mom;      // [nrows][4] reduced moments

@@ -132,6 +132,27 @@ __global__ __launch_bounds__(256) void fold_mirror(const double2* __restrict__ i
 	out[line*nr + j] = v;
 }
 
+// undo the pair packing of the theta-FFT chain: Z holds even(theta)+odd(theta) on the full circle of N points;
+// out[line 2p + (even? ..)][j] = (Z[j] +- Z[mirror(j)])/2 * w[j] for the real rings j < nr.
+__global__ __launch_bounds__(256) void split_pair(const double2* __restrict__ Z, double2* __restrict__ out,
+		int nr, long N, int c, long npairs, long nlines, int par0, const double2* __restrict__ w, double scale)
+{
+	const long idx = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (idx >= npairs*nr) return;
+	const long pr = idx / nr; const int j = (int)(idx - pr*nr);
+	long mj = N - j - c; if (mj >= N) mj -= N; if (mj < 0) mj += N;
+	const double2 z = Z[pr*N + j];
+	double2 ev, od;
+	if (mj == j) { ev = z; od = make_double2(0, 0); }
+	else { const double2 y = Z[pr*N + mj]; ev = make_double2(0.5*(z.x + y.x), 0.5*(z.y + y.y)); od = make_double2(0.5*(z.x - y.x), 0.5*(z.y - y.y)); }
+	const double f = scale*(w ? w[j].x : 1.0);
+	ev.x *= f; ev.y *= f; od.x *= f; od.y *= f;
+	const bool a_odd = (par0 & 1) != 0;
+	const long la = 2*pr, lb = la + 1;
+	out[la*nr + j] = a_odd ? od : ev;
+	if (lb < nlines) out[lb*nr + j] = a_odd ? ev : od;
+}
+
 } // namespace pxs
 
 using namespace pxs;
@@ -176,6 +197,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 	p->d_mstart = upload(ms);
 	p->fc = &fft_context(device);
 	{ const char* e = getenv("PXS_FFT_TEMP_MB"); if (e) p->fc->temp_budget = (size_t)atol(e) << 20; }
+	{ const char* e = getenv("PXS_PART_GB"); if (e) p->wk.part_budget = (size_t)atol(e) << 30; }
 	{ const char* e = getenv("PXS_RESAMPLE_MB"); if (e) p->resample_chunk_bytes = (size_t)atol(e) << 20; }
 	std::string why;
 	if (!FftContext::supported(p->nphi, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
@@ -278,43 +300,53 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map
 }
 
 // leg on the map's rings [c][m][nring] -> weighted leg on the CC grid [c][m][ncc].
-// The m columns are pushed through the whole 4-FFT chain in chunks small enough that the
-// intermediates (b1, b2 and the four-step scratch) stay resident in the 256 MiB Infinity Cache.
+// Columns m and m+1 have opposite theta-parity, so their mirror extensions are the even and the odd part
+// of ONE sequence: each pair shares the whole 4-FFT chain (every stage is linear and commutes with the
+// reflection theta -> -theta) and is separated again at the end -- half the FFT work.
 void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2* leg_cc, int nc, int spin) {
 	const int nm = p->mmax+1, nr = p->nring;
-	const long chunk = std::max<long>(32, std::min<long>(nm, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->M))));
-	p->b1.ensure(sizeof(double2)*(size_t)chunk*p->N);
+	const long npair_all = (nm + 1)/2;
+	const long chunk = std::max<long>(32, std::min<long>(npair_all, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->M))));
+	p->b1.ensure(sizeof(double2)*(size_t)chunk*std::max(p->N, p->Ncc));
 	p->b2.ensure(sizeof(double2)*(size_t)chunk*p->M);
 	p->prof.begin(st, PXS_STAGE_RESAMPLE);
 	for (int c = 0; c < nc; c++)
-	for (long m0 = 0; m0 < nm; m0 += chunk) {
-		const long nl = std::min<long>(chunk, nm - m0);
-		{	// (a) mirror-extend, forward FFT_N
-			FftDims d; d.n_i = nl; d.is_i = nr; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
-			FftLoad ld; ld.ptr = leg_in + ((size_t)c*nm + m0)*nr; ld.mode = LD_MIRROR; ld.ne = nr; ld.mir_c = p->mir_c; ld.par0 = (spin + (int)m0) & 1;
+	for (long p0 = 0; p0 < npair_all; p0 += chunk) {
+		const long np = std::min<long>(chunk, npair_all - p0);
+		const long m0 = 2*p0, nlines = std::min<long>(2*np, nm - m0);
+		{	// (a) packed mirror extension of lines (2i, 2i+1), forward FFT_N
+			FftDims d; d.n_i = np; d.is_i = nr; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = leg_in + ((size_t)c*nm + m0)*nr; ld.mode = LD_MIRROR_PAIR; ld.ne = nr; ld.mir_c = p->mir_c;
+			ld.par0 = (spin + (int)m0) & 1; ld.pair_lines = nlines;
 			FftStore sf; sf.ptr = p->b1.p;
 			p->fc->exec(st, p->N, true, d, ld, sf);
 		}
 		{	// (b) shift to theta0 = 0, pad to M, backward FFT_M, multiply by the |sin| series
-			FftDims d; d.n_i = nl; d.is_i = p->N; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftDims d; d.n_i = np; d.is_i = p->N; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->N; ld.nyq_half = 1; ld.mul = p->ph_shift.as<double2>();
 			FftStore sf; sf.ptr = p->b2.p; sf.mul = p->sigma.as<double2>();
 			p->fc->exec(st, p->M, false, d, ld, sf);
 		}
 		{	// (c) forward FFT_M in place; only |k| <= lmax are needed
-			FftDims d; d.n_i = nl; d.is_i = p->M; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftDims d; d.n_i = np; d.is_i = p->M; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b2.p;
 			FftStore sf; sf.ptr = p->b2.p; sf.two_sided_k = p->lmax;
 			p->fc->exec(st, p->M, true, d, ld, sf);
 		}
-		{	// (d) truncate to |k| <= lmax, backward FFT_Ncc, keep rings 0..ncc-1, apply weights
-			FftDims d; d.n_i = nl; d.is_i = p->M; d.os_i = p->ncc; d.is_e = 1; d.os_e = 1;
+		{	// (d) truncate to |k| <= lmax, backward FFT_Ncc onto the full CC circle
+			FftDims d; d.n_i = np; d.is_i = p->M; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b2.p; ld.mode = LD_SPEC; ld.ne = p->M; ld.kmax = p->lmax;
-			FftStore sf; sf.ptr = leg_cc + ((size_t)c*nm + m0)*p->ncc; sf.ne = p->ncc; sf.mul = p->wcc.as<double2>();
+			FftStore sf; sf.ptr = p->b1.p;
 			p->fc->exec(st, p->Ncc, false, d, ld, sf);
+		}
+		{	// (e) separate the pair by reflection symmetry, keep rings 0..ncc-1, apply the quadrature weights
+			const long tot = np*p->ncc;
+			hipLaunchKernelGGL(split_pair, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, (const double2*)p->b1.p,
+				leg_cc + ((size_t)c*nm + m0)*p->ncc, p->ncc, p->Ncc, 0, np, nlines, (spin + (int)m0) & 1, p->wcc.as<double2>(), 1.0);
 		}
 	}
 	p->prof.end(st, PXS_STAGE_RESAMPLE);
+	PXS_HIP(hipGetLastError());
 }
 
 // exact transpose of resample_to_cc: leg on the CC grid [c][m][ncc] -> leg on the map's rings [c][m][nring]
@@ -361,29 +393,40 @@ void resample_to_cc_adjoint(pxs_plan* p, hipStream_t st, const double2* leg_cc, 
 	PXS_HIP(hipGetLastError());
 }
 
-// band-limited leg on the CC grid [c][m][ncc] -> leg on the map's rings [c][m][nring] (exact for degree <= lmax)
+// band-limited leg on the CC grid [c][m][ncc] -> leg on the map's rings [c][m][nring] (exact for degree <= lmax);
+// columns (m, m+1) packed as in resample_to_cc
 void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double2* leg_out, int nc, int spin) {
 	const int nm = p->mmax+1, nr = p->nring;
-	const long chunk = std::max<long>(32, std::min<long>(nm, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->N))));
+	const long npair_all = (nm + 1)/2;
+	const long chunk = std::max<long>(32, std::min<long>(npair_all, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->N))));
 	p->b1.ensure(sizeof(double2)*(size_t)chunk*std::max(p->N, p->Ncc));
+	p->b2.ensure(sizeof(double2)*(size_t)chunk*p->N);
 	p->prof.begin(st, PXS_STAGE_RESAMPLE);
 	for (int c = 0; c < nc; c++)
-	for (long m0 = 0; m0 < nm; m0 += chunk) {
-		const long nl = std::min<long>(chunk, nm - m0);
-		{	// mirror-extend the CC rings to the full circle, forward FFT_Ncc
-			FftDims d; d.n_i = nl; d.is_i = p->ncc; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
-			FftLoad ld; ld.ptr = leg_cc + ((size_t)c*nm + m0)*p->ncc; ld.mode = LD_MIRROR; ld.ne = p->ncc; ld.mir_c = 0; ld.par0 = (spin + (int)m0) & 1;
+	for (long p0 = 0; p0 < npair_all; p0 += chunk) {
+		const long np = std::min<long>(chunk, npair_all - p0);
+		const long m0 = 2*p0, nlines = std::min<long>(2*np, nm - m0);
+		{	// packed mirror extension of the CC rings to the full circle, forward FFT_Ncc
+			FftDims d; d.n_i = np; d.is_i = p->ncc; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = leg_cc + ((size_t)c*nm + m0)*p->ncc; ld.mode = LD_MIRROR_PAIR; ld.ne = p->ncc; ld.mir_c = 0;
+			ld.par0 = (spin + (int)m0) & 1; ld.pair_lines = nlines;
 			FftStore sf; sf.ptr = p->b1.p;
 			p->fc->exec(st, p->Ncc, true, d, ld, sf);
 		}
-		{	// keep |k| <= lmax, shift to the target grid's theta0, backward FFT_N, keep the real rings
-			FftDims d; d.n_i = nl; d.is_i = p->Ncc; d.os_i = nr; d.is_e = 1; d.os_e = 1;
+		{	// keep |k| <= lmax, shift to the target grid's theta0, backward FFT_N onto the full circle
+			FftDims d; d.n_i = np; d.is_i = p->Ncc; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->Ncc; ld.kmax = p->lmax; ld.mul = p->ph_up.as<double2>();
-			FftStore sf; sf.ptr = leg_out + ((size_t)c*nm + m0)*nr; sf.ne = nr; sf.scale = 1.0/(double)p->Ncc;
+			FftStore sf; sf.ptr = p->b2.p;
 			p->fc->exec(st, p->N, false, d, ld, sf);
+		}
+		{	// separate the pair, keep the real rings
+			const long tot = np*nr;
+			hipLaunchKernelGGL(split_pair, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, (const double2*)p->b2.p,
+				leg_out + ((size_t)c*nm + m0)*nr, nr, p->N, p->mir_c, np, nlines, (spin + (int)m0) & 1, (const double2*)nullptr, 1.0/(double)p->Ncc);
 		}
 	}
 	p->prof.end(st, PXS_STAGE_RESAMPLE);
+	PXS_HIP(hipGetLastError());
 }
 
 } // namespace
