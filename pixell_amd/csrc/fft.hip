@@ -125,6 +125,24 @@ __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1,
 		if (selfm) vo = make_double2(0, 0);
 		else if (mir) { vo.x = -vo.x; vo.y = -vo.y; }
 		return cadd(va, vb); }
+	case LD_REAL_PAIR: {
+		// two real lines (2i, 2i+1) as one complex line: z = a + i b  (half the transforms for real data)
+		const long ba = (2*i)*a.d.is_i + o1*a.d.is_o1 + o2*a.d.is_o2;
+		const double va = read_elem(ld.ptr, ld.dtype, ba + e*a.d.is_e).x;
+		const double vb = (2*(i + a.i_base) + 1 < ld.pair_lines) ? read_elem(ld.ptr, ld.dtype, ba + a.d.is_i + e*a.d.is_e).x : 0.0;
+		return make_double2(va, vb); }
+	case LD_HERM_PAIR: {
+		// Z = X_A + i X_B with X the Hermitian extension of the half spectra of lines (2i, 2i+1); no aliasing (2 ne <= N)
+		long m; bool cj;
+		if (e < ld.ne) { m = e; cj = false; }
+		else if (N - e < ld.ne) { m = N - e; cj = true; }
+		else return make_double2(0, 0);
+		const long ba = (2*i)*a.d.is_i + o1*a.d.is_o1 + o2*a.d.is_o2;
+		double2 ha = read_elem(ld.ptr, ld.dtype, ba + m*a.d.is_e);
+		double2 hb = (2*(i + a.i_base) + 1 < ld.pair_lines) ? read_elem(ld.ptr, ld.dtype, ba + a.d.is_i + m*a.d.is_e) : make_double2(0, 0);
+		if (m == 0) { ha.y = 0; hb.y = 0; }
+		if (cj) { ha.y = -ha.y; hb.y = -hb.y; }
+		return make_double2(ha.x - hb.y, ha.y + hb.x); }
 	case LD_SPEC: {
 		const long Ns = ld.ne;
 		long k = (2*e <= N) ? e : e - N;
@@ -158,11 +176,21 @@ __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1,
 __device__ __forceinline__ void store_functor(const KArgs& a, long i, long o1, long o2, long e, double2 v) {
 	const FftStore& st = a.st;
 	if (st.ne >= 0 && e >= st.ne) return;
-	if (st.two_sided_k >= 0 && e > st.two_sided_k && e < a.N - st.two_sided_k) return;
+	long eo = e;
+	if (st.two_sided_k >= 0) {
+		if (e > st.two_sided_k && e < a.N - st.two_sided_k) return;
+		if (st.compact_two_sided && e > st.two_sided_k) eo = st.two_sided_k + (a.N - e);
+	}
 	if (st.conj_out) v.y = -v.y;
 	if (st.mul) v = cmul(v, st.mul[e]);
 	v.x *= st.scale; v.y *= st.scale;
-	const long off = i*a.d.os_i + o1*a.d.os_o1 + o2*a.d.os_o2 + e*a.d.os_e;
+	if (st.real_pair) {
+		const long off = (2*i)*a.d.os_i + o1*a.d.os_o1 + o2*a.d.os_o2 + eo*a.d.os_e;
+		write_elem(st.ptr, st.dtype, off, make_double2(v.x, 0));
+		if (2*(i + a.i_base) + 1 < st.pair_lines) write_elem(st.ptr, st.dtype, off + a.d.os_i, make_double2(v.y, 0));
+		return;
+	}
+	const long off = i*a.d.os_i + o1*a.d.os_o1 + o2*a.d.os_o2 + eo*a.d.os_e;
 	write_elem(st.ptr, st.dtype, off, v);
 }
 
@@ -503,8 +531,10 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		a.d.n_o1 = no1; a.d.n_o2 = 1; a.i_base = i0; a.i_count = ni;
 		// shift base pointers
 		auto esz = [](int dt) { return dt == PX_F32 ? 4 : dt == PX_F64 ? 8 : dt == PX_C64 ? 8 : 16; };
-		a.ld.ptr = (const char*)ld.ptr + esz(ld.dtype)*(o2*d.is_o2 + o1*d.is_o1 + i0*d.is_i);
-		a.st.ptr = (char*)stf.ptr + esz(stf.dtype)*(o2*d.os_o2 + o1*d.os_o1 + i0*d.os_i);
+		const long lmul = (ld.mode == LD_MIRROR_PAIR || ld.mode == LD_REAL_PAIR || ld.mode == LD_HERM_PAIR) ? 2 : 1;   // packed input lines
+		const long smul = stf.real_pair ? 2 : 1;
+		a.ld.ptr = (const char*)ld.ptr + esz(ld.dtype)*(o2*d.is_o2 + o1*d.is_o1 + lmul*i0*d.is_i);
+		a.st.ptr = (char*)stf.ptr + esz(stf.dtype)*(o2*d.os_o2 + o1*d.os_o1 + smul*i0*d.os_i);
 		a.temp = temp_.as<double2>(); a.bigtw = btw; a.n1 = (int)n1; a.n2 = (int)n2;
 		const int tile_i = (std::abs(d.is_i) < std::abs(d.is_e)) ? 1 : 0;
 		// pass A: n1-point FFTs over j1 for each (i, j2); tile over j2 (lines contiguous) or over i (lines adjacent)

@@ -12,7 +12,7 @@
 
 namespace pxs {
 
-enum LoadMode : int { LD_PLAIN = 0, LD_HERM = 1, LD_MIRROR = 2, LD_SPEC = 3, LD_SPEC_ADJ = 4, LD_MIRROR_PAIR = 5 };
+enum LoadMode : int { LD_PLAIN = 0, LD_HERM = 1, LD_MIRROR = 2, LD_SPEC = 3, LD_SPEC_ADJ = 4, LD_MIRROR_PAIR = 5, LD_REAL_PAIR = 6, LD_HERM_PAIR = 7 };
 
 // Line index space: a transform "line" is addressed by (i, o1, o2); element e along it.
 struct FftDims {
@@ -40,6 +40,9 @@ struct FftStore {
 	const double2* mul = nullptr; // multiplier indexed by e
 	double scale = 1.0;
 	int conj_out = 0;           // conjugate the result before mul/scale
+	int compact_two_sided = 0;  // with two_sided_k = k: e <= k stored at e, e >= n-k stored at k + (n - e)  (row length 2k+1)
+	int real_pair = 0;          // real output dtype: Re -> line 2i, Im -> line 2i+1 (os_i is the stride between real lines)
+	long pair_lines = 0;        // real_pair: number of real output lines
 };
 
 struct FftSub;   // per-length tables

@@ -102,6 +102,43 @@ __global__ __launch_bounds__(256) void transpose_mul_outcol(const double2* __res
 	}
 }
 
+// ring pairs were transformed as one complex line z = a + i b; rows hold Z[0..k] then Z[n-1..n-k] (k = mmax).
+// X_a[m] = (Z[m] + conj(Z[n-m]))/2, X_b[m] = -i (Z[m] - conj(Z[n-m]))/2  ->  leg[b][m][2q], leg[b][m][2q+1], times tab[m]*scale.
+__global__ __launch_bounds__(256) void unpack_pair_transpose(const double2* __restrict__ in, double2* __restrict__ out,
+		int nr, int nm, long in_bstride, long out_bstride, const double2* __restrict__ tab, double scale)
+{
+	PXS_SHARED(double2, tile);   // two [32][33] tiles
+	double2* tp = tile; double2* tm = tile + 32*33;
+	const int b = blockIdx.z;
+	const int q0 = blockIdx.y*32, m0 = blockIdx.x*32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	const int npair = (nr + 1)/2, k = nm - 1, rowlen = 2*k + 1;
+	in += (long)b*in_bstride; out += (long)b*out_bstride;
+	for (int j = ty; j < 32; j += 8) {
+		const int q = q0 + j, m = m0 + tx;
+		if (q < npair && m < nm) {
+			tp[j*33 + tx] = in[(long)q*rowlen + m];
+			tm[j*33 + tx] = in[(long)q*rowlen + (m == 0 ? 0 : k + m)];
+		}
+	}
+	__syncthreads();
+	for (int j = ty; j < 32; j += 8) {
+		const int m = m0 + j, q = q0 + tx;
+		if (q < npair && m < nm) {
+			const double2 zp = tp[tx*33 + j], zm = tm[tx*33 + j];
+			// conj(zm) = (zm.x, -zm.y)
+			double2 xa = make_double2(0.5*(zp.x + zm.x), 0.5*(zp.y - zm.y));
+			double2 d  = make_double2(zp.x - zm.x, zp.y + zm.y);
+			double2 xb = make_double2(0.5*d.y, -0.5*d.x);                 // -i d / 2
+			const double2 t = tab[m];
+			xa = make_double2((xa.x*t.x - xa.y*t.y)*scale, (xa.x*t.y + xa.y*t.x)*scale);
+			xb = make_double2((xb.x*t.x - xb.y*t.y)*scale, (xb.x*t.y + xb.y*t.x)*scale);
+			out[(long)m*nr + 2*q] = xa;
+			if (2*q + 1 < nr) out[(long)m*nr + 2*q + 1] = xb;
+		}
+	}
+}
+
 // aliased rings (mmax >= nphi): leg[b][m][r] = h[b][r][m mod nphi] * tab[m]   (rare; simple gather)
 __global__ __launch_bounds__(256) void gather_alias(const double2* __restrict__ in, double2* __restrict__ out,
 		int nr, int nm, int ncin, int nphi, long in_bstride, long out_bstride, const double2* __restrict__ tab, double scale)
@@ -174,6 +211,7 @@ struct pxs_plan {
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
 	DevBuf ph_shift, ph_up, sigma, wcc, b1, b2;
 	bool syn_via_cc = false;
+	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
 	LegProfile prof;
 	size_t resample_chunk_bytes = size_t(1) << 40;    // per intermediate buffer of the theta-FFT chain (chunking to stay in the
@@ -197,6 +235,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 	p->d_mstart = upload(ms);
 	p->fc = &fft_context(device);
 	{ const char* e = getenv("PXS_FFT_TEMP_MB"); if (e) p->fc->temp_budget = (size_t)atol(e) << 20; }
+	{ const char* e = getenv("PXS_RING_PAIRS"); if (e) p->ring_pairs = atoi(e) != 0; }
 	{ const char* e = getenv("PXS_PART_GB"); if (e) p->wk.part_budget = (size_t)atol(e) << 30; }
 	{ const char* e = getenv("PXS_RESAMPLE_MB"); if (e) p->resample_chunk_bytes = (size_t)atol(e) << 20; }
 	std::string why;
@@ -260,11 +299,27 @@ int ncomp_of(int spin, int mode, bool alm_side) {
 void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
+	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
+	if (2L*p->mmax < p->nphi && p->ring_pairs) {
+		// two real rings per complex transform; the pruned two-sided spectrum (|k| <= mmax) is unpacked in the transpose
+		const int npair = (nr + 1)/2; const long rowlen = 2L*p->mmax + 1;
+		p->hbuf.ensure(sizeof(double2)*(size_t)nc*std::max<size_t>((size_t)npair*rowlen, (size_t)nr*nm));
+		FftDims d; d.n_i = npair; d.is_i = p->ring_stride; d.os_i = rowlen; d.n_o1 = nc; d.is_o1 = map_cstride; d.os_o1 = (long)npair*rowlen;
+		d.is_e = p->pix_stride; d.os_e = 1;
+		FftLoad ld; ld.ptr = (const char*)map + esz(map_dtype)*p->ring_off0; ld.dtype = map_dtype; ld.mode = LD_REAL_PAIR; ld.pair_lines = nr;
+		FftStore sf; sf.ptr = p->hbuf.p; sf.two_sided_k = p->mmax; sf.compact_two_sided = 1;
+		p->fc->exec(st, p->nphi, true, d, ld, sf);
+		dim3 grid((nm+31)/32, (npair+31)/32, nc);
+		hipLaunchKernelGGL(unpack_pair_transpose, grid, dim3(256), sizeof(double2)*2*32*33, st, (const double2*)p->hbuf.p, leg, nr, nm,
+			(long)npair*rowlen, (long)nr*nm, (const double2*)p->phase.p, scale);
+		p->prof.end(st, PXS_STAGE_RING_FFT);
+		PXS_HIP(hipGetLastError());
+		return;
+	}
 	const int ncin = std::min(nm, p->nphi);           // distinct FFT bins needed (m >= nphi alias onto m mod nphi)
 	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
 	FftDims d; d.n_i = nr; d.is_i = p->ring_stride; d.os_i = ncin; d.n_o1 = nc; d.is_o1 = map_cstride; d.os_o1 = (long)nr*ncin;
 	d.is_e = p->pix_stride; d.os_e = 1;
-	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	FftLoad ld; ld.ptr = (const char*)map + esz(map_dtype)*p->ring_off0; ld.dtype = map_dtype;
 	FftStore sf; sf.ptr = p->hbuf.p; sf.ne = ncin;
 	p->fc->exec(st, p->nphi, true, d, ld, sf);
@@ -289,12 +344,21 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map
 	dim3 grid((nm+31)/32, (nr+31)/32, nc);
 	hipLaunchKernelGGL(transpose_mul_outcol, grid, dim3(256), sizeof(double2)*32*33, st, leg, (double2*)p->hbuf.p, nr, nm,
 		(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 1, 1.0);
-	FftDims d; d.n_i = nr; d.is_i = nm; d.os_i = p->ring_stride; d.n_o1 = nc; d.is_o1 = (long)nr*nm; d.os_o1 = map_cstride;
-	d.is_e = 1; d.os_e = p->pix_stride;
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
-	FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM; ld.ne = nm; ld.herm_fold = 1;
-	FftStore sf; sf.ptr = (char*)map + esz(map_dtype)*p->ring_off0; sf.dtype = map_dtype;
-	p->fc->exec(st, p->nphi, false, d, ld, sf);
+	if (2L*p->mmax < p->nphi && p->ring_pairs) {
+		// two rings per complex transform: Z = X_a + i X_b, real part -> ring 2q, imaginary part -> ring 2q+1
+		FftDims d; d.n_i = (nr + 1)/2; d.is_i = nm; d.os_i = p->ring_stride; d.n_o1 = nc; d.is_o1 = (long)nr*nm; d.os_o1 = map_cstride;
+		d.is_e = 1; d.os_e = p->pix_stride;
+		FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM_PAIR; ld.ne = nm; ld.pair_lines = nr;
+		FftStore sf; sf.ptr = (char*)map + esz(map_dtype)*p->ring_off0; sf.dtype = map_dtype; sf.real_pair = 1; sf.pair_lines = nr;
+		p->fc->exec(st, p->nphi, false, d, ld, sf);
+	} else {
+		FftDims d; d.n_i = nr; d.is_i = nm; d.os_i = p->ring_stride; d.n_o1 = nc; d.is_o1 = (long)nr*nm; d.os_o1 = map_cstride;
+		d.is_e = 1; d.os_e = p->pix_stride;
+		FftLoad ld; ld.ptr = p->hbuf.p; ld.mode = LD_HERM; ld.ne = nm; ld.herm_fold = 1;
+		FftStore sf; sf.ptr = (char*)map + esz(map_dtype)*p->ring_off0; sf.dtype = map_dtype;
+		p->fc->exec(st, p->nphi, false, d, ld, sf);
+	}
 	p->prof.end(st, PXS_STAGE_RING_FFT);
 	PXS_HIP(hipGetLastError());
 }
