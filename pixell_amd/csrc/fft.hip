@@ -476,7 +476,9 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	for (int p = 0; p < s.nfac; p++) k.pass[p] = s.pass[p];
 	k.perm = s.perm.as<int>(); k.tw = s.tw.as<double2>();
 	int bufs = s.generic ? 2 : 1;
-	const long pts = s.n <= 1024 ? FFT_LDS_PTS/2 : FFT_LDS_PTS;    // 32 KiB tiles for short lines: 4-5 workgroups per CU
+	static const long env_pts = [] { const char* e = getenv("PXS_FFT_PTS"); return e ? atol(e) : 0L; }();
+	long pts = s.n <= 1024 ? FFT_LDS_PTS/2 : FFT_LDS_PTS;    // 32 KiB tiles for short lines: 4-5 workgroups per CU
+	if (env_pts > 0 && s.n <= env_pts/2) pts = env_pts;
 	long T = (pts - s.n)/((long)bufs*s.n);
 	if (T < 1) T = 1;
 	if (T > maxlines) T = maxlines;

@@ -225,6 +225,10 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 		k += 4; \
 	}
 
+// (Rejected after measurement on MI355X: (1) merging the gated phase B into the fast pair loop behind a
+// wave-uniform `if (pend)`: leg_syn 118 -> 172 ms, leg_ana 171 -> 228 ms at config 3; (2) a branch-free pair-wise
+// phase B as its own loop: VGPRs 124 -> 192 (syn_spin<3>), occupancy 3 -> 2, leg_syn 118 -> 191 ms.  The short
+// per-step loop below keeps the register footprint of the kernel set by the fast loop.)
 // one recurrence step with rescaling (ramp phases)
 #define S0_STEP_RESCALE(cfa, cfb) \
 	_Pragma("unroll") for (int s = 0; s < K; s++) { \
