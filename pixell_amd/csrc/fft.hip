@@ -22,6 +22,9 @@ static constexpr int FFT_THREADS  = 256;
 static constexpr int FFT_NLOC_MAX = 2048;   // longest line done in one LDS pass
 static constexpr int FFT_LDS_PTS  = 4096;   // complex points of LDS per workgroup (64 KiB)
 static constexpr int FFT_MAXFAC   = 16;
+#ifndef FFT_LU
+#define FFT_LU 4                            // independent global loads in flight per thread in the load phase (8 measured slower: 2.4 -> 1.8 TB/s)
+#endif
 
 struct PassDesc { int R; int L; int tws; FastDiv dL; FastDiv dnb; };
 
@@ -301,10 +304,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 
 	// ---- load ---- (4 independent global loads in flight per thread before the LDS scatter)
 	const int total = T*n;
-	for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4*FFT_THREADS) {
-		double2 v[4]; int pos[4];
+	for (int idx0 = threadIdx.x; idx0 < total; idx0 += FFT_LU*FFT_THREADS) {
+		double2 v[FFT_LU]; int pos[FFT_LU];
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
+		for (int u = 0; u < FFT_LU; u++) {
 			const int idx = idx0 + u*FFT_THREADS;
 			pos[u] = -1;
 			if (idx >= total) continue;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 			pos[u] = (int)(t*n) + a.perm[j];
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
+		for (int u = 0; u < FFT_LU; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
 	}
 	__syncthreads();
 
