@@ -103,28 +103,34 @@ void sht_port_leg_s0(int lmax, int nmsel, const int* msel, int np, const double*
 				double c2r = l+2 <= lmax ? A[2*(l+2)] : 0, c2i = l+2 <= lmax ? A[2*(l+2)+1] : 0;
 				M[4*k] = al[k]*(e1*a0r+e2*c2r); M[4*k+1] = al[k]*(e1*a0i+e2*c2i); M[4*k+2] = al[k]*b1r; M[4*k+3] = al[k]*b1i;
 			}
-			int nscaled = 0;
-			for (int p = p0; p < np; p++) if (sc[p] < 0) nscaled++;
-			for (int k = 0; k < nk; k++) {
-				const double a = ca[k], b = cb[k];
-				if (nscaled > 0) {
-					for (int p = p0; p < np; p++) gate[p] = sc[p] == 0 ? lam2[p] : 0.0;
-				}
-				const double* g = nscaled > 0 ? gate : lam2;
-				if (dir == 0) {
-					const double er = M[4*k], ei = M[4*k+1], orr = M[4*k+2], oi = M[4*k+3];
+			/* ring blocks (like the GPU waves): only blocks that still hold a chain below scale 0 take the
+			 * gated / rescaling path; the others run the plain vectorised loops */
+			const int BLK = 128;
+			if (dir == 1) memset(M, 0, sizeof(double)*(size_t)nk*4);
+			for (int pb = p0; pb < np; pb += BLK) {
+				const int pe = pb+BLK < np ? pb+BLK : np;
+				int nscaled = 0, anylive = 0;
+				for (int p = pb; p < pe; p++) { if (sc[p] < 0) nscaled++; if (lam2[p] != 0.0) anylive = 1; }
+				if (!anylive) continue;
+				for (int k = 0; k < nk; k++) {
+					const double a = ca[k], b = cb[k];
+					if (nscaled > 0) for (int p = pb; p < pe; p++) gate[p] = sc[p] == 0 ? lam2[p] : 0.0;
+					const double* g = nscaled > 0 ? gate : lam2;
+					if (dir == 0) {
+						const double er = M[4*k], ei = M[4*k+1], orr = M[4*k+2], oi = M[4*k+3];
 #pragma omp simd
-					for (int p = p0; p < np; p++) { a1r[p] += g[p]*er; a1i[p] += g[p]*ei; a2r[p] += g[p]*orr; a2i[p] += g[p]*oi; }
-				} else {
-					double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+						for (int p = pb; p < pe; p++) { a1r[p] += g[p]*er; a1i[p] += g[p]*ei; a2r[p] += g[p]*orr; a2i[p] += g[p]*oi; }
+					} else {
+						double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma omp simd reduction(+:t0,t1,t2,t3)
-					for (int p = p0; p < np; p++) { t0 += g[p]*a1r[p]; t1 += g[p]*a1i[p]; t2 += g[p]*a2r[p]; t3 += g[p]*a2i[p]; }
-					M[4*k] = t0; M[4*k+1] = t1; M[4*k+2] = t2; M[4*k+3] = t3;
-				}
+						for (int p = pb; p < pe; p++) { t0 += g[p]*a1r[p]; t1 += g[p]*a1i[p]; t2 += g[p]*a2r[p]; t3 += g[p]*a2i[p]; }
+						M[4*k] += t0; M[4*k+1] += t1; M[4*k+2] += t2; M[4*k+3] += t3;
+					}
 #pragma omp simd
-				for (int p = p0; p < np; p++) { double t = (a*csq[p]+b)*lam2[p]+lam1[p]; lam1[p] = lam2[p]; lam2[p] = t; }
-				if (nscaled > 0) {
-					for (int p = p0; p < np; p++) if (sc[p] < 0 && fabs(lam2[p]) > BIG) { lam1[p] *= SMALL; lam2[p] *= SMALL; sc[p]++; if (sc[p] == 0) nscaled--; }
+					for (int p = pb; p < pe; p++) { double t = (a*csq[p]+b)*lam2[p]+lam1[p]; lam1[p] = lam2[p]; lam2[p] = t; }
+					if (nscaled > 0) {
+						for (int p = pb; p < pe; p++) if (sc[p] < 0 && fabs(lam2[p]) > BIG) { lam1[p] *= SMALL; lam2[p] *= SMALL; sc[p]++; if (sc[p] == 0) nscaled--; }
+					}
 				}
 			}
 			if (dir == 0) {
@@ -212,44 +218,57 @@ void sht_port_leg_spin(int spin, int lmax, int nmsel, const int* msel, int np, c
 					if (has_s[p]) { qr = legs[iq]; qi = legs[iq+1]; ur = legs[iu]; ui = legs[iu+1]; psr[p] = qr-ui; psi[p] = qi+ur; msr[p] = qr+ui; msi[p] = qi-ur; }
 				}
 			}
-			int nscaled = 0;
-			for (int p = p0; p < np; p++) { if (scp[p] < 0) nscaled++; if (scm[p] < 0) nscaled++; }
-			double sgn = ((l0+m) & 1) ? -1.0 : 1.0;
-			for (int j = 0; j < nl; j++, sgn = -sgn) {
-				const int l = l0+j;
-				const double a = ca[j], b = cb[j];
-				const double* Gp = gp2; const double* Gm = gm2;
-				if (nscaled > 0) { for (int p = p0; p < np; p++) { ggp[p] = scp[p] == 0 ? gp2[p] : 0; ggm[p] = scm[p] == 0 ? gm2[p] : 0; } Gp = ggp; Gm = ggm; }
-				if (dir == 0) {
-					const double Er = E[2*l], Ei = E[2*l+1], Br = B[2*l], Bi = B[2*l+1], bb = be[j];
-					const double apr = -bb*(Er-Bi), api = -bb*(Ei+Br), amr = -sg*bb*(Er+Bi), ami = -sg*bb*(Ei-Br);
-					const double sapr = sgn*apr, sapi = sgn*api, samr = sgn*amr, sami = sgn*ami;
+			const int BLK = 128;
+			double* Mt = (dir == 1) ? (double*)calloc((size_t)nl*4, sizeof(double)) : NULL;
+			for (int pb = p0; pb < np; pb += BLK) {
+				const int pe = pb+BLK < np ? pb+BLK : np;
+				int nscaled = 0, anylive = 0;
+				for (int p = pb; p < pe; p++) { if (scp[p] < 0) nscaled++; if (scm[p] < 0) nscaled++; if (gp2[p] != 0.0 || gm2[p] != 0.0) anylive = 1; }
+				if (!anylive) continue;
+				double sgn = ((l0+m) & 1) ? -1.0 : 1.0;
+				for (int j = 0; j < nl; j++, sgn = -sgn) {
+					const int l = l0+j;
+					const double a = ca[j], b = cb[j];
+					const double* Gp = gp2; const double* Gm = gm2;
+					if (nscaled > 0) { for (int p = pb; p < pe; p++) { ggp[p] = scp[p] == 0 ? gp2[p] : 0; ggm[p] = scm[p] == 0 ? gm2[p] : 0; } Gp = ggp; Gm = ggm; }
+					if (dir == 0) {
+						const double Er = E[2*l], Ei = E[2*l+1], Br = B[2*l], Bi = B[2*l+1], bb = be[j];
+						const double apr = -bb*(Er-Bi), api = -bb*(Ei+Br), amr = -sg*bb*(Er+Bi), ami = -sg*bb*(Ei-Br);
+						const double sapr = sgn*apr, sapi = sgn*api, samr = sgn*amr, sami = sgn*ami;
 #pragma omp simd
-					for (int p = p0; p < np; p++) {
-						pnr[p] += Gp[p]*apr; pni[p] += Gp[p]*api; mnr[p] += Gm[p]*amr; mni[p] += Gm[p]*ami;
-						psr[p] += Gm[p]*sapr; psi[p] += Gm[p]*sapi; msr[p] += Gp[p]*samr; msi[p] += Gp[p]*sami;
-					}
-				} else {
-					double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+						for (int p = pb; p < pe; p++) {
+							pnr[p] += Gp[p]*apr; pni[p] += Gp[p]*api; mnr[p] += Gm[p]*amr; mni[p] += Gm[p]*ami;
+							psr[p] += Gm[p]*sapr; psi[p] += Gm[p]*sapi; msr[p] += Gp[p]*samr; msi[p] += Gp[p]*sami;
+						}
+					} else {
+						double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma omp simd reduction(+:t0,t1,t2,t3)
-					for (int p = p0; p < np; p++) {
-						t0 += Gp[p]*pnr[p]+sgn*Gm[p]*psr[p]; t1 += Gp[p]*pni[p]+sgn*Gm[p]*psi[p];
-						t2 += Gm[p]*mnr[p]+sgn*Gp[p]*msr[p]; t3 += Gm[p]*mni[p]+sgn*Gp[p]*msi[p];
+						for (int p = pb; p < pe; p++) {
+							t0 += Gp[p]*pnr[p]+sgn*Gm[p]*psr[p]; t1 += Gp[p]*pni[p]+sgn*Gm[p]*psi[p];
+							t2 += Gm[p]*mnr[p]+sgn*Gp[p]*msr[p]; t3 += Gm[p]*mni[p]+sgn*Gp[p]*msi[p];
+						}
+						Mt[4*j] += t0; Mt[4*j+1] += t1; Mt[4*j+2] += t2; Mt[4*j+3] += t3;
 					}
-					const double bb = be[j];
+#pragma omp simd
+					for (int p = pb; p < pe; p++) {
+						double tp = a*cth[p]+b, tm = a*cth[p]-b;
+						double n1 = tp*gp2[p]-gp1[p], n2 = tm*gm2[p]-gm1[p];
+						gp1[p] = gp2[p]; gp2[p] = n1; gm1[p] = gm2[p]; gm2[p] = n2;
+					}
+					if (nscaled > 0) for (int p = pb; p < pe; p++) {
+						if (scp[p] < 0 && fabs(gp2[p]) > BIG) { gp1[p] *= SMALL; gp2[p] *= SMALL; scp[p]++; if (scp[p] == 0) nscaled--; }
+						if (scm[p] < 0 && fabs(gm2[p]) > BIG) { gm1[p] *= SMALL; gm2[p] *= SMALL; scm[p]++; if (scm[p] == 0) nscaled--; }
+					}
+				}
+			}
+			if (dir == 1) {
+				for (int j = 0; j < nl; j++) {
+					const int l = l0+j; const double bb = be[j];
+					const double t0 = Mt[4*j], t1 = Mt[4*j+1], t2 = Mt[4*j+2], t3 = Mt[4*j+3];
 					E[2*l] = -0.5*bb*(t0+sg*t2); E[2*l+1] = -0.5*bb*(t1+sg*t3);
 					B[2*l] = -0.5*bb*(t1-sg*t3); B[2*l+1] = 0.5*bb*(t0-sg*t2);
 				}
-#pragma omp simd
-				for (int p = p0; p < np; p++) {
-					double tp = a*cth[p]+b, tm = a*cth[p]-b;
-					double n1 = tp*gp2[p]-gp1[p], n2 = tm*gm2[p]-gm1[p];
-					gp1[p] = gp2[p]; gp2[p] = n1; gm1[p] = gm2[p]; gm2[p] = n2;
-				}
-				if (nscaled > 0) for (int p = p0; p < np; p++) {
-					if (scp[p] < 0 && fabs(gp2[p]) > BIG) { gp1[p] *= SMALL; gp2[p] *= SMALL; scp[p]++; if (scp[p] == 0) nscaled--; }
-					if (scm[p] < 0 && fabs(gm2[p]) > BIG) { gm1[p] *= SMALL; gm2[p] *= SMALL; scm[p]++; if (scm[p] == 0) nscaled--; }
-				}
+				free(Mt);
 			}
 			if (dir == 0) for (int p = 0; p < np; p++) {
 				size_t iq = (((size_t)im*2+0)*np+p)*2, iu = (((size_t)im*2+1)*np+p)*2;
