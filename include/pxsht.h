@@ -99,6 +99,17 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
                int naxes, const int* axes, int kind, int forward, double scale,
                int in_dtype, int out_dtype, const void* in, void* out, int device, void* stream);
 
+/* alm post-processing on the device (cython/cmisc_core.c of the reference, via alm_info.alm2cl / lmul,
+ * curvedsky.py:451-474, 630-712).  d_mstart: DEVICE array u64[mmax+1]; d_lmat: DEVICE f64[N][M][nl].
+ * pxa_alm2cl: cl[l] = 1/(2l+1) sum_m a1_lm conj(a2_lm) (m>0 counted twice), one pair of alm per call.
+ * pxa_lmatmul: out[a] = sum_b lmat[a][b][l] in[b] (N = M = 1 is almxfl); out may alias in.
+ * complex64 alm use single precision arithmetic with the filter rounded to float, as the reference does. */
+int pxa_alm2cl(int lmax, int mmax, const uint64_t* d_mstart, int64_t lstride, const void* alm1, const void* alm2, int alm_dtype,
+               void* cl, int cl_dtype, int device, void* stream);
+int pxa_lmatmul(int N, int M, int lmax, int mmax, const uint64_t* d_mstart, int64_t lstride,
+                const void* alm_in, int64_t in_cstride, void* alm_out, int64_t out_cstride, int alm_dtype,
+                const double* d_lmat, int nl, int device, void* stream);
+
 /* 1 if the engine can transform this length (2,3,5-smooth or prime factors small enough) */
 int pxf_fft_supported(int64_t n);
 int64_t pxf_fft_good_size(int64_t n);

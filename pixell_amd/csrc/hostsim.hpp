@@ -109,6 +109,8 @@ static inline void __syncthreads() { if (pxsim::t_ctx->nthreads > 1) pxsim::t_ct
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a*b) >> 32); }
 static inline double __shfl_xor(double v, int mask) { uint64_t u; std::memcpy(&u, &v, 8); u = pxsim::xchg(u, pxsim::lane_id() ^ mask); std::memcpy(&v, &u, 8); return v; }
 static inline double __shfl(double v, int src) { uint64_t u; std::memcpy(&u, &v, 8); u = pxsim::xchg(u, src); std::memcpy(&v, &u, 8); return v; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a*b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a+b; return r; }
 static inline int __shfl(int v, int src) { return (int)pxsim::xchg((uint64_t)(uint32_t)v, src); }
 static inline unsigned long long __ballot(int pred) {
 	pxsim::BlockCtx* c = pxsim::t_ctx; int w = pxsim::wave_id(), l = pxsim::lane_id();

@@ -39,6 +39,7 @@ static int k_syn0() { static int k = env_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; 
 static int k_ana0() { static int k0 = env_k("PXS_K_ANA0", 8, 4, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : 4); return k; }
 static int k_syns() { static int k = env_k("PXS_K_SYNS", 3, 2, 4); return k; }
 static int k_anas() { static int k = env_k("PXS_K_ANAS", 6, 2, 6); return k; }
+static int xcd_map() { static int k = env_k("PXS_XCD_MAP", 1, 0, 1); return k; }
 
 struct double4_t { double a, b, c, d; };
 
@@ -51,7 +52,26 @@ struct LegK {
 	double2* leg;
 	double ofs;
 	int m0; long rowbase, rows_chunk;   // analysis processes m in chunks to bound the partial-moment scratch
+	int nmc, xcd;                       // m count of this launch; XCD-aware block order on/off
 };
+
+// Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
+// scalar cache; workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  With the plain
+// (chunk, m) grid the nwave readers of a stream were spread over all XCDs and drifted apart, and FETCH_SIZE
+// showed every one of them going to the fabric (49 GB per leg_syn_spin launch at config 3 = nwave x the
+// table).  This order gives all chunks of one m the same `block % 8`, back to back in that XCD's queue, so
+// one reader misses and the others hit in L2.
+__device__ __forceinline__ bool leg_block(const LegK& a, int& wv, int& m) {
+	if (!a.xcd) { wv = blockIdx.x; m = blockIdx.y + a.m0; return true; }
+	const unsigned b = blockIdx.x, x = b & 7u, j = b >> 3;
+	const unsigned ml = j / (unsigned)a.nwave;
+	wv = (int)(j - ml*a.nwave);
+	const unsigned mi = ml*8u + x;
+	m = (int)mi + a.m0;
+	return mi < (unsigned)a.nmc;
+}
+static inline dim3 leg_grid(const LegK& a) { return a.xcd ? dim3((unsigned)(8*((a.nmc+7)/8)*a.nwave)) : dim3(a.nwave, a.nmc); }
+
 
 // ---------------------------------------------------------------------------------
 // scaled powers
@@ -238,7 +258,8 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 {
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
+	const int lane = threadIdx.x; int wv, m;
+	if (!leg_block(a, wv, m)) return;
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
@@ -394,7 +415,8 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
 	PXS_SHARED(double, red);
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
+	const int lane = threadIdx.x; int wv, m;
+	if (!leg_block(a, wv, m)) return;
 	const long row0 = a.row[m];
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
@@ -563,7 +585,8 @@ template<int K> __device__ __forceinline__ void spin_step_rescale(SpinState<K>& 
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
+	const int lane = threadIdx.x; int wv, m;
+	if (!leg_block(a, wv, m)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	double2* __restrict__ outq = a.leg + (long)m*a.nring;
@@ -666,7 +689,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 {
 	PXS_SHARED(double, red);
-	const int lane = threadIdx.x, wv = blockIdx.x, m = blockIdx.y + a.m0;
+	const int lane = threadIdx.x; int wv, m;
+	if (!leg_block(a, wv, m)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	if (nl <= 0) return;
@@ -914,6 +938,7 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	a.almt = wk.almt.as<double>(); a.part = wk.part.as<double>(); a.mom = wk.mom.as<double>();
 	a.leg = leg;
 	a.ofs = std::max(100.0, 0.01*tb.lmax);
+	a.nmc = a.nm; a.xcd = xcd_map();
 	return a;
 }
 
@@ -939,8 +964,8 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		const int K = k_syn0();
 		LegK a = make_legk(rs, tb, wk, leg, K);
 		if (prof) prof->begin(st, 0);
-		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, dim3(a.nwave, nm), dim3(64), 0, st, a);
-		else        hipLaunchKernelGGL(leg_syn_s0<4>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
+		else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
 	} else {
 		const int nlmax = tb.lmax + 1;
@@ -948,9 +973,9 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		const int K = k_syns();
 		LegK a = make_legk(rs, tb, wk, leg, K);
 		if (prof) prof->begin(st, 0);
-		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, dim3(a.nwave, nm), dim3(64), 0, st, a);
-		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, dim3(a.nwave, nm), dim3(64), 0, st, a);
-		else             hipLaunchKernelGGL(leg_syn_spin<2>, dim3(a.nwave, nm), dim3(64), 0, st, a);
+		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
+		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
+		else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
 	}
 	PXS_HIP(hipGetLastError());
@@ -983,10 +1008,10 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		const long rows = tb.row[m1]-tb.row[m0];
 		if (rows <= 0) continue;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
-		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows;
+		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0;
 		PXS_HIP(hipMemsetAsync(wk.part.p, 0, sizeof(double)*4*rows*nwave, st));
 		if (prof) prof->begin(st, 1);
-		const dim3 grid(a.nwave, m1-m0);
+		const dim3 grid = leg_grid(a);
 		if (tb.spin == 0) {
 			if (K == 12)     hipLaunchKernelGGL(leg_ana_s0<12>, grid, dim3(64), sh, st, a);
 			else if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);

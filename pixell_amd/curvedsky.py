@@ -66,6 +66,17 @@ class alm_info:
 	def nm(self): return self.mmax+1
 	def lm2ind(self, l, m):
 		return (self.mstart[m].astype(int, copy=False)+l*self.stride).astype(int, copy=False)
+	def get_map(self):
+		raise NotImplementedError
+	def alm2cl(self, alm, alm2=None, dtype=None):
+		"""cross power spectrum of alm and alm2, which broadcast (curvedsky.py:451-462); e.g.
+		cl[{T,E,B},{T,E,B},nl] = ainfo.alm2cl(alm[:,None,:], alm[None,:,:])"""
+		from . import almops
+		return almops.alm2cl(self, alm, alm2=alm2, cl_dtype=dtype)
+	def lmul(self, alm, lmat, out=None):
+		"""res[a,lm] = lmat[a,b,l]*alm[b,lm] (or the broadcasting product for lmat[...,l]) (curvedsky.py:463-466)"""
+		from . import almops
+		return almops.lmul(self, alm, lmat, out=out)
 	def __repr__(self):
 		return "alm_info(lmax=%s,mmax=%s,mstart=%s)" % (str(self.lmax), str(self.mmax), str(self.mstart))
 
@@ -390,3 +401,116 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 			else:       alm_full[Ij] = jacobi_inverse(Y, YTW, map_full[Ij], niter=niter)
 	if adjoint: return map
 	else:       return alm
+
+# ---------------------------------------------------------------------------------------
+# alm post-processing either side of the transforms: almxfl, alm2cl, rand_alm.
+# The per-element arithmetic (lmul, alm2cl) runs on the GPU (almops.py -> pxa_*); the random
+# numbers come from numpy's legacy global RNG exactly as in the reference, so that a seed gives the
+# same alm as pixell (curvedsky.py:61-79, 600-628).
+# ---------------------------------------------------------------------------------------
+def almxfl(alm, lfilter=None, ainfo=None, out=None):
+	"""a_lm * lfilter(l); lfilter is an array starting at l=0 or a function of l (curvedsky.py:630-652)"""
+	if not _is_tensor(alm): alm = np.asarray(alm)
+	ainfo = alm_info(nalm=alm.shape[-1]) if ainfo is None else ainfo
+	if callable(lfilter):
+		l = np.arange(ainfo.lmax+1.0)
+		lfilter = lfilter(l)
+	return ainfo.lmul(alm, lfilter, out=out)
+
+def alm2cl(alm, alm2=None, ainfo=None, dtype=None):
+	"""(cross) power spectrum of alm (and alm2, which must broadcast) (curvedsky.py:674-712)"""
+	if not _is_tensor(alm): alm = np.asarray(alm)
+	ainfo = alm_info(nalm=alm.shape[-1]) if ainfo is None else ainfo
+	return ainfo.alm2cl(alm, alm2=alm2, dtype=dtype)
+
+def pad_spectrum(ps, lmax):
+	ps = np.asarray(ps)
+	ops = np.zeros(ps.shape[:-1]+(lmax+1,), ps.dtype)
+	ops[..., :ps.shape[-1]] = ps[..., :ps.shape[-1]]
+	return ops
+
+def _sym_expand_diag(ps):
+	"""powspec.sym_expand(ps, scheme="diag") (powspec.py:22-36, 53-100): [nspec,nl] -> [ncomp,ncomp,nl],
+	healpy order: main diagonal first, then successive off-diagonals"""
+	n = ps.shape[0]
+	ncomp = int(np.ceil((np.sqrt(8*n+1)-1)/2))   # a truncated list: the smallest ncomp whose full list covers it
+	which = [(i, i+d) for d in range(ncomp) for i in range(ncomp-d)][:n]
+	res = np.zeros((ncomp, ncomp)+ps.shape[1:], ps.dtype)
+	for v, (i, j) in zip(ps, which):
+		res[i, j] = v; res[j, i] = v
+	return res
+
+def prepare_ps(ps, ainfo=None, lmax=None):
+	ps = np.asarray(ps)
+	if ainfo is None:
+		if lmax is None: lmax = ps.shape[-1]-1
+		if lmax > ps.shape[-1]-1: ps = pad_spectrum(ps, lmax)
+		ainfo = alm_info(lmax)
+	if   ps.ndim == 1: wps = ps[None, None]
+	elif ps.ndim == 2: wps = _sym_expand_diag(ps)
+	elif ps.ndim == 3: wps = ps
+	else: raise ValueError("power spectrum must be [nl], [nspec,nl] or [ncomp,ncomp,nl]")
+	return wps, ainfo
+
+def _multi_sqrt(wps):
+	"""enmap.multi_pow(wps, 0.5) (enmap.py:2021-2024 -> utils.eigpow): matrix square root of each
+	[ncomp,ncomp] slice through its eigen-decomposition, negative eigenvalues set to zero"""
+	A = np.moveaxis(np.asarray(wps, dtype=np.float64), (0, 1), (-2, -1))
+	E, V = np.linalg.eigh(A)
+	E = np.where(E < 0, 0, np.sqrt(np.abs(E)))
+	res = np.einsum("...ij,...j,...kj->...ik", V, E, V)
+	return np.moveaxis(res, (-2, -1), (0, 1))
+
+def fill_gauss(arr, bsize=0x10000):
+	rtype = real_dtype(arr.dtype)
+	arr = arr.reshape(-1).view(rtype)
+	for i in range(0, arr.size, bsize):
+		arr[i:i+bsize] = np.random.standard_normal(min(bsize, arr.size-i))
+
+def _transpose_index(ainfo):
+	"""Source and destination positions of alm_info.transpose_alm (cmisc_core.c:116-135): the k-th
+	element in storage order (m-major) moves to the k-th (l,m) pair in l-major order."""
+	lmax, mmax = ainfo.lmax, ainfo.mmax
+	m_src = np.repeat(np.arange(mmax+1), lmax+1-np.arange(mmax+1))
+	first = np.concatenate([[0], np.cumsum(lmax+1-np.arange(mmax+1))[:-1]])
+	l_src = np.arange(len(m_src))-np.repeat(first, lmax+1-np.arange(mmax+1))+m_src
+	cnt = np.minimum(np.arange(lmax+1), mmax)+1
+	l_dst = np.repeat(np.arange(lmax+1), cnt)
+	firstl = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+	m_dst = np.arange(len(l_dst))-np.repeat(firstl, cnt)
+	ms = ainfo.mstart.astype(np.int64)
+	return ms[m_src]+l_src*ainfo.stride, ms[m_dst]+l_dst*ainfo.stride
+
+def transpose_alm(ainfo, alm, out=None):
+	"""alm_info.transpose_alm (curvedsky.py:443-451): reorder numbers generated in l-major order into
+	the m-major layout.  alm is out is allowed."""
+	src, dst = _transpose_index(ainfo)
+	if out is None: out = alm.copy()
+	vals = alm[..., src]
+	out[..., dst] = vals
+	return out
+alm_info.transpose_alm = lambda self, alm, out=None: transpose_alm(self, alm, out=out)
+
+def rand_alm_white(ainfo, pre=None, alm=None, seed=None, dtype=np.complex128, m_major=True):
+	if seed is not None: np.random.seed(seed)
+	if alm is None:
+		if pre is None: alm = np.empty(ainfo.nelem, dtype)
+		else:           alm = np.empty(tuple(pre)+(ainfo.nelem,), dtype)
+	fill_gauss(alm)
+	if m_major: ainfo.transpose_alm(alm, alm)
+	return alm
+
+def rand_alm(ps, ainfo=None, lmax=None, seed=None, dtype=np.complex128, m_major=True, return_ainfo=False):
+	"""Gaussian alm with (cross) spectrum ps (curvedsky.py:61-79): white numbers drawn in l-major order
+	from numpy's legacy RNG, then coloured with sqrt(ps) on the GPU (alm_info.lmul)."""
+	ps = np.asarray(ps)
+	rtype = real_dtype(dtype)
+	wps, ainfo = prepare_ps(ps, ainfo=ainfo, lmax=lmax)
+	alm = rand_alm_white(ainfo, pre=[wps.shape[0]], seed=seed, dtype=dtype, m_major=m_major)
+	ps12 = _multi_sqrt(wps)
+	alm = ainfo.lmul(alm, (ps12/2**0.5).astype(rtype, copy=False))
+	alm[:, :ainfo.lmax+1].imag  = 0
+	alm[:, :ainfo.lmax+1].real *= 2**0.5
+	if ps.ndim == 1: alm = alm[0]
+	if return_ainfo: return alm, ainfo
+	else: return alm

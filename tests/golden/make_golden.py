@@ -14,6 +14,7 @@ What it does
        geometry.json       analyse_geometry / get_ring_info / alm_info results for the path's geometries
        fft_golden.npz      pixell.fft / enmap.fft outputs from the reference's numpy engine
        alm_ops.npz         cmisc alm2cl / lmul outputs (next-row f1)
+       alm_rand.npz        rand_alm / rand_alm_white / transpose_alm / lmul matrix form / alm2cl dtypes (f1)
 """
 import sys, os, json, types
 import numpy as np
@@ -32,6 +33,36 @@ def read_fits_f64(fname):
 	n = int(np.prod(shape))
 	return np.frombuffer(raw[2880:2880+8*n], ">f8").reshape(shape).astype(np.float64), cards
 
+def alm_rand_fixture(curvedsky):
+	"""rand_alm / rand_alm_white / alm2cl / lmul (matrix and broadcasting forms) of the reference -> alm_rand.npz"""
+	rng = np.random.default_rng(77)
+	lmax = 24; nl = lmax+1
+	A = rng.standard_normal((3, 3, nl)); ps3 = np.einsum("ikl,jkl->ijl", A, A)+0.1*np.eye(3)[:, :, None]
+	ps1 = rng.random(nl)+0.1
+	ps2 = np.stack([ps3[0, 0], ps3[1, 1], ps3[2, 2], ps3[0, 1]])       # healpy 'diag' order, truncated
+	out = dict(lmax=lmax, ps3=ps3, ps1=ps1, ps2=ps2)
+	out["alm3"] = curvedsky.rand_alm(ps3, seed=5)
+	out["alm1"] = curvedsky.rand_alm(ps1, seed=6)
+	out["alm2"] = curvedsky.rand_alm(ps2, seed=7)
+	out["alm3_sp"] = curvedsky.rand_alm(ps3, seed=5, dtype=np.complex64)
+	out["alm_lmax"] = curvedsky.rand_alm(ps1, lmax=30, seed=8)          # spectrum padded with zeros
+	ai = curvedsky.alm_info(lmax)
+	out["white"] = curvedsky.rand_alm_white(ai, pre=[2], seed=9)
+	out["white_lmajor"] = curvedsky.rand_alm_white(ai, pre=[2], seed=9, m_major=False)
+	ai2 = curvedsky.alm_info(lmax=lmax, mmax=10)
+	w = rng.standard_normal((2, ai2.nelem))+1j*rng.standard_normal((2, ai2.nelem))
+	out["mmax_alm"] = w; out["mmax_tr"] = ai2.transpose_alm(w)
+	out["mmax_cl"] = ai2.alm2cl(w[:, None], w[None, :])
+	lm = rng.standard_normal((2, 3, nl-4))                              # short filter: zero beyond its end
+	out["lmat"] = lm; out["lmatmul"] = ai.lmul(out["alm3"], lm)
+	lb = rng.standard_normal((3, nl))
+	out["lbro"] = lb; out["lmul_bro"] = ai.lmul(out["alm3"], lb)
+	sp = out["alm3_sp"]
+	out["cl_sp"] = ai.alm2cl(sp[:, None], sp[None, :]); out["cl_sp_dp"] = ai.alm2cl(sp[:, None], sp[None, :], dtype=np.float64)
+	out["cl_cross"] = ai.alm2cl(out["alm3"][:, None], out["white"][None, :])
+	out["xfl_fun"] = curvedsky.almxfl(out["alm1"], lambda l: 1/(1+l)**2)
+	np.savez_compressed(os.path.join(HERE, "alm_rand.npz"), **out)
+
 def main():
 	sht = types.ModuleType("sht_exp")
 	for name in ["synthesis_2d", "adjoint_synthesis_2d", "analysis_2d", "adjoint_analysis_2d",
@@ -40,6 +71,8 @@ def main():
 	ns = H.load_reference(sht)
 	enmap, curvedsky, powspec, lensing, utils, pfft = ns.enmap, ns.curvedsky, ns.powspec, ns.lensing, ns.utils, ns.fft
 	data = "/root/reference/tests/data/"
+	if "--only-alm-rand" in sys.argv:
+		alm_rand_fixture(curvedsky); print("alm_rand.npz written"); return
 
 	# ---- 1. the one true golden vector -------------------------------------------------
 	shape, wcs = enmap.fullsky_geometry(res=np.deg2rad(1.0), variant="CC")
@@ -194,6 +227,7 @@ def main():
 	fl = rng.random(lmax+1)
 	np.savez_compressed(os.path.join(HERE, "alm_ops.npz"), alm=al, cl=cl, fl=fl, almxfl=curvedsky.almxfl(al, fl),
 		mstart=ai.mstart, lmax=lmax)
+	alm_rand_fixture(curvedsky)
 	print("fixtures written to", HERE)
 
 if __name__ == "__main__":

@@ -1,0 +1,26 @@
+"""Summarise FETCH_SIZE / WRITE_SIZE counter passes (tools/pmc_traffic.sh) per kernel.
+FETCH_SIZE and WRITE_SIZE are reported in KB by rocprofv3; on gfx950 FETCH_SIZE counts a wide
+coalesced read at half its bytes (MI355X_MICROARCH.md, HBM section), so both the raw and the x2
+figure are given.  Writes profiles/<tag>_traffic.json."""
+import csv, json, sys, collections, re
+def load(path, name):
+	out = collections.defaultdict(lambda: [0, 0.0, 0.0])
+	with open(path) as f:
+		for row in csv.DictReader(f):
+			if row["Counter_Name"] != name: continue
+			k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
+			if len(k) > 60: k = k[:60]
+			o = out[k]; o[0] += 1; o[1] += float(row["Counter_Value"]); o[2] += (int(row["End_Timestamp"])-int(row["Start_Timestamp"]))*1e-6
+	return out
+cfg, tag = sys.argv[1], sys.argv[2]
+ROUND_TRIPS = 2   # tools/pmc_traffic.sh runs bench.py --steps 1 --warmup 0: one validation round trip in setup + one timed
+f = load(f"gpurun_out/pmc_fetch_{cfg}/f_counter_collection.csv", "FETCH_SIZE")
+w = load(f"gpurun_out/pmc_write_{cfg}/w_counter_collection.csv", "WRITE_SIZE")
+res = {}
+for k in sorted(set(f) | set(w)):
+	nf, kbf, msf = f.get(k, [0, 0, 0]); nw, kbw, _ = w.get(k, [0, 0, 0])
+	if not k.startswith("pxs::"): continue
+	res[k] = {"launches": nf, "launches_per_round_trip": nf/ROUND_TRIPS, "ms_total_under_pmc": round(msf, 3), "fetch_MB_per_launch_raw": round(kbf/1024/max(nf, 1), 3),
+		"fetch_MB_per_launch_x2": round(2*kbf/1024/max(nf, 1), 3), "write_MB_per_launch": round(kbw/1024/max(nw, 1), 3)}
+json.dump({"config": cfg, "round_trips_in_trace": ROUND_TRIPS, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB counters / 1024); x2 = gfx950 wide-read correction of MI355X_MICROARCH.md", "kernels": res}, open(f"profiles/{tag}_traffic_{cfg}.json", "w"), indent=1)
+for k, v in res.items(): print(f"{k:62s} n={v['launches']:4d} ms={v['ms_total_under_pmc']:9.2f} fetch={v['fetch_MB_per_launch_raw']:10.2f} (x2 {v['fetch_MB_per_launch_x2']:10.2f}) write={v['write_MB_per_launch']:10.2f} MB/launch")
