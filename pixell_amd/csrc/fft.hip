@@ -22,16 +22,14 @@ static constexpr int FFT_THREADS  = 256;
 static constexpr int FFT_NLOC_MAX = 2048;   // longest line done in one LDS pass
 static constexpr int FFT_LDS_PTS  = 4096;   // complex points of LDS per workgroup (64 KiB)
 static constexpr int FFT_MAXFAC   = 16;
-#ifndef FFT_LU
-#define FFT_LU 4                            // independent global loads in flight per thread in the load phase (8 measured slower: 2.4 -> 1.8 TB/s)
-#endif
 
 struct PassDesc { int R; int L; int tws; FastDiv dL; FastDiv dnb; };
 
 struct KArgs {
 	int n, nfac, T, generic, mode, forward, n1, n2;
 	long N;
-	PassDesc pass[FFT_MAXFAC];
+	const PassDesc* pass;            // device table (a by-value array indexed at run time made the compiler spill the whole
+	                                 // argument struct to scratch in the larger kernels)
 	const int* perm; const double2* tw;
 	FastDiv dn, dT;
 	FftDims d; long i_base, i_count;
@@ -69,11 +67,11 @@ __device__ __forceinline__ void write_elem(void* p, int dtype, long off, double2
 }
 
 // value of input element e (0 <= e < N) of line (i,o1,o2)
-__device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1, long o2, long e) {
+template<int LM> __device__ __forceinline__ double2 load_functor(const KArgs& a, long i, long o1, long o2, long e) {
 	const FftLoad& ld = a.ld;
 	const long base = i*a.d.is_i + o1*a.d.is_o1 + o2*a.d.is_o2;
 	const long N = a.N;
-	switch (ld.mode) {
+	switch (LM) {      // compile-time: one instantiation of the kernels per load mode keeps the prefetch code small
 	case LD_PLAIN: {
 		if (ld.ne >= 0 && e >= ld.ne) return make_double2(0, 0);
 		double2 v = read_elem(ld.ptr, ld.dtype, base + e*a.d.is_e);
@@ -279,62 +277,53 @@ __device__ __forceinline__ void generic_pass(const double2* src, double2* dst, c
 	}
 }
 
-__global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
-{
-	PXS_SHARED(double2, lds);
-	const int n = a.n, T = a.T;
-	double2* tw = lds;                 // [n]
-	double2* bufA = lds + n;           // [T*n]
-	double2* bufB = bufA + LPAD((size_t)T*n) + 1; // only if generic
+// workgroup barrier that only waits for LDS traffic: __syncthreads() also drains vmcnt, which would stall on the
+// global loads the pipelined kernel keeps in flight for its next tile
+#ifdef PXS_HOST_SIM
+#define PXS_LDS_BARRIER() __syncthreads()
+#else
+#define PXS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
-	// decode block -> (tile, other, o1, o2).  mode 0: tile over lines i.  modes 1/2 (four-step):
-	// sub-lines are (i, s) with s = j2 (pass A) or k1 (pass B); tile_i selects which one is tiled.
-	long bx = blockIdx.x;
+// block -> (tile, other, o1, o2).  mode 0: tile over lines i.  modes 1/2 (four-step): sub-lines are (i, s) with
+// s = j2 (pass A) or k1 (pass B); tile_i selects which one is tiled.
+struct TileCtx { long s0, other, o1, o2, lo; int nl; };
+__device__ __forceinline__ TileCtx tile_decode(const KArgs& a, long bx) {
+	TileCtx c;
 	const long tile = bx % a.ntile; bx /= a.ntile;
 	const long slim = (a.mode == 1) ? a.n2 : a.n1;
-	long other = 0;
-	if (a.mode != 0) { const long no = a.tile_i ? slim : a.i_count; other = bx % no; bx /= no; }
-	const long o1 = bx % a.d.n_o1, o2 = bx / a.d.n_o1;
-	const long s0 = tile*T;
+	c.other = 0;
+	if (a.mode != 0) { const long no = a.tile_i ? slim : a.i_count; c.other = bx % no; bx /= no; }
+	c.o1 = bx % a.d.n_o1; c.o2 = bx / a.d.n_o1;
+	c.s0 = tile*a.T;
 	const long tlim = (a.mode == 0 || a.tile_i) ? a.i_count : slim;
-	const int nl = (int)min((long)T, tlim - s0);
-	const long lo = o2*a.d.n_o1 + o1;                  // outer line index (four-step scratch)
-
-	for (int k = threadIdx.x; k < n; k += FFT_THREADS) tw[k] = a.tw[k];
-
-	// ---- load ---- (4 independent global loads in flight per thread before the LDS scatter)
-	const int total = T*n;
-	for (int idx0 = threadIdx.x; idx0 < total; idx0 += FFT_LU*FFT_THREADS) {
-		double2 v[FFT_LU]; int pos[FFT_LU];
-#pragma unroll
-		for (int u = 0; u < FFT_LU; u++) {
-			const int idx = idx0 + u*FFT_THREADS;
-			pos[u] = -1;
-			if (idx >= total) continue;
-			uint32_t t, j;
-			if (a.load_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
-			else                   { t = fdiv(idx, a.dn); j = idx - t*n; }
-			if ((int)t >= nl) continue;
-			const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
-			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
-			if (a.mode == 0)      v[u] = load_functor(a, il, o1, o2, j);
-			else if (a.mode == 1) v[u] = load_functor(a, il, o1, o2, (long)j*a.n2 + sv);
-			else {
-				const long p2 = sv*a.n2 + j;
-				v[u] = a.temp[a.tile_i ? (lo*a.N + p2)*a.i_count + il : (lo*a.i_count + il)*a.N + p2];
-			}
-			if (!a.forward && a.mode != 2) v[u].y = -v[u].y;
-			pos[u] = (int)(t*n) + a.perm[j];
-		}
-#pragma unroll
-		for (int u = 0; u < FFT_LU; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
+	c.nl = (int)min((long)a.T, tlim - c.s0);
+	c.lo = c.o2*a.d.n_o1 + c.o1;                  // outer line index (four-step scratch)
+	return c;
+}
+// input element idx of the tile -> value and LDS slot (digit-reversed); slot -1 = nothing to load
+template<int LM> __device__ __forceinline__ void tile_load_one(const KArgs& a, const TileCtx& c, int idx, int total, double2& v, int& pos) {
+	const int n = a.n, T = a.T;
+	pos = -1; v = make_double2(0, 0);
+	if (idx >= total) return;
+	uint32_t t, j;
+	if (a.load_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
+	else                   { t = fdiv(idx, a.dn); j = idx - t*n; }
+	if ((int)t >= c.nl) return;
+	const long il = (a.mode == 0 || a.tile_i) ? c.s0 + t : c.other;
+	const long sv = (a.mode == 0) ? 0 : (a.tile_i ? c.other : c.s0 + t);
+	if (a.mode == 0)      v = load_functor<LM>(a, il, c.o1, c.o2, j);
+	else if (a.mode == 1) v = load_functor<LM>(a, il, c.o1, c.o2, (long)j*a.n2 + sv);
+	else {
+		const long p2 = sv*a.n2 + j;
+		v = a.temp[a.tile_i ? (c.lo*a.N + p2)*a.i_count + il : (c.lo*a.i_count + il)*a.N + p2];
 	}
-	__syncthreads();
-
-	// ---- passes ----
-	double2* cur = bufA; double2* oth = bufB;
+	if (!a.forward && a.mode != 2) v.y = -v.y;
+	pos = (int)(t*n) + a.perm[j];
+}
+__device__ __forceinline__ double2* tile_passes(const KArgs& a, double2* cur, double2* oth, const double2* tw) {
 	for (int p = 0; p < a.nfac; p++) {
-		const PassDesc& ps = a.pass[p];
+		const PassDesc ps = a.pass[p];
 		switch (ps.R) {
 			case 2: radix_pass<2>(cur, tw, a, ps); break;
 			case 3: radix_pass<3>(cur, tw, a, ps); break;
@@ -342,10 +331,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 			case 5: radix_pass<5>(cur, tw, a, ps); break;
 			default: generic_pass(cur, oth, tw, a, ps); { double2* x = cur; cur = oth; oth = x; } break;
 		}
-		__syncthreads();
+		PXS_LDS_BARRIER();
 	}
-
-	// ---- store ----
+	return cur;
+}
+__device__ __forceinline__ void tile_store(const KArgs& a, const TileCtx& c, const double2* cur) {
+	const int n = a.n, T = a.T, total = T*n;
 	for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4*FFT_THREADS) {
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
@@ -354,20 +345,74 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 			uint32_t t, j;
 			if (a.store_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
 			else                    { t = fdiv(idx, a.dn); j = idx - t*n; }
-			if ((int)t >= nl) continue;
-			const long il = (a.mode == 0 || a.tile_i) ? s0 + t : other;
-			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? other : s0 + t);
+			if ((int)t >= c.nl) continue;
+			const long il = (a.mode == 0 || a.tile_i) ? c.s0 + t : c.other;
+			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? c.other : c.s0 + t);
 			double2 v = cur[LPAD(t*n + j)];
 			if (a.mode == 1) {
 				v = cmul(v, a.bigtw[(long)j*sv]);
 				const long p2 = (long)j*a.n2 + sv;
-				a.temp[a.tile_i ? (lo*a.N + p2)*a.i_count + il : (lo*a.i_count + il)*a.N + p2] = v;
+				a.temp[a.tile_i ? (c.lo*a.N + p2)*a.i_count + il : (c.lo*a.i_count + il)*a.N + p2] = v;
 			} else {
 				if (!a.forward) v.y = -v.y;
-				if (a.mode == 0) store_functor(a, il, o1, o2, j, v);
-				else             store_functor(a, il, o1, o2, sv + (long)a.n1*j, v);
+				if (a.mode == 0) store_functor(a, il, c.o1, c.o2, j, v);
+				else             store_functor(a, il, c.o1, c.o2, sv + (long)a.n1*j, v);
 			}
 		}
+	}
+}
+
+// one tile per workgroup
+template<int LM, int LU> __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
+{
+	PXS_SHARED(double2, lds);
+	const int n = a.n, T = a.T;
+	double2* tw = lds;                 // [n]
+	double2* bufA = lds + n;           // [T*n]
+	double2* bufB = bufA + LPAD((size_t)T*n) + 1; // only if generic
+	const TileCtx c = tile_decode(a, blockIdx.x);
+	for (int k = threadIdx.x; k < n; k += FFT_THREADS) tw[k] = a.tw[k];
+	// ---- load ---- (LU independent global loads in flight per thread before the LDS scatter)
+	const int total = T*n;
+	for (int idx0 = threadIdx.x; idx0 < total; idx0 += LU*FFT_THREADS) {
+		double2 v[LU]; int pos[LU];
+#pragma unroll
+		for (int u = 0; u < LU; u++) tile_load_one<LM>(a, c, idx0 + u*FFT_THREADS, total, v[u], pos[u]);
+#pragma unroll
+		for (int u = 0; u < LU; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
+	}
+	PXS_LDS_BARRIER();
+	const double2* cur = tile_passes(a, bufA, bufB, tw);
+	tile_store(a, c, cur);
+}
+
+// (Tried: a persistent variant of this kernel that issues the global loads of its NEXT tile into registers before the
+// passes of the current one.  The compiler needed 200-260 VGPRs for it (2 waves per SIMD), or 70-230 spills when held
+// to 128; not pursued.  What the attempt left behind: the LDS-only barrier, the per-load-mode instantiation and the pass
+// table in device memory, which keep the argument struct out of scratch.)
+// launch one of the two kernels over nblk tiles
+template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
+	static const int lu8 = [] { const char* e = getenv("PXS_FFT_LU"); return e ? atoi(e) == 8 : 0; }();
+	static const bool once = [] {
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		return true; }();
+	(void)once;
+	if (lu8) hipLaunchKernelGGL((fft_lds_kernel<LM, 8>), dim3((unsigned)nblk), dim3(FFT_THREADS), sh, st, k);
+	else     hipLaunchKernelGGL((fft_lds_kernel<LM, 4>), dim3((unsigned)nblk), dim3(FFT_THREADS), sh, st, k);
+}
+static void launch_tiles(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
+	const int lm = k.mode == 2 ? (int)LD_PLAIN : k.ld.mode;      // pass B reads the four-step scratch, no functor
+	switch (lm) {
+		case LD_PLAIN:       launch_tiles_m<LD_PLAIN>(k, nblk, sh, st); break;
+		case LD_HERM:        launch_tiles_m<LD_HERM>(k, nblk, sh, st); break;
+		case LD_MIRROR:      launch_tiles_m<LD_MIRROR>(k, nblk, sh, st); break;
+		case LD_SPEC:        launch_tiles_m<LD_SPEC>(k, nblk, sh, st); break;
+		case LD_SPEC_ADJ:    launch_tiles_m<LD_SPEC_ADJ>(k, nblk, sh, st); break;
+		case LD_MIRROR_PAIR: launch_tiles_m<LD_MIRROR_PAIR>(k, nblk, sh, st); break;
+		case LD_REAL_PAIR:   launch_tiles_m<LD_REAL_PAIR>(k, nblk, sh, st); break;
+		case LD_HERM_PAIR:   launch_tiles_m<LD_HERM_PAIR>(k, nblk, sh, st); break;
+		default: throw Error(PXS_ERR_ARG, "fft: unknown load mode");
 	}
 }
 
@@ -376,7 +421,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
 // ------------------------------------------------------------------------------------
 struct FftSub {
 	int n; std::vector<int> fac; bool generic = false;
-	DevBuf perm, tw;
+	DevBuf perm, tw, d_pass;
 	PassDesc pass[FFT_MAXFAC]; int nfac = 0;
 };
 
@@ -406,9 +451,16 @@ FftContext::~FftContext() {}
 
 static bool split_two(long n, long& n1, long& n2) {
 	// choose n1*n2 = n, both <= FFT_NLOC_MAX, as balanced as possible
-	long best = -1;
-	for (long a = 1; a*a <= n; a++) if (n % a == 0) { long b = n/a; if (b <= FFT_NLOC_MAX) best = a; }
+	// prefer both factors multiples of 8 (column runs and row starts then fall on 128-byte lines), not more lopsided than 1:4
+	long best = -1, best8 = -1;
+	for (long a = 1; a*a <= n; a++) if (n % a == 0) {
+		long b = n/a; if (b > FFT_NLOC_MAX) continue;
+		best = a;
+		if (a % 8 == 0 && b % 8 == 0 && 4*a >= b) best8 = a;
+	}
 	if (best < 0) return false;
+	static const int align8 = [] { const char* e = getenv("PXS_FFT_ALIGN8"); return e ? atoi(e) : 1; }();
+	if (best8 > 0 && align8) best = best8;
 	n1 = best; n2 = n/best;
 	return n1 <= FFT_NLOC_MAX && n2 <= FFT_NLOC_MAX;
 }
@@ -461,6 +513,7 @@ std::shared_ptr<FftSub> FftContext::sub(long n) {
 	}
 	std::vector<double2> tw; twiddles(n, tw);
 	s->perm = upload(perm); s->tw = upload(tw);
+	s->d_pass = upload(std::vector<PassDesc>(s->pass, s->pass + FFT_MAXFAC));
 	subs_[n] = s;
 	return s;
 }
@@ -476,7 +529,8 @@ const double2* FftContext::bigtw(long n) {
 
 static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	k.n = s.n; k.nfac = s.nfac; k.generic = s.generic;
-	for (int p = 0; p < s.nfac; p++) k.pass[p] = s.pass[p];
+	{ static const int nopass = [] { const char* e = getenv("PXS_FFT_DEBUG_NOPASS"); return e ? atoi(e) : 0; }(); if (nopass) k.nfac = 0; }   // timing experiments only: wrong results
+	k.pass = s.d_pass.as<PassDesc>();
 	k.perm = s.perm.as<int>(); k.tw = s.tw.as<double2>();
 	int bufs = s.generic ? 2 : 1;
 	static const long env_pts = [] { const char* e = getenv("PXS_FFT_PTS"); return e ? atol(e) : 0L; }();
@@ -484,8 +538,16 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	if (env_pts > 0 && s.n <= env_pts/2) pts = env_pts;
 	long T = (pts - s.n)/((long)bufs*s.n);
 	if (T < 1) T = 1;
-	if (T > maxlines) T = maxlines;
 	if (T > 64) T = 64;
+	// Tiles that run along the contiguous memory direction (four-step column passes, adjacent lines) move T*16-byte
+	// runs: keep them whole 128-byte lines.  Neighbouring tiles are handled by workgroups on different XCDs, so a
+	// line shared by two tiles is fetched from HBM twice (FETCH_SIZE of this kernel was 1.6x its WRITE_SIZE).
+	static const int align8 = [] { const char* e = getenv("PXS_FFT_ALIGN8"); return e ? atoi(e) : 1; }();
+	if (align8) {
+		if (T >= 8) T -= T % 8;
+		else if (T >= 5 && (long)bufs*8*s.n + s.n <= FFT_LDS_PTS) T = 8;
+	}
+	if (T > maxlines) T = maxlines;
 	k.T = (int)T;
 	k.dn = make_fastdiv(s.n); k.dT = make_fastdiv((uint32_t)T);
 }
@@ -496,8 +558,6 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 	std::string why;
 	if (!supported(n, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
 	if (d.n_i <= 0 || d.n_o1 <= 0 || d.n_o2 <= 0) return;
-	static std::once_flag once;
-	std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)fft_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); });
 	KArgs k; memset(&k, 0, sizeof(k));
 	k.N = n; k.forward = forward ? 1 : 0; k.d = d; k.ld = ld; k.st = stf; k.i_base = 0; k.i_count = d.n_i;
 	if (n <= FFT_NLOC_MAX) {
@@ -510,7 +570,7 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		k.store_inner_fast = (std::abs(d.os_i) < std::abs(d.os_e)) ? 1 : 0;
 		long nblk = k.ntile*d.n_o1*d.n_o2;
 		size_t sh = lds_bytes(k);
-		hipLaunchKernelGGL(fft_lds_kernel, dim3((unsigned)nblk), dim3(FFT_THREADS), sh, st, k);
+		launch_tiles(k, nblk, sh, st);
 		PXS_HIP(hipGetLastError());
 		return;
 	}
@@ -519,10 +579,12 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 	const double2* btw = bigtw(n);
 	// chunk lines so that the scratch stays below temp_budget
 	long lines_budget = std::max<long>(1, (long)(temp_budget/(sizeof(double2)*n)));
+	DevBuf* tbuf = nullptr;
 	{
 		std::lock_guard<std::mutex> g(mu_);
 		size_t want = sizeof(double2)*n*std::min<long>(lines_budget, d.n_i*d.n_o1*d.n_o2);
-		temp_.ensure(want);
+		tbuf = &temps_[st];     // one scratch per stream: transforms issued on different streams may overlap
+		tbuf->ensure(want);
 	}
 	// iterate over o2, o1 chunks, i chunks
 	long o1_per = 1, i_per = d.n_i;
@@ -540,20 +602,20 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		const long smul = stf.real_pair ? 2 : 1;
 		a.ld.ptr = (const char*)ld.ptr + esz(ld.dtype)*(o2*d.is_o2 + o1*d.is_o1 + lmul*i0*d.is_i);
 		a.st.ptr = (char*)stf.ptr + esz(stf.dtype)*(o2*d.os_o2 + o1*d.os_o1 + smul*i0*d.os_i);
-		a.temp = temp_.as<double2>(); a.bigtw = btw; a.n1 = (int)n1; a.n2 = (int)n2;
+		a.temp = tbuf->as<double2>(); a.bigtw = btw; a.n1 = (int)n1; a.n2 = (int)n2;
 		const int tile_i = (std::abs(d.is_i) < std::abs(d.is_e)) ? 1 : 0;
 		// pass A: n1-point FFTs over j1 for each (i, j2); tile over j2 (lines contiguous) or over i (lines adjacent)
 		KArgs pa = a; fill_sub(pa, *s1, tile_i ? ni : n2); pa.mode = 1; pa.tile_i = tile_i;
 		pa.ntile = ((tile_i ? ni : n2) + pa.T - 1)/pa.T;
 		pa.load_inner_fast = 1; pa.store_inner_fast = 1;
 		long nblkA = pa.ntile*(tile_i ? n2 : ni)*no1;
-		hipLaunchKernelGGL(fft_lds_kernel, dim3((unsigned)nblkA), dim3(FFT_THREADS), lds_bytes(pa), st, pa);
+		launch_tiles(pa, nblkA, lds_bytes(pa), st);
 		// pass B: n2-point FFTs over j2 for each (i, k1)
 		KArgs pb = a; fill_sub(pb, *s2, tile_i ? ni : n1); pb.mode = 2; pb.tile_i = tile_i;
 		pb.ntile = ((tile_i ? ni : n1) + pb.T - 1)/pb.T;
 		pb.load_inner_fast = tile_i ? 1 : 0; pb.store_inner_fast = 1;
 		long nblkB = pb.ntile*(tile_i ? n1 : ni)*no1;
-		hipLaunchKernelGGL(fft_lds_kernel, dim3((unsigned)nblkB), dim3(FFT_THREADS), lds_bytes(pb), st, pb);
+		launch_tiles(pb, nblkB, lds_bytes(pb), st);
 		PXS_HIP(hipGetLastError());
 	}
 }

@@ -61,7 +61,7 @@ private:
 	std::mutex mu_;
 	std::map<long, std::shared_ptr<FftSub>> subs_;
 	std::map<long, DevBuf> bigtw_;
-	DevBuf temp_;
+	std::map<hipStream_t, DevBuf> temps_;
 	std::shared_ptr<FftSub> sub(long n);
 	const double2* bigtw(long n);
 };

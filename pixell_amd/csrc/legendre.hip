@@ -583,6 +583,8 @@ template<int K> __device__ __forceinline__ void spin_step_rescale(SpinState<K>& 
 		j += 4; \
 	}
 
+// (leg_syn_spin<3> sits at 126 VGPRs = 4 waves per SIMD; computing the lane as threadIdx.x & 63 for multi-wave
+// workgroups pushed it to 132 = 3 waves and leg_syn from 120 to 151 ms at config 3 -- keep an eye on that cliff.)
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
 	const int lane = threadIdx.x; int wv, m;
