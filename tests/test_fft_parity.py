@@ -72,7 +72,7 @@ def test_fft_golden_hostsim(golden_dir): check_golden(golden_dir)
 @pytest.mark.hostsim
 def test_fft_known_answers_hostsim(): check_known_answers()
 @pytest.mark.hostsim
-def test_fft_lengths_hostsim(): check_lengths([1, 2, 3, 4, 5, 7, 8, 12, 61, 100, 122, 216, 1000, 2048, 2304, 4320, 10800])
+def test_fft_lengths_hostsim(): check_lengths([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 18, 36, 54, 61, 72, 100, 122, 135, 150, 200, 216, 320, 432, 1000, 2048, 2304, 4320, 10800])
 
 @pytest.mark.gpu
 def test_fft_golden_gpu(golden_dir): check_golden(golden_dir)
