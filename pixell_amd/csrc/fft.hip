@@ -14,11 +14,6 @@
 
 namespace pxs {
 
-#ifdef PXS_HOST_SIM
-static constexpr int FFT_THREADS  = 1;     // index logic only; see hostsim.hpp
-#else
-static constexpr int FFT_THREADS  = 256;
-#endif
 static constexpr int FFT_NLOC_MAX = 2048;   // longest line done in one LDS pass
 static constexpr int FFT_LDS_PTS  = 4096;   // complex points of LDS per workgroup (64 KiB)
 static constexpr int FFT_MAXFAC   = 16;
@@ -27,6 +22,7 @@ struct PassDesc { int R; int L; int tws; FastDiv dL; FastDiv dnb; };
 
 struct KArgs {
 	int n, nfac, T, generic, mode, forward, n1, n2;
+	int ns;                          // LDS line stride in points (n padded to odd: see fill_sub)
 	long N;
 	const PassDesc* pass;            // device table (a by-value array indexed at run time made the compiler spill the whole
 	                                 // argument struct to scratch in the larger kernels)
@@ -231,15 +227,15 @@ template<> __device__ __forceinline__ void butterfly<5>(double2* v) {
 // (Tried: radix 6/8/9 butterflies (216 = 8.9.3 in 3 passes instead of 5).  Per-length gain <= 4 %, but the larger
 // kernel ran every length slower (n = 200: 0.200 -> 0.238 ms, config 3 FFT stages +10 %); removed.  With the passes
 // skipped altogether the kernel moves data at 3.4-3.9 TB/s versus 2.5-2.7 TB/s with them.)
-template<int R> __device__ __forceinline__ void radix_pass(double2* buf, const double2* tw, const KArgs& a, const PassDesc& ps) {
+template<int R, int NT> __device__ __forceinline__ void radix_pass(double2* buf, const double2* tw, const KArgs& a, const PassDesc& ps) {
 	const int nb = a.n / R;
 	const int total = a.T*nb;
-	for (int b = threadIdx.x; b < total; b += FFT_THREADS) {
+	for (int b = threadIdx.x; b < total; b += NT) {
 		const uint32_t t = fdiv(b, ps.dnb);
 		const uint32_t bb = b - t*nb;
 		const uint32_t blk = fdiv(bb, ps.dL);
 		const uint32_t q = bb - blk*ps.L;
-		const uint32_t p0 = t*a.n + blk*ps.L*R + q;
+		const uint32_t p0 = t*a.ns + blk*ps.L*R + q;
 		double2 v[R];
 #pragma unroll
 		for (int i = 0; i < R; i++) v[i] = buf[LPAD(p0 + i*ps.L)];
@@ -255,11 +251,11 @@ template<int R> __device__ __forceinline__ void radix_pass(double2* buf, const d
 }
 
 // generic radix: out of place src -> dst, one thread per output point
-__device__ __forceinline__ void generic_pass(const double2* src, double2* dst, const double2* tw, const KArgs& a, const PassDesc& ps) {
+template<int NT> __device__ __forceinline__ void generic_pass(const double2* src, double2* dst, const double2* tw, const KArgs& a, const PassDesc& ps) {
 	const int R = ps.R, n = a.n;
 	const int total = a.T*n;
 	const int wstep = n / R;
-	for (int idx = threadIdx.x; idx < total; idx += FFT_THREADS) {
+	for (int idx = threadIdx.x; idx < total; idx += NT) {
 		const uint32_t t = fdiv(idx, a.dn);
 		const uint32_t j = idx - t*n;                 // output position within line
 		const uint32_t LR = ps.L*R;
@@ -267,7 +263,7 @@ __device__ __forceinline__ void generic_pass(const double2* src, double2* dst, c
 		const uint32_t r = j - blk*LR;
 		const uint32_t ip = r / ps.L;                 // output digit i'
 		const uint32_t q = r - ip*ps.L;
-		const uint32_t p0 = t*n + blk*LR + q;
+		const uint32_t p0 = t*a.ns + blk*LR + q;
 		double2 acc = make_double2(0, 0);
 		uint32_t widx = 0;                            // (i*ip) mod R
 		for (int i = 0; i < R; i++) {
@@ -276,7 +272,7 @@ __device__ __forceinline__ void generic_pass(const double2* src, double2* dst, c
 			acc = cadd(acc, cmul(v, tw[widx*wstep]));
 			widx += ip; if (widx >= (uint32_t)R) widx -= R;
 		}
-		dst[LPAD(t*n + j)] = acc;
+		dst[LPAD(t*a.ns + j)] = acc;
 	}
 }
 
@@ -322,28 +318,28 @@ template<int LM> __device__ __forceinline__ void tile_load_one(const KArgs& a, c
 		v = a.temp[a.tile_i ? (c.lo*a.N + p2)*a.i_count + il : (c.lo*a.i_count + il)*a.N + p2];
 	}
 	if (!a.forward && a.mode != 2) v.y = -v.y;
-	pos = (int)(t*n) + a.perm[j];
+	pos = (int)(t*a.ns) + a.perm[j];
 }
-__device__ __forceinline__ double2* tile_passes(const KArgs& a, double2* cur, double2* oth, const double2* tw) {
+template<int NT> __device__ __forceinline__ double2* tile_passes(const KArgs& a, double2* cur, double2* oth, const double2* tw) {
 	for (int p = 0; p < a.nfac; p++) {
 		const PassDesc ps = a.pass[p];
 		switch (ps.R) {
-			case 2: radix_pass<2>(cur, tw, a, ps); break;
-			case 3: radix_pass<3>(cur, tw, a, ps); break;
-			case 4: radix_pass<4>(cur, tw, a, ps); break;
-			case 5: radix_pass<5>(cur, tw, a, ps); break;
-			default: generic_pass(cur, oth, tw, a, ps); { double2* x = cur; cur = oth; oth = x; } break;
+			case 2: radix_pass<2, NT>(cur, tw, a, ps); break;
+			case 3: radix_pass<3, NT>(cur, tw, a, ps); break;
+			case 4: radix_pass<4, NT>(cur, tw, a, ps); break;
+			case 5: radix_pass<5, NT>(cur, tw, a, ps); break;
+			default: generic_pass<NT>(cur, oth, tw, a, ps); { double2* x = cur; cur = oth; oth = x; } break;
 		}
 		PXS_LDS_BARRIER();
 	}
 	return cur;
 }
-__device__ __forceinline__ void tile_store(const KArgs& a, const TileCtx& c, const double2* cur) {
+template<int NT> __device__ __forceinline__ void tile_store(const KArgs& a, const TileCtx& c, const double2* cur) {
 	const int n = a.n, T = a.T, total = T*n;
-	for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4*FFT_THREADS) {
+	for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4*NT) {
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
-			const int idx = idx0 + u*FFT_THREADS;
+			const int idx = idx0 + u*NT;
 			if (idx >= total) continue;
 			uint32_t t, j;
 			if (a.store_inner_fast) { j = fdiv(idx, a.dT); t = idx - j*T; }
@@ -351,7 +347,7 @@ __device__ __forceinline__ void tile_store(const KArgs& a, const TileCtx& c, con
 			if ((int)t >= c.nl) continue;
 			const long il = (a.mode == 0 || a.tile_i) ? c.s0 + t : c.other;
 			const long sv = (a.mode == 0) ? 0 : (a.tile_i ? c.other : c.s0 + t);
-			double2 v = cur[LPAD(t*n + j)];
+			double2 v = cur[LPAD(t*a.ns + j)];
 			if (a.mode == 1) {
 				v = cmul(v, a.bigtw[(long)j*sv]);
 				const long p2 = (long)j*a.n2 + sv;
@@ -366,27 +362,28 @@ __device__ __forceinline__ void tile_store(const KArgs& a, const TileCtx& c, con
 }
 
 // one tile per workgroup
-template<int LM, int LU> __global__ __launch_bounds__(FFT_THREADS) void fft_lds_kernel(const KArgs a)
+template<int LM, int NT> __global__ __launch_bounds__(NT) void fft_lds_kernel(const KArgs a)
 {
 	PXS_SHARED(double2, lds);
 	const int n = a.n, T = a.T;
 	double2* tw = lds;                 // [n]
 	double2* bufA = lds + n;           // [T*n]
-	double2* bufB = bufA + LPAD((size_t)T*n) + 1; // only if generic
+	double2* bufB = bufA + (size_t)T*a.ns + 1;    // only if generic
 	const TileCtx c = tile_decode(a, blockIdx.x);
-	for (int k = threadIdx.x; k < n; k += FFT_THREADS) tw[k] = a.tw[k];
+	for (int k = threadIdx.x; k < n; k += NT) tw[k] = a.tw[k];
 	// ---- load ---- (LU independent global loads in flight per thread before the LDS scatter)
 	const int total = T*n;
-	for (int idx0 = threadIdx.x; idx0 < total; idx0 += LU*FFT_THREADS) {
+	constexpr int LU = 4;
+	for (int idx0 = threadIdx.x; idx0 < total; idx0 += LU*NT) {
 		double2 v[LU]; int pos[LU];
 #pragma unroll
-		for (int u = 0; u < LU; u++) tile_load_one<LM>(a, c, idx0 + u*FFT_THREADS, total, v[u], pos[u]);
+		for (int u = 0; u < LU; u++) tile_load_one<LM>(a, c, idx0 + u*NT, total, v[u], pos[u]);
 #pragma unroll
 		for (int u = 0; u < LU; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
 	}
 	PXS_LDS_BARRIER();
-	const double2* cur = tile_passes(a, bufA, bufB, tw);
-	tile_store(a, c, cur);
+	const double2* cur = tile_passes<NT>(a, bufA, bufB, tw);
+	tile_store<NT>(a, c, cur);
 }
 
 // (Tried: a persistent variant of this kernel that issues the global loads of its NEXT tile into registers before the
@@ -395,14 +392,19 @@ template<int LM, int LU> __global__ __launch_bounds__(FFT_THREADS) void fft_lds_
 // table in device memory, which keep the argument struct out of scratch.)
 // launch one of the two kernels over nblk tiles
 template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
-	static const int lu8 = [] { const char* e = getenv("PXS_FFT_LU"); return e ? atoi(e) == 8 : 0; }();
+#ifdef PXS_HOST_SIM
+	hipLaunchKernelGGL((fft_lds_kernel<LM, 1>), dim3((unsigned)nblk), dim3(1), sh, st, k);
+#else
+	// 512 threads per workgroup: LDS allows 4 workgroups of 2048 points per CU, and at < 64 VGPRs twice the waves fit
+	static const int nt = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 256; }();
 	static const bool once = [] {
-		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
-		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		return true; }();
 	(void)once;
-	if (lu8) hipLaunchKernelGGL((fft_lds_kernel<LM, 8>), dim3((unsigned)nblk), dim3(FFT_THREADS), sh, st, k);
-	else     hipLaunchKernelGGL((fft_lds_kernel<LM, 4>), dim3((unsigned)nblk), dim3(FFT_THREADS), sh, st, k);
+	if (nt == 512) hipLaunchKernelGGL((fft_lds_kernel<LM, 512>), dim3((unsigned)nblk), dim3(512), sh, st, k);
+	else           hipLaunchKernelGGL((fft_lds_kernel<LM, 256>), dim3((unsigned)nblk), dim3(256), sh, st, k);
+#endif
 }
 static void launch_tiles(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
 	const int lm = k.mode == 2 ? (int)LD_PLAIN : k.ld.mode;      // pass B reads the four-step scratch, no functor
@@ -430,6 +432,17 @@ struct FftSub {
 
 static std::vector<int> factorize(long n) {
 	std::vector<int> f;
+	// Odd radices first: in the first pass (L = 1) lane b touches points b*R + i, a stride of R points of 16 bytes:
+	// conflict-free over the 64 LDS banks for R = 3, 5 but 4-way for R = 4.  The last radix sets the stride n/R of the
+	// digit-reversed scatter on load; 4 keeps it the least harmful for lengths that are multiples of 8.
+	static const int oddfirst = [] { const char* e = getenv("PXS_FFT_ODDFIRST"); return e ? atoi(e) : 1; }();
+	if (oddfirst) {
+		while (n % 3 == 0) { f.push_back(3); n /= 3; }
+		while (n % 5 == 0) { f.push_back(5); n /= 5; }
+		int twos = 0; while (n % 2 == 0) { twos++; n /= 2; }
+		if (twos & 1) { f.push_back(2); twos--; }
+		while (twos >= 2) { f.push_back(4); twos -= 2; }
+	}
 	while (n % 4 == 0) { f.push_back(4); n /= 4; }
 	while (n % 2 == 0) { f.push_back(2); n /= 2; }
 	while (n % 3 == 0) { f.push_back(3); n /= 3; }
@@ -553,9 +566,15 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	if (T > maxlines) T = maxlines;
 	k.T = (int)T;
 	k.dn = make_fastdiv(s.n); k.dT = make_fastdiv((uint32_t)T);
+	// Lines of the tile are read and written across lanes (stride = line stride) whenever the tile runs along the
+	// contiguous memory direction.  With 16-byte points a stride that is a multiple of 8 points (which the 128-byte
+	// alignment rule above makes the normal case: 200, 216, 320) puts 16 lanes on 1-2 bank groups: 8-16-way LDS bank
+	// conflicts (SQ_LDS_BANK_CONFLICT was 1.9x SQ_ACTIVE_INST_LDS).  An odd stride spreads them over all banks.
+	static const int lpad = [] { const char* e = getenv("PXS_FFT_LINEPAD"); return e ? atoi(e) : 1; }();
+	k.ns = lpad ? (s.n | 1) : s.n;
 }
 
-static size_t lds_bytes(const KArgs& k) { const size_t pts = (size_t)k.T*k.n; const size_t padded = pts + (pts >> 4) + 2; return sizeof(double2)*((size_t)k.n + padded*(k.generic ? 2 : 1)); }
+static size_t lds_bytes(const KArgs& k) { const size_t pts = (size_t)k.T*k.ns + 2; return sizeof(double2)*((size_t)k.n + pts*(k.generic ? 2 : 1)); }
 
 void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, const FftLoad& ld, const FftStore& stf) {
 	std::string why;

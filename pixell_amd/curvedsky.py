@@ -246,9 +246,30 @@ def _check_shapes(alm_full, map_full, deriv):
 	else:
 		assert tuple(map_full.shape[:-2]) == tuple(alm_full.shape[:-1]), "map and alm must agree on pre-dimensions"
 
-def _pad_unsupported(minfo):
-	if np.any(np.array(minfo.ypad) != 0) or np.any(np.array(minfo.xpad) != 0):
-		raise NotImplementedError("maps that need padding to a full ducc grid are not supported by the accelerated 2d path; use method='cyl'")
+def _native_pads(minfo, use_y):
+	"""((y_before, y_after), (x_before, x_after)) in the map's own pixel order.  minfo.ypad/xpad are in
+	ducc orientation, i.e. after the flips of map2buffer (curvedsky.py:1384-1403)."""
+	yp = tuple(int(v) for v in minfo.ypad) if use_y else (0, 0)
+	xp = tuple(int(v) for v in minfo.xpad)
+	if min(yp+xp) < 0: raise ValueError("map extends beyond the matching full-sky grid")
+	if minfo.flip[0]: yp = yp[::-1]
+	if minfo.flip[1]: xp = xp[::-1]
+	return yp, xp
+
+def _padded_like(map, pads, fill):
+	"""zero-padded copy of the map (ndmap, or dmap on the GPU) with the wcs moved accordingly; this is the
+	buffer map2buffer builds in the reference (curvedsky.py:1384-1403), without the flipped copy"""
+	(y0, y1), (x0, x1) = pads
+	mdata = _mdata(map)
+	shape = tuple(map.shape[:-2])+(map.shape[-2]+y0+y1, map.shape[-1]+x0+x1)
+	w = map.wcs.deepcopy(); w.wcs.crpix[0] += x0; w.wcs.crpix[1] += y0
+	buf = _zeros_like_kind(shape, _np_dtype(mdata), mdata)
+	if fill: buf[..., y0:y0+map.shape[-2], x0:x0+map.shape[-1]] = mdata
+	return (enmap.dmap(buf, w) if isinstance(map, enmap.dmap) else enmap.ndmap(buf, w))
+
+def _crop_into(map, pmap, pads):
+	(y0, y1), (x0, x1) = pads
+	_mdata(map)[...] = _mdata(pmap)[..., y0:y0+map.shape[-2], x0:x0+map.shape[-1]]
 
 def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=False, verbose=False, adjoint=False, nthread=None, pix_tol=1e-6):
 	"""curvedsky.alm2map_2d + alm2map_raw_2d (curvedsky.py:756-774, 900-926)"""
@@ -259,7 +280,14 @@ def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=
 	if adjoint: alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, pre=map.shape[:-2], dtype=_np_dtype(mdata), convert=False, like=mdata)
 	else:       alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, pre=map.shape[:-2], dtype=_np_dtype(mdata), convert=True, like=mdata)
 	if minfo is None: minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
-	_pad_unsupported(minfo)
+	pads = _native_pads(minfo, use_y=True)
+	if pads != ((0, 0), (0, 0)):
+		# pad to the full grid as the reference does (curvedsky.py:766-772); the padded geometry is case "2d"
+		pmap = _padded_like(map, pads, fill=adjoint)
+		res = alm2map_2d(alm, pmap, ainfo=ainfo, spin=spin, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol)
+		if adjoint: return res
+		_crop_into(map, pmap, pads)
+		return map
 	alm_full = _atleast(alm, 2 if deriv else 3)
 	map_full = _atleast(mdata, 4)
 	_check_shapes(alm_full, map_full, deriv)
@@ -289,9 +317,15 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 	mdata = _mdata(map)
 	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, lmax=lmax, pre=map.shape[:-2], dtype=_np_dtype(mdata), convert=adjoint, like=mdata)
 	if minfo is None: minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
-	_pad_unsupported(minfo)
 	if deriv:
 		raise NotImplementedError("ducc does not support derivatives for map2alm operations. Can be worked around if necessary.")
+	pads = _native_pads(minfo, use_y=True)
+	if pads != ((0, 0), (0, 0)):
+		pmap = _padded_like(map, pads, fill=not adjoint)
+		res = map2alm_2d(pmap, alm=alm, ainfo=ainfo, lmax=lmax, spin=spin, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol)
+		if not adjoint: return res
+		_crop_into(map, pmap, pads)
+		return map
 	alm_full = _atleast(alm, 3)
 	map_full = _atleast(mdata, 4)
 	_check_shapes(alm_full, map_full, False)
@@ -313,8 +347,7 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 def _ring_kwargs(map, minfo, ainfo):
 	"""ring tables of the map in ducc orientation, with the flips of map2buffer expressed as
 	a descending ringstart / negative pixel stride (no copy)."""
-	if np.any(np.array(minfo.xpad) != 0):
-		raise NotImplementedError("partial-width maps (xpad != 0) are not supported by the accelerated cyl path yet")
+	assert not np.any(np.array(minfo.xpad) != 0), "partial-width maps are padded by the callers"
 	shape = map.shape; ny, nx = shape[-2:]
 	fshape, fwcs = wcsutils.flipped(shape, map.wcs, minfo.flip)
 	rinfo = get_ring_info(fshape, fwcs)
@@ -334,6 +367,14 @@ def alm2map_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy
 	mdata = _mdata(map)
 	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, pre=map.shape[:-2], dtype=_np_dtype(mdata), convert=not adjoint, like=mdata)
 	if minfo is None: minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
+	pads = _native_pads(minfo, use_y=False)
+	if pads != ((0, 0), (0, 0)):
+		# partial-width map: extend the rings to the full circle (curvedsky.py:786-792)
+		pmap = _padded_like(map, pads, fill=adjoint)
+		res = alm2map_cyl(alm, pmap, ainfo=ainfo, spin=spin, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol)
+		if adjoint: return res
+		_crop_into(map, pmap, pads)
+		return map
 	kwargs = _ring_kwargs(map, minfo, ainfo)
 	alm_full = _atleast(alm, 2 if deriv else 3)
 	map_full = _atleast(mdata, 4)
@@ -382,6 +423,14 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 			dec = np.clip(dec, -np.pi/2, np.pi/2)
 			weights = np.abs(np.sin(dec[1:])-np.sin(dec[:-1]))*abs(map.wcs.wcs.cdelt[0])*degree
 	weights = np.asarray(weights, dtype=_np_dtype(mdata))
+	pads = _native_pads(minfo, use_y=False)
+	if pads != ((0, 0), (0, 0)):
+		# partial-width map: zero-extend the rings to the full circle (curvedsky.py:866-871); weights are per row
+		pmap = _padded_like(map, pads, fill=not adjoint)
+		res = map2alm_cyl(pmap, alm=alm, ainfo=ainfo, lmax=lmax, spin=spin, weights=weights, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol, niter=niter)
+		if not adjoint: return res
+		_crop_into(map, pmap, pads)
+		return map
 	kwargs = _ring_kwargs(map, minfo, ainfo)
 	alm_full = _atleast(alm, 3)
 	map_full = _atleast(mdata, 4)
@@ -514,3 +563,23 @@ def rand_alm(ps, ainfo=None, lmax=None, seed=None, dtype=np.complex128, m_major=
 	if ps.ndim == 1: alm = alm[0]
 	if return_ainfo: return alm, ainfo
 	else: return alm
+
+def transfer_alm(iainfo, ialm, oainfo, oalm=None, op=lambda a, b: b):
+	"""Copy alm between layouts / band limits (curvedsky.py:744-750 -> cmisc.pyx:131-151): for every (l,m) both
+	layouts hold, oalm = op(oalm, ialm).  Works on numpy arrays and on torch CUDA tensors (one gather/scatter)."""
+	tens = _is_tensor(ialm)
+	if oalm is None:
+		oalm = _zeros_like_kind(tuple(ialm.shape[:-1])+(oainfo.nelem,), _np_dtype(ialm), ialm)
+	if tuple(ialm.shape[:-1]) != tuple(oalm.shape[:-1]):
+		raise ValueError("ialm and oalm must agree on pre-dimensions")
+	lmax = min(iainfo.lmax, oainfo.lmax); mmax = min(iainfo.mmax, oainfo.mmax)
+	m = np.repeat(np.arange(mmax+1), lmax+1-np.arange(mmax+1))
+	first = np.concatenate([[0], np.cumsum(lmax+1-np.arange(mmax+1))[:-1]])
+	l = np.arange(len(m))-np.repeat(first, lmax+1-np.arange(mmax+1))+m
+	src = iainfo.mstart.astype(np.int64)[m]+l*iainfo.stride
+	dst = oainfo.mstart.astype(np.int64)[m]+l*oainfo.stride
+	if tens:
+		torch = _torch()
+		src = torch.as_tensor(src, device=ialm.device); dst = torch.as_tensor(dst, device=oalm.device)
+	oalm[..., dst] = op(oalm[..., dst], ialm[..., src])
+	return oalm

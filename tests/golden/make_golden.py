@@ -61,6 +61,9 @@ def alm_rand_fixture(curvedsky):
 	out["cl_sp"] = ai.alm2cl(sp[:, None], sp[None, :]); out["cl_sp_dp"] = ai.alm2cl(sp[:, None], sp[None, :], dtype=np.float64)
 	out["cl_cross"] = ai.alm2cl(out["alm3"][:, None], out["white"][None, :])
 	out["xfl_fun"] = curvedsky.almxfl(out["alm1"], lambda l: 1/(1+l)**2)
+	out["transfer_down"] = curvedsky.transfer_alm(ai, out["alm3"], curvedsky.alm_info(lmax=16, mmax=9))
+	out["transfer_up"] = curvedsky.transfer_alm(ai2, w, curvedsky.alm_info(lmax=30, layout="rect"))
+	out["transfer_add"] = curvedsky.transfer_alm(ai2, w, ai, oalm=out["white"].copy(), op=lambda a, b: a+b)
 	np.savez_compressed(os.path.join(HERE, "alm_rand.npz"), **out)
 
 def main():

@@ -125,6 +125,50 @@ def cyl_body():
 	at[:, :lmax+1] = at[:, :lmax+1].real
 	assert abs(np.sum(np.asarray(sa)*m)-np.sum(wt*(alm[:1].real*at.real+alm[:1].imag*at.imag))) < 1e-10
 
+def padding_body():
+	"""patches that need padding (curvedsky.py:766-772, 786-792, 832-841, 866-871): a band of a full-sky grid through
+	method="2d" (ypad), and a patch with partial rows (case "partial", xpad) through "cyl": synthesis must equal the
+	crop of the full-sky map, analysis/adjoints must equal the same call on the zero-padded full map."""
+	from oracle import sht_oracle as so
+	lmax = 10
+	fshape, fwcs = enmap.fullsky_geometry(shape=(20, 24))
+	alm = so.rand_alm_simple(lmax, 3, 7, spin=(0, 2))
+	full = enmap.zeros((3,)+fshape, fwcs); curvedsky.alm2map(alm, full, spin=[0, 2])
+	fullv = np.asarray(full)
+	# band rows 3..16 of the full grid, forced through the 2d method
+	wb = fwcs.deepcopy(); wb.wcs.crpix[1] -= 3
+	band = enmap.zeros((3, 14, 24), wb)
+	mi = curvedsky.analyse_geometry(band.shape, band.wcs)
+	assert mi.case == "cyl" and tuple(int(v) for v in mi.ypad) != (0, 0)
+	curvedsky.alm2map(alm, band, spin=[0, 2], method="2d")
+	assert np.max(np.abs(np.asarray(band)-fullv[:, 3:17])) < 1e-12
+	padded = np.zeros_like(fullv); padded[:, 3:17] = fullv[:, 3:17]
+	a_band = curvedsky.map2alm(enmap.ndmap(fullv[:, 3:17].copy(), wb), lmax=lmax, spin=[0, 2], method="2d")
+	a_pad  = curvedsky.map2alm(enmap.ndmap(padded, fwcs), lmax=lmax, spin=[0, 2], method="2d")
+	assert np.max(np.abs(a_band-a_pad)) < 1e-13
+	# patch: rows 3..16, columns 5..19 -> case "partial"
+	wp = wb.deepcopy(); wp.wcs.crpix[0] -= 5
+	patch = enmap.zeros((3, 14, 15), wp)
+	mi = curvedsky.analyse_geometry(patch.shape, patch.wcs)
+	assert mi.case == "partial" and curvedsky.get_method(patch.shape, patch.wcs) == "cyl"
+	curvedsky.alm2map(alm, patch, spin=[0, 2])
+	assert np.max(np.abs(np.asarray(patch)-fullv[:, 3:17, 5:20])) < 1e-12
+	rowpad = np.zeros((3, 14, 24)); rowpad[:, :, 5:20] = fullv[:, 3:17, 5:20]
+	a_patch = curvedsky.map2alm(enmap.ndmap(fullv[:, 3:17, 5:20].copy(), wp), lmax=lmax, spin=[0, 2], niter=1)
+	a_rows  = curvedsky.map2alm(enmap.ndmap(rowpad, wb), lmax=lmax, spin=[0, 2], niter=1)
+	assert np.max(np.abs(a_patch-a_rows)) < 1e-13
+	# adjoint of synthesis on the patch = adjoint on the zero-padded rows
+	m = np.random.default_rng(1).standard_normal((1, 14, 15))
+	rp = np.zeros((1, 14, 24)); rp[:, :, 5:20] = m
+	at1 = curvedsky.alm2map_adjoint(enmap.ndmap(m, wp), spin=0, ainfo=curvedsky.alm_info(lmax))
+	at2 = curvedsky.alm2map_adjoint(enmap.ndmap(rp, wb), spin=0, ainfo=curvedsky.alm_info(lmax))
+	assert np.max(np.abs(at1-at2)) < 1e-13
+
+@pytest.mark.hostsim
+def test_padding_hostsim(): padding_body()
+@pytest.mark.gpu
+def test_padding_gpu(): padding_body()
+
 @pytest.mark.hostsim
 def test_roundtrip_hostsim(): roundtrip_body(12)
 @pytest.mark.hostsim
