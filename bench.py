@@ -116,6 +116,8 @@ def main():
 	torch.cuda.synchronize()
 	rt_err = float((alm_out-alm_in).abs().pow(2).mean().sqrt()/alm_in.abs().pow(2).mean().sqrt())
 	log("[rank %d] setup %.1fs; round-trip rms error %.2e" % (rank, time.time()-t0, rt_err))
+	# north_star: alm must come back to < 1e-8 relative rms.  A throughput number of a transform that does not is worthless.
+	if not (rt_err < 1e-8): raise SystemExit("bench.py: round-trip rms error %.3e exceeds 1e-8 -- refusing to time a wrong transform" % rt_err)
 	minfo = curvedsky.analyse_geometry(dmap.shape, wcs)
 	plan = sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1)
 	info = plan.info()

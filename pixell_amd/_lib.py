@@ -57,6 +57,11 @@ def load():
 	if not os.path.exists(path):
 		raise ImportError("pixell_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
 			"(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+	if not _is_hostsim:
+		# torch ships its own libamdhip64: let it be the HIP runtime of the process.  Loading libpxsht.so (which pulls in
+		# /opt/rocm's runtime) before torch left two runtimes in one process and hipSetDevice then reported no device.
+		try: import torch  # noqa: F401
+		except ImportError: pass
 	_lib = _declare(ctypes.CDLL(path))
 	return _lib
 

@@ -245,16 +245,25 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 		k += 4; \
 	}
 
-// (Rejected after measurement on MI355X: (1) merging the gated phase B into the fast pair loop behind a
-// wave-uniform `if (pend)`: leg_syn 118 -> 172 ms, leg_ana 171 -> 228 ms at config 3; (2) a branch-free pair-wise
-// phase B as its own loop: VGPRs 124 -> 192 (syn_spin<3>), occupancy 3 -> 2, leg_syn 118 -> 191 ms.  The short
-// per-step loop below keeps the register footprint of the kernel set by the fast loop.)
-// one recurrence step with rescaling (ramp phases)
-#define S0_STEP_RESCALE(cfa, cfb) \
+// Phase B history: it used to be a per-step loop with per-lane gating (cndmask) and a rescale test in every step:
+// 207 instructions per step for leg_ana_spin<6> against 97 per step in the fast loop, ~18 % of the kernel time in a
+// phase that covers ~8 % of the steps.  (Rejected before that: merging the gated steps into the fast pair loop behind
+// a wave-uniform `if (pend)`: leg_syn 118 -> 172 ms at config 3; a branch-free pair-wise gated loop: VGPRs 124 -> 192.)
+// Now phase B runs the ungated fast steps and only tests / rescales every 4 steps, see the kernels.
+// two fast steps of the spin-0 synthesis (lam1/lam2 swap roles)
+#define S0_SYN_PAIR(c0, c1, a0, a1) { \
+	PXS_VCOPY(vb0, polar ? c0.c : c0.b); \
+	PXS_VCOPY(vb1, polar ? c1.c : c1.b); \
 	_Pragma("unroll") for (int s = 0; s < K; s++) { \
-		const double t = fma(fma(cfa, csq[s], cfb), lam2[s], lam1[s]); \
-		lam1[s] = lam2[s]; lam2[s] = t; \
-		if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; } }
+		p1r[s] = fma(lam2[s], a0.a, p1r[s]); p1i[s] = fma(lam2[s], a0.b, p1i[s]); \
+		p2r[s] = fma(lam2[s], a0.c, p2r[s]); p2i[s] = fma(lam2[s], a0.d, p2i[s]); \
+		lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]); \
+	} \
+	_Pragma("unroll") for (int s = 0; s < K; s++) { \
+		p1r[s] = fma(lam1[s], a1.a, p1r[s]); p1i[s] = fma(lam1[s], a1.b, p1i[s]); \
+		p2r[s] = fma(lam1[s], a1.c, p2r[s]); p2i[s] = fma(lam1[s], a1.d, p2i[s]); \
+		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
+	} }
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 {
@@ -286,42 +295,33 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 	if (__any(alive_any)) {
 		// phase A: nobody at scale 0 yet -> recurrence only, 4 steps per check (S0_PHASE_A)
 		S0_PHASE_A
-		// phase B: gated accumulation until every lane is at scale 0
-		while (k < nk) {
+		// phase B: some lanes are still below scale 0.  The steps are the plain fast steps (no per-lane gating); every
+		// 4 steps the lanes below scale 0 are rescaled.  Such a lane accumulates scaled-up garbage meanwhile; its sums are
+		// reset when it reaches scale 0 (its true terms before that are < 2^-340 of the final value).
+		while (k + 1 < nk) {
 			bool pend = false;
 #pragma unroll
 			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 			if (!__any(pend)) break;
-			const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
-			const double4_t al = at[k];
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				const double g = (sc[s] == 0) ? lam2[s] : 0.0;
-				p1r[s] = fma(g, al.a, p1r[s]); p1i[s] = fma(g, al.b, p1i[s]);
-				p2r[s] = fma(g, al.c, p2r[s]); p2i[s] = fma(g, al.d, p2i[s]);
+			for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
+				const double4_t c0 = coef[k], c1 = coef[k+1], a0 = at[k], a1 = at[k+1];
+				S0_SYN_PAIR(c0, c1, a0, a1)
 			}
-			S0_STEP_RESCALE(cf.a, cb)
-			k++;
+#pragma unroll
+			for (int s = 0; s < K; s++)
+				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) {
+					lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL;
+					if (++sc[s] == 0) p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0;
+				}
 		}
+#pragma unroll
+		for (int s = 0; s < K; s++) if (sc[s] < 0) { p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0; lam1[s] = lam2[s] = 0; }   // never reached scale 0
 		// phase C: fast loop, two steps per iteration (lam1/lam2 swap roles, no register moves),
 		// coefficients of the next iteration prefetched with scalar loads (tables are padded by 2 rows)
 		double4_t c0 = coef[k], c1 = coef[k+1], a0 = at[k], a1 = at[k+1];
 		for (; k + 1 < nk; k += 2) {
 			const double4_t n0 = coef[k+2], n1 = coef[k+3], m0 = at[k+2], m1 = at[k+3];
-			PXS_VCOPY(vb0, polar ? c0.c : c0.b);
-			PXS_VCOPY(vb1, polar ? c1.c : c1.b);
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				p1r[s] = fma(lam2[s], a0.a, p1r[s]); p1i[s] = fma(lam2[s], a0.b, p1i[s]);
-				p2r[s] = fma(lam2[s], a0.c, p2r[s]); p2i[s] = fma(lam2[s], a0.d, p2i[s]);
-				lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]);
-			}
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				p1r[s] = fma(lam1[s], a1.a, p1r[s]); p1i[s] = fma(lam1[s], a1.b, p1i[s]);
-				p2r[s] = fma(lam1[s], a1.c, p2r[s]); p2i[s] = fma(lam1[s], a1.d, p2i[s]);
-				lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]);
-			}
+			S0_SYN_PAIR(c0, c1, a0, a1)
 			c0 = n0; c1 = n1; a0 = m0; a1 = m1;
 		}
 		if (k < nk) {
@@ -412,6 +412,31 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 	red[(kk)*64 + lane] = u_ + v_; }
 #endif
 
+// two fast steps of the spin-0 analysis: 2 x 4 lane sums into the LDS reduction tile, flush every 4 steps
+#define S0_ANA_PAIR(c0, c1) { \
+	PXS_VCOPY(vb0, polar ? c0.c : c0.b); \
+	PXS_VCOPY(vb1, polar ? c1.c : c1.b); \
+	double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0; \
+	_Pragma("unroll") for (int s = 0; s < K; s++) { \
+		t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3); \
+		lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]); \
+	} \
+	_Pragma("unroll") for (int s = 0; s < K; s++) { \
+		u0 = fma(lam1[s], d1r[s], u0); u1 = fma(lam1[s], d1i[s], u1); u2 = fma(lam1[s], d2r[s], u2); u3 = fma(lam1[s], d2i[s], u3); \
+		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
+	} \
+	if (kk == 3) {   /* keep pairs within one flush group */ \
+		LEG_RED_PUT(3, t0, t1, t2, t3) \
+		leg_flush(red, pout + 4*kbase, lane, 4); kbase = k+1; \
+		LEG_RED_PUT(0, u0, u1, u2, u3) \
+		kk = 1; \
+	} else { \
+		LEG_RED_PUT(kk, t0, t1, t2, t3) \
+		LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
+		kk += 2; \
+		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+2; } \
+	} }
+
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
 	PXS_SHARED(double, red);
@@ -426,73 +451,62 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	int sc[K];
 	bool alive_any = false;
 	const bool polar = leg_wave_polar(a, wv, K);
+	// ring data of slot s: sum and (difference x cos theta) of the north and south ring
+	auto load_data = [&](int s) {
+		const int p = (wv*K + s)*64 + lane;
+		const bool valid = p < a.npairs;
+		const int rn = valid ? a.ring_n[p] : -1, rs = valid ? a.ring_s[p] : -1;
+		const double x = valid ? a.cth[p] : 0.0;
+		const double2 vn = rn >= 0 ? in[rn] : make_double2(0, 0);
+		const double2 vs = rs >= 0 ? in[rs] : make_double2(0, 0);
+		d1r[s] = vn.x + vs.x; d1i[s] = vn.y + vs.y;
+		d2r[s] = (vn.x - vs.x)*x; d2i[s] = (vn.y - vs.y)*x;
+	};
 #pragma unroll
 	for (int s = 0; s < K; s++) {
 		const int p = (wv*K + s)*64 + lane;
 		const bool valid = p < a.npairs;
-		const int rn = valid ? a.ring_n[p] : -1, rs = valid ? a.ring_s[p] : -1;
 		const double x = valid ? a.cth[p] : 0.0;
 		const double sth = valid ? a.sth[p] : 0.0;
 		csq[s] = polar ? -sth*sth : x*x;
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
 		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
-		double2 vn = (alive && rn >= 0) ? in[rn] : make_double2(0, 0);
-		double2 vs = (alive && rs >= 0) ? in[rs] : make_double2(0, 0);
-		d1r[s] = vn.x + vs.x; d1i[s] = vn.y + vs.y;
-		d2r[s] = (vn.x - vs.x)*x; d2i[s] = (vn.y - vs.y)*x;
+		// a lane below scale 0 keeps zero data until it gets there, so that it can run the ungated steps
+		d1r[s] = d1i[s] = d2r[s] = d2i[s] = 0;
 		alive_any |= alive;
 	}
 	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
 	int k = 0;
 	S0_PHASE_A
+	// ring data of the lanes that start at scale 0 or reached it during phase A (rings without signal have lam = 0)
+#pragma unroll
+	for (int s = 0; s < K; s++) if (sc[s] == 0) load_data(s);
 	int kk = 0, kbase = k;
-	while (k < nk) {
+	// phase B: plain fast steps; every 4 steps the lanes below scale 0 are rescaled, and a lane that reaches scale 0
+	// fetches its ring data (its true terms before that are < 2^-340 of the result)
+	while (k + 1 < nk) {
 		bool pend = false;
 #pragma unroll
 		for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 		if (!__any(pend)) break;
-		const double4_t cf = coef[k]; const double cb = polar ? cf.c : cf.b;
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-		for (int s = 0; s < K; s++) {
-			const double g = (sc[s] == 0) ? lam2[s] : 0.0;
-			t0 = fma(g, d1r[s], t0); t1 = fma(g, d1i[s], t1); t2 = fma(g, d2r[s], t2); t3 = fma(g, d2i[s], t3);
+		for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
+			const double4_t c0 = coef[k], c1 = coef[k+1];
+			S0_ANA_PAIR(c0, c1)
 		}
-		S0_STEP_RESCALE(cf.a, cb)
-		LEG_RED_PUT(kk, t0, t1, t2, t3)
-		k++; kk++;
-		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k; }
+#pragma unroll
+		for (int s = 0; s < K; s++)
+			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) {
+				lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL;
+				if (++sc[s] == 0) load_data(s);
+			}
 	}
-	// align to a flush boundary with single steps, then run 4 steps per flush (two unrolled pairs)
+	// phase C: every lane at scale 0 (or without data): next coefficients prefetched with scalar loads
 	double4_t c0 = coef[k], c1 = coef[k+1];
 	for (; k + 1 < nk; k += 2) {
 		const double4_t n0 = coef[k+2], n1 = coef[k+3];
-		PXS_VCOPY(vb0, polar ? c0.c : c0.b);
-		PXS_VCOPY(vb1, polar ? c1.c : c1.b);
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-#pragma unroll
-		for (int s = 0; s < K; s++) {
-			t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3);
-			lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]);
-		}
-#pragma unroll
-		for (int s = 0; s < K; s++) {
-			u0 = fma(lam1[s], d1r[s], u0); u1 = fma(lam1[s], d1i[s], u1); u2 = fma(lam1[s], d2r[s], u2); u3 = fma(lam1[s], d2i[s], u3);
-			lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]);
-		}
+		S0_ANA_PAIR(c0, c1)
 		c0 = n0; c1 = n1;
-		if (kk == 3) {   // keep pairs within one flush group
-			LEG_RED_PUT(3, t0, t1, t2, t3)
-			leg_flush(red, pout + 4*kbase, lane, 4); kbase = k+1;
-			LEG_RED_PUT(0, u0, u1, u2, u3)
-			kk = 1;
-		} else {
-			LEG_RED_PUT(kk, t0, t1, t2, t3)
-			LEG_RED_PUT(kk+1, u0, u1, u2, u3)
-			kk += 2;
-			if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+2; }
-		}
 	}
 	if (k < nk) {
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -555,15 +569,6 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 	return alive_any;
 }
 
-// ramp-phase step with rescaling
-template<int K> __device__ __forceinline__ void spin_step_rescale(SpinState<K>& S, int s, double ca, double c1, double c2) {
-	const double ax = ca*S.x[s];
-	const double np_ = fma(ax + c1, S.gp2[s], -S.gp1[s]), nm_ = fma(ax + c2, S.gm2[s], -S.gm1[s]);
-	S.gp1[s] = S.gp2[s]; S.gp2[s] = np_; S.gm1[s] = S.gm2[s]; S.gm2[s] = nm_;
-	if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
-	if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
-}
-#define SPIN_COEF(cf) const double ca = cf.a, c1 = polar ? cf.c : cf.b, c2 = polar ? cf.d : -cf.b
 // phase A of the spin kernels (see S0_PHASE_A): 4 steps per rescale / activity test; sgn is unchanged by 4 steps
 #define SPIN_PHASE_A \
 	while (j + 4 <= nl) { \
@@ -583,8 +588,36 @@ template<int K> __device__ __forceinline__ void spin_step_rescale(SpinState<K>& 
 		j += 4; \
 	}
 
-// (leg_syn_spin<3> sits at 126 VGPRs = 4 waves per SIMD; computing the lane as threadIdx.x & 63 for multi-wave
-// workgroups pushed it to 132 = 3 waves and leg_syn from 120 to 151 ms at config 3 -- keep an eye on that cliff.)
+// two fast steps of the spin synthesis (G1/G2 swap roles).  The south-ring sums take (-1)^(l+m) a: they are
+// accumulated with sign +1 on even steps and -1 on odd steps and multiplied by the sign of the first step at the end.
+#define SPIN_SYN_PAIR(f0, f1, a0, a1) { \
+	{ \
+		const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			const double gp = S.gp2[s], gm = S.gm2[s]; \
+			pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]); \
+			mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]); \
+			qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]); \
+			nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]); \
+			const double ax = ca*S.x[s]; \
+			S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]); \
+		} \
+	} \
+	{ \
+		const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			const double gp = S.gp1[s], gm = S.gm1[s]; \
+			pnr[s] = fma(gp, a1.a, pnr[s]); pni[s] = fma(gp, a1.b, pni[s]); \
+			mnr[s] = fma(gm, a1.c, mnr[s]); mni[s] = fma(gm, a1.d, mni[s]); \
+			qsr[s] = fma(-gm, a1.a, qsr[s]); qsi[s] = fma(-gm, a1.b, qsi[s]); \
+			nsr[s] = fma(-gp, a1.c, nsr[s]); nsi[s] = fma(-gp, a1.d, nsi[s]); \
+			const double ax = ca*S.x[s]; \
+			S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]); \
+		} \
+	} }
+
+// (leg_syn_spin<3> must stay below 128 VGPRs = 4 waves per SIMD; computing the lane as threadIdx.x & 63 for multi-wave
+// workgroups once pushed it to 132 = 3 waves and leg_syn from 120 to 151 ms at config 3 -- keep an eye on that cliff.)
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
 	const int lane = threadIdx.x; int wv, m;
@@ -594,71 +627,50 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	double2* __restrict__ outq = a.leg + (long)m*a.nring;
 	double2* __restrict__ outu = a.leg + ((long)a.nm + m)*a.nring;
 	SpinState<K> S; int rn[K], rs[K];
-	double pnr[K], pni[K], mnr[K], mni[K], psr[K], psi[K], msr[K], msi[K];
+	// north: P = sum G+ a+, M = sum G- a-;  south (before the sign): qs = sum +-G- a+, ns = sum +-G+ a-
+	double pnr[K], pni[K], mnr[K], mni[K], qsr[K], qsi[K], nsr[K], nsi[K];
 #pragma unroll
-	for (int s = 0; s < K; s++) pnr[s] = pni[s] = mnr[s] = mni[s] = psr[s] = psi[s] = msr[s] = msi[s] = 0;
+	for (int s = 0; s < K; s++) pnr[s] = pni[s] = mnr[s] = mni[s] = qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
 	const bool polar = leg_wave_polar(a, wv, K);
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
+	double sg0 = 1.0;
 	if (nl > 0 && __any(alive_any)) {
 		const long row0 = a.row[m];
 		const double4_t* __restrict__ coef = a.coef + row0;
 		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
-		double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m)
 		int j = 0;
 		SPIN_PHASE_A
-		while (j < nl) {
+		sg0 = ((l0 + j + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m) of the first accumulated step; pairs of steps keep the parity
+		// phase B: plain fast steps; every 4 steps the chains below scale 0 are rescaled.  A lane's sums hold scaled-up
+		// garbage until both of its chains are at scale 0, when they are reset (true terms before that: < 2^-340 of the result)
+		while (j + 1 < nl) {
 			bool pend = false;
 #pragma unroll
 			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 			if (!__any(pend)) break;
-			const double4_t cf = coef[j]; SPIN_COEF(cf);
-			const double4_t al = at[j];
+			for (int it = 0; it < 2 && j + 1 < nl; it++, j += 2) {
+				const double4_t f0 = coef[j], f1 = coef[j+1], a0 = at[j], a1 = at[j+1];
+				SPIN_SYN_PAIR(f0, f1, a0, a1)
+			}
 #pragma unroll
 			for (int s = 0; s < K; s++) {
-				const double gp = (S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (S.scm[s] == 0) ? S.gm2[s] : 0.0;
-				pnr[s] = fma(gp, al.a, pnr[s]); pni[s] = fma(gp, al.b, pni[s]);
-				mnr[s] = fma(gm, al.c, mnr[s]); mni[s] = fma(gm, al.d, mni[s]);
-				psr[s] = fma(gm, sgn*al.a, psr[s]); psi[s] = fma(gm, sgn*al.b, psi[s]);
-				msr[s] = fma(gp, sgn*al.c, msr[s]); msi[s] = fma(gp, sgn*al.d, msi[s]);
-				spin_step_rescale<K>(S, s, ca, c1, c2);
+				const bool was = (S.scp[s] < 0) || (S.scm[s] < 0);
+				if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
+				if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
+				if (was && S.scp[s] == 0 && S.scm[s] == 0) pnr[s] = pni[s] = mnr[s] = mni[s] = qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
 			}
-			j++; sgn = -sgn;
 		}
-		// fast loop: two l per iteration (signs explicit, G1/G2 swap roles), next coefficients prefetched.
-		// The south-ring accumulators take sgn * a: fold the overall sign of the pair into the final result.
-		const double sg0 = sgn;            // sign of the first (even-offset) step; the second has -sg0
-		double qsr[K], qsi[K], nsr[K], nsi[K];   // accumulate with sign +1 on even steps, -1 on odd steps, multiply by sg0 at the end
 #pragma unroll
-		for (int s = 0; s < K; s++) qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
+		for (int s = 0; s < K; s++)
+			if (S.scp[s] < 0 || S.scm[s] < 0) {      // never reached scale 0
+				pnr[s] = pni[s] = mnr[s] = mni[s] = qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
+				S.gp1[s] = S.gp2[s] = S.gm1[s] = S.gm2[s] = 0;
+			}
+		// phase C: fast loop, next coefficients prefetched
 		double4_t f0 = coef[j], f1 = coef[j+1], a0 = at[j], a1 = at[j+1];
 		for (; j + 1 < nl; j += 2) {
 			const double4_t n0 = coef[j+2], n1 = coef[j+3], m0 = at[j+2], m1 = at[j+3];
-			{
-				const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b;
-#pragma unroll
-				for (int s = 0; s < K; s++) {
-					const double gp = S.gp2[s], gm = S.gm2[s];
-					pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]);
-					mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]);
-					qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]);
-					nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]);
-					const double ax = ca*S.x[s];
-					S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]);
-				}
-			}
-			{
-				const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b;
-#pragma unroll
-				for (int s = 0; s < K; s++) {
-					const double gp = S.gp1[s], gm = S.gm1[s];
-					pnr[s] = fma(gp, a1.a, pnr[s]); pni[s] = fma(gp, a1.b, pni[s]);
-					mnr[s] = fma(gm, a1.c, mnr[s]); mni[s] = fma(gm, a1.d, mni[s]);
-					qsr[s] = fma(-gm, a1.a, qsr[s]); qsi[s] = fma(-gm, a1.b, qsi[s]);
-					nsr[s] = fma(-gp, a1.c, nsr[s]); nsi[s] = fma(-gp, a1.d, nsi[s]);
-					const double ax = ca*S.x[s];
-					S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]);
-				}
-			}
+			SPIN_SYN_PAIR(f0, f1, a0, a1)
 			f0 = n0; f1 = n1; a0 = m0; a1 = m1;
 		}
 		if (j < nl) {
@@ -671,8 +683,6 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 				nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]);
 			}
 		}
-#pragma unroll
-		for (int s = 0; s < K; s++) { psr[s] = fma(sg0, qsr[s], psr[s]); psi[s] = fma(sg0, qsi[s], psi[s]); msr[s] = fma(sg0, nsr[s], msr[s]); msi[s] = fma(sg0, nsi[s], msi[s]); }
 	}
 	// Q = (P+M)/2, U = -i (P-M)/2
 #pragma unroll
@@ -682,11 +692,52 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 			outu[rn[s]] = make_double2(0.5*(pni[s] - mni[s]), -0.5*(pnr[s] - mnr[s]));
 		}
 		if (rs[s] >= 0) {
-			outq[rs[s]] = make_double2(0.5*(psr[s] + msr[s]), 0.5*(psi[s] + msi[s]));
-			outu[rs[s]] = make_double2(0.5*(psi[s] - msi[s]), -0.5*(psr[s] - msr[s]));
+			const double psr = sg0*qsr[s], psi = sg0*qsi[s], msr = sg0*nsr[s], msi = sg0*nsi[s];
+			outq[rs[s]] = make_double2(0.5*(psr + msr), 0.5*(psi + msi));
+			outu[rs[s]] = make_double2(0.5*(psi - msi), -0.5*(psr - msr));
 		}
 	}
 }
+
+// two fast steps of the spin analysis; mu+ = G+ T+_N + sgn G- T+_S, mu- = G- T-_N + sgn G+ T-_S with the sign of the
+// first step already folded into the south-ring data (even steps +, odd steps -)
+#define SPIN_ANA_PAIR(f0, f1) { \
+	double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0; \
+	{ \
+		const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			const double gp = S.gp2[s], gm = S.gm2[s]; \
+			t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0); \
+			t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1); \
+			t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2); \
+			t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3); \
+			const double ax = ca*S.x[s]; \
+			S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]); \
+		} \
+	} \
+	{ \
+		const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b; \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			const double gp = S.gp1[s], gm = S.gm1[s]; \
+			u0 = fma(gp, tpnr[s], u0); u0 = fma(-gm, tpsr[s], u0); \
+			u1 = fma(gp, tpni[s], u1); u1 = fma(-gm, tpsi[s], u1); \
+			u2 = fma(gm, tmnr[s], u2); u2 = fma(-gp, tmsr[s], u2); \
+			u3 = fma(gm, tmni[s], u3); u3 = fma(-gp, tmsi[s], u3); \
+			const double ax = ca*S.x[s]; \
+			S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]); \
+		} \
+	} \
+	if (kk == 3) { \
+		LEG_RED_PUT(3, t0, t1, t2, t3) \
+		leg_flush(red, pout + 4*jbase, lane, 4); jbase = j+1; \
+		LEG_RED_PUT(0, u0, u1, u2, u3) \
+		kk = 1; \
+	} else { \
+		LEG_RED_PUT(kk, t0, t1, t2, t3) \
+		LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
+		kk += 2; \
+		if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+2; } \
+	} }
 
 template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 {
@@ -705,88 +756,53 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	const bool polar = leg_wave_polar(a, wv, K);
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
 	if (!__any(alive_any)) return;
-	// T+ = Q + iU, T- = Q - iU for north and south rings
+	// T+ = Q + iU, T- = Q - iU for north and south rings; the south values carry (-1)^(l+m) of the first accumulated
+	// step (phase A advances in multiples of 4, so that is the sign at l0).  A lane whose chains are still below scale 0
+	// keeps zero data until both get there (phase B), so that it can run the ungated steps.
+	const double sgn0 = ((l0 + m) & 1) ? -1.0 : 1.0;
 	double tpnr[K], tpni[K], tmnr[K], tmni[K], tpsr[K], tpsi[K], tmsr[K], tmsi[K];
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		double2 q = rn[s] >= 0 ? inq[rn[s]] : make_double2(0, 0), u = rn[s] >= 0 ? inu[rn[s]] : make_double2(0, 0);
+	auto load_data = [&](int s) {
+		// ring indices are re-read here rather than kept in registers through the loops (the kernel sits at the 256-VGPR line)
+		const int p = (wv*K + s)*64 + lane;
+		const int rn_ = p < a.npairs ? a.ring_n[p] : -1, rs_ = p < a.npairs ? a.ring_s[p] : -1;
+		double2 q = rn_ >= 0 ? inq[rn_] : make_double2(0, 0), u = rn_ >= 0 ? inu[rn_] : make_double2(0, 0);
 		tpnr[s] = q.x - u.y; tpni[s] = q.y + u.x; tmnr[s] = q.x + u.y; tmni[s] = q.y - u.x;
-		q = rs[s] >= 0 ? inq[rs[s]] : make_double2(0, 0); u = rs[s] >= 0 ? inu[rs[s]] : make_double2(0, 0);
-		tpsr[s] = q.x - u.y; tpsi[s] = q.y + u.x; tmsr[s] = q.x + u.y; tmsi[s] = q.y - u.x;
-	}
-	double sgn = ((l0 + m) & 1) ? -1.0 : 1.0;
+		q = rs_ >= 0 ? inq[rs_] : make_double2(0, 0); u = rs_ >= 0 ? inu[rs_] : make_double2(0, 0);
+		tpsr[s] = sgn0*(q.x - u.y); tpsi[s] = sgn0*(q.y + u.x); tmsr[s] = sgn0*(q.x + u.y); tmsi[s] = sgn0*(q.y - u.x);
+	};
+#pragma unroll
+	for (int s = 0; s < K; s++) tpnr[s] = tpni[s] = tmnr[s] = tmni[s] = tpsr[s] = tpsi[s] = tmsr[s] = tmsi[s] = 0;
 	int j = 0;
 	SPIN_PHASE_A
+	// ring data of the lanes whose chains start at scale 0 or both reached it during phase A
+#pragma unroll
+	for (int s = 0; s < K; s++) if (S.scp[s] == 0 && S.scm[s] == 0) load_data(s);
 	int kk = 0, jbase = j;
-	while (j < nl) {
+	// phase B: plain fast steps; every 4 steps the chains below scale 0 are rescaled, and a lane whose two chains
+	// have both reached scale 0 fetches its ring data (true terms before that: < 2^-340 of the result)
+	while (j + 1 < nl) {
 		bool pend = false;
 #pragma unroll
 		for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 		if (!__any(pend)) break;
-		const double4_t cf = coef[j]; SPIN_COEF(cf);
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+		for (int it = 0; it < 2 && j + 1 < nl; it++, j += 2) {
+			const double4_t f0 = coef[j], f1 = coef[j+1];
+			SPIN_ANA_PAIR(f0, f1)
+		}
 #pragma unroll
 		for (int s = 0; s < K; s++) {
-			const double gp = (S.scp[s] == 0) ? S.gp2[s] : 0.0, gm = (S.scm[s] == 0) ? S.gm2[s] : 0.0;
-			const double sgp = sgn*gp, sgm = sgn*gm;
-			// mu+ = G+ T+_N + sgn G- T+_S ;  mu- = G- T-_N + sgn G+ T-_S
-			t0 = fma(gp, tpnr[s], t0); t0 = fma(sgm, tpsr[s], t0);
-			t1 = fma(gp, tpni[s], t1); t1 = fma(sgm, tpsi[s], t1);
-			t2 = fma(gm, tmnr[s], t2); t2 = fma(sgp, tmsr[s], t2);
-			t3 = fma(gm, tmni[s], t3); t3 = fma(sgp, tmsi[s], t3);
-			spin_step_rescale<K>(S, s, ca, c1, c2);
+			const bool was = (S.scp[s] < 0) || (S.scm[s] < 0);
+			if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
+			if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
+			if (was && S.scp[s] == 0 && S.scm[s] == 0) load_data(s);
 		}
-		LEG_RED_PUT(kk, t0, t1, t2, t3)
-		kk++; j++; sgn = -sgn;
-		if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j; }
 	}
-	// fast loop: fold the sign of the south rings into the data once (even steps +sg0, odd steps -sg0)
-	if (sgn < 0) {
-#pragma unroll
-		for (int s = 0; s < K; s++) { tpsr[s] = -tpsr[s]; tpsi[s] = -tpsi[s]; tmsr[s] = -tmsr[s]; tmsi[s] = -tmsi[s]; }
-	}
+	// phase C: next coefficients prefetched
 	double4_t f0 = coef[j], f1 = coef[j+1];
 	for (; j + 1 < nl; j += 2) {
 		const double4_t n0 = coef[j+2], n1 = coef[j+3];
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-		{
-			const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b;
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				const double gp = S.gp2[s], gm = S.gm2[s];
-				t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0);
-				t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1);
-				t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2);
-				t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3);
-				const double ax = ca*S.x[s];
-				S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]);
-			}
-		}
-		{
-			const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b;
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				const double gp = S.gp1[s], gm = S.gm1[s];
-				u0 = fma(gp, tpnr[s], u0); u0 = fma(-gm, tpsr[s], u0);
-				u1 = fma(gp, tpni[s], u1); u1 = fma(-gm, tpsi[s], u1);
-				u2 = fma(gm, tmnr[s], u2); u2 = fma(-gp, tmsr[s], u2);
-				u3 = fma(gm, tmni[s], u3); u3 = fma(-gp, tmsi[s], u3);
-				const double ax = ca*S.x[s];
-				S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]);
-			}
-		}
+		SPIN_ANA_PAIR(f0, f1)
 		f0 = n0; f1 = n1;
-		if (kk == 3) {
-			LEG_RED_PUT(3, t0, t1, t2, t3)
-			leg_flush(red, pout + 4*jbase, lane, 4); jbase = j+1;
-			LEG_RED_PUT(0, u0, u1, u2, u3)
-			kk = 1;
-		} else {
-			LEG_RED_PUT(kk, t0, t1, t2, t3)
-			LEG_RED_PUT(kk+1, u0, u1, u2, u3)
-			kk += 2;
-			if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+2; }
-		}
 	}
 	if (j < nl) {
 		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;

@@ -26,11 +26,17 @@ def _np_dtype(x):
 		return np.dtype({torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64, torch.complex128: np.complex128}[x.dtype])
 	return np.dtype(x.dtype)
 
+_cuda_ready = False
 def device_index():
 	if _lib.is_hostsim(): return 0
 	torch = _torch()
 	if not torch.cuda.is_available():
 		raise RuntimeError("pixell_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+	global _cuda_ready
+	if not _cuda_ready:
+		# make torch create its HIP context before libpxsht.so makes its first runtime call: a process whose first HIP
+		# call came from the library (numpy-only callers) got "no ROCm-capable device" from hipSetDevice on the GPU box
+		torch.cuda.init(); torch.zeros(1, device="cuda"); _cuda_ready = True
 	return torch.cuda.current_device()
 
 def current_stream():

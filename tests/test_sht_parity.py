@@ -123,6 +123,54 @@ def check_rings():
 		ra[:, :lmax+1] = ra[:, :lmax+1].real
 		assert relrms(oa, ra) < TOL
 
+def check_deep_scaling(lmax=260):
+	"""rings so close to the poles that sin^m(theta) needs two and three 2^-800 scale steps, next to equatorial rings in
+	the same wave: lanes reach scale 0 at very different l (the ungated phase-B steps, data fetch / sum reset on arrival)"""
+	rng = np.random.default_rng(4)
+	th = np.array([0.0015, 0.004, 0.02, 0.3, 1.1, np.pi/2, np.pi-0.004, np.pi-0.3, np.pi-1.1, 2.5]); nr = len(th); nph = 8
+	kw = dict(theta=th, nphi=np.full(nr, nph, np.uint64), phi0=np.full(nr, 0.1), ringstart=np.arange(nr, dtype=np.uint64)*nph,
+		lmax=lmax, mstart=so._tri_mstart(lmax, lmax))
+	for spin in (0, 2):
+		alm = so.rand_alm_simple(lmax, 1 if spin == 0 else 2, 6, spin=(spin,))
+		ref = so.synthesis(alm=alm, spin=spin, **kw); out = sht.synthesis(alm=alm, spin=spin, **kw)
+		assert rel(out, ref) < TOL
+		pix = rng.standard_normal(ref.shape)
+		ra = so.adjoint_synthesis(map=pix, spin=spin, **kw); oa = sht.adjoint_synthesis(map=pix, spin=spin, **kw)
+		ra[:, :lmax+1] = ra[:, :lmax+1].real
+		assert relrms(oa, ra) < TOL
+
+def check_large_subset(lmax):
+	"""full ring set of a CC-like grid at large lmax (several waves per m, every lane passing through the scaled phases
+	at a different l) against the oracle evaluated on a subset of the rings: synthesis ring by ring, adjoint synthesis
+	with the map supported on the subset.  (A missing data fetch for lanes that reach scale 0 during phase A once gave
+	4e-2 errors at lmax 4000 that no smaller case showed.)"""
+	nr = lmax+2; nph = 8
+	th = np.arange(nr)*np.pi/(nr-1); th[0] = 1e-4; th[-1] = np.pi-1e-4
+	sub = np.unique(np.concatenate([np.arange(0, 8), np.arange(8, nr//2, max(1, nr//40)), nr-1-np.arange(0, 8), [nr//2]]))
+	ms = so._tri_mstart(lmax, lmax)
+	def kw(t): return dict(theta=t, nphi=np.full(len(t), nph, np.uint64), phi0=np.full(len(t), 0.1), ringstart=np.arange(len(t), dtype=np.uint64)*nph, lmax=lmax, mstart=ms)
+	rng = np.random.default_rng(1)
+	for spin in (0, 2):
+		nc = 1 if spin == 0 else 2
+		alm = so.rand_alm_simple(lmax, nc, 6, spin=(spin,))
+		out = sht.synthesis(alm=alm, spin=spin, **kw(th)).reshape(nc, nr, nph)
+		ref = so.synthesis(alm=alm, spin=spin, **kw(th[sub])).reshape(nc, len(sub), nph)
+		assert rel(out[:, sub], ref) < TOL
+		pix = np.zeros((nc, nr, nph)); pix[:, sub] = rng.standard_normal((nc, len(sub), nph))
+		oa = sht.adjoint_synthesis(map=pix.reshape(nc, -1), spin=spin, **kw(th))
+		ra = so.adjoint_synthesis(map=pix[:, sub].reshape(nc, -1), spin=spin, **kw(th[sub]))
+		ra[:, :lmax+1] = ra[:, :lmax+1].real
+		assert relrms(oa, ra) < TOL
+		assert np.max(np.abs(oa-ra)) < 1e-8*np.sqrt(np.mean(np.abs(ra)**2))
+
+@pytest.mark.gpu
+def test_large_lmax_subset_gpu(): check_large_subset(2600)
+
+@pytest.mark.hostsim
+def test_deep_scaling_hostsim(): check_deep_scaling(120)
+@pytest.mark.gpu
+def test_deep_scaling_gpu(): check_deep_scaling(700)
+
 @pytest.mark.hostsim
 def test_rings_hostsim(): check_rings()
 @pytest.mark.gpu
