@@ -110,6 +110,17 @@ int pxa_lmatmul(int N, int M, int lmax, int mmax, const uint64_t* d_mstart, int6
                 const void* alm_in, int64_t in_cstride, void* alm_out, int64_t out_cstride, int alm_dtype,
                 const double* d_lmat, int nl, int device, void* stream);
 
+/* flat-sky harmonic helpers around the 2-D map FFT (pixell/enmap.py:1358-1400 map2harm / harm2map / queb_rotmat,
+ * :1959-2011 calc_ps2d, :2526-2556 lbin).  d_ly[ny], d_lx[nx]: DEVICE f64 wavenumber axes (enmap.laxes); maps [ny][nx] contiguous.
+ * pxm_rotate_queb: in place (a, b) <- (c a - s b, s a + c b) with c + i s = exp(i spin atan2(+-lx, ly)); inverse_sign selects -.
+ * pxm_ps2d: out = Re(a conj b).   pxm_lbin: ADDS, per bin floor(|l|/bsize) < nbin, the map value to d_sum and (when both
+ * are given) |l| to d_lsum and 1 to d_hit; the caller zeroes the accumulators. */
+int pxm_rotate_queb(int ny, int nx, const double* d_ly, const double* d_lx, int spin, int inverse_sign,
+                    void* a, void* b, int dtype, int device, void* stream);
+int pxm_ps2d(int64_t n, const void* a, const void* b, int dtype, void* out, int out_dtype, int device, void* stream);
+int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsize, int nbin,
+             const void* map, int dtype, double* d_sum, double* d_lsum, double* d_hit, int device, void* stream);
+
 /* 1 if the engine can transform this length (2,3,5-smooth or prime factors small enough) */
 int pxf_fft_supported(int64_t n);
 int64_t pxf_fft_good_size(int64_t n);

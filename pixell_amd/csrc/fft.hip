@@ -396,7 +396,10 @@ template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh
 	hipLaunchKernelGGL((fft_lds_kernel<LM, 1>), dim3((unsigned)nblk), dim3(1), sh, st, k);
 #else
 	// 512 threads per workgroup: LDS allows 4 workgroups of 2048 points per CU, and at < 64 VGPRs twice the waves fit
-	static const int nt = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 256; }();
+	// tiles of more than 2048 points (lines of 1025..2048 points: 64 KiB of LDS, 2 workgroups per CU) get 512 threads:
+	// measured 1.39 -> 1.86 TB/s at n = 2048; for the 32 KiB tiles 512 threads were 3-8 % slower
+	static const int nt_env = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 0; }();
+	const int nt = nt_env ? nt_env : ((long)k.T*k.n > 2048 ? 512 : 256);
 	static const bool once = [] {
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);

@@ -1,0 +1,108 @@
+// Flat-sky harmonic helpers around the 2-D map FFT: the Q/U <-> E/B rotation of enmap.map2harm / harm2map
+// (pixell/enmap.py:1358-1389, queb_rotmat :1391-1400), enmap.calc_ps2d (:1959-2011) and the radial binning of enmap.lbin
+// (:2526-2556).  All are one streaming pass over the harmonic map; the reference materialises a [2,2,ny,nx] rotation
+// matrix and an [ny,nx] |l| map on the host for them, here the angle and |l| come from the two l axes on the fly.
+#include "../../include/pxsht.h"
+#include "common.hpp"
+
+namespace pxs {
+
+__device__ __forceinline__ double2 ld_cx(const void* p, int dtype, long i) {
+	if (dtype == PX_C64) { float2 v = ((const float2*)p)[i]; return make_double2(v.x, v.y); }
+	return ((const double2*)p)[i];
+}
+__device__ __forceinline__ void st_cx(void* p, int dtype, long i, double2 v) {
+	if (dtype == PX_C64) ((float2*)p)[i] = make_float2((float)v.x, (float)v.y);
+	else ((double2*)p)[i] = v;
+}
+
+// (a, b) <- (c a - s b, s a + c b), c + i s = e^{i spin atan2(sign lx, ly)}
+__global__ __launch_bounds__(256) void rotate_queb_kernel(int ny, int nx, const double* __restrict__ ly, const double* __restrict__ lx,
+		int spin, double sign, void* __restrict__ a, void* __restrict__ b, int dtype)
+{
+	const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= nx) return;
+	const double ang = spin*atan2(sign*lx[x], ly[y]);
+	double s, c; sincos(ang, &s, &c);
+	const long i = (long)y*nx + x;
+	const double2 va = ld_cx(a, dtype, i), vb = ld_cx(b, dtype, i);
+	st_cx(a, dtype, i, make_double2(c*va.x - s*vb.x, c*va.y - s*vb.y));
+	st_cx(b, dtype, i, make_double2(s*va.x + c*vb.x, s*va.y + c*vb.y));
+}
+
+// out = Re(a conj(b))
+__global__ __launch_bounds__(256) void ps2d_kernel(long n, const void* __restrict__ a, const void* __restrict__ b, int dtype, void* __restrict__ out, int odtype)
+{
+	const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const double2 va = ld_cx(a, dtype, i), vb = ld_cx(b, dtype, i);
+	double r;
+	if (dtype == PX_C64) r = (double)(__fadd_rn(__fmul_rn((float)va.x, (float)vb.x), __fmul_rn((float)va.y, (float)vb.y)));   // numpy's complex64 product
+	else r = va.x*vb.x + va.y*vb.y;
+	if (odtype == PX_F32) ((float*)out)[i] = (float)r; else ((double*)out)[i] = r;
+}
+
+// sums of map, |l| and counts per bin floor(|l| / bsize); bins >= nbin are dropped (enmap._bin_helper, enmap.py:2533-2556)
+__global__ __launch_bounds__(256) void lbin_kernel(int ny, int nx, const double* __restrict__ ly, const double* __restrict__ lx, double bsize, int nbin,
+		const void* __restrict__ map, int dtype, int with_l, double* __restrict__ osum, double* __restrict__ olsum, double* __restrict__ ohit)
+{
+	const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= nx) return;
+	const double l = sqrt(ly[y]*ly[y] + lx[x]*lx[x]);
+	const long bin = (long)floor(l/bsize);
+	if (bin < 0 || bin >= nbin) return;
+	const long i = (long)y*nx + x;
+	const double v = dtype == PX_F32 ? (double)((const float*)map)[i] : ((const double*)map)[i];
+	atomicAdd(osum + bin, v);
+	if (with_l) { atomicAdd(olsum + bin, l); atomicAdd(ohit + bin, 1.0); }
+}
+
+} // namespace pxs
+
+using namespace pxs;
+#define PXS_TRY try {
+#define PXS_CATCH } catch (const pxs::Error& e) { pxs::set_last_error(e.what()); return e.code; } \
+	catch (const std::exception& e) { pxs::set_last_error(e.what()); return pxs::PXS_ERR_ARG; } return 0;
+
+extern "C" {
+
+int pxm_rotate_queb(int ny, int nx, const double* d_ly, const double* d_lx, int spin, int inverse_sign,
+                    void* a, void* b, int dtype, int device, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(ny > 0 && nx > 0 && d_ly && d_lx && a && b, "pxm_rotate_queb: bad arguments");
+	PXS_REQUIRE(dtype == PX_C64 || dtype == PX_C128, "pxm_rotate_queb: maps must be complex64 or complex128");
+	PXS_HIP(hipSetDevice(device));
+	hipLaunchKernelGGL(rotate_queb_kernel, dim3((nx+255)/256, ny), dim3(256), 0, (hipStream_t)stream, ny, nx, d_ly, d_lx, spin,
+		inverse_sign ? -1.0 : 1.0, a, b, dtype);
+	PXS_HIP(hipGetLastError());
+	PXS_CATCH
+}
+
+int pxm_ps2d(int64_t n, const void* a, const void* b, int dtype, void* out, int out_dtype, int device, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(n >= 0 && a && b && out, "pxm_ps2d: bad arguments");
+	PXS_REQUIRE(dtype == PX_C64 || dtype == PX_C128, "pxm_ps2d: inputs must be complex64 or complex128");
+	PXS_REQUIRE(out_dtype == PX_F32 || out_dtype == PX_F64, "pxm_ps2d: output must be float32 or float64");
+	PXS_HIP(hipSetDevice(device));
+	if (n > 0) hipLaunchKernelGGL(ps2d_kernel, dim3((unsigned)((n+255)/256)), dim3(256), 0, (hipStream_t)stream, (long)n, a, b, dtype, out, out_dtype);
+	PXS_HIP(hipGetLastError());
+	PXS_CATCH
+}
+
+int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsize, int nbin,
+             const void* map, int dtype, double* d_sum, double* d_lsum, double* d_hit, int device, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(ny > 0 && nx > 0 && d_ly && d_lx && map && d_sum && bsize > 0 && nbin >= 0, "pxm_lbin: bad arguments");
+	PXS_REQUIRE(dtype == PX_F32 || dtype == PX_F64, "pxm_lbin: map must be float32 or float64");
+	PXS_REQUIRE((d_lsum == nullptr) == (d_hit == nullptr), "pxm_lbin: give both or none of lsum, hit");
+	PXS_HIP(hipSetDevice(device));
+	if (nbin > 0) hipLaunchKernelGGL(lbin_kernel, dim3((nx+255)/256, ny), dim3(256), 0, (hipStream_t)stream, ny, nx, d_ly, d_lx, bsize, nbin,
+		map, dtype, d_lsum ? 1 : 0, d_sum, d_lsum, d_hit);
+	PXS_HIP(hipGetLastError());
+	PXS_CATCH
+}
+
+} // extern "C"

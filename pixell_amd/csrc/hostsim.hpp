@@ -109,6 +109,10 @@ static inline void __syncthreads() { if (pxsim::t_ctx->nthreads > 1) pxsim::t_ct
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a*b) >> 32); }
 static inline double __shfl_xor(double v, int mask) { uint64_t u; std::memcpy(&u, &v, 8); u = pxsim::xchg(u, pxsim::lane_id() ^ mask); std::memcpy(&v, &u, 8); return v; }
 static inline double __shfl(double v, int src) { uint64_t u; std::memcpy(&u, &v, 8); u = pxsim::xchg(u, src); std::memcpy(&v, &u, 8); return v; }
+static inline double atomicAdd(double* p, double v) {   // lanes are OS threads here
+	uint64_t* q = reinterpret_cast<uint64_t*>(p); uint64_t old = __atomic_load_n(q, __ATOMIC_RELAXED), nw; double o;
+	do { std::memcpy(&o, &old, 8); double n = o + v; std::memcpy(&nw, &n, 8); } while (!__atomic_compare_exchange_n(q, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+	return o; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a*b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a+b; return r; }
 static inline int __shfl(int v, int src) { return (int)pxsim::xchg((uint64_t)(uint32_t)v, src); }

@@ -14,6 +14,7 @@ What it does
        geometry.json       analyse_geometry / get_ring_info / alm_info results for the path's geometries
        fft_golden.npz      pixell.fft / enmap.fft outputs from the reference's numpy engine
        alm_ops.npz         cmisc alm2cl / lmul outputs (next-row f1)
+       flatsky.npz         enmap.map2harm / harm2map / calc_ps2d / lbin / laxes / extent (f3)
        alm_rand.npz        rand_alm / rand_alm_white / transpose_alm / lmul matrix form / alm2cl dtypes (f1)
 """
 import sys, os, json, types
@@ -66,6 +67,32 @@ def alm_rand_fixture(curvedsky):
 	out["transfer_add"] = curvedsky.transfer_alm(ai2, w, ai, oalm=out["white"].copy(), op=lambda a, b: a+b)
 	np.savez_compressed(os.path.join(HERE, "alm_rand.npz"), **out)
 
+def flatsky_fixture(enmap):
+	"""enmap.map2harm / harm2map / calc_ps2d / lbin / laxes / extent of the reference (numpy FFT engine) -> flatsky.npz"""
+	rng = np.random.default_rng(31)
+	shape, wcs = enmap.band_geometry(np.deg2rad(20), res=np.deg2rad(2.0))
+	shape = tuple(int(v) for v in shape)
+	m = enmap.ndmap(rng.standard_normal((3,)+shape), wcs)
+	out = dict(map=np.asarray(m), cdelt=np.array(wcs.wcs.cdelt), crval=np.array(wcs.wcs.crval), crpix=np.array(wcs.wcs.crpix))
+	out["extent"] = enmap.extent(shape, wcs); out["extent_signed"] = enmap.extent(shape, wcs, signed=True)
+	ly, lx = enmap.laxes(shape, wcs); out["ly"] = ly; out["lx"] = lx
+	out["modlmap"] = np.asarray(enmap.modlmap(shape, wcs)); out["pixsize"] = enmap.pixsize(shape, wcs)
+	h = enmap.map2harm(m); out["harm"] = np.asarray(h)
+	out["harm_phys"] = np.asarray(enmap.map2harm(m, normalize="phys"))
+	out["harm_iau"] = np.asarray(enmap.map2harm(m, iau=True))
+	out["harm_spin1"] = np.asarray(enmap.map2harm(m[:2], spin=1))
+	out["harm_adj"] = np.asarray(enmap.harm2map_adjoint(m, normalize="phys"))
+	c = enmap.ndmap(rng.standard_normal((3,)+shape)+1j*rng.standard_normal((3,)+shape), wcs)
+	out["cplx"] = np.asarray(c)
+	out["back"] = np.asarray(enmap.harm2map(c)); out["back_phys_keep"] = np.asarray(enmap.harm2map(c, normalize="phys", keep_imag=True))
+	out["back_adj"] = np.asarray(enmap.map2harm_adjoint(c))
+	ps = enmap.calc_ps2d(h[:, None], h[None, :]); out["ps2d"] = np.asarray(ps)
+	out["ps2d_cross"] = np.asarray(enmap.calc_ps2d(h[0], c[1]))
+	out["ps2d_sp"] = np.asarray(enmap.calc_ps2d(h[0].astype(np.complex64)))
+	b, l, nhit = enmap.lbin(ps[0, 0], return_nhit=True); out["lbin_b"] = b; out["lbin_l"] = l; out["lbin_nhit"] = nhit
+	b3, l3 = enmap.lbin(enmap.ndmap(np.asarray(ps)[:, 0], wcs), brel=2.5, return_bins=True); out["lbin3_b"] = b3; out["lbin3_l"] = l3
+	np.savez_compressed(os.path.join(HERE, "flatsky.npz"), **out)
+
 def main():
 	sht = types.ModuleType("sht_exp")
 	for name in ["synthesis_2d", "adjoint_synthesis_2d", "analysis_2d", "adjoint_analysis_2d",
@@ -76,6 +103,8 @@ def main():
 	data = "/root/reference/tests/data/"
 	if "--only-alm-rand" in sys.argv:
 		alm_rand_fixture(curvedsky); print("alm_rand.npz written"); return
+	if "--only-flatsky" in sys.argv:
+		pfft.set_engine("numpy"); flatsky_fixture(enmap); print("flatsky.npz written"); return
 
 	# ---- 1. the one true golden vector -------------------------------------------------
 	shape, wcs = enmap.fullsky_geometry(res=np.deg2rad(1.0), variant="CC")
@@ -231,6 +260,7 @@ def main():
 	np.savez_compressed(os.path.join(HERE, "alm_ops.npz"), alm=al, cl=cl, fl=fl, almxfl=curvedsky.almxfl(al, fl),
 		mstart=ai.mstart, lmax=lmax)
 	alm_rand_fixture(curvedsky)
+	flatsky_fixture(enmap)
 	print("fixtures written to", HERE)
 
 if __name__ == "__main__":

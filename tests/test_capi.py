@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
 	txt = open(os.path.join(ROOT, "include", "pxsht.h")).read()
 	txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-	return sorted(set(re.findall(r"\b(px[sfa]_[a-z0-9_]+)\s*\(", txt)))
+	return sorted(set(re.findall(r"\b(px[sfam]_[a-z0-9_]+)\s*\(", txt)))
 
 def test_header_declares_expected_entry_points():
 	syms = _header_symbols()
