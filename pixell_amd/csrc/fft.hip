@@ -399,7 +399,7 @@ template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh
 	// tiles of more than 2048 points (lines of 1025..2048 points: 64 KiB of LDS, 2 workgroups per CU) get 512 threads:
 	// measured 1.39 -> 1.86 TB/s at n = 2048; for the 32 KiB tiles 512 threads were 3-8 % slower
 	static const int nt_env = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 0; }();
-	const int nt = nt_env ? nt_env : ((long)k.T*k.n > 2048 ? 512 : 256);
+	const int nt = nt_env ? nt_env : ((long)k.T*k.n >= 2048 ? 512 : 256);
 	static const bool once = [] {
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);

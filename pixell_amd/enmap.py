@@ -131,6 +131,7 @@ def ifft(emap, omap=None, nthread=0, normalize=True, adjoint_fft=False, dct=Fals
 def _data(m):
 	if m is None: return None
 	if isinstance(m, dmap): return m.tensor
+	if hasattr(m, "data_ptr"): return m          # a bare torch tensor
 	return np.asarray(m)
 def _wrap(res, like):
 	if isinstance(like, dmap): return dmap(res, like.wcs)
