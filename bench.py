@@ -90,12 +90,12 @@ def main():
 	import torch
 	import torch.distributed as dist
 	rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+	assert torch.cuda.is_available(), "bench.py needs a GPU"
+	torch.cuda.set_device(local)             # before the process group: RCCL binds the communicator to the current device
+	device = torch.device("cuda", local)
 	if world > 1:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 		dist.init_process_group("nccl")
-	assert torch.cuda.is_available(), "bench.py needs a GPU"
-	torch.cuda.set_device(local)
-	device = torch.device("cuda", local)
 	from pixell_amd import curvedsky, enmap, sht
 	cfg = CONFIGS[args.config]
 	lmax = cfg["lmax"]; ny, nx = cfg["shape"]; ncomp = cfg["ncomp"]
