@@ -42,6 +42,20 @@ static int k_anas() { static int k = env_k("PXS_K_ANAS", 6, 2, 6); return k; }
 static int xcd_map() { static int k = env_k("PXS_XCD_MAP", 1, 0, 1); return k; }
 
 struct double4_t { double a, b, c, d; };
+// Wave-uniform table rows are fetched through the constant address space: that makes them scalar loads (s_load_dwordx8)
+// even in kernels that also store to global memory inside their loops.  Without it the analysis kernels, whose flush
+// stores precede later row loads, got per-lane global_load broadcasts for every coefficient row (SQ_INSTS_SMEM 5.5e7
+// against SQ_INSTS_VMEM_RD 2.2e9 for leg_ana_spin<6> at config 3; the synthesis kernels had 4e9 scalar loads).
+#ifdef PXS_HOST_SIM
+#define LDC(p, i) ((p)[i])
+#else
+typedef double pxs_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double4_t ldc_row(const double4_t* p, long i) {
+	const __attribute__((address_space(4))) pxs_d4* c = (const __attribute__((address_space(4))) pxs_d4*)(unsigned long long)p;
+	const pxs_d4 v = c[i]; double4_t r; r.a = v.x; r.b = v.y; r.c = v.z; r.d = v.w; return r;
+}
+#define LDC(p, i) ldc_row((p), (i))
+#endif
 
 struct LegK {
 	int lmax, mmax, spin, nm, npairs, nring, nwave;
@@ -233,7 +247,7 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 		bool act = false; \
 		_Pragma("unroll") for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0); \
 		if (__any(act)) break; \
-		const double4_t q0 = coef[k], q1 = coef[k+1], q2 = coef[k+2], q3 = coef[k+3]; \
+		const double4_t q0 = LDC(coef, k), q1 = LDC(coef, k+1), q2 = LDC(coef, k+2), q3 = LDC(coef, k+3); \
 		const double b0 = polar ? q0.c : q0.b, b1 = polar ? q1.c : q1.b, b2 = polar ? q2.c : q2.b, b3 = polar ? q3.c : q3.b; \
 		_Pragma("unroll") for (int s = 0; s < K; s++) { \
 			lam1[s] = fma(fma(q0.a, csq[s], b0), lam2[s], lam1[s]); \
@@ -304,7 +318,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 			if (!__any(pend)) break;
 			for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
-				const double4_t c0 = coef[k], c1 = coef[k+1], a0 = at[k], a1 = at[k+1];
+				const double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1), a0 = LDC(at, k), a1 = LDC(at, k+1);
 				S0_SYN_PAIR(c0, c1, a0, a1)
 			}
 #pragma unroll
@@ -318,9 +332,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 		for (int s = 0; s < K; s++) if (sc[s] < 0) { p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0; lam1[s] = lam2[s] = 0; }   // never reached scale 0
 		// phase C: fast loop, two steps per iteration (lam1/lam2 swap roles, no register moves),
 		// coefficients of the next iteration prefetched with scalar loads (tables are padded by 2 rows)
-		double4_t c0 = coef[k], c1 = coef[k+1], a0 = at[k], a1 = at[k+1];
+		double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1), a0 = LDC(at, k), a1 = LDC(at, k+1);
 		for (; k + 1 < nk; k += 2) {
-			const double4_t n0 = coef[k+2], n1 = coef[k+3], m0 = at[k+2], m1 = at[k+3];
+			const double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3), m0 = LDC(at, k+2), m1 = LDC(at, k+3);
 			S0_SYN_PAIR(c0, c1, a0, a1)
 			c0 = n0; c1 = n1; a0 = m0; a1 = m1;
 		}
@@ -491,7 +505,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 		for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
 		if (!__any(pend)) break;
 		for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
-			const double4_t c0 = coef[k], c1 = coef[k+1];
+			const double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1);
 			S0_ANA_PAIR(c0, c1)
 		}
 #pragma unroll
@@ -502,9 +516,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 			}
 	}
 	// phase C: every lane at scale 0 (or without data): next coefficients prefetched with scalar loads
-	double4_t c0 = coef[k], c1 = coef[k+1];
+	double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1);
 	for (; k + 1 < nk; k += 2) {
-		const double4_t n0 = coef[k+2], n1 = coef[k+3];
+		const double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3);
 		S0_ANA_PAIR(c0, c1)
 		c0 = n0; c1 = n1;
 	}
@@ -575,7 +589,7 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 		bool act = false; \
 		_Pragma("unroll") for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0); \
 		if (__any(act)) break; \
-		const double4_t q0 = coef[j], q1 = coef[j+1], q2 = coef[j+2], q3 = coef[j+3]; \
+		const double4_t q0 = LDC(coef, j), q1 = LDC(coef, j+1), q2 = LDC(coef, j+2), q3 = LDC(coef, j+3); \
 		_Pragma("unroll") for (int s = 0; s < K; s++) { \
 			double ax; \
 			ax = q0.a*S.x[s]; S.gp1[s] = fma(ax + (polar ? q0.c : q0.b), S.gp2[s], -S.gp1[s]); S.gm1[s] = fma(ax + (polar ? q0.d : -q0.b), S.gm2[s], -S.gm1[s]); \
@@ -649,7 +663,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 			if (!__any(pend)) break;
 			for (int it = 0; it < 2 && j + 1 < nl; it++, j += 2) {
-				const double4_t f0 = coef[j], f1 = coef[j+1], a0 = at[j], a1 = at[j+1];
+				const double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1), a0 = LDC(at, j), a1 = LDC(at, j+1);
 				SPIN_SYN_PAIR(f0, f1, a0, a1)
 			}
 #pragma unroll
@@ -667,9 +681,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 				S.gp1[s] = S.gp2[s] = S.gm1[s] = S.gm2[s] = 0;
 			}
 		// phase C: fast loop, next coefficients prefetched
-		double4_t f0 = coef[j], f1 = coef[j+1], a0 = at[j], a1 = at[j+1];
+		double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1), a0 = LDC(at, j), a1 = LDC(at, j+1);
 		for (; j + 1 < nl; j += 2) {
-			const double4_t n0 = coef[j+2], n1 = coef[j+3], m0 = at[j+2], m1 = at[j+3];
+			const double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3), m0 = LDC(at, j+2), m1 = LDC(at, j+3);
 			SPIN_SYN_PAIR(f0, f1, a0, a1)
 			f0 = n0; f1 = n1; a0 = m0; a1 = m1;
 		}
@@ -786,7 +800,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 		for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
 		if (!__any(pend)) break;
 		for (int it = 0; it < 2 && j + 1 < nl; it++, j += 2) {
-			const double4_t f0 = coef[j], f1 = coef[j+1];
+			const double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1);
 			SPIN_ANA_PAIR(f0, f1)
 		}
 #pragma unroll
@@ -798,9 +812,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 		}
 	}
 	// phase C: next coefficients prefetched
-	double4_t f0 = coef[j], f1 = coef[j+1];
+	double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1);
 	for (; j + 1 < nl; j += 2) {
-		const double4_t n0 = coef[j+2], n1 = coef[j+3];
+		const double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3);
 		SPIN_ANA_PAIR(f0, f1)
 		f0 = n0; f1 = n1;
 	}
