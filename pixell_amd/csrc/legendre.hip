@@ -38,7 +38,7 @@ static int env_k(const char* name, int def, int lo, int hi) {
 static int k_syn0() { static int k = env_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
 static int k_ana0() { static int k0 = env_k("PXS_K_ANA0", 8, 4, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : 4); return k; }
 static int k_syns() { static int k = env_k("PXS_K_SYNS", 3, 2, 4); return k; }
-static int k_anas() { static int k = env_k("PXS_K_ANAS", 6, 2, 6); return k; }
+static int k_anas() { static int k = env_k("PXS_K_ANAS", 4, 2, 6); return k; }   // 4: 149 VGPRs = 3 waves per SIMD (6: 227 = 2 waves; measured 146.9 vs 150.5 ms at config 3)
 static int xcd_map() { static int k = env_k("PXS_XCD_MAP", 1, 0, 1); return k; }
 
 struct double4_t { double a, b, c, d; };
@@ -439,17 +439,11 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 		u0 = fma(lam1[s], d1r[s], u0); u1 = fma(lam1[s], d1i[s], u1); u2 = fma(lam1[s], d2r[s], u2); u3 = fma(lam1[s], d2i[s], u3); \
 		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
 	} \
-	if (kk == 3) {   /* keep pairs within one flush group */ \
-		LEG_RED_PUT(3, t0, t1, t2, t3) \
-		leg_flush(red, pout + 4*kbase, lane, 4); kbase = k+1; \
-		LEG_RED_PUT(0, u0, u1, u2, u3) \
-		kk = 1; \
-	} else { \
-		LEG_RED_PUT(kk, t0, t1, t2, t3) \
-		LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
-		kk += 2; \
-		if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+2; } \
-	} }
+	/* steps come in aligned pairs (phase A advances by 4, phases B and C by 2): kk is 0 or 2 here */ \
+	LEG_RED_PUT(kk, t0, t1, t2, t3) \
+	LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
+	kk += 2; \
+	if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+2; } }
 
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
@@ -741,17 +735,11 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 			S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]); \
 		} \
 	} \
-	if (kk == 3) { \
-		LEG_RED_PUT(3, t0, t1, t2, t3) \
-		leg_flush(red, pout + 4*jbase, lane, 4); jbase = j+1; \
-		LEG_RED_PUT(0, u0, u1, u2, u3) \
-		kk = 1; \
-	} else { \
-		LEG_RED_PUT(kk, t0, t1, t2, t3) \
-		LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
-		kk += 2; \
-		if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+2; } \
-	} }
+	/* steps come in aligned pairs: kk is 0 or 2 here */ \
+	LEG_RED_PUT(kk, t0, t1, t2, t3) \
+	LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
+	kk += 2; \
+	if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+2; } }
 
 template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 {
