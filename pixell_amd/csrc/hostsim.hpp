@@ -36,6 +36,7 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std:
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memmove(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return 0; }
+static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = size_t(2) << 30; *tot = size_t(2) << 30; return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
