@@ -230,3 +230,39 @@ def test_config5_pipeline_gpu():
 	ok = (l > 30) & (l < 0.8*lmax) & np.isfinite(b)
 	ratio = b[ok]/np.interp(l[ok], np.arange(lmax+1), cl_in)
 	assert 0.7 < np.median(ratio) < 1.3
+
+def edge_body():
+	"""edge cases of the reference interface: lmax 0 and 1, explicit alm layouts (stride 2, rectangular), all-scalar
+	spin list on 3 components, unpaired spin component (IndexError, enmap.py:3384), zero-size pre-dimension"""
+	from oracle import sht_oracle as so
+	shape, wcs = enmap.fullsky_geometry(shape=(12, 20))       # nx > 2 lmax: no aliased m in the round trips
+	for lmax in (0, 1):
+		ai = curvedsky.alm_info(lmax)
+		alm = (np.arange(ai.nelem)+1.0).astype(np.complex128)
+		m = enmap.zeros(shape, wcs); curvedsky.alm2map(alm, m, spin=0, ainfo=ai)
+		if lmax == 0: assert np.allclose(np.asarray(m), 1/np.sqrt(4*np.pi), rtol=1e-13)
+		back = curvedsky.map2alm(m, ainfo=ai, spin=0)
+		np.testing.assert_allclose(back, alm, atol=1e-12)
+	lmax = 8
+	tri = curvedsky.alm_info(lmax)
+	alm = so.rand_alm_simple(lmax, 3, 9, spin=(0, 2))
+	ref = enmap.zeros((3,)+shape, wcs); curvedsky.alm2map(alm, ref, spin=[0, 2], ainfo=tri)
+	for ai in (curvedsky.alm_info(lmax, stride=2), curvedsky.alm_info(lmax, layout="rect"), curvedsky.alm_info(lmax=lmax, mmax=lmax, layout=tri.mstart[::-1].copy()*0+tri.mstart)):
+		a2 = curvedsky.transfer_alm(tri, alm, ai)
+		m2 = enmap.zeros((3,)+shape, wcs); curvedsky.alm2map(a2, m2, spin=[0, 2], ainfo=ai)
+		np.testing.assert_allclose(np.asarray(m2), np.asarray(ref), atol=1e-12)
+		b2 = curvedsky.map2alm(ref, ainfo=ai, spin=[0, 2])
+		np.testing.assert_allclose(curvedsky.transfer_alm(ai, b2, tri), alm, atol=1e-11)
+	m3 = enmap.zeros((3,)+shape, wcs); curvedsky.alm2map(alm, m3, spin=[0], ainfo=tri)          # three scalar maps
+	for i in range(3):
+		mi = enmap.zeros(shape, wcs); curvedsky.alm2map(alm[i], mi, spin=0, ainfo=tri)
+		np.testing.assert_allclose(np.asarray(m3)[i], np.asarray(mi), atol=1e-13)
+	with pytest.raises(IndexError):
+		curvedsky.alm2map(alm[:2], enmap.zeros((2,)+shape, wcs), spin=[0, 2], ainfo=tri)          # spin-2 needs a pair
+	e = curvedsky.alm2map(np.zeros((0, 3, tri.nelem), complex), enmap.zeros((0, 3)+shape, wcs), spin=[0, 2], ainfo=tri)
+	assert e.shape == (0, 3)+tuple(shape)
+
+@pytest.mark.hostsim
+def test_edges_hostsim(): edge_body()
+@pytest.mark.gpu
+def test_edges_gpu(): edge_body()
