@@ -410,9 +410,9 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 	else:
 		if copy and alm is not None: alm = alm.clone() if _is_tensor(alm) else alm.copy()
 	mdata = _mdata(map)
-	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, lmax=lmax, pre=map.shape[:-2], dtype=_np_dtype(mdata), convert=adjoint, like=mdata)
+	# (with deriv the alm has no component axis; the reference allocates [2,nelem] here and then fails its shape check)
+	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, lmax=lmax, pre=map.shape[:-3] if deriv else map.shape[:-2], dtype=_np_dtype(mdata), convert=adjoint, like=mdata)
 	if minfo is None: minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
-	if deriv: raise NotImplementedError("deriv in map2alm_cyl is not supported by the accelerated path yet")
 	if weights is None:
 		if minfo.ducc_geo is not None and minfo.ducc_geo.name in ("CC", "F1", "MW", "MWflip"):
 			weights = quad_weights(map.shape, map.wcs, pix_tol=pix_tol)
@@ -432,12 +432,24 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 		_crop_into(map, pmap, pads)
 		return map
 	kwargs = _ring_kwargs(map, minfo, ainfo)
-	alm_full = _atleast(alm, 3)
+	alm_full = _atleast(alm, 2 if deriv else 3)
 	map_full = _atleast(mdata, 4)
-	_check_shapes(alm_full, map_full, False)
+	_check_shapes(alm_full, map_full, deriv)
 	if _is_tensor(mdata): w = _torch().as_tensor(weights, device=mdata.device)[:, None]
 	else: w = weights[:, None]
 	def wmul(m): return m*w
+	if deriv:
+		# gradient maps [ddec, dra] <-> alm through the DERIV1 transforms (curvedsky.py:1067-1076)
+		decflip = (_torch().as_tensor([-1.0, 1.0], device=mdata.device, dtype=mdata.dtype) if _is_tensor(mdata) else np.array([-1.0, 1.0], _np_dtype(mdata)))[:, None, None]
+		for I in nditer(map_full.shape[:-3]):
+			shp = map_full[I].shape
+			def Y(a):   return sht.synthesis(alm=_contig(a), spin=1, mode="DERIV1", **kwargs).reshape(shp)
+			def YT(m):  return sht.adjoint_synthesis(map=_flat(_contig(m)), spin=1, mode="DERIV1", **kwargs)
+			def YTW(m): return YT(wmul(m))
+			def WY(a):  return wmul(Y(a))
+			if adjoint: map_full[I] = jacobi_inverse(YT, WY, _contig(alm_full[I][None]), niter=niter)*decflip
+			else:       alm_full[I] = jacobi_inverse(Y, YTW, map_full[I]*decflip, niter=niter)[0]
+		return map if adjoint else alm
 	for I in nditer(map_full.shape[:-3]):
 		for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
 			Ij = I+(slice(j1, j2),)

@@ -266,3 +266,35 @@ def edge_body():
 def test_edges_hostsim(): edge_body()
 @pytest.mark.gpu
 def test_edges_gpu(): edge_body()
+
+def deriv_cyl_body():
+	"""map2alm(deriv=True) on the cyl path (curvedsky.py:1067-1076) is Y_grad^T W: on the gradient maps of
+	alm2map(deriv=True) it returns l(l+1) a_lm up to the accuracy of the ring weights for the 1/sin(theta) terms of the
+	gradient (exact to 1e-6 for l <= 6 on this grid, per cent level at l ~ lmax)"""
+	from oracle import sht_oracle as so
+	lmax = 12
+	shape, wcs = enmap.fullsky_geometry(shape=(20, 32))
+	alm = so.rand_alm_simple(lmax, 1, 3, spin=(0,))[0]
+	ai = curvedsky.alm_info(lmax)
+	g = enmap.zeros((2,)+shape, wcs); curvedsky.alm2map(alm, g, deriv=True)
+	with pytest.raises(NotImplementedError): curvedsky.map2alm(g, lmax=lmax, deriv=True, method="2d")
+	back = curvedsky.map2alm(g, lmax=lmax, deriv=True, method="cyl")
+	assert back.shape == alm.shape
+	l = np.concatenate([np.arange(m, lmax+1) for m in range(lmax+1)])
+	lo = l <= 6
+	np.testing.assert_allclose(back[lo], (l*(l+1)*alm)[lo], atol=1e-5)
+	assert np.max(np.abs(back-l*(l+1)*alm)) < 0.05*np.max(np.abs(l*(l+1)*alm))
+	# adjoint pair: <map2alm_adjoint(a), m> == <a, map2alm(m)> with niter = 0
+	rng = np.random.default_rng(2)
+	m = enmap.ndmap(rng.standard_normal((2,)+shape), wcs)
+	a1 = curvedsky.map2alm(m, lmax=lmax, deriv=True, method="cyl")
+	mt = enmap.zeros((2,)+shape, wcs); curvedsky.map2alm(mt, alm=alm.copy(), lmax=lmax, deriv=True, method="cyl", adjoint=True)
+	wt = np.full(alm.shape, 2.0); wt[:lmax+1] = 1
+	a1[:lmax+1] = a1[:lmax+1].real
+	lhs = np.sum(np.asarray(mt)*np.asarray(m)); rhs = np.sum(wt*(alm.real*a1.real+alm.imag*a1.imag))
+	assert abs(lhs-rhs) < 1e-10*max(1.0, abs(rhs))
+
+@pytest.mark.hostsim
+def test_deriv_cyl_hostsim(): deriv_cyl_body()
+@pytest.mark.gpu
+def test_deriv_cyl_gpu(): deriv_cyl_body()
