@@ -84,14 +84,21 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 {
 	PXS_TRY
 	PXS_REQUIRE(ndim >= 1 && ndim <= 16 && naxes >= 1 && naxes <= ndim, "pxf_fft_nd: bad ndim/naxes");
-	PXS_REQUIRE(kind >= 0 && kind <= 2, "pxf_fft_nd: kind must be 0 (c2c), 1 (r2c) or 2 (c2r)");
+	PXS_REQUIRE(kind >= 0 && kind <= 3, "pxf_fft_nd: kind must be 0 (c2c), 1 (r2c), 2 (c2r) or 3 (DCT-I)");
+	if (kind == 3) PXS_REQUIRE(in_dtype <= PX_F64 && out_dtype <= PX_F64, "DCT-I needs real in, real out");
 	if (kind == 0) PXS_REQUIRE(out_dtype >= PX_C64, "c2c needs complex output (real input is read with zero imaginary part)");
 	if (kind == 1) PXS_REQUIRE(in_dtype <= PX_F64 && out_dtype >= PX_C64, "r2c needs real in, complex out");
 	if (kind == 2) PXS_REQUIRE(in_dtype >= PX_C64 && out_dtype <= PX_F64, "c2r needs complex in, real out");
 	std::vector<int> axes(axes_in, axes_in+naxes);
 	for (auto& a : axes) { if (a < 0) a += ndim; PXS_REQUIRE(a >= 0 && a < ndim, "pxf_fft_nd: axis out of range"); }
 	for (int k = 0; k < ndim; k++) if (shape[k] == 0) return 0;
-	for (int a : axes) { std::string why; if (!FftContext::supported(shape[a], &why)) throw Error(PXS_ERR_UNSUPPORTED, why); }
+	for (int a : axes) {
+		std::string why;
+		if (kind == 3) {   // DCT-I of n points = real part of the FFT of the even extension to 2(n-1) points
+			if (shape[a] < 2) throw Error(PXS_ERR_ARG, "DCT-I needs at least 2 points along each axis");
+			if (!FftContext::supported(2*(shape[a]-1), &why)) throw Error(PXS_ERR_UNSUPPORTED, "DCT-I of " + std::to_string(shape[a]) + " points: " + why);
+		} else if (!FftContext::supported(shape[a], &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
+	}
 	PXS_HIP(hipSetDevice(device));
 	FftContext& fc = fft_context(device);
 	hipStream_t st = (hipStream_t)stream;
@@ -105,7 +112,21 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 		for (int k = 0; k < ndim; k++) if (k != ax) d.push_back({shp[k], (long)is[k], (long)os[k]});
 		return d;
 	};
-	if (kind == 0) {
+	if (kind == 3) {
+		// FFTW_REDFT00 (pixell/fft.py:211-231, the transform behind enmap.fft(dct=True)): y_k = x_0 + (-1)^k x_{n-1} + 2 sum x_j cos(pi jk/(n-1)),
+		// i.e. Re FFT_{2(n-1)} of the even mirror extension; the extension is a load functor, only the first n bins are stored
+		std::vector<long> rshape(shape, shape+ndim);
+		for (int t = 0; t < naxes; t++) {
+			int ax = axes[naxes-1-t];
+			bool first = (t == 0), lastpass = (t == naxes-1);
+			FftLoad ld; FftStore stf;
+			ld.ptr = first ? in : out; ld.dtype = first ? in_dtype : out_dtype;
+			ld.mode = LD_MIRROR; ld.ne = shape[ax]; ld.mir_c = 0; ld.par0 = 0; ld.par_step = 0;
+			stf.ptr = out; stf.dtype = out_dtype; stf.ne = shape[ax]; stf.scale = lastpass ? scale : 1.0;
+			const int64_t* is = first ? istride : ostride;
+			fft_axis(fc, st, 2*(shape[ax]-1), true, other_dims(ax, rshape, is, ostride), is[ax], ostride[ax], ld, stf);
+		}
+	} else if (kind == 0) {
 		for (int t = 0; t < naxes; t++) {
 			int ax = axes[naxes-1-t];
 			bool first = (t == 0), lastpass = (t == naxes-1);

@@ -98,7 +98,7 @@ template<int LM> __device__ __forceinline__ double2 load_functor(const KArgs& a,
 		return acc; }
 	case LD_MIRROR: {
 		long src = e;
-		const bool odd = ((i + a.i_base + ld.par0) & 1) != 0;
+		const bool odd = ((ld.par_step*(i + a.i_base) + ld.par0) & 1) != 0;
 		bool neg = false;
 		if (e >= ld.ne) { src = N - e - ld.mir_c; if (src < 0) src += N; neg = odd; }
 		// a sample that is its own mirror image (a pole ring) cannot carry odd parity: project it out

@@ -26,7 +26,8 @@ struct FftLoad {
 	long ne = -1;               // PLAIN: elements >= ne read as zero (-1: all n); HERM: half-spectrum length (mmax+1);
 	                            // MIRROR: number of real rings; SPEC*: source spectrum length Ns
 	const double2* mul = nullptr; // PLAIN: multiplier indexed by e. SPEC: phase indexed by |k| (conjugated for k<0)
-	int mir_c = 0, par0 = 0;    // MIRROR: src index for e>=ne is (-e-c) mod n, sign -1 if ((i+par0)&1)
+	int mir_c = 0, par0 = 0;    // MIRROR: src index for e>=ne is (-e-c) mod n, sign -1 if ((par_step*i+par0)&1)
+	int par_step = 1;           // MIRROR: 1 = parity alternates with the line index (SHT m columns), 0 = same parity for every line (DCT/DST)
 	long kmax = -1;             // SPEC: keep |k| <= kmax (-1: all representable)
 	int nyq_half = 0;           // SPEC: source Nyquist bin (Ns even) is split 1/2,1/2 onto +-Ns/2
 	long pair_lines = 0;        // MIRROR_PAIR: number of source lines (line i packs source lines 2i [parity par0] and 2i+1 [opposite parity])

@@ -107,26 +107,31 @@ def area(shape, wcs):
 	return (np.sin(dec2)-np.sin(dec1))*abs(wcs.wcs.cdelt[0])*shape[-1]*degree
 def pixsize(shape, wcs): return area(shape, wcs)/np.prod(shape[-2:])
 
-def _norm(emap, normalize, sign):
+def _norm(emap, normalize, sign, dct=False):
 	norm = 1.0
-	if normalize: norm /= np.prod(emap.shape[-2:])**0.5
+	if normalize: norm /= (np.prod(2*np.array(emap.shape[-2:])-1)**0.5 if dct else np.prod(emap.shape[-2:])**0.5)   # (enmap.py:1318,1331)
 	if normalize in ["phy", "phys", "physical"]: norm *= emap.pixsize()**(0.5*sign)
 	return norm
 
 def fft(emap, omap=None, nthread=0, normalize=True, adjoint_ifft=False, dct=False):
 	"""enmap.fft (enmap.py:1307-1323): 2-D FFT over the last two axes, scaling fused into the
 	last kernel pass instead of a separate `res *= norm` sweep."""
-	if dct: raise NotImplementedError("dct is outside the accelerated path")
-	norm = _norm(emap, normalize, -1 if adjoint_ifft else +1)
+	norm = _norm(emap, normalize, -1 if adjoint_ifft else +1, dct=dct)
+	if dct: return _wrap(enfft.dct(_data(emap), _data(omap) if omap is not None else None, axes=[-2, -1], nthread=nthread, _scale=norm), emap)
 	res = enfft.fft(_data(emap), _data(omap) if omap is not None else None, axes=[-2, -1], nthread=nthread, _scale=norm)
 	return _wrap(res, emap)
 
 def ifft(emap, omap=None, nthread=0, normalize=True, adjoint_fft=False, dct=False):
 	"""enmap.ifft (enmap.py:1325-1337)"""
-	if dct: raise NotImplementedError("dct is outside the accelerated path")
-	norm = _norm(emap, normalize, +1 if adjoint_fft else -1)
+	norm = _norm(emap, normalize, +1 if adjoint_fft else -1, dct=dct)
+	if dct: return _wrap(enfft.idct(_data(emap), _data(omap) if omap is not None else None, axes=[-2, -1], nthread=nthread, normalize=False, _scale=norm), emap)
 	res = enfft.ifft(_data(emap), _data(omap) if omap is not None else None, axes=[-2, -1], nthread=nthread, normalize=False, _scale=norm)
 	return _wrap(res, emap)
+
+def dct(emap, omap=None, nthread=0, normalize=True): return fft(emap, omap=omap, nthread=nthread, normalize=normalize, dct=True)
+def idct(emap, omap=None, nthread=0, normalize=True): return ifft(emap, omap=omap, nthread=nthread, normalize=normalize, dct=True)
+def fft_adjoint(emap, omap=None, nthread=0, normalize=True): return ifft(emap, omap=omap, nthread=nthread, normalize=normalize, adjoint_fft=True)
+def ifft_adjoint(emap, omap=None, nthread=0, normalize=True): return fft(emap, omap=omap, nthread=nthread, normalize=normalize, adjoint_ifft=True)
 
 def _data(m):
 	if m is None: return None

@@ -25,14 +25,17 @@ def _strides(x):
 	if _is_tensor(x): return list(x.stride())
 	return [s//x.itemsize for s in x.strides]
 
-def _exec(a, b, axes, forward, scale):
+def _exec(a, b, axes, forward, scale, dct1=False):
 	"""a -> b along axes; kind from shapes/dtypes (fft.py:14-31)"""
 	ad, bd = _np_dtype(a), _np_dtype(b)
 	nd = a.ndim
 	axes = [ax % nd for ax in astuple(axes)]
 	ashape, bshape = tuple(a.shape), tuple(b.shape)
 	half = lambda shp: tuple(n//2+1 if i == axes[-1] else n for i, n in enumerate(shp))
-	if bd.kind == "c" and ashape == bshape:
+	if dct1:
+		if ad.kind == "c" or bd.kind == "c" or ashape != bshape: raise ValueError("dct: real arrays of equal shape are needed")
+		kind, shape = 3, ashape
+	elif bd.kind == "c" and ashape == bshape:
 		kind, shape = 0, ashape
 	elif bd.kind == "c":
 		if ad.kind == "c" or bshape != half(ashape): raise ValueError("r2c: output shape %s does not match input %s" % (str(bshape), str(ashape)))
@@ -92,6 +95,34 @@ def irfft(ft, tod=None, n=None, nthread=0, normalize=False, axes=[-1], flags=Non
 	axes = astuple(-1 if axes is None else axes)
 	if tod is None: tod = _empty_like(irfft_shape(ft.shape, axes, n), np.zeros([], _np_dtype(ft)).real.dtype, ft)
 	return ifft(ft, tod, nthread, normalize, axes, flags=flags)
+
+_dct_names = {"DCT-I": "FFTW_REDFT00", "FFTW_REDFT00": "FFTW_REDFT00"}
+def _dct_check(type):
+	if type not in _dct_names:
+		raise NotImplementedError("only DCT-I (FFTW_REDFT00, the transform behind enmap.fft(dct=True)) is implemented on the GPU; got %s" % str(type))
+
+def dct(tod, dt=None, nthread=0, normalize=False, axes=[-1], flags=None, type="DCT-I", engine="auto", _scale=1.0):
+	"""pixell.fft.dct (fft.py:211-231): unnormalised DCT-I along axes (normalize is ignored there too)"""
+	_dct_check(type)
+	axes = astuple(-1 if axes is None else axes)
+	if not _is_tensor(tod): tod = np.asarray(tod); tod = tod if tod.dtype.kind == "f" else tod.astype(np.result_type(tod.dtype, 0.0))
+	if dt is None: dt = _empty_like(tod.shape, _np_dtype(tod), tod)
+	return _exec(tod, dt, axes, True, _scale, dct1=True)
+
+def idct(dt, tod=None, nthread=0, normalize=False, axes=[-1], flags=None, type="DCT-I", engine="auto", _scale=1.0):
+	"""pixell.fft.idct (fft.py:233-267): DCT-I is its own inverse; normalize divides by prod 2(n-1)"""
+	_dct_check(type)
+	axes = astuple(-1 if axes is None else axes)
+	if not _is_tensor(dt): dt = np.asarray(dt); dt = dt if dt.dtype.kind == "f" else dt.astype(np.result_type(dt.dtype, 0.0))
+	if tod is None: tod = _empty_like(dt.shape, _np_dtype(dt), dt)
+	scale = _scale
+	if normalize: scale = scale/float(np.prod([2*(dt.shape[i]-1) for i in axes]))
+	return _exec(dt, tod, axes, True, scale, dct1=True)
+
+def redft00(a, b=None, nthread=0, normalize=False, flags=None, engine="auto"):
+	"""pixell.fft.redft00 (fft.py:292-307): DCT-I along the last axis"""
+	n = a.shape[-1]
+	return dct(a, b, axes=[-1], _scale=1.0/(2*(n-1)) if normalize else 1.0)
 
 def fft_len(n, direction="below", factors=None):
 	"""nearest length the engine handles well (2,3,5-smooth), cf. pixell.fft.fft_len (fft.py:319)"""

@@ -98,3 +98,32 @@ def test_unsupported_length_raises():
 	with pytest.raises(PxsError):
 		pfft.fft(np.zeros((1, 2*4099), complex))      # prime factor > 2048: no Bluestein yet
 	assert pfft.fft_len(4099, "above") == 4320 or pfft.fft_len(4099, "above") >= 4099
+
+def check_dct():
+	"""DCT-I (FFTW_REDFT00; pixell.fft.dct / idct / redft00 and enmap.fft(dct=True), fft.py:211-307, enmap.py:1314-1342)
+	against scipy.fft.dct(type=1), which has the same unnormalised definition; the reference's numpy engine has no DCT"""
+	import scipy.fft as sfft
+	from pixell_amd import enmap
+	rng = np.random.default_rng(5)
+	for n in (2, 3, 9, 17, 33, 101, 1025, 1537, 4097):
+		x = rng.standard_normal((3, n))
+		np.testing.assert_allclose(pfft.dct(x), sfft.dct(x, type=1, axis=-1), rtol=1e-12, atol=1e-11*np.sqrt(n))
+	x = rng.standard_normal((2, 33, 49))
+	ref = sfft.dctn(x, type=1, axes=(-2, -1))
+	np.testing.assert_allclose(pfft.dct(x, axes=[-2, -1]), ref, rtol=1e-12, atol=1e-10)
+	np.testing.assert_allclose(pfft.dct(x, axes=[0]), sfft.dct(x, type=1, axis=0), rtol=1e-12, atol=1e-11)
+	np.testing.assert_allclose(pfft.idct(ref, axes=[-2, -1], normalize=True), x, rtol=1e-12, atol=1e-12)
+	np.testing.assert_allclose(pfft.redft00(x, normalize=True), sfft.dct(x, type=1, axis=-1)/(2*48), rtol=1e-12, atol=1e-13)
+	xf = x.astype(np.float32); o = pfft.dct(xf, axes=[-1]); assert o.dtype == np.float32
+	np.testing.assert_allclose(o, sfft.dct(xf.astype(np.float64), type=1, axis=-1), rtol=2e-5, atol=2e-4)
+	with pytest.raises(NotImplementedError): pfft.dct(x, type="DCT-II")
+	shape, wcs = enmap.fullsky_geometry(shape=(33, 64))
+	m = enmap.ndmap(rng.standard_normal((2,)+tuple(shape)), wcs)
+	d = enmap.dct(m); norm = np.prod(2*np.array(shape)-1)**0.5
+	np.testing.assert_allclose(np.asarray(d), sfft.dctn(np.asarray(m), type=1, axes=(-2, -1))/norm, rtol=1e-12, atol=1e-12)
+	np.testing.assert_allclose(np.asarray(enmap.idct(d)), sfft.dctn(np.asarray(d), type=1, axes=(-2, -1))/norm, rtol=1e-12, atol=1e-12)
+
+@pytest.mark.hostsim
+def test_dct_hostsim(): check_dct()
+@pytest.mark.gpu
+def test_dct_gpu(): check_dct()
