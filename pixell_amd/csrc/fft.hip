@@ -388,7 +388,9 @@ template<int LM, int NT> __global__ __launch_bounds__(NT) void fft_lds_kernel(co
 
 // (Tried: a persistent variant of this kernel that issues the global loads of its NEXT tile into registers before the
 // passes of the current one.  The compiler needed 200-260 VGPRs for it (2 waves per SIMD), or 70-230 spills when held
-// to 128; not pursued.  What the attempt left behind: the LDS-only barrier, the per-load-mode instantiation and the pass
+// to 128; not pursued.  A second form that issued the next tile's loads only after the passes (prefetch registers live
+// across the store loop only) still took 200-260 VGPRs -- the persistent loop makes every load-functor invariant live -- and
+// ran 2x slower (n = 200: 0.19 -> 0.44 ms).  What the attempts left behind: the LDS-only barrier, the per-load-mode instantiation and the pass
 // table in device memory, which keep the argument struct out of scratch.)
 // launch one of the two kernels over nblk tiles
 template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
