@@ -91,11 +91,15 @@ def main():
 	import torch.distributed as dist
 	rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
 	assert torch.cuda.is_available(), "bench.py needs a GPU"
+	# PXS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the gather goes
+	# through host memory); the driver's runs use nccl (= RCCL) with one rank per GPU
+	backend = os.environ.get("PXS_BENCH_BACKEND", "nccl")
+	if backend != "nccl": local = local % torch.cuda.device_count()
 	torch.cuda.set_device(local)             # before the process group: RCCL binds the communicator to the current device
 	device = torch.device("cuda", local)
 	if world > 1:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		dist.init_process_group("nccl")
+		dist.init_process_group(backend)
 	from pixell_amd import curvedsky, enmap, sht
 	cfg = CONFIGS[args.config]
 	lmax = cfg["lmax"]; ny, nx = cfg["shape"]; ncomp = cfg["ncomp"]
@@ -132,7 +136,13 @@ def main():
 			ev = torch.cuda.Event(); ev.record()
 			side.wait_event(ev)
 			with torch.cuda.stream(side):
-				dist.all_gather_into_tensor(gather_buf.view(torch.float64).view(world, -1), alm_out.view(torch.float64).view(-1))
+				if backend == "nccl":
+					dist.all_gather_into_tensor(gather_buf.view(torch.float64).view(world, -1), alm_out.view(torch.float64).view(-1))
+				else:   # rehearsal: gloo has no device all-gather
+					side.synchronize()
+					host = [torch.empty(alm_out.shape, dtype=alm_out.dtype) for _ in range(world)]
+					dist.all_gather(host, alm_out.cpu())
+					for r in range(world): gather_buf[r].copy_(host[r])
 		curvedsky.alm2map(alm_out, dmap, spin=cfg["spin"], ainfo=ainfo)
 		if gather_buf is not None: torch.cuda.current_stream().wait_stream(side)   # alm_out is rewritten by the next step
 
@@ -149,7 +159,7 @@ def main():
 	dt = time.perf_counter()-t0
 	prof = plan.profile_read(reset=True); plan.profile(False)
 	if world > 1:
-		t = torch.tensor([dt], device=device, dtype=torch.float64)
+		t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 	ms_step = dt/args.steps*1e3
 	value = world*args.steps/dt
