@@ -67,6 +67,7 @@ struct LegK {
 	double ofs;
 	int m0; long rowbase, rows_chunk;   // analysis processes m in chunks to bound the partial-moment scratch
 	int nmc, xcd;                       // m count of this launch; XCD-aware block order on/off
+	int* first;                         // analysis: see LegWork::first
 };
 
 // Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
@@ -206,12 +207,24 @@ __global__ __launch_bounds__(256) void alm_post_spin(AlmK a) {
 	else { st_alm(a.alm, a.dtype, idx, E); st_alm(a.alm, a.dtype, idx + a.cstride, B); }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials(const double* part, double* mom, long n4, int nwave) {
-	const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
-	if (i >= n4) return;
+// mom[row] = sum over the waves that wrote that row.  A wave writes rows from the end of its phase A on and nothing at all
+// when none of its rings is live for this m; `first` says which (36 % of the (wave, m) pairs are dead at config 3, and the
+// 16 GiB partial buffer no longer needs a memset before every launch).
+__global__ __launch_bounds__(256) void reduce_partials(const double* __restrict__ part, double* __restrict__ mom, const long* __restrict__ row,
+		const int* __restrict__ first, int m0, int nmc, long rowbase, long rows_chunk, int nwave)
+{
+	const int mi = blockIdx.y;
+	const long r0 = row[m0 + mi], nrow = row[m0 + mi + 1] - r0;
+	const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;      // 4*step + component
+	if (i >= 4*nrow) return;
+	const int step = (int)(i >> 2);
+	const long off = (r0 - rowbase)*4 + i;
 	double s = 0;
-	for (int w = 0; w < nwave; w++) s += part[(long)w*n4 + i];
-	mom[i] = s;
+	for (int w = 0; w < nwave; w++) {
+		const int f = first[w*nmc + mi];
+		if (f > 0 && step >= f - 1) s += part[(long)w*rows_chunk*4 + off];
+	}
+	mom[r0*4 + i] = s;
 }
 
 // A wave is 'polar' when all its rings have cos^2 > 1/2: it then runs the recurrences in the variable
@@ -487,6 +500,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
 	int k = 0;
 	S0_PHASE_A
+	if (lane == 0) a.first[wv*a.nmc + (m - a.m0)] = k + 1;      // rows before k are not written (reduce_partials skips them)
 	// ring data of the lanes that start at scale 0 or reached it during phase A (rings without signal have lam = 0)
 #pragma unroll
 	for (int s = 0; s < K; s++) if (sc[s] == 0) load_data(s);
@@ -776,6 +790,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	for (int s = 0; s < K; s++) tpnr[s] = tpni[s] = tmnr[s] = tmni[s] = tpsr[s] = tpsi[s] = tmsr[s] = tmsi[s] = 0;
 	int j = 0;
 	SPIN_PHASE_A
+	if (lane == 0) a.first[wv*a.nmc + (m - a.m0)] = j + 1;      // rows before j are not written (reduce_partials skips them)
 	// ring data of the lanes whose chains start at scale 0 or both reached it during phase A
 #pragma unroll
 	for (int s = 0; s < K; s++) if (S.scp[s] == 0 && S.scm[s] == 0) load_data(s);
@@ -1029,7 +1044,9 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		if (rows <= 0) continue;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0;
-		PXS_HIP(hipMemsetAsync(wk.part.p, 0, sizeof(double)*4*rows*nwave, st));
+		wk.first.ensure(sizeof(int)*(size_t)nwave*(m1-m0));
+		PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));
+		a.first = wk.first.as<int>();
 		if (prof) prof->begin(st, 1);
 		const dim3 grid = leg_grid(a);
 		if (tb.spin == 0) {
@@ -1044,8 +1061,9 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 			else             hipLaunchKernelGGL(leg_ana_spin<2>, grid, dim3(64), sh, st, a);
 		}
 		if (prof) prof->end(st, 1);
-		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*rows+255)/256)), dim3(256), 0, st, (const double*)wk.part.p,
-			(double*)wk.mom.p + 4*tb.row[m0], 4*rows, a.nwave);
+		const long maxrow = tb.row[m0+1] - tb.row[m0];       // rows per m shrink with m
+		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*maxrow+255)/256), m1-m0), dim3(256), 0, st, (const double*)wk.part.p,
+			(double*)wk.mom.p, tb.d_row.as<long>(), (const int*)wk.first.p, m0, m1-m0, tb.row[m0], rows, a.nwave);
 	}
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm), dim3(256), 0, st, ak);

@@ -40,6 +40,7 @@ struct LegWork {     // scratch owned by the SHT plan
 	DevBuf almt;     // [nrows][4] doubles
 	DevBuf part;     // [nwave][nrows][4] doubles (analysis partial moments)
 	DevBuf mom;      // [nrows][4] reduced moments
+	DevBuf first;    // [nwave][m chunk] int: 1 + first row a wave wrote for that m (0: the wave had no live ring and wrote nothing)
 };
 
 
