@@ -260,6 +260,7 @@ void setup_resampling(pxs_plan* p) {
 	while (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
 	p->ncc = (int)(p->Ncc/2 + 1);
 	p->M = FftContext::good_size(p->N + 2L*lmax + 2);
+	{ const char* e = getenv("PXS_M_FINE"); if (e && atol(e) >= p->M && FftContext::supported(atol(e))) p->M = atol(e); }   // experiments: a larger fine grid with friendlier factors
 	std::string why;
 	if (!FftContext::supported(p->N, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
 	// CC ring set
