@@ -93,7 +93,8 @@ int pxs_profile_read(pxs_plan* plan, double* ms, int* counts, int reset);
 /* N-d FFT over `naxes` axes of a strided array: the engine behind fft.engines["hip"].FFTW(a,b,axes,
  * direction) (pixell/fft.py:8-64,133-209) and enmap.fft/ifft (enmap.py:1307-1337).
  * kind 0: c2c (in/out same shape), 1: r2c (out last transformed axis n//2+1), 2: c2r,
- * 3: DCT-I (FFTW_REDFT00, real in/out of the same shape, unnormalised; `forward` is ignored: the transform is its own inverse up to 2(n-1)).
+ * 3..10: the FFTW r2r kinds REDFT00, REDFT10, REDFT01, REDFT11, RODFT00, RODFT10, RODFT01, RODFT11 (DCT-I..IV, DST-I..IV;
+ *   pixell/fft.py:211-290): real in/out of the same shape, unnormalised, `forward` ignored.
  * shape[ndim] is the LOGICAL (real-space) shape; istride/ostride in elements of in/out dtype.
  * forward: e^{-i...}; unnormalised, result multiplied by `scale`. */
 int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int64_t* ostride,

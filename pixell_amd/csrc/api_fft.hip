@@ -5,6 +5,8 @@
 #include <mutex>
 #include <memory>
 #include <algorithm>
+#include <tuple>
+#include <cmath>
 
 namespace pxs {
 
@@ -57,6 +59,54 @@ static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::
 	}
 }
 
+// ---- r2r (DCT / DST) as functor-wrapped complex FFTs ---------------------------------------------------------------
+struct R2RPlan { long N = 0; bool forward = true, mirror = false; int mir_c = 0; long ld_shift = 0, st_shift = 0; double scale = 1.0; DevBuf ld_mul, st_mul; };
+long r2r_length(int kind, long n) {
+	switch (kind) { case 3: return 2*(n-1); case 7: return 2*(n+1); default: return 2*n; }
+}
+const R2RPlan& r2r_plan(int device, int kind, long n) {
+	static std::mutex mu; static std::map<std::tuple<int, int, long>, std::unique_ptr<R2RPlan>> plans;
+	std::lock_guard<std::mutex> g(mu);
+	auto& p = plans[std::make_tuple(device, kind, n)];
+	if (p) return *p;
+	p.reset(new R2RPlan());
+	typedef long double LD;
+	const LD pi = 3.141592653589793238462643383279502884L;
+	p->N = r2r_length(kind, n);
+	auto tab = [&](long len, auto f) { std::vector<double2> t(len); for (long e = 0; e < len; e++) { LD re, im; f(e, re, im); t[e] = make_double2((double)re, (double)im); } return upload(t); };
+	const LD h = pi/(2*(LD)n);      // half-sample phase step pi/(2n)
+	switch (kind) {
+	case 3:  /* REDFT00  DCT-I   */ p->mirror = true; p->mir_c = 0; break;
+	case 4:  /* REDFT10  DCT-II  y_k = Re(e^{-i pi k/2n} Z_k), Z = FFT_2n of the half-sample mirror extension */
+		p->mirror = true; p->mir_c = 1;
+		p->st_mul = tab(n, [&](long k, LD& re, LD& im) { re = cosl(h*k); im = -sinl(h*k); }); break;
+	case 5:  /* REDFT01  DCT-III y_k = 2 Re sum_j c_j x_j e^{i pi j/2n} e^{+2 pi i jk/2n}, c_0 = 1/2 */
+		p->forward = false; p->scale = 2;
+		p->ld_mul = tab(n, [&](long j, LD& re, LD& im) { const LD c = j == 0 ? 0.5L : 1.0L; re = c*cosl(h*j); im = c*sinl(h*j); }); break;
+	case 6:  /* REDFT11  DCT-IV  y_k = 2 Re[e^{-i pi (k+1/2)/2n} sum_j x_j e^{-i pi j/2n} e^{-2 pi i jk/2n}] */
+		p->scale = 2;
+		p->ld_mul = tab(n, [&](long j, LD& re, LD& im) { re = cosl(h*j); im = -sinl(h*j); });
+		p->st_mul = tab(n, [&](long k, LD& re, LD& im) { re = cosl(h*(k+0.5L)); im = -sinl(h*(k+0.5L)); }); break;
+	case 7: { /* RODFT00 DST-I   y_k = 2 Re[i e^{-2 pi i q/N} F_q], q = k+1, F = FFT_N of the zero-padded line */
+		p->scale = 2; p->st_shift = 1;
+		const LD w = 2*pi/(LD)p->N;
+		p->st_mul = tab(n+1, [&](long q, LD& re, LD& im) { re = sinl(w*q); im = cosl(w*q); }); break; }   // i e^{-ia} = sin a + i cos a
+	case 8:  /* RODFT10  DST-II  y_k = 2 Re[i e^{-i pi q/2n} F_q], q = k+1 */
+		p->scale = 2; p->st_shift = 1;
+		p->st_mul = tab(n+1, [&](long q, LD& re, LD& im) { re = sinl(h*q); im = cosl(h*q); }); break;
+	case 9:  /* RODFT01  DST-III y_k = 2 Re[i sum_j c_j x_j e^{-i pi (j+1)/2n} e^{-2 pi i (j+1)k/2n}], c_{n-1} = 1/2: element j sits at j+1 */
+		p->scale = 2; p->ld_shift = 1;
+		p->ld_mul = tab(n+1, [&](long e, LD& re, LD& im) { const LD c = e == n ? 0.5L : 1.0L; re = c*cosl(h*e); im = -c*sinl(h*e); });
+		p->st_mul = tab(n, [&](long, LD& re, LD& im) { re = 0; im = 1; }); break;
+	case 10: /* RODFT11  DST-IV  y_k = 2 Re[i e^{-i pi (k+1/2)/2n} sum_j x_j e^{-i pi j/2n} e^{-2 pi i jk/2n}] */
+		p->scale = 2;
+		p->ld_mul = tab(n, [&](long j, LD& re, LD& im) { re = cosl(h*j); im = -sinl(h*j); });
+		p->st_mul = tab(n, [&](long k, LD& re, LD& im) { re = sinl(h*(k+0.5L)); im = cosl(h*(k+0.5L)); }); break;
+	default: throw Error(PXS_ERR_ARG, "unknown r2r kind");
+	}
+	return *p;
+}
+
 } // namespace pxs
 
 using namespace pxs;
@@ -84,8 +134,8 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 {
 	PXS_TRY
 	PXS_REQUIRE(ndim >= 1 && ndim <= 16 && naxes >= 1 && naxes <= ndim, "pxf_fft_nd: bad ndim/naxes");
-	PXS_REQUIRE(kind >= 0 && kind <= 3, "pxf_fft_nd: kind must be 0 (c2c), 1 (r2c), 2 (c2r) or 3 (DCT-I)");
-	if (kind == 3) PXS_REQUIRE(in_dtype <= PX_F64 && out_dtype <= PX_F64, "DCT-I needs real in, real out");
+	PXS_REQUIRE(kind >= 0 && kind <= 10, "pxf_fft_nd: kind must be 0 (c2c), 1 (r2c), 2 (c2r) or 3..10 (DCT-I..IV, DST-I..IV)");
+	if (kind >= 3) PXS_REQUIRE(in_dtype <= PX_F64 && out_dtype <= PX_F64, "DCT/DST need real in, real out");
 	if (kind == 0) PXS_REQUIRE(out_dtype >= PX_C64, "c2c needs complex output (real input is read with zero imaginary part)");
 	if (kind == 1) PXS_REQUIRE(in_dtype <= PX_F64 && out_dtype >= PX_C64, "r2c needs real in, complex out");
 	if (kind == 2) PXS_REQUIRE(in_dtype >= PX_C64 && out_dtype <= PX_F64, "c2r needs complex in, real out");
@@ -94,9 +144,10 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 	for (int k = 0; k < ndim; k++) if (shape[k] == 0) return 0;
 	for (int a : axes) {
 		std::string why;
-		if (kind == 3) {   // DCT-I of n points = real part of the FFT of the even extension to 2(n-1) points
-			if (shape[a] < 2) throw Error(PXS_ERR_ARG, "DCT-I needs at least 2 points along each axis");
-			if (!FftContext::supported(2*(shape[a]-1), &why)) throw Error(PXS_ERR_UNSUPPORTED, "DCT-I of " + std::to_string(shape[a]) + " points: " + why);
+		if (kind >= 3) {
+			const long N = r2r_length(kind, shape[a]);
+			if (N < 2) throw Error(PXS_ERR_ARG, "DCT-I needs at least 2 points along each axis");
+			if (!FftContext::supported(N, &why)) throw Error(PXS_ERR_UNSUPPORTED, "DCT/DST of " + std::to_string(shape[a]) + " points: " + why);
 		} else if (!FftContext::supported(shape[a], &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
 	}
 	PXS_HIP(hipSetDevice(device));
@@ -112,19 +163,24 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 		for (int k = 0; k < ndim; k++) if (k != ax) d.push_back({shp[k], (long)is[k], (long)os[k]});
 		return d;
 	};
-	if (kind == 3) {
-		// FFTW_REDFT00 (pixell/fft.py:211-231, the transform behind enmap.fft(dct=True)): y_k = x_0 + (-1)^k x_{n-1} + 2 sum x_j cos(pi jk/(n-1)),
-		// i.e. Re FFT_{2(n-1)} of the even mirror extension; the extension is a load functor, only the first n bins are stored
+	if (kind >= 3) {
+		// FFTW r2r kinds (pixell/fft.py:211-290): each is the real part of a complex FFT of an extension of the line --
+		// mirror extension or zero padding with a half-sample phase ramp as a load functor, the other phase ramp, the bin
+		// offset and "2 Re" / "-2 Im" in the store functor.  Only the first n bins are stored.
 		std::vector<long> rshape(shape, shape+ndim);
 		for (int t = 0; t < naxes; t++) {
 			int ax = axes[naxes-1-t];
 			bool first = (t == 0), lastpass = (t == naxes-1);
+			const R2RPlan& rp = r2r_plan(device, kind, shape[ax]);
 			FftLoad ld; FftStore stf;
 			ld.ptr = first ? in : out; ld.dtype = first ? in_dtype : out_dtype;
-			ld.mode = LD_MIRROR; ld.ne = shape[ax]; ld.mir_c = 0; ld.par0 = 0; ld.par_step = 0;
-			stf.ptr = out; stf.dtype = out_dtype; stf.ne = shape[ax]; stf.scale = lastpass ? scale : 1.0;
+			ld.mode = rp.mirror ? LD_MIRROR : LD_PLAIN; ld.ne = shape[ax]; ld.mir_c = rp.mir_c; ld.par0 = 0; ld.par_step = 0;
+			ld.shift = rp.ld_shift; ld.mul = rp.ld_mul.p ? rp.ld_mul.as<double2>() : nullptr;
+			stf.ptr = out; stf.dtype = out_dtype; stf.ne = shape[ax] + rp.st_shift; stf.shift = rp.st_shift;
+			stf.mul = rp.st_mul.p ? rp.st_mul.as<double2>() : nullptr;
+			stf.scale = (lastpass ? scale : 1.0)*rp.scale;
 			const int64_t* is = first ? istride : ostride;
-			fft_axis(fc, st, 2*(shape[ax]-1), true, other_dims(ax, rshape, is, ostride), is[ax], ostride[ax], ld, stf);
+			fft_axis(fc, st, rp.N, rp.forward, other_dims(ax, rshape, is, ostride), is[ax], ostride[ax], ld, stf);
 		}
 	} else if (kind == 0) {
 		for (int t = 0; t < naxes; t++) {

@@ -69,8 +69,9 @@ template<int LM> __device__ __forceinline__ double2 load_functor(const KArgs& a,
 	const long N = a.N;
 	switch (LM) {      // compile-time: one instantiation of the kernels per load mode keeps the prefetch code small
 	case LD_PLAIN: {
-		if (ld.ne >= 0 && e >= ld.ne) return make_double2(0, 0);
-		double2 v = read_elem(ld.ptr, ld.dtype, base + e*a.d.is_e);
+		const long se = e - ld.shift;
+		if (se < 0 || (ld.ne >= 0 && se >= ld.ne)) return make_double2(0, 0);
+		double2 v = read_elem(ld.ptr, ld.dtype, base + se*a.d.is_e);
 		if (ld.mul) v = cmul(v, ld.mul[e]);
 		return v; }
 	case LD_HERM: {
@@ -172,11 +173,11 @@ template<int LM> __device__ __forceinline__ double2 load_functor(const KArgs& a,
 
 __device__ __forceinline__ void store_functor(const KArgs& a, long i, long o1, long o2, long e, double2 v) {
 	const FftStore& st = a.st;
-	if (st.ne >= 0 && e >= st.ne) return;
-	long eo = e;
+	if ((st.ne >= 0 && e >= st.ne) || e < st.shift) return;
+	long eo = e - st.shift;
 	if (st.two_sided_k >= 0) {
 		if (e > st.two_sided_k && e < a.N - st.two_sided_k) return;
-		if (st.compact_two_sided && e > st.two_sided_k) eo = st.two_sided_k + (a.N - e);
+		if (st.compact_two_sided && e > st.two_sided_k) eo = st.two_sided_k + (a.N - e);   // (never combined with shift)
 	}
 	if (st.conj_out) v.y = -v.y;
 	if (st.mul) v = cmul(v, st.mul[e]);

@@ -26,6 +26,7 @@ struct FftLoad {
 	long ne = -1;               // PLAIN: elements >= ne read as zero (-1: all n); HERM: half-spectrum length (mmax+1);
 	                            // MIRROR: number of real rings; SPEC*: source spectrum length Ns
 	const double2* mul = nullptr; // PLAIN: multiplier indexed by e. SPEC: phase indexed by |k| (conjugated for k<0)
+	long shift = 0;             // PLAIN: element e reads source element e - shift (zero outside 0..ne-1)
 	int mir_c = 0, par0 = 0;    // MIRROR: src index for e>=ne is (-e-c) mod n, sign -1 if ((par_step*i+par0)&1)
 	int par_step = 1;           // MIRROR: 1 = parity alternates with the line index (SHT m columns), 0 = same parity for every line (DCT/DST)
 	long kmax = -1;             // SPEC: keep |k| <= kmax (-1: all representable)
@@ -40,6 +41,7 @@ struct FftStore {
 	long two_sided_k = -1;      // if >= 0: store only e <= k or e >= n-k
 	const double2* mul = nullptr; // multiplier indexed by e
 	double scale = 1.0;
+	long shift = 0;             // bins e < shift are dropped, bin e is stored at position e - shift (ne counts bins)
 	int conj_out = 0;           // conjugate the result before mul/scale
 	int compact_two_sided = 0;  // with two_sided_k = k: e <= k stored at e, e >= n-k stored at k + (n - e)  (row length 2k+1)
 	int real_pair = 0;          // real output dtype: Re -> line 2i, Im -> line 2i+1 (os_i is the stride between real lines)

@@ -25,16 +25,16 @@ def _strides(x):
 	if _is_tensor(x): return list(x.stride())
 	return [s//x.itemsize for s in x.strides]
 
-def _exec(a, b, axes, forward, scale, dct1=False):
+def _exec(a, b, axes, forward, scale, r2r=0):
 	"""a -> b along axes; kind from shapes/dtypes (fft.py:14-31)"""
 	ad, bd = _np_dtype(a), _np_dtype(b)
 	nd = a.ndim
 	axes = [ax % nd for ax in astuple(axes)]
 	ashape, bshape = tuple(a.shape), tuple(b.shape)
 	half = lambda shp: tuple(n//2+1 if i == axes[-1] else n for i, n in enumerate(shp))
-	if dct1:
+	if r2r:
 		if ad.kind == "c" or bd.kind == "c" or ashape != bshape: raise ValueError("dct: real arrays of equal shape are needed")
-		kind, shape = 3, ashape
+		kind, shape = r2r, ashape
 	elif bd.kind == "c" and ashape == bshape:
 		kind, shape = 0, ashape
 	elif bd.kind == "c":
@@ -96,33 +96,53 @@ def irfft(ft, tod=None, n=None, nthread=0, normalize=False, axes=[-1], flags=Non
 	if tod is None: tod = _empty_like(irfft_shape(ft.shape, axes, n), np.zeros([], _np_dtype(ft)).real.dtype, ft)
 	return ifft(ft, tod, nthread, normalize, axes, flags=flags)
 
-_dct_names = {"DCT-I": "FFTW_REDFT00", "FFTW_REDFT00": "FFTW_REDFT00"}
-def _dct_check(type):
-	if type not in _dct_names:
-		raise NotImplementedError("only DCT-I (FFTW_REDFT00, the transform behind enmap.fft(dct=True)) is implemented on the GPU; got %s" % str(type))
+# names, inverses and normalisation offsets as in pixell/fft.py:269-290
+_dct_names = {
+	"DCT-I": "FFTW_REDFT00", "DCT-II": "FFTW_REDFT10", "DCT-III": "FFTW_REDFT01", "DCT-IV": "FFTW_REDFT11",
+	"DST-I": "FFTW_RODFT00", "DST-II": "FFTW_RODFT10", "DST-III": "FFTW_RODFT01", "DST-IV": "FFTW_RODFT11"}
+_dct_names.update({v: v for v in list(_dct_names.values())})
+_dct_inverses = {"FFTW_REDFT00": "FFTW_REDFT00", "FFTW_REDFT10": "FFTW_REDFT01", "FFTW_REDFT01": "FFTW_REDFT10", "FFTW_REDFT11": "FFTW_REDFT11",
+	"FFTW_RODFT00": "FFTW_RODFT00", "FFTW_RODFT10": "FFTW_RODFT01", "FFTW_RODFT01": "FFTW_RODFT10", "FFTW_RODFT11": "FFTW_RODFT11"}
+_dct_sizes = {"FFTW_REDFT00": -1, "FFTW_REDFT10": 0, "FFTW_REDFT01": 0, "FFTW_REDFT11": 0, "FFTW_RODFT00": +1, "FFTW_RODFT10": 0, "FFTW_RODFT01": 0, "FFTW_RODFT11": 0}
+_r2r_kind = {"FFTW_REDFT00": 3, "FFTW_REDFT10": 4, "FFTW_REDFT01": 5, "FFTW_REDFT11": 6, "FFTW_RODFT00": 7, "FFTW_RODFT10": 8, "FFTW_RODFT01": 9, "FFTW_RODFT11": 10}
+def _dct_type(type):
+	if type not in _dct_names: raise ValueError("unknown DCT/DST type %s" % str(type))
+	return _dct_names[type]
+def _asreal(a):
+	if _is_tensor(a): return a
+	a = np.asarray(a)
+	return a if a.dtype.kind == "f" else a.astype(np.result_type(a.dtype, 0.0))
 
 def dct(tod, dt=None, nthread=0, normalize=False, axes=[-1], flags=None, type="DCT-I", engine="auto", _scale=1.0):
-	"""pixell.fft.dct (fft.py:211-231): unnormalised DCT-I along axes (normalize is ignored there too)"""
-	_dct_check(type)
+	"""pixell.fft.dct (fft.py:211-231): unnormalised DCT / DST of the given type along axes (normalize is ignored there too)"""
+	t = _dct_type(type)
 	axes = astuple(-1 if axes is None else axes)
-	if not _is_tensor(tod): tod = np.asarray(tod); tod = tod if tod.dtype.kind == "f" else tod.astype(np.result_type(tod.dtype, 0.0))
+	tod = _asreal(tod)
 	if dt is None: dt = _empty_like(tod.shape, _np_dtype(tod), tod)
-	return _exec(tod, dt, axes, True, _scale, dct1=True)
+	return _exec(tod, dt, axes, True, _scale, r2r=_r2r_kind[t])
 
 def idct(dt, tod=None, nthread=0, normalize=False, axes=[-1], flags=None, type="DCT-I", engine="auto", _scale=1.0):
-	"""pixell.fft.idct (fft.py:233-267): DCT-I is its own inverse; normalize divides by prod 2(n-1)"""
-	_dct_check(type)
+	"""pixell.fft.idct (fft.py:233-267): applies the transform that inverts `type` (e.g. DCT-III for DCT-II); normalize divides
+	by prod 2(n+d), d = -1 for DCT-I, +1 for DST-I, 0 otherwise"""
+	t = _dct_inverses[_dct_type(type)]
+	off = _dct_sizes[t]
 	axes = astuple(-1 if axes is None else axes)
-	if not _is_tensor(dt): dt = np.asarray(dt); dt = dt if dt.dtype.kind == "f" else dt.astype(np.result_type(dt.dtype, 0.0))
+	dt = _asreal(dt)
 	if tod is None: tod = _empty_like(dt.shape, _np_dtype(dt), dt)
 	scale = _scale
-	if normalize: scale = scale/float(np.prod([2*(dt.shape[i]-1) for i in axes]))
-	return _exec(dt, tod, axes, True, scale, dct1=True)
+	if normalize: scale = scale/float(np.prod([2*(dt.shape[i]+off) for i in axes]))
+	return _exec(dt, tod, axes, True, scale, r2r=_r2r_kind[t])
 
 def redft00(a, b=None, nthread=0, normalize=False, flags=None, engine="auto"):
 	"""pixell.fft.redft00 (fft.py:292-307): DCT-I along the last axis"""
 	n = a.shape[-1]
 	return dct(a, b, axes=[-1], _scale=1.0/(2*(n-1)) if normalize else 1.0)
+
+def chebt(a, b=None, nthread=0, flags=None, engine="auto"):
+	"""pixell.fft.chebt (fft.py:309-313): Chebyshev transform along the last axis"""
+	b = redft00(a, b, nthread, normalize=True)
+	b[..., 1:-1] *= 2
+	return b
 
 def fft_len(n, direction="below", factors=None):
 	"""nearest length the engine handles well (2,3,5-smooth), cf. pixell.fft.fft_len (fft.py:319)"""

@@ -116,7 +116,18 @@ def check_dct():
 	np.testing.assert_allclose(pfft.redft00(x, normalize=True), sfft.dct(x, type=1, axis=-1)/(2*48), rtol=1e-12, atol=1e-13)
 	xf = x.astype(np.float32); o = pfft.dct(xf, axes=[-1]); assert o.dtype == np.float32
 	np.testing.assert_allclose(o, sfft.dct(xf.astype(np.float64), type=1, axis=-1), rtol=2e-5, atol=2e-4)
-	with pytest.raises(NotImplementedError): pfft.dct(x, type="DCT-II")
+	# all eight FFTW r2r kinds against scipy (same unnormalised definitions), 1-D and 2-D, and their inverses
+	for name, fun, ty in [("DCT-I", sfft.dct, 1), ("DCT-II", sfft.dct, 2), ("DCT-III", sfft.dct, 3), ("DCT-IV", sfft.dct, 4),
+			("DST-I", sfft.dst, 1), ("DST-II", sfft.dst, 2), ("DST-III", sfft.dst, 3), ("DST-IV", sfft.dst, 4)]:
+		big = {"DCT-I": 3001, "DST-I": 2999}.get(name, 3000)          # extended length 6000: four-step path
+		for n in (2, 5, 16, 31, 100, 1200, big):
+			y = rng.standard_normal((2, n))
+			np.testing.assert_allclose(pfft.dct(y, type=name), fun(y, type=ty, axis=-1), rtol=1e-11, atol=1e-10*np.sqrt(n), err_msg="%s n=%d" % (name, n))
+		y = rng.standard_normal((3, 20, 27))
+		f2 = pfft.dct(y, axes=[-2, -1], type=name)
+		np.testing.assert_allclose(f2, fun(fun(y, type=ty, axis=-1), type=ty, axis=-2), rtol=1e-11, atol=1e-10, err_msg=name)
+		np.testing.assert_allclose(pfft.idct(f2, axes=[-2, -1], type=name, normalize=True), y, rtol=1e-11, atol=1e-11, err_msg=name+" inverse")
+	with pytest.raises(ValueError): pfft.dct(x, type="DCT-V")
 	shape, wcs = enmap.fullsky_geometry(shape=(33, 64))
 	m = enmap.ndmap(rng.standard_normal((2,)+tuple(shape)), wcs)
 	d = enmap.dct(m); norm = np.prod(2*np.array(shape)-1)**0.5
