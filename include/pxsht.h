@@ -122,6 +122,9 @@ int pxm_rotate_queb(int ny, int nx, const double* d_ly, const double* d_lx, int 
 int pxm_ps2d(int64_t n, const void* a, const void* b, int dtype, void* out, int out_dtype, int device, void* stream);
 int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsize, int nbin,
              const void* map, int dtype, double* d_sum, double* d_lsum, double* d_hit, int device, void* stream);
+/* data[i] *= vec[(i / inner) % n] on a contiguous complex array of `total` elements; d_vec: DEVICE complex128[n]
+ * (the per-axis phase ramps of pixell.fft.shift, fft.py:347-368) */
+int pxm_mul_axis(int64_t total, int64_t n, int64_t inner, void* data, int dtype, const void* d_vec, int device, void* stream);
 
 /* 1 if the engine can transform this length (2,3,5-smooth or prime factors small enough) */
 int pxf_fft_supported(int64_t n);

@@ -34,17 +34,18 @@ def _declare(lib):
 	lib.pxm_rotate_queb.argtypes = [i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
 	lib.pxm_ps2d.argtypes = [i64, vp, vp, i32, vp, i32, i32, vp]
 	lib.pxm_lbin.argtypes = [i32, i32, vp, vp, f64, i32, vp, i32, vp, vp, vp, i32, vp]
+	lib.pxm_mul_axis.argtypes = [i64, i64, i64, vp, i32, vp, i32, vp]
 	lib.pxf_fft_nd.argtypes = [i32, vp, vp, vp, i32, vp, i32, i32, dbl, i32, i32, vp, vp, i32, vp]
 	lib.pxf_fft_supported.argtypes = [i64]
 	lib.pxf_fft_good_size.argtypes = [i64]; lib.pxf_fft_good_size.restype = i64
 	for name in ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_synthesis", "pxs_analysis", "pxs_gridweights",
-			"pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported", "pxs_profile", "pxs_profile_read", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin"]:
+			"pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported", "pxs_profile", "pxs_profile_read", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]:
 		getattr(lib, name).restype = i32
 	return lib
 
 EXPORTS = ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_plan_destroy", "pxs_synthesis", "pxs_analysis",
 	"pxs_gridweights", "pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported",
-	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin"]
+	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]
 
 def lib_path():
 	return os.path.join(HERE, "libpxsht.so")

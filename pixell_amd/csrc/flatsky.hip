@@ -57,6 +57,16 @@ __global__ __launch_bounds__(256) void lbin_kernel(int ny, int nx, const double*
 	if (with_l) { atomicAdd(olsum + bin, l); atomicAdd(ohit + bin, 1.0); }
 }
 
+// data[i] *= vec[(i / inner) % n]: multiply along one axis of a contiguous complex array (fft.shift's phase ramps, fft.py:347-368)
+__global__ __launch_bounds__(256) void mul_axis_kernel(long total, long n, long inner, void* __restrict__ data, int dtype, const double2* __restrict__ vec)
+{
+	const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= total) return;
+	const double2 w = vec[(i/inner) % n];
+	const double2 v = ld_cx(data, dtype, i);
+	st_cx(data, dtype, i, make_double2(v.x*w.x - v.y*w.y, v.x*w.y + v.y*w.x));
+}
+
 } // namespace pxs
 
 using namespace pxs;
@@ -101,6 +111,17 @@ int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsiz
 	PXS_HIP(hipSetDevice(device));
 	if (nbin > 0) hipLaunchKernelGGL(lbin_kernel, dim3((nx+255)/256, ny), dim3(256), 0, (hipStream_t)stream, ny, nx, d_ly, d_lx, bsize, nbin,
 		map, dtype, d_lsum ? 1 : 0, d_sum, d_lsum, d_hit);
+	PXS_HIP(hipGetLastError());
+	PXS_CATCH
+}
+
+int pxm_mul_axis(int64_t total, int64_t n, int64_t inner, void* data, int dtype, const void* d_vec, int device, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(total >= 0 && n > 0 && inner > 0 && data && d_vec, "pxm_mul_axis: bad arguments");
+	PXS_REQUIRE(dtype == PX_C64 || dtype == PX_C128, "pxm_mul_axis: data must be complex64 or complex128");
+	PXS_HIP(hipSetDevice(device));
+	if (total > 0) hipLaunchKernelGGL(mul_axis_kernel, dim3((unsigned)((total+255)/256)), dim3(256), 0, (hipStream_t)stream, (long)total, (long)n, (long)inner, data, dtype, (const double2*)d_vec);
 	PXS_HIP(hipGetLastError());
 	PXS_CATCH
 }

@@ -179,3 +179,90 @@ def register(pixell_fft_module, make_default=True):
 	pixell_fft_module.engines["hip"] = hip_engine
 	if make_default: pixell_fft_module.set_engine("hip")
 	return hip_engine
+
+# ---------------------------------------------------------------------------------------
+# shift / resample (pixell/fft.py:347-420): Fourier shifting and resizing on top of the transforms above
+# ---------------------------------------------------------------------------------------
+def fftfreq(n, d=1.0, dtype=np.float64): return np.fft.fftfreq(n, d=d).astype(dtype, copy=False)
+def rfftfreq(n, d=1.0, dtype=np.float64): return np.arange(n//2+1, dtype=dtype)/(n*d)
+
+def _to_dev(a):
+	"""contiguous device copy of a numpy array (tensors pass through); second value: was it a host array"""
+	if _is_tensor(a): return a, False
+	a = np.ascontiguousarray(a)
+	if _lib.is_hostsim(): return a, False
+	device_index()
+	import torch
+	return torch.from_numpy(a).cuda(), True
+def _to_host(a, was_host): return a.cpu().numpy() if was_host else a
+
+def _mul_axis(ca, ax, vec):
+	"""ca *= vec along axis ax (ca: contiguous complex array on the device / in the simulator)"""
+	n = ca.shape[ax]; inner = int(np.prod(ca.shape[ax+1:], dtype=np.int64)); total = int(np.prod(ca.shape, dtype=np.int64))
+	v = _Buf(np.ascontiguousarray(vec, dtype=np.complex128))
+	ptr = ca.data_ptr() if _is_tensor(ca) else ca.ctypes.data
+	_lib.check(_lib.load().pxm_mul_axis(total, n, inner, ptr, _DT[_np_dtype(ca)], v.ptr, device_index(), current_stream()))
+
+def shift(a, shift, axes=None, nofft=False, deriv=None, engine="auto"):
+	"""pixell.fft.shift (fft.py:347-368): shift a by a (fractional) number of samples along the given axes through phase
+	ramps in Fourier space; deriv = i differentiates along the i-th listed axis as well"""
+	host_in = not _is_tensor(a)
+	if host_in: a = np.asanyarray(a)
+	iscomplex = _np_dtype(a).kind == "c"
+	ctype = np.result_type(_np_dtype(a), np.complex64)
+	shift_ = np.atleast_1d(shift)
+	if axes is None: axes = range(-len(shift_), 0)
+	axes = astuple(axes)
+	if host_in: ca = np.ascontiguousarray(a, dtype=ctype)+0
+	else:
+		import torch
+		ca = a.to(getattr(torch, np.dtype(ctype).name)).contiguous().clone()
+	ca, was_host = _to_dev(ca)
+	fa = fft(ca, axes=axes) if not nofft else ca
+	for i, ax in enumerate(axes):
+		ax %= fa.ndim
+		freqs = fftfreq(fa.shape[ax])
+		phase = np.exp(-2j*np.pi*freqs*shift_[i])
+		if deriv == i: phase = phase*(-2j*np.pi*freqs)
+		_mul_axis(fa, ax, phase)
+	res = ifft(fa, axes=axes, normalize=True) if not nofft else fa
+	res = _to_host(res, was_host)
+	return res if iscomplex else res.real
+
+def resample_fft(fa, n, out=None, axes=-1, norm=1, op=lambda a, b: b):
+	"""pixell.fft.resample_fft (fft.py:389-434): pad or truncate the Fourier array fa so that it is the transform of the
+	same signal on n samples (pure block copies; works on numpy arrays and on CUDA tensors)"""
+	axes = astuple(axes)
+	n = np.zeros(len(axes), int)+n
+	oshape = list(fa.shape)
+	for i, ax in enumerate(axes): oshape[ax] = int(n[i])
+	oshape = tuple(oshape)
+	if out is None: out = _empty_like(oshape, _np_dtype(fa), fa); out[...] = 0
+	elif tuple(out.shape) != oshape:
+		raise ValueError("out argument has wrong shape in resample. Expected %s but got %s" % (str(oshape), str(tuple(out.shape))))
+	for I in np.ndindex(*([2]*len(axes))):
+		sel = [slice(None) for _ in oshape]
+		for ai, ax in enumerate(axes):
+			c = min(fa.shape[ax], oshape[ax])
+			sel[ax] = slice(0, c//2) if I[ai] == 0 else slice(-(c-c//2), None)
+		sel = tuple(sel)
+		src = fa[sel]*norm if norm != 1 else fa[sel]
+		out[sel] = op(out[sel], src)
+	return out
+
+def resample(a, n, axes=None, nthread=0, engine="auto"):
+	"""pixell.fft.resample (fft.py:370-387): Fourier-resize the given axes of a to length n"""
+	host_in = not _is_tensor(a)
+	if host_in: a = np.asarray(a)
+	n = astuple(n)
+	if axes is None: axes = [-len(n)+i for i in range(len(n))]
+	axes = astuple(axes)
+	if len(n) != len(axes): raise ValueError("Resize size n = %s does not match axes = %s" % (str(n), str(axes)))
+	iscomplex = _np_dtype(a).kind == "c"
+	da, was_host = _to_dev(a)
+	fa = fft(da, axes=axes)
+	norm = 1/np.prod([a.shape[ax] for ax in axes])
+	fa = resample_fft(fa, n, axes=axes, norm=norm)
+	out = ifft(fa, axes=axes, normalize=False)
+	out = _to_host(out, was_host)
+	return out if iscomplex else out.real

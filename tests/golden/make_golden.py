@@ -14,6 +14,7 @@ What it does
        geometry.json       analyse_geometry / get_ring_info / alm_info results for the path's geometries
        fft_golden.npz      pixell.fft / enmap.fft outputs from the reference's numpy engine
        alm_ops.npz         cmisc alm2cl / lmul outputs (next-row f1)
+       fft_ops.npz         pixell.fft.shift / resample / resample_fft (f4)
        flatsky.npz         enmap.map2harm / harm2map / calc_ps2d / lbin / laxes / extent (f3)
        alm_rand.npz        rand_alm / rand_alm_white / transpose_alm / lmul matrix form / alm2cl dtypes (f1)
 """
@@ -93,6 +94,19 @@ def flatsky_fixture(enmap):
 	b3, l3 = enmap.lbin(enmap.ndmap(np.asarray(ps)[:, 0], wcs), brel=2.5, return_bins=True); out["lbin3_b"] = b3; out["lbin3_l"] = l3
 	np.savez_compressed(os.path.join(HERE, "flatsky.npz"), **out)
 
+def fftops_fixture(pfft):
+	"""pixell.fft.shift / resample / resample_fft with the reference's numpy engine -> fft_ops.npz"""
+	rng = np.random.default_rng(41)
+	a = rng.standard_normal((3, 12, 20)); c = a+1j*rng.standard_normal(a.shape)
+	out = dict(a=a, c=c)
+	out["shift1"] = pfft.shift(a, 2.5); out["shift2"] = pfft.shift(a, [1.25, -3.0]); out["shiftc"] = pfft.shift(c, [0.5], axes=[1])
+	out["shift_deriv"] = pfft.shift(a, [0.0, 0.0], deriv=1)
+	out["res_up"] = pfft.resample(a, 31); out["res_dn"] = pfft.resample(a, (7, 9)); out["res_c"] = pfft.resample(c, 33, axes=[1])
+	fa = np.fft.fft2(c)
+	out["rfft_a"] = pfft.resample_fft(fa, (16, 11), axes=(-2, -1), norm=0.5)
+	out["rfft_op"] = pfft.resample_fft(fa, 25, out=np.ones((3, 12, 25), complex), op=lambda x, y: x+y)
+	np.savez_compressed(os.path.join(HERE, "fft_ops.npz"), **out)
+
 def main():
 	sht = types.ModuleType("sht_exp")
 	for name in ["synthesis_2d", "adjoint_synthesis_2d", "analysis_2d", "adjoint_analysis_2d",
@@ -103,6 +117,8 @@ def main():
 	data = "/root/reference/tests/data/"
 	if "--only-alm-rand" in sys.argv:
 		alm_rand_fixture(curvedsky); print("alm_rand.npz written"); return
+	if "--only-fftops" in sys.argv:
+		pfft.set_engine("numpy"); fftops_fixture(pfft); print("fft_ops.npz written"); return
 	if "--only-flatsky" in sys.argv:
 		pfft.set_engine("numpy"); flatsky_fixture(enmap); print("flatsky.npz written"); return
 
@@ -261,6 +277,7 @@ def main():
 		mstart=ai.mstart, lmax=lmax)
 	alm_rand_fixture(curvedsky)
 	flatsky_fixture(enmap)
+	fftops_fixture(pfft)
 	print("fixtures written to", HERE)
 
 if __name__ == "__main__":

@@ -138,3 +138,25 @@ def check_dct():
 def test_dct_hostsim(): check_dct()
 @pytest.mark.gpu
 def test_dct_gpu(): check_dct()
+
+def check_fftops(golden_dir):
+	"""fft.shift / resample / resample_fft against the reference's own functions run with its numpy engine (fft_ops.npz)"""
+	d = np.load(os.path.join(golden_dir, "fft_ops.npz"))
+	a, c = d["a"], d["c"]; tol = dict(rtol=1e-12, atol=1e-12)
+	s1 = pfft.shift(a, 2.5); assert s1.dtype == np.float64
+	np.testing.assert_allclose(s1, d["shift1"], **tol)
+	np.testing.assert_allclose(pfft.shift(a, [1.25, -3.0]), d["shift2"], **tol)
+	np.testing.assert_allclose(pfft.shift(c, [0.5], axes=[1]), d["shiftc"], **tol)
+	np.testing.assert_allclose(pfft.shift(a, [0.0, 0.0], deriv=1), d["shift_deriv"], **tol)
+	np.testing.assert_allclose(pfft.resample(a, 31), d["res_up"], **tol)
+	np.testing.assert_allclose(pfft.resample(a, (7, 9)), d["res_dn"], **tol)
+	np.testing.assert_allclose(pfft.resample(c, 33, axes=[1]), d["res_c"], **tol)
+	fa = np.fft.fft2(c)
+	assert np.array_equal(pfft.resample_fft(fa, (16, 11), axes=(-2, -1), norm=0.5), d["rfft_a"])
+	assert np.array_equal(pfft.resample_fft(fa, 25, out=np.ones((3, 12, 25), complex), op=lambda x, y: x+y), d["rfft_op"])
+	with pytest.raises(ValueError): pfft.resample_fft(fa, 25, out=np.ones((3, 12, 24), complex))
+
+@pytest.mark.hostsim
+def test_fftops_hostsim(golden_dir): check_fftops(golden_dir)
+@pytest.mark.gpu
+def test_fftops_gpu(golden_dir): check_fftops(golden_dir)
