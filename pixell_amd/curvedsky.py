@@ -595,3 +595,27 @@ def transfer_alm(iainfo, ialm, oainfo, oalm=None, op=lambda a, b: b):
 		src = torch.as_tensor(src, device=ialm.device); dst = torch.as_tensor(dst, device=oalm.device)
 	oalm[..., dst] = op(oalm[..., dst], ialm[..., src])
 	return oalm
+
+def rand_map(shape, wcs, ps, lmax=None, dtype=np.float64, seed=None, spin=[0, 2], method="auto", verbose=False):
+	"""Gaussian realisation of the (cross) spectrum ps on the given geometry (curvedsky.rand_map, curvedsky.py:17-37).
+	The reference draws its alm with healpy.synalm (healpy is absent here); this uses rand_alm, i.e. the same
+	distribution but pixell's own random-number order (SURVEY: 'replace by rand_alm semantics')."""
+	ps = np.asarray(ps)
+	while ps.ndim < 3: ps = ps[None]
+	if ps.shape[0] != ps.shape[1]: raise ValueError("ps must be [ncomp,ncomp,nl] or [nl]")
+	if len(shape) not in (2, 3): raise ValueError("shape must be (ncomp,ny,nx) or (ny,nx)")
+	ncomp = 1 if len(shape) == 2 else shape[-3]
+	ps = ps[:ncomp, :ncomp]
+	ctype = np.result_type(dtype, 0j)
+	alm = rand_alm(ps, lmax=lmax, seed=seed, dtype=ctype)
+	map = enmap.empty((ncomp,)+tuple(shape[-2:]), wcs, dtype=dtype)
+	alm2map(alm, map, spin=spin, method=method, verbose=verbose)
+	if len(shape) == 2: map = map[0]
+	return map
+
+def filter(imap, lfilter, ainfo=None, lmax=None):
+	"""alm2map(almxfl(map2alm(imap), lfilter)): isotropic filtering of a map (curvedsky.filter, curvedsky.py:654-671)"""
+	alm = map2alm(imap, ainfo=ainfo, lmax=lmax, spin=0)
+	alm = almxfl(alm, lfilter=lfilter, ainfo=ainfo)
+	out = enmap.dmap(_torch().empty_like(imap.tensor), imap.wcs) if isinstance(imap, enmap.dmap) else enmap.empty(imap.shape, imap.wcs, dtype=imap.dtype)
+	return alm2map(alm, out, spin=0, ainfo=ainfo)

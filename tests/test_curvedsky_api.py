@@ -298,3 +298,25 @@ def deriv_cyl_body():
 def test_deriv_cyl_hostsim(): deriv_cyl_body()
 @pytest.mark.gpu
 def test_deriv_cyl_gpu(): deriv_cyl_body()
+
+def filter_randmap_body():
+	"""curvedsky.filter and rand_map (curvedsky.py:17-37, 654-671): filtering a band-limited map with 1 returns it, with
+	a top-hat it removes exactly the other multipoles; rand_map reproduces alm2map(rand_alm(seed))"""
+	lmax = 14
+	shape, wcs = enmap.fullsky_geometry(shape=(20, 32))
+	cl = 1.0/(np.arange(lmax+1)+1.0)**2
+	m = curvedsky.rand_map((3,)+tuple(shape), wcs, np.array([[cl, 0*cl, 0*cl], [0*cl, cl, 0*cl], [0*cl, 0*cl, cl]]), lmax=lmax, seed=4)
+	alm = curvedsky.rand_alm(np.array([[cl, 0*cl, 0*cl], [0*cl, cl, 0*cl], [0*cl, 0*cl, cl]]), lmax=lmax, seed=4)
+	ref = enmap.zeros((3,)+tuple(shape), wcs); curvedsky.alm2map(alm, ref, spin=[0, 2])
+	np.testing.assert_allclose(np.asarray(m), np.asarray(ref), atol=1e-13)
+	t = enmap.ndmap(np.asarray(m)[0].copy(), wcs)
+	np.testing.assert_allclose(np.asarray(curvedsky.filter(t, lambda l: 1+0*l, lmax=lmax)), np.asarray(t), atol=1e-12)
+	lo = curvedsky.filter(t, lambda l: 1.0*(l <= 6), lmax=lmax)
+	a_lo = curvedsky.map2alm(lo, lmax=lmax, spin=0); a_t = curvedsky.map2alm(t, lmax=lmax, spin=0)
+	ai = curvedsky.alm_info(lmax); l = np.concatenate([np.arange(mm, lmax+1) for mm in range(lmax+1)])
+	np.testing.assert_allclose(a_lo, np.where(l <= 6, a_t, 0), atol=1e-12)
+
+@pytest.mark.hostsim
+def test_filter_randmap_hostsim(): filter_randmap_body()
+@pytest.mark.gpu
+def test_filter_randmap_gpu(): filter_randmap_body()
