@@ -321,7 +321,7 @@ template<int LM> __device__ __forceinline__ void tile_load_one(const KArgs& a, c
 	if (!a.forward && a.mode != 2) v.y = -v.y;
 	pos = (int)(t*a.ns) + a.perm[j];
 }
-template<int NT> __device__ __forceinline__ double2* tile_passes(const KArgs& a, double2* cur, double2* oth, const double2* tw) {
+template<int NT, bool GEN> __device__ __forceinline__ double2* tile_passes(const KArgs& a, double2* cur, double2* oth, const double2* tw) {
 	for (int p = 0; p < a.nfac; p++) {
 		const PassDesc ps = a.pass[p];
 		switch (ps.R) {
@@ -329,7 +329,7 @@ template<int NT> __device__ __forceinline__ double2* tile_passes(const KArgs& a,
 			case 3: radix_pass<3, NT>(cur, tw, a, ps); break;
 			case 4: radix_pass<4, NT>(cur, tw, a, ps); break;
 			case 5: radix_pass<5, NT>(cur, tw, a, ps); break;
-			default: generic_pass<NT>(cur, oth, tw, a, ps); { double2* x = cur; cur = oth; oth = x; } break;
+			default: if constexpr (GEN) { generic_pass<NT>(cur, oth, tw, a, ps); double2* x = cur; cur = oth; oth = x; } break;
 		}
 		PXS_LDS_BARRIER();
 	}
@@ -363,7 +363,9 @@ template<int NT> __device__ __forceinline__ void tile_store(const KArgs& a, cons
 }
 
 // one tile per workgroup
-template<int LM, int NT> __global__ __launch_bounds__(NT) void fft_lds_kernel(const KArgs a)
+// GEN: the line length has a radix other than 2,3,4,5 (direct-DFT pass, second LDS buffer).  Kept out of the common
+// instantiation: these kernels are 30-50 KB of code and run measurably slower when they grow (instruction cache).
+template<int LM, int NT, bool GEN> __global__ __launch_bounds__(NT) void fft_lds_kernel(const KArgs a)
 {
 	PXS_SHARED(double2, lds);
 	const int n = a.n, T = a.T;
@@ -383,7 +385,7 @@ template<int LM, int NT> __global__ __launch_bounds__(NT) void fft_lds_kernel(co
 		for (int u = 0; u < LU; u++) if (pos[u] >= 0) bufA[LPAD(pos[u])] = v[u];
 	}
 	PXS_LDS_BARRIER();
-	const double2* cur = tile_passes<NT>(a, bufA, bufB, tw);
+	const double2* cur = tile_passes<NT, GEN>(a, bufA, bufB, tw);
 	tile_store<NT>(a, c, cur);
 }
 
@@ -396,7 +398,7 @@ template<int LM, int NT> __global__ __launch_bounds__(NT) void fft_lds_kernel(co
 // launch one of the two kernels over nblk tiles
 template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
 #ifdef PXS_HOST_SIM
-	hipLaunchKernelGGL((fft_lds_kernel<LM, 1>), dim3((unsigned)nblk), dim3(1), sh, st, k);
+	hipLaunchKernelGGL((fft_lds_kernel<LM, 1, true>), dim3((unsigned)nblk), dim3(1), sh, st, k);
 #else
 	// 512 threads per workgroup: LDS allows 4 workgroups of 2048 points per CU, and at < 64 VGPRs twice the waves fit
 	// tiles of more than 2048 points (lines of 1025..2048 points: 64 KiB of LDS, 2 workgroups per CU) get 512 threads:
@@ -404,12 +406,14 @@ template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh
 	static const int nt_env = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 0; }();
 	const int nt = nt_env ? nt_env : ((long)k.T*k.n >= 2048 ? 512 : 256);
 	static const bool once = [] {
-		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
-		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		return true; }();
 	(void)once;
-	if (nt == 512) hipLaunchKernelGGL((fft_lds_kernel<LM, 512>), dim3((unsigned)nblk), dim3(512), sh, st, k);
-	else           hipLaunchKernelGGL((fft_lds_kernel<LM, 256>), dim3((unsigned)nblk), dim3(256), sh, st, k);
+	if (k.generic)      hipLaunchKernelGGL((fft_lds_kernel<LM, 256, true>), dim3((unsigned)nblk), dim3(256), sh, st, k);
+	else if (nt == 512) hipLaunchKernelGGL((fft_lds_kernel<LM, 512, false>), dim3((unsigned)nblk), dim3(512), sh, st, k);
+	else                hipLaunchKernelGGL((fft_lds_kernel<LM, 256, false>), dim3((unsigned)nblk), dim3(256), sh, st, k);
 #endif
 }
 static void launch_tiles(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
