@@ -104,23 +104,23 @@ def cyl_body():
 	"""band map (case 'cyl'): alm2map agrees with the rows of the full-sky map; map2alm with Jacobi
 	iterations approaches the input alm (curvedsky.py:843-873, 1122-1136)"""
 	from oracle import sht_oracle as so
-	lmax = 24
-	fshape, fwcs = enmap.fullsky_geometry(shape=(40, 64))
+	lmax = 14
+	fshape, fwcs = enmap.fullsky_geometry(shape=(24, 32))
 	alm = so.rand_alm_simple(lmax, 3, 4, spin=(0, 2))
 	full = enmap.zeros((3,)+fshape, fwcs); curvedsky.alm2map(alm, full, spin=[0, 2])
 	w = fwcs.deepcopy(); w.wcs.crpix[1] -= 5
-	band = enmap.zeros((3, 30, 64), w)
+	band = enmap.zeros((3, 14, 32), w)
 	assert curvedsky.analyse_geometry(band.shape, band.wcs).case == "cyl"
 	curvedsky.alm2map(alm, band, spin=[0, 2])
-	assert np.max(np.abs(np.asarray(band)-np.asarray(full)[:, 5:35])) < 1e-12
+	assert np.max(np.abs(np.asarray(band)-np.asarray(full)[:, 5:19])) < 1e-12
 	a0 = curvedsky.map2alm(full, lmax=lmax, spin=[0, 2], method="cyl", niter=0)
 	a3 = curvedsky.map2alm(full, lmax=lmax, spin=[0, 2], method="cyl", niter=3)
 	e0 = np.std(a0-alm)/np.std(alm); e3 = np.std(a3-alm)/np.std(alm)
 	assert e3 <= e0*1.0001 and e3 < 1e-6
 	# adjoint consistency of the cyl path
-	m = np.random.default_rng(0).standard_normal((1, 30, 64)); bm = enmap.ndmap(m, w)
+	m = np.random.default_rng(0).standard_normal((1, 14, 32)); bm = enmap.ndmap(m, w)
 	at = curvedsky.alm2map_adjoint(bm, spin=0, ainfo=curvedsky.alm_info(lmax))
-	sa = enmap.zeros((1, 30, 64), w); curvedsky.alm2map(alm[:1], sa, spin=0)
+	sa = enmap.zeros((1, 14, 32), w); curvedsky.alm2map(alm[:1], sa, spin=0)
 	wt = np.full(alm.shape[1], 2.0); wt[:lmax+1] = 1
 	at[:, :lmax+1] = at[:, :lmax+1].real
 	assert abs(np.sum(np.asarray(sa)*m)-np.sum(wt*(alm[:1].real*at.real+alm[:1].imag*at.imag))) < 1e-10
@@ -170,11 +170,11 @@ def test_padding_hostsim(): padding_body()
 def test_padding_gpu(): padding_body()
 
 @pytest.mark.hostsim
-def test_roundtrip_hostsim(): roundtrip_body(12)
+def test_roundtrip_hostsim(): roundtrip_body(8)
 @pytest.mark.hostsim
 def test_alm_conversion_hostsim(): alm_conversion_body()
 @pytest.mark.hostsim
-def test_adjointness_hostsim(): adjointness_body(variants=("fejer1",), ncomps=(1,), do_analysis=True)
+def test_adjointness_hostsim(): adjointness_body(variants=("fejer1",), ncomps=(1,), do_analysis=False)   # (analysis adjoint vs oracle: test_sht_parity)
 @pytest.mark.hostsim
 def test_cyl_hostsim(): cyl_body()
 
@@ -302,8 +302,8 @@ def test_deriv_cyl_gpu(): deriv_cyl_body()
 def filter_randmap_body():
 	"""curvedsky.filter and rand_map (curvedsky.py:17-37, 654-671): filtering a band-limited map with 1 returns it, with
 	a top-hat it removes exactly the other multipoles; rand_map reproduces alm2map(rand_alm(seed))"""
-	lmax = 14
-	shape, wcs = enmap.fullsky_geometry(shape=(20, 32))
+	lmax = 8
+	shape, wcs = enmap.fullsky_geometry(shape=(12, 20))
 	cl = 1.0/(np.arange(lmax+1)+1.0)**2
 	m = curvedsky.rand_map((3,)+tuple(shape), wcs, np.array([[cl, 0*cl, 0*cl], [0*cl, cl, 0*cl], [0*cl, 0*cl, cl]]), lmax=lmax, seed=4)
 	alm = curvedsky.rand_alm(np.array([[cl, 0*cl, 0*cl], [0*cl, cl, 0*cl], [0*cl, 0*cl, cl]]), lmax=lmax, seed=4)
@@ -311,10 +311,10 @@ def filter_randmap_body():
 	np.testing.assert_allclose(np.asarray(m), np.asarray(ref), atol=1e-13)
 	t = enmap.ndmap(np.asarray(m)[0].copy(), wcs)
 	np.testing.assert_allclose(np.asarray(curvedsky.filter(t, lambda l: 1+0*l, lmax=lmax)), np.asarray(t), atol=1e-12)
-	lo = curvedsky.filter(t, lambda l: 1.0*(l <= 6), lmax=lmax)
+	lo = curvedsky.filter(t, lambda l: 1.0*(l <= 4), lmax=lmax)
 	a_lo = curvedsky.map2alm(lo, lmax=lmax, spin=0); a_t = curvedsky.map2alm(t, lmax=lmax, spin=0)
 	ai = curvedsky.alm_info(lmax); l = np.concatenate([np.arange(mm, lmax+1) for mm in range(lmax+1)])
-	np.testing.assert_allclose(a_lo, np.where(l <= 6, a_t, 0), atol=1e-12)
+	np.testing.assert_allclose(a_lo, np.where(l <= 4, a_t, 0), atol=1e-12)
 
 @pytest.mark.hostsim
 def test_filter_randmap_hostsim(): filter_randmap_body()
