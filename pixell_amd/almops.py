@@ -124,7 +124,7 @@ def lmul(ainfo, alm, lfun, out=None):
 		work = np.ascontiguousarray((fa.cpu().numpy() if tens else fa)[ia]); ptr = work.ctypes.data
 	else:
 		torch = _torch()
-		dev_in = fa if tens else torch.from_numpy(fa).cuda()
+		dev_in = fa if tens else torch.from_numpy(fa if fa.flags.writeable else fa.copy()).cuda()
 		work = dev_in[torch.as_tensor(ia, device=dev_in.device)]          # gather = fresh contiguous copy
 		ptr = work.data_ptr()
 	for i in range(npre):
