@@ -85,7 +85,14 @@ int pxs_plan_info(const pxs_plan* plan, int* nring_legendre_syn, int* nring_lege
 #define PXS_STAGE_LEG_SYN  0   /* Legendre synthesis kernel (alm2leg) */
 #define PXS_STAGE_LEG_ANA  1   /* Legendre analysis kernel (leg2alm) */
 #define PXS_STAGE_RING_FFT 2   /* ring FFTs + transposes (map2leg / leg2map) */
-#define PXS_STAGE_RESAMPLE 3   /* theta resampling FFT chain */
+#define PXS_STAGE_RESAMPLE 3   /* Ordering between two plans whose transforms are issued on DIFFERENT streams (one plan per stream; a plan owns its scratch).
+ * Every pxs_synthesis / pxs_analysis call records two events of its plan on its stream: "before the Legendre stage" (which 0)
+ * and "after the Legendre stage" (which 1).  pxs_plan_chain makes the NEXT call on `plan` wait for `other`'s event, either at
+ * its start (at 0) or just before its own Legendre stage (at 1).  Issue the call on `other` first.  Used to run the memory-bound
+ * stages (ring FFT, theta resampling) of one spin group while the FP64-bound Legendre stage of another one runs. */
+int pxs_plan_chain(pxs_plan* plan, int at, pxs_plan* other, int which);
+
+/* theta resampling FFT chain */
 #define PXS_NSTAGE 4
 int pxs_profile(pxs_plan* plan, int enable);
 int pxs_profile_read(pxs_plan* plan, double* ms, int* counts, int reset);

@@ -49,6 +49,9 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
+static const unsigned hipEventDisableTiming = 2;
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { static int dummy; *e = &dummy; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 
 #define __global__
 #define __device__

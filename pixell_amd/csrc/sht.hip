@@ -214,6 +214,10 @@ struct pxs_plan {
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
 	LegProfile prof;
+	// stage events for chaining two plans that run on different streams (pxs_plan_chain): recorded by every call
+	hipEvent_t ev_before_leg = nullptr, ev_after_leg = nullptr;
+	hipEvent_t wait_at[2] = {nullptr, nullptr};     // one-shot: [0] at the start of the next call, [1] before its Legendre stage
+	~pxs_plan() { if (ev_before_leg) (void)hipEventDestroy(ev_before_leg); if (ev_after_leg) (void)hipEventDestroy(ev_after_leg); }
 	size_t resample_chunk_bytes = size_t(1) << 40;    // per intermediate buffer of the theta-FFT chain (chunking to stay in the
 	                                                  // Infinity Cache was measured slower: 22.4 -> 26.2 ms at config 2; PXS_RESAMPLE_MB re-enables it)
 
@@ -501,6 +505,21 @@ void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double
 
 } // namespace
 
+namespace {
+void plan_events(pxs_plan* p) {
+	if (!p->ev_before_leg) { PXS_HIP(hipEventCreateWithFlags(&p->ev_before_leg, hipEventDisableTiming)); PXS_HIP(hipEventCreateWithFlags(&p->ev_after_leg, hipEventDisableTiming)); }
+}
+void hook_start(pxs_plan* p, hipStream_t st) {
+	plan_events(p);
+	if (p->wait_at[0]) { PXS_HIP(hipStreamWaitEvent(st, p->wait_at[0], 0)); p->wait_at[0] = nullptr; }
+}
+void hook_before_leg(pxs_plan* p, hipStream_t st) {
+	PXS_HIP(hipEventRecord(p->ev_before_leg, st));
+	if (p->wait_at[1]) { PXS_HIP(hipStreamWaitEvent(st, p->wait_at[1], 0)); p->wait_at[1] = nullptr; }
+}
+void hook_after_leg(pxs_plan* p, hipStream_t st) { PXS_HIP(hipEventRecord(p->ev_after_leg, st)); }
+}
+
 #define PXS_TRY try {
 #define PXS_CATCH } catch (const pxs::Error& e) { pxs::set_last_error(e.what()); return e.code; } \
 	catch (const std::exception& e) { pxs::set_last_error(e.what()); return pxs::PXS_ERR_ARG; } return 0;
@@ -583,6 +602,15 @@ int pxs_plan_info(const pxs_plan* p, int* nsyn, int* nana, int64_t* scratch) {
 	return 0;
 }
 
+int pxs_plan_chain(pxs_plan* p, int at, pxs_plan* other, int which) {
+	PXS_TRY
+	PXS_REQUIRE(p && other && p != other && (at == 0 || at == 1) && (which == 0 || which == 1), "pxs_plan_chain: bad arguments");
+	PXS_HIP(hipSetDevice(other->device));
+	plan_events(other);
+	p->wait_at[at] = which == 0 ? other->ev_before_leg : other->ev_after_leg;
+	PXS_CATCH
+}
+
 int pxs_profile(pxs_plan* p, int enable) { if (!p) return PXS_ERR_ARG; p->prof.enabled = enable != 0; return 0; }
 
 int pxs_profile_read(pxs_plan* p, double* ms, int* counts, int reset) {
@@ -607,18 +635,24 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 	const int nm = p->mmax+1;
 	LegTables& tb = p->table(spin);
 	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*p->nring);
+	hook_start(p, st);
 	if (!adjoint) {
+		hook_before_leg(p, st);
 		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
 			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*p->ncc);
 			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+			hook_after_leg(p, st);
 			resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin);
 		} else {
 			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+			hook_after_leg(p, st);
 		}
 		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm);
 	} else {
 		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0);
+		hook_before_leg(p, st);
 		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1, &p->prof);
+		hook_after_leg(p, st);
 	}
 	PXS_CATCH
 }
@@ -639,13 +673,18 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint,
 	LegTables& tb = p->table(spin);
 	p->leg.ensure(sizeof(double2)*(size_t)nc*nm*p->nring);
 	p->leg2.ensure(sizeof(double2)*(size_t)nc*nm*p->ncc);
+	hook_start(p, st);
 	if (!adjoint) {
 		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0);
 		resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
+		hook_before_leg(p, st);
 		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof);
+		hook_after_leg(p, st);
 	} else {
 		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
+		hook_before_leg(p, st);
 		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof);
+		hook_after_leg(p, st);
 		resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin);
 		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, nc);
 	}
