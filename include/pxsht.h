@@ -91,6 +91,8 @@ int pxs_plan_info(const pxs_plan* plan, int* nring_legendre_syn, int* nring_lege
  * its start (at 0) or just before its own Legendre stage (at 1).  Issue the call on `other` first.  Used to run the memory-bound
  * stages (ring FFT, theta resampling) of one spin group while the FP64-bound Legendre stage of another one runs. */
 int pxs_plan_chain(pxs_plan* plan, int at, pxs_plan* other, int which);
+/* tuning knobs of a plan: "fft_threads" = 0 (automatic), 128, 256 or 512 threads per FFT workgroup for this plan's transforms */
+int pxs_plan_option(pxs_plan* plan, const char* key, int64_t value);
 
 /* theta resampling FFT chain */
 #define PXS_NSTAGE 4

@@ -396,7 +396,7 @@ template<int LM, int NT, bool GEN> __global__ __launch_bounds__(NT) void fft_lds
 // ran 2x slower (n = 200: 0.19 -> 0.44 ms).  What the attempts left behind: the LDS-only barrier, the per-load-mode instantiation and the pass
 // table in device memory, which keep the argument struct out of scratch.)
 // launch one of the two kernels over nblk tiles
-template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
+template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh, hipStream_t st, int nt_override) {
 #ifdef PXS_HOST_SIM
 	hipLaunchKernelGGL((fft_lds_kernel<LM, 1, true>), dim3((unsigned)nblk), dim3(1), sh, st, k);
 #else
@@ -404,29 +404,31 @@ template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh
 	// tiles of more than 2048 points (lines of 1025..2048 points: 64 KiB of LDS, 2 workgroups per CU) get 512 threads:
 	// measured 1.39 -> 1.86 TB/s at n = 2048; for the 32 KiB tiles 512 threads were 3-8 % slower
 	static const int nt_env = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 0; }();
-	const int nt = nt_env ? nt_env : ((long)k.T*k.n >= 2048 ? 512 : 256);
+	const int nt = nt_override ? nt_override : nt_env ? nt_env : ((long)k.T*k.n >= 2048 ? 512 : 256);
 	static const bool once = [] {
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
 		return true; }();
 	(void)once;
 	if (k.generic)      hipLaunchKernelGGL((fft_lds_kernel<LM, 256, true>), dim3((unsigned)nblk), dim3(256), sh, st, k);
 	else if (nt == 512) hipLaunchKernelGGL((fft_lds_kernel<LM, 512, false>), dim3((unsigned)nblk), dim3(512), sh, st, k);
+	else if (nt == 128) hipLaunchKernelGGL((fft_lds_kernel<LM, 128, false>), dim3((unsigned)nblk), dim3(128), sh, st, k);
 	else                hipLaunchKernelGGL((fft_lds_kernel<LM, 256, false>), dim3((unsigned)nblk), dim3(256), sh, st, k);
 #endif
 }
-static void launch_tiles(const KArgs& k, long nblk, size_t sh, hipStream_t st) {
+static void launch_tiles(const KArgs& k, long nblk, size_t sh, hipStream_t st, int nt_override = 0) {
 	const int lm = k.mode == 2 ? (int)LD_PLAIN : k.ld.mode;      // pass B reads the four-step scratch, no functor
 	switch (lm) {
-		case LD_PLAIN:       launch_tiles_m<LD_PLAIN>(k, nblk, sh, st); break;
-		case LD_HERM:        launch_tiles_m<LD_HERM>(k, nblk, sh, st); break;
-		case LD_MIRROR:      launch_tiles_m<LD_MIRROR>(k, nblk, sh, st); break;
-		case LD_SPEC:        launch_tiles_m<LD_SPEC>(k, nblk, sh, st); break;
-		case LD_SPEC_ADJ:    launch_tiles_m<LD_SPEC_ADJ>(k, nblk, sh, st); break;
-		case LD_MIRROR_PAIR: launch_tiles_m<LD_MIRROR_PAIR>(k, nblk, sh, st); break;
-		case LD_REAL_PAIR:   launch_tiles_m<LD_REAL_PAIR>(k, nblk, sh, st); break;
-		case LD_HERM_PAIR:   launch_tiles_m<LD_HERM_PAIR>(k, nblk, sh, st); break;
+		case LD_PLAIN:       launch_tiles_m<LD_PLAIN>(k, nblk, sh, st, nt_override); break;
+		case LD_HERM:        launch_tiles_m<LD_HERM>(k, nblk, sh, st, nt_override); break;
+		case LD_MIRROR:      launch_tiles_m<LD_MIRROR>(k, nblk, sh, st, nt_override); break;
+		case LD_SPEC:        launch_tiles_m<LD_SPEC>(k, nblk, sh, st, nt_override); break;
+		case LD_SPEC_ADJ:    launch_tiles_m<LD_SPEC_ADJ>(k, nblk, sh, st, nt_override); break;
+		case LD_MIRROR_PAIR: launch_tiles_m<LD_MIRROR_PAIR>(k, nblk, sh, st, nt_override); break;
+		case LD_REAL_PAIR:   launch_tiles_m<LD_REAL_PAIR>(k, nblk, sh, st, nt_override); break;
+		case LD_HERM_PAIR:   launch_tiles_m<LD_HERM_PAIR>(k, nblk, sh, st, nt_override); break;
 		default: throw Error(PXS_ERR_ARG, "fft: unknown load mode");
 	}
 }
@@ -602,7 +604,7 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		k.store_inner_fast = (std::abs(d.os_i) < std::abs(d.os_e)) ? 1 : 0;
 		long nblk = k.ntile*d.n_o1*d.n_o2;
 		size_t sh = lds_bytes(k);
-		launch_tiles(k, nblk, sh, st);
+		launch_tiles(k, nblk, sh, st, nt_override);
 		PXS_HIP(hipGetLastError());
 		return;
 	}
@@ -641,13 +643,13 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		pa.ntile = ((tile_i ? ni : n2) + pa.T - 1)/pa.T;
 		pa.load_inner_fast = 1; pa.store_inner_fast = 1;
 		long nblkA = pa.ntile*(tile_i ? n2 : ni)*no1;
-		launch_tiles(pa, nblkA, lds_bytes(pa), st);
+		launch_tiles(pa, nblkA, lds_bytes(pa), st, nt_override);
 		// pass B: n2-point FFTs over j2 for each (i, k1)
 		KArgs pb = a; fill_sub(pb, *s2, tile_i ? ni : n1); pb.mode = 2; pb.tile_i = tile_i;
 		pb.ntile = ((tile_i ? ni : n1) + pb.T - 1)/pb.T;
 		pb.load_inner_fast = tile_i ? 1 : 0; pb.store_inner_fast = 1;
 		long nblkB = pb.ntile*(tile_i ? n1 : ni)*no1;
-		launch_tiles(pb, nblkB, lds_bytes(pb), st);
+		launch_tiles(pb, nblkB, lds_bytes(pb), st, nt_override);
 		PXS_HIP(hipGetLastError());
 	}
 }

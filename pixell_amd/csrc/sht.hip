@@ -216,6 +216,7 @@ struct pxs_plan {
 	LegProfile prof;
 	// stage events for chaining two plans that run on different streams (pxs_plan_chain): recorded by every call
 	hipEvent_t ev_before_leg = nullptr, ev_after_leg = nullptr;
+	int fft_nt = 0;                                  // threads per FFT workgroup for this plan's launches (0: automatic)
 	hipEvent_t wait_at[2] = {nullptr, nullptr};     // one-shot: [0] at the start of the next call, [1] before its Legendre stage
 	~pxs_plan() { if (ev_before_leg) (void)hipEventDestroy(ev_before_leg); if (ev_after_leg) (void)hipEventDestroy(ev_after_leg); }
 	size_t resample_chunk_bytes = size_t(1) << 40;    // per intermediate buffer of the theta-FFT chain (chunking to stay in the
@@ -511,6 +512,7 @@ void plan_events(pxs_plan* p) {
 }
 void hook_start(pxs_plan* p, hipStream_t st) {
 	plan_events(p);
+	p->fc->nt_override = p->fft_nt;
 	if (p->wait_at[0]) { PXS_HIP(hipStreamWaitEvent(st, p->wait_at[0], 0)); p->wait_at[0] = nullptr; }
 }
 void hook_before_leg(pxs_plan* p, hipStream_t st) {
@@ -608,6 +610,14 @@ int pxs_plan_chain(pxs_plan* p, int at, pxs_plan* other, int which) {
 	PXS_HIP(hipSetDevice(other->device));
 	plan_events(other);
 	p->wait_at[at] = which == 0 ? other->ev_before_leg : other->ev_after_leg;
+	PXS_CATCH
+}
+
+int pxs_plan_option(pxs_plan* p, const char* key, int64_t value) {
+	PXS_TRY
+	PXS_REQUIRE(p && key, "pxs_plan_option: null argument");
+	if (std::string(key) == "fft_threads") { PXS_REQUIRE(value == 0 || value == 128 || value == 256 || value == 512, "fft_threads must be 0, 128, 256 or 512"); p->fft_nt = (int)value; }
+	else throw Error(PXS_ERR_ARG, std::string("pxs_plan_option: unknown key ") + key);
 	PXS_CATCH
 }
 

@@ -145,6 +145,8 @@ def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1,
 		_lib.check(_lib.load().pxs_plan_grid2d(ctypes.byref(h), geometry.encode(), int(ntheta), int(nphi), float(phi0),
 			int(bool(flip[0])), int(bool(flip[1])), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
 		p = _plans[key] = Plan(h)
+		nt = int(os.environ.get("PIXELL_AMD_LANE1_FFT_THREADS", "0"))
+		if lane == 1 and nt: _lib.check(_lib.load().pxs_plan_option(h, b"fft_threads", nt))
 	return p
 
 def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
