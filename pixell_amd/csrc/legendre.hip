@@ -76,6 +76,9 @@ struct LegK {
 // showed every one of them going to the fabric (49 GB per leg_syn_spin launch at config 3 = nwave x the
 // table).  This order gives all chunks of one m the same `block % 8`, back to back in that XCD's queue, so
 // one reader misses and the others hit in L2.
+// (Workgroups of 2-4 independent waves of the same m -- to share the rows in the CU's scalar cache -- were measured twice:
+// with __launch_bounds__(256) and the lane taken as threadIdx.x & 63 every kernel got slower even at one wave per workgroup
+// (config 3: leg_syn 106 -> 113 ms, leg_ana 144 -> 151 ms), 4 waves per workgroup 128 / 165 ms.  One wave per workgroup stays.)
 __device__ __forceinline__ bool leg_block(const LegK& a, int& wv, int& m) {
 	if (!a.xcd) { wv = blockIdx.x; m = blockIdx.y + a.m0; return true; }
 	const unsigned b = blockIdx.x, x = b & 7u, j = b >> 3;
