@@ -6,8 +6,7 @@
 // thread->element map chosen so that the unit-stride direction of global memory is the
 // fast lane direction (coalesced 16-byte accesses).  Lines longer than FFT_NLOC_MAX use
 // the four-step split N = n1*n2 (pass A strided + twiddle, pass B contiguous), with the
-// intermediate kept below `temp_budget` bytes so that it stays in the 256 MiB Infinity
-// Cache between the two launches.
+// intermediate processed in chunks of `temp_budget` bytes (see the constructor).
 #include "fft.hpp"
 #include <cmath>
 #include <algorithm>
@@ -474,7 +473,13 @@ static void twiddles(long n, std::vector<double2>& tw) {
 	}
 }
 
-FftContext::FftContext(int device) : device_(device) {}
+FftContext::FftContext(int device) : device_(device) {
+	// Four-step scratch: lines are processed in chunks of at most this many bytes.  It used to be 192 MiB so that the
+	// intermediate would stay in the 256 MiB Infinity Cache between the two passes; measured at config 3 the chunk count is
+	// what matters (192 MiB 431.8 ms, 1 GiB 420.0, 4 GiB 415.9 per round trip), so: 4 GiB, never more than 1/16 of free memory.
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) temp_budget = std::min<size_t>(size_t(4) << 30, std::max<size_t>(fr/16, size_t(64) << 20));
+}
 FftContext::~FftContext() {}
 
 static bool split_two(long n, long& n1, long& n2) {

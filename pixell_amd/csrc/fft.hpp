@@ -58,7 +58,7 @@ public:
 	void exec(hipStream_t st, long n, bool forward, const FftDims& d, const FftLoad& ld, const FftStore& stf);
 	static long good_size(long n);          // smallest 2^a 3^b 5^c >= n that the engine can factor
 	static bool supported(long n, std::string* why = nullptr);
-	size_t temp_budget = size_t(192) << 20; // bytes of four-step scratch kept cache resident
+	size_t temp_budget = size_t(4) << 30;   // bytes of four-step scratch per stream (set from the free memory in the constructor)
 	int nt_override = 0;                    // 0: automatic; 128/256/512: threads per workgroup for the launches that follow (experiments)
 private:
 	int device_;
