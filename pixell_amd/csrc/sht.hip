@@ -190,6 +190,38 @@ __global__ __launch_bounds__(256) void split_pair(const double2* __restrict__ Z,
 	if (lb < nlines) out[lb*nr + j] = a_odd ? ev : od;
 }
 
+// split_pair fused with the transpose of leg2map (synthesis through the CC grid): Z[pair][N] -> h[ring][m] * conj(tab[m]) * scale,
+// through a 32 (m) x 32 (ring) LDS tile; saves writing and re-reading leg[m][ring] (2 x 10 GB at config 3)
+__global__ __launch_bounds__(256) void split_pair_transposed(const double2* __restrict__ Z, double2* __restrict__ out,
+		int nr, int nm, long N, int c, int par0, const double2* __restrict__ tab, double scale)
+{
+	PXS_SHARED(double2, tile);                       // [32 m][33]
+	const int r0 = blockIdx.y*32, m0 = blockIdx.x*32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // tx: ring within tile, ty: 0..7
+	const bool a_odd = (par0 & 1) != 0;              // parity of column 0; m0 is even, so of every even column
+	for (int pj = ty; pj < 16; pj += 8) {            // 16 pairs = 32 columns m0 + 2 pj, m0 + 2 pj + 1
+		const long pr = (m0 >> 1) + pj; const int j = r0 + tx;
+		double2 ev = make_double2(0, 0), od = make_double2(0, 0);
+		if (j < nr && 2*pr < nm) {
+			long mj = N - j - c; if (mj >= N) mj -= N; if (mj < 0) mj += N;
+			const double2 z = Z[pr*N + j];
+			if (mj == j) ev = z;
+			else { const double2 y = Z[pr*N + mj]; ev = make_double2(0.5*(z.x + y.x), 0.5*(z.y + y.y)); od = make_double2(0.5*(z.x - y.x), 0.5*(z.y - y.y)); }
+		}
+		tile[(2*pj)*33 + tx] = a_odd ? od : ev;
+		tile[(2*pj+1)*33 + tx] = a_odd ? ev : od;
+	}
+	__syncthreads();
+	for (int j = ty; j < 32; j += 8) {
+		const int r = r0 + j, m = m0 + tx;
+		if (r < nr && m < nm) {
+			const double2 v = tile[tx*33 + j];
+			const double2 t = tab[m];
+			out[(long)r*nm + m] = make_double2((v.x*t.x + v.y*t.y)*scale, (v.y*t.x - v.x*t.y)*scale);     // * conj(tab[m]) * scale
+		}
+	}
+}
+
 } // namespace pxs
 
 using namespace pxs;
@@ -348,13 +380,15 @@ void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long m
 }
 
 // leg[c][m][ring] * e^{+i m phi0} -> hbuf[c][ring][m] -> c2r ring FFT -> user map
-void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map_dtype, long map_cstride, int nc) {
+void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map_dtype, long map_cstride, int nc, bool have_h = false) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
 	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
-	dim3 grid((nm+31)/32, (nr+31)/32, nc);
-	hipLaunchKernelGGL(transpose_mul_outcol, grid, dim3(256), sizeof(double2)*32*33, st, leg, (double2*)p->hbuf.p, nr, nm,
-		(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 1, 1.0);
+	if (!have_h) {      // (the CC synthesis path has written hbuf already, see resample_from_cc)
+		dim3 grid((nm+31)/32, (nr+31)/32, nc);
+		hipLaunchKernelGGL(transpose_mul_outcol, grid, dim3(256), sizeof(double2)*32*33, st, leg, (double2*)p->hbuf.p, nr, nm,
+			(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 1, 1.0);
+	}
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	if (2L*p->mmax < p->nphi && p->ring_pairs) {
 		// two rings per complex transform: Z = X_a + i X_b, real part -> ring 2q, imaginary part -> ring 2q+1
@@ -470,7 +504,7 @@ void resample_to_cc_adjoint(pxs_plan* p, hipStream_t st, const double2* leg_cc, 
 
 // band-limited leg on the CC grid [c][m][ncc] -> leg on the map's rings [c][m][nring] (exact for degree <= lmax);
 // columns (m, m+1) packed as in resample_to_cc
-void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double2* leg_out, int nc, int spin) {
+void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double2* leg_out, int nc, int spin, double2* h_out = nullptr) {
 	const int nm = p->mmax+1, nr = p->nring;
 	const long npair_all = (nm + 1)/2;
 	const long chunk = std::max<long>(32, std::min<long>(npair_all, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->N))));
@@ -494,7 +528,11 @@ void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double
 			FftStore sf; sf.ptr = p->b2.p;
 			p->fc->exec(st, p->N, false, d, ld, sf);
 		}
-		{	// separate the pair, keep the real rings
+		if (h_out && np == npair_all) {	// separate the pair straight into the ring-major layout of the ring FFT (times e^{+i m phi0})
+			dim3 grid((nm+31)/32, (nr+31)/32);
+			hipLaunchKernelGGL(split_pair_transposed, grid, dim3(256), sizeof(double2)*32*33, st, (const double2*)p->b2.p,
+				h_out + (size_t)c*nr*nm, nr, nm, p->N, p->mir_c, spin & 1, (const double2*)p->phase.p, 1.0/(double)p->Ncc);
+		} else {	// separate the pair, keep the real rings
 			const long tot = np*nr;
 			hipLaunchKernelGGL(split_pair, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, (const double2*)p->b2.p,
 				leg_out + ((size_t)c*nm + m0)*nr, nr, p->N, p->mir_c, np, nlines, (spin + (int)m0) & 1, (const double2*)nullptr, 1.0/(double)p->Ncc);
@@ -646,18 +684,22 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 	LegTables& tb = p->table(spin);
 	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*p->nring);
 	hook_start(p, st);
+	bool via_h = false;
 	if (!adjoint) {
 		hook_before_leg(p, st);
 		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
 			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*p->ncc);
 			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
 			hook_after_leg(p, st);
-			resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin);
+			static const bool fuse = [] { const char* e = getenv("PXS_FUSE_SPLIT"); return e ? atoi(e) != 0 : true; }();
+			via_h = fuse;
+			if (via_h) p->hbuf.ensure(sizeof(double2)*(size_t)ncm*p->nring*nm);
+			resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin, via_h ? p->hbuf.as<double2>() : nullptr);
 		} else {
 			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
 			hook_after_leg(p, st);
 		}
-		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm);
+		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm, via_h);
 	} else {
 		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0);
 		hook_before_leg(p, st);
