@@ -364,9 +364,13 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 	}
 	double2* __restrict__ out = a.leg + (long)m*a.nring;
 #pragma unroll
-	for (int s = 0; s < K; s++) {
-		if (rn[s] >= 0) out[rn[s]] = make_double2(p1r[s] + x[s]*p2r[s], p1i[s] + x[s]*p2i[s]);
-		if (rs[s] >= 0) out[rs[s]] = make_double2(p1r[s] - x[s]*p2r[s], p1i[s] - x[s]*p2i[s]);
+	for (int s = 0; s < K; s++) {      // ring indices and cos(theta) are re-read here rather than kept in registers through the loops
+		const int p = (wv*K + s)*64 + lane;
+		const bool valid = p < a.npairs;
+		const int rn_ = valid ? a.ring_n[p] : -1, rs_ = valid ? a.ring_s[p] : -1;
+		const double x_ = valid ? a.cth[p] : 0.0;
+		if (rn_ >= 0) out[rn_] = make_double2(p1r[s] + x_*p2r[s], p1i[s] + x_*p2i[s]);
+		if (rs_ >= 0) out[rs_] = make_double2(p1r[s] - x_*p2r[s], p1i[s] - x_*p2i[s]);
 	}
 }
 
@@ -709,17 +713,19 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 			}
 		}
 	}
-	// Q = (P+M)/2, U = -i (P-M)/2
+	// Q = (P+M)/2, U = -i (P-M)/2.  The ring indices are re-read here rather than kept in registers through the loops.
 #pragma unroll
 	for (int s = 0; s < K; s++) {
-		if (rn[s] >= 0) {
-			outq[rn[s]] = make_double2(0.5*(pnr[s] + mnr[s]), 0.5*(pni[s] + mni[s]));
-			outu[rn[s]] = make_double2(0.5*(pni[s] - mni[s]), -0.5*(pnr[s] - mnr[s]));
+		const int p = (wv*K + s)*64 + lane;
+		const int rn_ = p < a.npairs ? a.ring_n[p] : -1, rs_ = p < a.npairs ? a.ring_s[p] : -1;
+		if (rn_ >= 0) {
+			outq[rn_] = make_double2(0.5*(pnr[s] + mnr[s]), 0.5*(pni[s] + mni[s]));
+			outu[rn_] = make_double2(0.5*(pni[s] - mni[s]), -0.5*(pnr[s] - mnr[s]));
 		}
-		if (rs[s] >= 0) {
+		if (rs_ >= 0) {
 			const double psr = sg0*qsr[s], psi = sg0*qsi[s], msr = sg0*nsr[s], msi = sg0*nsi[s];
-			outq[rs[s]] = make_double2(0.5*(psr + msr), 0.5*(psi + msi));
-			outu[rs[s]] = make_double2(0.5*(psi - msi), -0.5*(psr - msr));
+			outq[rs_] = make_double2(0.5*(psr + msr), 0.5*(psi + msi));
+			outu[rs_] = make_double2(0.5*(psi - msi), -0.5*(psr - msr));
 		}
 	}
 }
