@@ -26,8 +26,71 @@ struct AxisDim { long n, is, os; };
 
 // transform along one axis of an N-d array; other dims become line dims (<= 3 after merging,
 // extra leading dims looped on the host)
+// ---- Bluestein (chirp-z) for lengths the mixed-radix engine cannot factor (a prime factor > 2048) -------------------
+// X_k = w_k sum_j (x_j w_j) conj(w)_{k-j}, w_j = e^{-+ i pi j^2/n}: two FFTs of a 5-smooth length M >= 2n-1 with the chirp
+// multiplications and the zero padding as load / store functors (numpy, the reference's fallback engine, takes any n).
+struct BluePlan { long n = 0, M = 0; DevBuf w, wout, bhat; };
+static const BluePlan& blue_plan(FftContext& fc, int device, hipStream_t st, long n, bool forward) {
+	static std::mutex mu; static std::map<std::tuple<int, long, int>, std::unique_ptr<BluePlan>> plans;
+	std::lock_guard<std::mutex> g(mu);
+	auto& p = plans[std::make_tuple(device, n, forward ? 1 : 0)];
+	if (p) return *p;
+	p.reset(new BluePlan());
+	typedef long double LD;
+	const LD pi = 3.141592653589793238462643383279502884L;
+	p->n = n; p->M = FftContext::good_size(2*n - 1);
+	const long M = p->M;
+	const LD sgn = forward ? -1.0L : 1.0L;
+	std::vector<double2> w(n), wout(n), b(M, make_double2(0, 0));
+	for (long j = 0; j < n; j++) {
+		const long q = (long)(((unsigned long long)j*(unsigned long long)j) % (unsigned long long)(2*n));   // j^2 mod 2n keeps the phase accurate
+		const LD a = pi*(LD)q/(LD)n;
+		const LD c = cosl(a), s_ = sgn*sinl(a);
+		w[j] = make_double2((double)c, (double)s_);
+		wout[j] = make_double2((double)(c/(LD)M), (double)(s_/(LD)M));        // w_k / M: the backward transform below is unnormalised
+		b[j] = make_double2((double)c, (double)(-s_));
+		if (j > 0) b[M - j] = b[j];
+	}
+	p->w = upload(w); p->wout = upload(wout);
+	DevBuf db = upload(b);
+	p->bhat.alloc(sizeof(double2)*M);
+	FftDims d; d.n_i = 1; d.is_e = 1; d.os_e = 1;
+	FftLoad ld; ld.ptr = db.p; FftStore sf; sf.ptr = p->bhat.p;
+	fc.exec(st, M, true, d, ld, sf);
+	PXS_HIP(hipStreamSynchronize(st));      // db is freed on return
+	return *p;
+}
+
+static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
+                     FftLoad ld, FftStore stf);
+
+static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
+                           FftLoad ld, FftStore stf) {
+	if (ld.mode != LD_PLAIN || ld.mul || stf.mul) throw Error(PXS_ERR_UNSUPPORTED, "FFT length " + std::to_string(n) + " has a prime factor > 2048: only c2c and r2c transforms are available for it (Bluestein)");
+	const BluePlan& bp = blue_plan(fc, device, st, n, forward);
+	const long M = bp.M;
+	// dense scratch [lines][M]
+	std::vector<AxisDim> d1 = dims, d2 = dims;
+	long lines = 1;
+	for (size_t k = dims.size(); k-- > 0;) { d1[k].os = lines*M; d2[k].is = lines*M; lines *= dims[k].n; }
+	DevBuf scratch; scratch.alloc(sizeof(double2)*(size_t)lines*M);
+	{	// y = FFT_M(x w, zero padded)
+		FftLoad l1 = ld; l1.mul = bp.w.as<double2>(); l1.ne = (ld.ne >= 0 && ld.ne < n) ? ld.ne : n;
+		FftStore s1; s1.ptr = scratch.p; s1.dtype = PX_C128;
+		fft_axis(fc, st, M, true, d1, is_e, 1, l1, s1);
+	}
+	{	// X = w/M * IFFT_M(y bhat), first n (or ne) outputs
+		FftLoad l2; l2.ptr = scratch.p; l2.dtype = PX_C128; l2.mul = bp.bhat.as<double2>();
+		FftStore s2 = stf; s2.mul = bp.wout.as<double2>(); s2.ne = (stf.ne >= 0 && stf.ne < n) ? stf.ne : n;
+		fft_axis(fc, st, M, false, d2, 1, os_e, l2, s2);
+	}
+	PXS_HIP(hipStreamSynchronize(st));          // scratch is freed on return
+}
+
+static int g_fft_device = 0;
 static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
                      FftLoad ld, FftStore stf) {
+	if (!FftContext::supported(n)) { bluestein_axis(fc, g_fft_device, st, n, forward, dims, is_e, os_e, ld, stf); return; }
 	// drop singleton dims, merge mergeable neighbours (outer,inner): outer.s == inner.s*inner.n for both in and out
 	std::vector<AxisDim> d;
 	for (auto& x : dims) if (x.n > 1) d.push_back(x);
@@ -148,11 +211,11 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 			const long N = r2r_length(kind, shape[a]);
 			if (N < 2) throw Error(PXS_ERR_ARG, "DCT-I needs at least 2 points along each axis");
 			if (!FftContext::supported(N, &why)) throw Error(PXS_ERR_UNSUPPORTED, "DCT/DST of " + std::to_string(shape[a]) + " points: " + why);
-		} else if (!FftContext::supported(shape[a], &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
+		} else if (!FftContext::supported(shape[a], &why) && kind == 2 && a == axes.back()) throw Error(PXS_ERR_UNSUPPORTED, why + " (c2r along such an axis is not implemented)");
 	}
 	PXS_HIP(hipSetDevice(device));
 	FftContext& fc = fft_context(device);
-	fc.nt_override = 0;
+	fc.nt_override = 0; g_fft_device = device;
 	hipStream_t st = (hipStream_t)stream;
 	const int last = axes.back();
 	const long nlast = shape[last], nh = nlast/2 + 1;

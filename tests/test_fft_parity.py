@@ -93,11 +93,28 @@ def test_fft_2d_large_gpu():
 	assert rel(h, np.fft.rfftn(a, axes=(-2, -1))) < 1e-12
 	assert rel(pfft.irfft(h, n=5400, axes=[-2, -1], normalize=True), a) < 1e-12
 
-def test_unsupported_length_raises():
+def check_bluestein():
+	"""lengths with a prime factor > 2048 (numpy, the reference's fallback engine, takes any n): chirp-z through two 5-smooth FFTs"""
 	from pixell_amd._lib import PxsError
+	rng = np.random.default_rng(8)
+	for n in (2053, 4099, 2*4099):
+		x = rng.standard_normal((3, n))+1j*rng.standard_normal((3, n))
+		assert rel(pfft.fft(x), np.fft.fft(x, axis=-1)) < 1e-12
+		assert rel(pfft.ifft(x, normalize=True), np.fft.ifft(x, axis=-1)) < 1e-12
+		r = rng.standard_normal((2, n))
+		assert rel(pfft.rfft(r), np.fft.rfft(r, axis=-1)) < 1e-12
+	a = rng.standard_normal((2, 2053, 24))                       # prime length on a strided axis, 2-D with one awkward axis
+	assert rel(pfft.fft(a+0j, axes=[-2]), np.fft.fft(a, axis=-2)) < 1e-12
+	assert rel(pfft.fft(a+0j, axes=[-2, -1]), np.fft.fft2(a)) < 1e-12
+	assert rel(pfft.rfft(a.transpose(0, 2, 1).copy(), axes=[-2, -1]), np.fft.rfft2(a.transpose(0, 2, 1))) < 1e-12
 	with pytest.raises(PxsError):
-		pfft.fft(np.zeros((1, 2*4099), complex))      # prime factor > 2048: no Bluestein yet
-	assert pfft.fft_len(4099, "above") == 4320 or pfft.fft_len(4099, "above") >= 4099
+		pfft.irfft(np.zeros((1, 2053//2+1), complex), n=2053)       # c2r along such an axis is not implemented
+	assert pfft.fft_len(4099, "above") >= 4099
+
+@pytest.mark.hostsim
+def test_bluestein_hostsim(): check_bluestein()
+@pytest.mark.gpu
+def test_bluestein_gpu(): check_bluestein()
 
 def check_dct():
 	"""DCT-I (FFTW_REDFT00; pixell.fft.dct / idct / redft00 and enmap.fft(dct=True), fft.py:211-307, enmap.py:1314-1342)
