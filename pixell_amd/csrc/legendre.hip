@@ -617,31 +617,33 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 		j += 4; \
 	}
 
+// (step coefficient a x +- b as one FMA with the additive constant copied to a VGPR once per step -- gfx950 allows one
+// scalar source per VALU op -- instead of a multiply shared by two adds: 12 + 2/K instead of 13 VALU ops per ring pair and l)
 // two fast steps of the spin synthesis (G1/G2 swap roles).  The south-ring sums take (-1)^(l+m) a: they are
 // accumulated with sign +1 on even steps and -1 on odd steps and multiplied by the sign of the first step at the end.
 #define SPIN_SYN_PAIR(f0, f1, a0, a1) { \
 	{ \
 		const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b; \
+		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
 		_Pragma("unroll") for (int s = 0; s < K; s++) { \
 			const double gp = S.gp2[s], gm = S.gm2[s]; \
 			pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]); \
 			mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]); \
 			qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]); \
 			nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]); \
-			const double ax = ca*S.x[s]; \
-			S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]); \
+			S.gp1[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp1[s]); S.gm1[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm1[s]); \
 		} \
 	} \
 	{ \
 		const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b; \
+		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
 		_Pragma("unroll") for (int s = 0; s < K; s++) { \
 			const double gp = S.gp1[s], gm = S.gm1[s]; \
 			pnr[s] = fma(gp, a1.a, pnr[s]); pni[s] = fma(gp, a1.b, pni[s]); \
 			mnr[s] = fma(gm, a1.c, mnr[s]); mni[s] = fma(gm, a1.d, mni[s]); \
 			qsr[s] = fma(-gm, a1.a, qsr[s]); qsi[s] = fma(-gm, a1.b, qsi[s]); \
 			nsr[s] = fma(-gp, a1.c, nsr[s]); nsi[s] = fma(-gp, a1.d, nsi[s]); \
-			const double ax = ca*S.x[s]; \
-			S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]); \
+			S.gp2[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp2[s]); S.gm2[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm2[s]); \
 		} \
 	} }
 
@@ -736,26 +738,26 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0; \
 	{ \
 		const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b; \
+		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
 		_Pragma("unroll") for (int s = 0; s < K; s++) { \
 			const double gp = S.gp2[s], gm = S.gm2[s]; \
 			t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0); \
 			t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1); \
 			t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2); \
 			t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3); \
-			const double ax = ca*S.x[s]; \
-			S.gp1[s] = fma(ax + c1, gp, -S.gp1[s]); S.gm1[s] = fma(ax + c2, gm, -S.gm1[s]); \
+			S.gp1[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp1[s]); S.gm1[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm1[s]); \
 		} \
 	} \
 	{ \
 		const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b; \
+		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
 		_Pragma("unroll") for (int s = 0; s < K; s++) { \
 			const double gp = S.gp1[s], gm = S.gm1[s]; \
 			u0 = fma(gp, tpnr[s], u0); u0 = fma(-gm, tpsr[s], u0); \
 			u1 = fma(gp, tpni[s], u1); u1 = fma(-gm, tpsi[s], u1); \
 			u2 = fma(gm, tmnr[s], u2); u2 = fma(-gp, tmsr[s], u2); \
 			u3 = fma(gm, tmni[s], u3); u3 = fma(-gp, tmsi[s], u3); \
-			const double ax = ca*S.x[s]; \
-			S.gp2[s] = fma(ax + c1, gp, -S.gp2[s]); S.gm2[s] = fma(ax + c2, gm, -S.gm2[s]); \
+			S.gp2[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp2[s]); S.gm2[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm2[s]); \
 		} \
 	} \
 	/* steps come in aligned pairs: kk is 0 or 2 here */ \
