@@ -400,6 +400,7 @@ def alm2map_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy
 	map_full = _atleast(mdata, 4)
 	_check_shapes(alm_full, map_full, deriv)
 	func = sht.adjoint_synthesis if adjoint else sht.synthesis
+	lanes = sht.Lanes(_is_tensor(mdata) and _is_tensor(alm))
 	for I in nditer(map_full.shape[:-3]):
 		if deriv:
 			a = _contig(alm_full[I][None]); m = _flat(map_full[I])
@@ -407,11 +408,20 @@ def alm2map_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy
 			if adjoint: alm_full[I] = a[0]
 			else: map_full[I+(0,)] *= -1
 		else:
-			for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
+			# spin groups on two streams, chained as in alm2map_2d
+			groups = list(enmap.spin_helper(spin, alm_full.shape[-2])); lanes.mixed([int(g[0]) for g in groups])
+			if adjoint: groups, at, which = groups[::-1], 0, 0
+			else:       at, which = 1, 1
+			prev = None
+			for gi, (s, j1, j2) in enumerate(groups):
 				Ij = I+(slice(j1, j2),)
-				a = _contig(alm_full[Ij]); m = _flat(map_full[Ij])
-				func(alm=a, map=m, spin=int(s), **kwargs)
-				if adjoint and a is not alm_full[Ij]: alm_full[Ij] = a
+				ln = lanes.lane(gi, int(s))
+				with lanes.stream(ln):
+					a = _contig(alm_full[Ij]); m = _flat(map_full[Ij])
+					func(alm=a, map=m, spin=int(s), lane=ln, after=(prev, at, which) if (lanes.enabled and prev is not None) else None, **kwargs)
+					prev = func.last_plan
+					if adjoint and a is not alm_full[Ij]: alm_full[Ij] = a
+	lanes.join()
 	if adjoint: return alm
 	else:       return map
 

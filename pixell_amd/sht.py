@@ -149,11 +149,11 @@ def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1,
 		if lane == 1 and nt: _lib.check(_lib.load().pxs_plan_option(h, b"fft_threads", nt))
 	return p
 
-def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
+def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1, lane=0):
 	th = np.ascontiguousarray(theta, dtype=np.float64); nph = np.ascontiguousarray(nphi, dtype=np.uint64)
 	p0 = np.ascontiguousarray(phi0, dtype=np.float64); rs = np.ascontiguousarray(ringstart, dtype=np.uint64)
 	ms = np.ascontiguousarray(np.asarray(mstart)[:mmax+1], dtype=np.uint64)
-	key = ("r", th.tobytes(), nph.tobytes(), p0.tobytes(), rs.tobytes(), int(pixstride), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index())
+	key = ("r", th.tobytes(), nph.tobytes(), p0.tobytes(), rs.tobytes(), int(pixstride), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index(), int(lane))
 	p = _plans.get(key)
 	if p is None:
 		h = ctypes.c_void_p()
@@ -223,14 +223,15 @@ def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=Non
 	_run_ana(plan, map, alm, spin, True)
 	return plan if return_plan else map
 
-def _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode):
+def _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode, lane=0):
 	if mmax is None: mmax = lmax
 	if mstart is None: mstart = tri_mstart(lmax, mmax)
-	return ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride, pixstride), mmax, mstart
+	return ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride, pixstride, lane), mmax, mstart
 
-def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, map=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD"):
+def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, map=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD", lane=0, after=None):
 	"""ducc0.sht.experimental.synthesis as called at curvedsky.py:936-960 (map[nc, npix])"""
-	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
+	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode, lane)
+	if after is not None: plan.chain(after[1], after[0], after[2])
 	nca, ncm = _ncomp(spin, mode)
 	if map is None:
 		rs_ = np.asarray(ringstart).astype(np.int64); last_ = rs_+(np.asarray(nphi).astype(np.int64)-1)*pixstride
@@ -239,11 +240,13 @@ def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None
 		map = _torch().zeros((ncm, npix), dtype=getattr(_torch(), np.dtype(rdt).name), device=alm.device) if _is_tensor(alm) else np.zeros((ncm, npix), rdt)
 	_check_pair(alm, map, spin, mode, 1)
 	_run_syn(plan, alm, map, spin, mode, False)
+	synthesis.last_plan = plan
 	return map
 
-def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, alm=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD"):
+def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, alm=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD", lane=0, after=None):
 	"""ducc0.sht.experimental.adjoint_synthesis as called at curvedsky.py:1068-1084"""
-	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
+	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode, lane)
+	if after is not None: plan.chain(after[1], after[0], after[2])
 	nca, ncm = _ncomp(spin, mode)
 	if alm is None:
 		nelem = int(np.max(np.asarray(mstart).astype(np.int64))+lmax*lstride+1)
@@ -251,6 +254,7 @@ def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mst
 		alm = _torch().zeros((nca, nelem), dtype=getattr(_torch(), np.dtype(cdt).name), device=map.device) if _is_tensor(map) else np.zeros((nca, nelem), cdt)
 	_check_pair(alm, map, spin, mode, 1)
 	_run_syn(plan, alm, map, spin, mode, True)
+	adjoint_synthesis.last_plan = plan
 	return alm
 
 def get_gridweights(geometry, ntheta):

@@ -339,9 +339,13 @@ def test_lanes_equal_single_stream_gpu():
 				curvedsky.alm2map(alm, m, spin=[0, 2])
 				back = curvedsky.map2alm(m, lmax=lmax, spin=[0, 2])
 			at = curvedsky.alm2map_adjoint(m, spin=[0, 2], ainfo=curvedsky.alm_info(lmax))
+			mc = enmap.dmap(torch.zeros((3,)+tuple(shape), dtype=torch.float64, device="cuda"), wcs)
+			curvedsky.alm2map(alm, mc, spin=[0, 2], method="cyl")                       # explicit-ring path
+			atc = curvedsky.alm2map_adjoint(mc, spin=[0, 2], method="cyl", ainfo=curvedsky.alm_info(lmax))
 			torch.cuda.synchronize()
-			res[flag] = (m.tensor.cpu().numpy().copy(), back.cpu().numpy().copy(), at.cpu().numpy().copy())
+			res[flag] = (m.tensor.cpu().numpy().copy(), back.cpu().numpy().copy(), at.cpu().numpy().copy(), mc.tensor.cpu().numpy().copy(), atc.cpu().numpy().copy())
 		finally:
 			os.environ.pop("PIXELL_AMD_LANES", None)
 	for a, b in zip(res["1"], res["0"]): assert np.array_equal(a, b)
 	assert np.max(np.abs(res["1"][1]-alm.cpu().numpy())) < 1e-11
+	assert np.max(np.abs(res["1"][3]-res["1"][0])) < 1e-11                                  # cyl and 2d agree
