@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
 		o = os.path.join(bdir, os.path.basename(s)+".o")
 		if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s),
 				max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.hpp")))):
-			cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+			cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]+os.environ.get("PXS_EXTRA_HIPCC_FLAGS", "").split()+["-c", s, "-o", o]
 			if verbose: print(" ".join(cmd))
 			procs.append((cmd, subprocess.Popen(cmd)))
 		objs.append(o)

@@ -383,8 +383,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 #else
 #define PXS_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
-#ifdef PXS_HOST_SIM
-// simulator path: transpose the per-lane partial sums through a 16x66 LDS tile
+#if defined(PXS_HOST_SIM) || defined(PXS_LDS_REDUCE)
+// simulator path: transpose the per-lane partial sums through a 16x66 LDS tile.  (-DPXS_LDS_REDUCE compiles it for the device:
+// re-measured with the final kernels at config 3, leg_ana 142.2 ms against 139.2 ms for the lane-swap reduction below.)
 __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk) {
 	PXS_WAVE_LDS_SYNC();
 	const int rowi = lane >> 2, part = lane & 3;
