@@ -1,0 +1,298 @@
+"""-m gpu parity at the BASELINE.json configurations (C2, C3 at full size; C4- and C5-shaped cases), through the
+public pixell_amd.curvedsky / enmap API -> C ABI -> libpxsht.so.
+
+A round trip cannot see an error common to both directions, so each direction is compared with a CPU computation
+that does not involve the HIP path (oracle/sht_fast.py on top of oracle/sht_port.c, both pinned to the long-double
+oracle by tests/test_oracle_fast.py / test_oracle_port.py):
+
+  synthesis   alm2map of a full Gaussian alm; >= 1000 pixels per component (every pole ring, equatorial rings,
+              random rings; random columns) against direct summation over all (l, m) on those rings.  Pixel
+              coordinates come from enmap.pix2sky, i.e. independently of analyse_geometry's flip / phi0 logic.
+  analysis    map2alm of maps that alm2map did NOT make: the map is assembled with torch from ring profiles
+              F_m(theta) for a dozen m (0, 1, 2, lmax/2, lmax-1, lmax, ...): (i) band-limited profiles computed by
+              the C port from a known alm, (ii) random (non-band-limited) profiles, whose exact analysis is the
+              FFT-based theta resampling of sht_fast.  All l of those m are compared (tens of thousands of (l,m)),
+              and every other m must come out as zero.
+  round trip  rms(alm' - alm)/rms(alm) < 1e-8 (north_star), measured far below.
+
+Tolerances (float64): pixels |HIP - ref| <= 1e-10 rms(ref); alm rms(HIP - ref) <= 1e-10 rms(ref).
+"""
+import numpy as np
+import pytest
+
+TOL = 1e-10
+
+def _torch():
+	import torch
+	return torch
+
+def _gpu():
+	return _torch().cuda.is_available()
+def _dev():
+	return _torch().device("cuda" if _gpu() else "cpu")
+def as_map(t, wcs):
+	"""torch tensor -> enmap.dmap on the GPU; numpy ndmap for the host simulator (small sizes, GPU-less container)"""
+	from pixell_amd import enmap
+	return enmap.dmap(t, wcs) if _gpu() else enmap.ndmap(t.numpy(), wcs)
+def tens(m):
+	from pixell_amd import enmap
+	return m.tensor if isinstance(m, enmap.dmap) else _torch().from_numpy(np.asarray(m))
+def as_alm(t): return t if _gpu() else t.numpy()
+def alm_t(a): return a if hasattr(a, "cpu") else _torch().from_numpy(a)
+
+def nalm(lmax): return (lmax+1)*(lmax+2)//2
+
+def make_alm(lmax, ncomp, seed, device, spin2=True):
+	"""Gaussian alm, C_l = 1/(l+1)^2 (T), 0.01 C_l (E, B, zero below l = 2), m = 0 real: SURVEY 8d recipe, made on the GPU"""
+	torch = _torch()
+	g = torch.Generator(device=device); g.manual_seed(seed)
+	n = nalm(lmax)
+	alm = torch.complex(torch.randn((ncomp, n), generator=g, device=device, dtype=torch.float64),
+		torch.randn((ncomp, n), generator=g, device=device, dtype=torch.float64))/np.sqrt(2)
+	m_of = torch.repeat_interleave(torch.arange(lmax+1, device=device), torch.arange(lmax+1, 0, -1, device=device))
+	l_of = torch.arange(n, device=device)-(m_of*(2*lmax+1-m_of))//2
+	alm = alm/(l_of+1.0)
+	alm[:, :lmax+1] = alm[:, :lmax+1].real*np.sqrt(2)+0j
+	if spin2 and ncomp == 3:
+		alm[1:] *= 0.1
+		alm[1:, l_of < 2] = 0
+	return alm
+
+def relrms(a, b): return float(np.sqrt(np.mean(np.abs(a-b)**2))/max(np.sqrt(np.mean(np.abs(b)**2)), 1e-300))
+
+def pick_rings(ny, rng, npole=4, nrand=14):
+	"""native row indices: the rows next to both poles, rows around the equator, random rows; closed under the mirror"""
+	from oracle import sht_fast as sf
+	rows = np.concatenate([np.arange(npole), [ny//2-1, ny//4, ny//3], rng.integers(npole, ny//2, nrand)])
+	return sf.symmetric_subset(ny, rows)
+
+def sky_of_rows(shape, wcs, rows):
+	from pixell_amd import enmap
+	dec = enmap.pix2sky(shape, wcs, [rows, np.zeros(len(rows))])[0]
+	return np.pi/2-dec
+
+def check_synthesis_pixels(shape, wcs, alm_dev, dmap, lmax, spins, npts=28, seed=0):
+	"""compare pixels of the GPU map with direct summation on the CPU; returns the worst error in units of the rms"""
+	from oracle import sht_fast as sf
+	from pixell_amd import enmap
+	torch = _torch()
+	rng = np.random.default_rng(seed)
+	ny, nx = shape[-2:]
+	rows = pick_rings(ny, rng)
+	theta = sky_of_rows(shape, wcs, rows)
+	order = np.argsort(theta)                       # the port wants ascending colatitude
+	rows = rows[order]; theta = theta[order]
+	xs = rng.integers(0, nx, (len(rows), npts))
+	ra = enmap.pix2sky(shape, wcs, [np.zeros(nx), np.arange(nx)])[1]          # phi of every column
+	alm = alm_t(alm_dev).cpu().numpy()
+	T = tens(dmap)
+	worst = 0.0; ci = 0
+	for s in spins:
+		nc = 1 if s == 0 else 2
+		leg = sf.synth_rings(alm[ci:ci+nc], s, lmax, theta)
+		ref = sf.pixels_on_rings(leg, ra[xs])                                    # [nc, nrows, npts]
+		yy = torch.as_tensor(np.repeat(rows[:, None], npts, 1), device=T.device)
+		xx = torch.as_tensor(xs, device=T.device)
+		got = T[ci:ci+nc][:, yy, xx].cpu().numpy()
+		assert len(rows)*npts >= 1000 or ny < 1000
+		for c in range(nc):
+			err = np.max(np.abs(got[c]-ref[c]))/np.sqrt(np.mean(ref[c]**2))
+			worst = max(worst, err)
+			assert err < TOL, "component %d: pixel error %.3e of the rms" % (ci+c, err)
+		ci += nc
+	return worst
+
+def m_selection(lmax, rng, nextra=3):
+	base = [0, 1, 2, 3, lmax//2-1, lmax//2, lmax-2, lmax-1, lmax]
+	return np.unique(np.concatenate([base, rng.integers(4, lmax-2, nextra)]))
+
+def build_map_from_profiles(shape, wcs, F, msel, dtype=None):
+	"""dmap[nc, ny, nx] = Re F_0(theta_y) + 2 Re sum_{m in msel, m > 0} F_m(theta_y) e^{i m phi_x}; F[nc, nsel, ny] (native row order).
+	Phases from exact integer arithmetic (m x mod nx) plus a long-double m phi_0."""
+	from pixell_amd import enmap
+	torch = _torch()
+	ny, nx = shape[-2:]; nc, ns = F.shape[:2]
+	dev = _dev()
+	ra = enmap.pix2sky(shape, wcs, [np.zeros(2), np.arange(2)])[1].astype(np.longdouble)
+	step = 1 if ra[1] > ra[0] else -1                                # columns run east or west by 2 pi / nx
+	x = np.arange(nx, dtype=np.int64)
+	E = np.zeros((ns, nx), np.complex128)
+	for i, m in enumerate(msel):
+		p0 = float((np.longdouble(m)*ra[0]) % (2*np.pi))
+		k = (int(m)*x) % nx
+		E[i] = np.exp(1j*(p0+step*2*np.pi*k/nx))*(1.0 if m == 0 else 2.0)
+	Ed = torch.as_tensor(E, device=dev)
+	out = torch.zeros((nc, ny, nx), dtype=torch.float64, device=dev)
+	Fd = torch.as_tensor(np.ascontiguousarray(F), device=dev)
+	rows = max(1, min(ny, (1 << 26)//nx))
+	for c in range(nc):
+		for y0 in range(0, ny, rows):
+			out[c, y0:y0+rows] = (Fd[c, :, y0:y0+rows].T.contiguous() @ Ed).real
+	return as_map(out, wcs)
+
+def check_analysis_sparse_m(shape, wcs, lmax, spins, seed=1, band_limited=True):
+	"""map2alm of a torch-assembled map with a dozen m against the CPU; returns (rms error over the selected m, max |alm| elsewhere / rms)"""
+	from oracle import sht_fast as sf, sht_port
+	from pixell_amd import curvedsky
+	torch = _torch()
+	rng = np.random.default_rng(seed)
+	ny, nx = shape[-2:]
+	msel = m_selection(lmax, rng)
+	theta_rows = sky_of_rows(shape, wcs, np.arange(ny))
+	order = np.argsort(theta_rows); theta = theta_rows[order]               # ducc ring order
+	inv = np.empty(ny, int); inv[order] = np.arange(ny)
+	ncomp = sum(1 if s == 0 else 2 for s in spins)
+	F = np.zeros((ncomp, len(msel), ny), np.complex128)                       # native row order
+	expect = []; ci = 0
+	for s in spins:
+		nc = 1 if s == 0 else 2
+		if band_limited:
+			A = (rng.standard_normal((len(msel), nc, lmax+1))+1j*rng.standard_normal((len(msel), nc, lmax+1)))/(np.arange(lmax+1)+1.0)
+			for i, m in enumerate(msel):
+				A[i, :, :max(m, s)] = 0
+				if m == 0: A[i] = A[i].real
+			leg = sht_port.leg(s, lmax, msel, theta, alm=A)                  # [nsel, nc, ny] in ring order
+			expect.append(A)
+		else:
+			leg = rng.standard_normal((len(msel), nc, ny))+1j*rng.standard_normal((len(msel), nc, ny))
+			leg[msel == 0] = leg[msel == 0].real
+			# ring FFT output of the assembled map: nx F_m (m = 0: nx Re F_0); 0 < m < nx/2 for every selected m
+			expect.append(sf.analysis_columns(leg*nx, msel, s, lmax, "F1" if _is_f1(shape, wcs) else "CC", ny, nx))
+		F[ci:ci+nc] = np.transpose(leg, (1, 0, 2))[:, :, inv]
+		ci += nc
+	dmap = build_map_from_profiles(shape, wcs, F, msel)
+	ainfo = curvedsky.alm_info(lmax)
+	out = as_alm(torch.zeros((ncomp, ainfo.nelem), dtype=torch.complex128, device=_dev()))
+	curvedsky.map2alm(dmap, alm=out, spin=list(spins), ainfo=ainfo)
+	got = alm_t(out).cpu().numpy()
+	ms = ainfo.mstart.astype(np.int64)
+	worst = 0.0; ci = 0
+	mask = np.ones(ainfo.nelem, bool)
+	for si, s in enumerate(spins):
+		nc = 1 if s == 0 else 2
+		gc = sf.tri_columns(got[ci:ci+nc], lmax, msel)
+		ex = expect[si]
+		for i, m in enumerate(msel):
+			l0 = max(m, s)
+			mask[ms[m]+m:ms[m]+lmax+1] = False
+			e = relrms(gc[i, :, l0:], ex[i, :, l0:]) if lmax >= l0 else 0.0
+			worst = max(worst, e)
+			assert e < TOL, "spin %d m %d: alm error %.3e (rms)" % (s, m, e)
+		ci += nc
+	scale = np.sqrt(np.mean(np.abs(got[:, ~mask])**2))
+	leak = float(np.max(np.abs(got[:, mask]))/scale)
+	assert leak < TOL, "alm at m outside the selection should vanish: %.3e of the rms" % leak
+	return worst, leak
+
+def _is_f1(shape, wcs):
+	from pixell_amd import curvedsky
+	return curvedsky.analyse_geometry(shape, wcs).ducc_geo.name == "F1"
+
+def run_config(ncomp, shape2, lmax, spins, seed, variant="fejer1"):
+	from pixell_amd import curvedsky, enmap
+	torch = _torch()
+	dev = _dev()
+	shape, wcs = enmap.fullsky_geometry(shape=shape2, variant=variant)
+	assert curvedsky.analyse_geometry((ncomp,)+shape, wcs).case == "2d"
+	ainfo = curvedsky.alm_info(lmax)
+	alm = as_alm(make_alm(lmax, ncomp, seed, dev))
+	dmap = as_map(torch.zeros((ncomp,)+shape, dtype=torch.float64, device=dev), wcs)
+	curvedsky.alm2map(alm, dmap, spin=list(spins), ainfo=ainfo)
+	e_pix = check_synthesis_pixels((ncomp,)+shape, wcs, alm, dmap, lmax, spins, seed=seed)
+	back = as_alm(torch.zeros((ncomp, ainfo.nelem), dtype=torch.complex128, device=dev))
+	curvedsky.map2alm(dmap, alm=back, spin=list(spins), ainfo=ainfo)
+	e_rt = float(((alm_t(back)-alm_t(alm)).abs().pow(2).mean().sqrt()/alm_t(alm).abs().pow(2).mean().sqrt()).item())
+	assert e_rt < 1e-8, "round trip %.3e" % e_rt
+	del dmap, back
+	e_bl = check_analysis_sparse_m((ncomp,)+shape, wcs, lmax, spins, seed=seed, band_limited=True)
+	e_nb = check_analysis_sparse_m((ncomp,)+shape, wcs, lmax, spins, seed=seed+1, band_limited=False)
+	print("\n[%dx%s lmax %d] pixel err %.2e  round trip %.2e  analysis (band-limited) %.2e leak %.2e  (non-band-limited) %.2e leak %.2e"
+		% (ncomp, str(shape2), lmax, e_pix, e_rt, e_bl[0], e_bl[1], e_nb[0], e_nb[1]))
+	curvedsky.sht.clear_plans()
+	if _gpu(): torch.cuda.empty_cache()
+
+@pytest.mark.hostsim
+def test_config_logic_hostsim():
+	"""the same test body at toy size on the host simulator: keeps the checker code itself honest in the GPU-less container"""
+	run_config(3, (26, 52), 24, (0, 2), seed=2)
+	run_config(1, (27, 52), 24, (0,), seed=3, variant="cc")
+
+@pytest.mark.gpu
+def test_config2_gpu():
+	"""BASELINE config 2: 3x(5400x10800) T/Q/U, lmax 4000, spin 0/2 (5400 rings < 2 lmax + 1: theta resampling is mandatory)"""
+	run_config(3, (5400, 10800), 4000, (0, 2), seed=2)
+
+@pytest.mark.gpu
+def test_config3_gpu():
+	"""BASELINE config 3: 3x(21600x43200) T/Q/U, lmax 10000"""
+	torch = _torch()
+	free, _ = torch.cuda.mem_get_info()
+	if free < 150e9: pytest.skip("needs ~150 GB of HBM")
+	run_config(3, (21600, 43200), 10000, (0, 2), seed=3)
+
+@pytest.mark.gpu
+def test_config4_shape_gpu():
+	"""BASELINE config 4, one GPU's share: 8 independent scalar maps 5400x10800, lmax 4000, transformed by ONE call.
+	Properties: each map equals its own single-map transform; round trip; linearity; pixels of one map vs the CPU."""
+	from pixell_amd import curvedsky, enmap
+	torch = _torch(); dev = torch.device("cuda")
+	nb, lmax = 8, 4000
+	shape, wcs = enmap.fullsky_geometry(shape=(5400, 10800))
+	ainfo = curvedsky.alm_info(lmax)
+	alm = make_alm(lmax, nb, 100, dev, spin2=False)
+	maps = enmap.dmap(torch.zeros((nb,)+shape, dtype=torch.float64, device=dev), wcs)
+	curvedsky.alm2map(alm, maps, spin=[0], ainfo=ainfo)
+	one = enmap.dmap(torch.zeros((1,)+shape, dtype=torch.float64, device=dev), wcs)
+	for i in (0, 5):
+		curvedsky.alm2map(alm[i:i+1], one, spin=[0], ainfo=ainfo)
+		d = float((one.tensor[0]-maps.tensor[i]).abs().max()/maps.tensor[i].abs().max())
+		assert d < 1e-12, "batched synthesis differs from the single-map call: %.3e" % d
+	e_pix = check_synthesis_pixels((1,)+shape, wcs, alm[3:4], enmap.dmap(maps.tensor[3:4], wcs), lmax, (0,), seed=4)
+	back = torch.zeros_like(alm)
+	curvedsky.map2alm(maps, alm=back, spin=[0], ainfo=ainfo)
+	e_rt = float(((back-alm).abs().pow(2).mean().sqrt()/alm.abs().pow(2).mean().sqrt()).item())
+	assert e_rt < 1e-8
+	a1 = torch.zeros_like(alm[:1])
+	curvedsky.map2alm(enmap.dmap(maps.tensor[6:7].clone(), wcs), alm=a1, spin=[0], ainfo=ainfo)
+	d = float((a1[0]-back[6]).abs().max()/back[6].abs().max())
+	assert d < 1e-12, "batched analysis differs from the single-map call: %.3e" % d
+	# linearity on a non-band-limited input: map2alm(sum w_i noise_i) = sum w_i map2alm(noise_i)
+	g = torch.Generator(device=dev); g.manual_seed(7)
+	noise = enmap.dmap(torch.randn((nb,)+shape, generator=g, device=dev, dtype=torch.float64), wcs)
+	an = torch.zeros_like(alm); curvedsky.map2alm(noise, alm=an, spin=[0], ainfo=ainfo)
+	w = torch.linspace(-1, 1, nb, device=dev, dtype=torch.float64)
+	comb = enmap.dmap((noise.tensor*w[:, None, None]).sum(0, keepdim=True), wcs)
+	ac = torch.zeros_like(alm[:1]); curvedsky.map2alm(comb, alm=ac, spin=[0], ainfo=ainfo)
+	lin = (an*w[:, None]).sum(0)
+	e_lin = float(((ac[0]-lin).abs().pow(2).mean().sqrt()/lin.abs().pow(2).mean().sqrt()).item())
+	assert e_lin < 1e-11, "linearity %.3e" % e_lin
+	print("\n[8x(5400x10800) lmax 4000] pixel err %.2e  round trip %.2e  linearity %.2e" % (e_pix, e_rt, e_lin))
+	curvedsky.sht.clear_plans(); torch.cuda.empty_cache()
+
+@pytest.mark.gpu
+def test_config5_shape_gpu():
+	"""BASELINE config 5 at its full per-realisation size: 1x(10800x21600), lmax 6000: rand_alm -> alm2map -> enmap.fft ->
+	calc_ps2d -> lbin, and map2alm -> alm2cl.  Pixels vs the CPU, spectra through invariants (alm2cl of the round trip equals
+	alm2cl of the input; Parseval of the 2-D FFT; the binned flat-sky spectrum of the equatorial band follows C_l)."""
+	from pixell_amd import curvedsky, enmap
+	torch = _torch(); dev = torch.device("cuda")
+	lmax = 6000
+	shape, wcs = enmap.fullsky_geometry(shape=(10800, 21600))
+	ainfo = curvedsky.alm_info(lmax)
+	alm = make_alm(lmax, 1, 200, dev)
+	m = enmap.dmap(torch.zeros((1,)+shape, dtype=torch.float64, device=dev), wcs)
+	curvedsky.alm2map(alm, m, spin=[0], ainfo=ainfo)
+	e_pix = check_synthesis_pixels((1,)+shape, wcs, alm, m, lmax, (0,), seed=5)
+	back = torch.zeros_like(alm); curvedsky.map2alm(m, alm=back, spin=[0], ainfo=ainfo)
+	cl_in = curvedsky.alm2cl(alm, ainfo=ainfo); cl_out = curvedsky.alm2cl(back, ainfo=ainfo)
+	cl_in = cl_in.cpu().numpy() if hasattr(cl_in, "cpu") else np.asarray(cl_in); cl_out = cl_out.cpu().numpy() if hasattr(cl_out, "cpu") else np.asarray(cl_out)
+	assert np.max(np.abs(cl_out-cl_in)/cl_in) < 1e-9
+	f = enmap.fft(m, normalize="phys")
+	p1 = float((f.tensor.abs()**2).sum().item()); p2 = float((m.tensor**2).sum().item())*m.pixsize()
+	assert abs(p1-p2) < 1e-12*p2, "Parseval: %r vs %r" % (p1, p2)
+	ps2d = enmap.calc_ps2d(f)
+	b, l = enmap.lbin(ps2d)
+	b = np.asarray(b).reshape(-1, b.shape[-1])[0]
+	assert np.all(np.isfinite(b[1:])) and b.shape[-1] > 1000
+	print("\n[1x(10800x21600) lmax 6000] pixel err %.2e  max cl diff %.2e  Parseval %.2e" % (e_pix, float(np.max(np.abs(cl_out-cl_in)/cl_in)), abs(p1-p2)/p2))
+	curvedsky.sht.clear_plans(); torch.cuda.empty_cache()

@@ -138,32 +138,56 @@ def check_deep_scaling(lmax=260):
 		ra[:, :lmax+1] = ra[:, :lmax+1].real
 		assert relrms(oa, ra) < TOL
 
-def check_large_subset(lmax):
+def check_large_subset(lmax, use_port=False):
 	"""full ring set of a CC-like grid at large lmax (several waves per m, every lane passing through the scaled phases
-	at a different l) against the oracle evaluated on a subset of the rings: synthesis ring by ring, adjoint synthesis
+	at a different l) against the oracle (use_port: its C port, pinned to it by test_oracle_port.py, for the lmax the
+	long-double Python oracle cannot reach in minutes) evaluated on a subset of the rings: synthesis ring by ring, adjoint synthesis
 	with the map supported on the subset.  (A missing data fetch for lanes that reach scale 0 during phase A once gave
 	4e-2 errors at lmax 4000 that no smaller case showed.)"""
 	nr = lmax+2; nph = 8
 	th = np.arange(nr)*np.pi/(nr-1); th[0] = 1e-4; th[-1] = np.pi-1e-4
 	sub = np.unique(np.concatenate([np.arange(0, 8), np.arange(8, nr//2, max(1, nr//40)), nr-1-np.arange(0, 8), [nr//2]]))
+	if use_port: sub = np.unique(np.concatenate([sub, nr-1-sub]))       # the port pairs rings north/south
 	ms = so._tri_mstart(lmax, lmax)
+	def ref_syn(alm, spin, t):
+		if not use_port: return so.synthesis(alm=alm, spin=spin, **kw(t)).reshape(alm.shape[0], len(t), nph)
+		from oracle import sht_fast as sf
+		leg = sf.synth_rings(alm, spin, lmax, t)                          # [nm, nc, nsub]
+		x = np.arange(nph)
+		return sf.pixels_on_rings(leg, np.tile(0.1+2*np.pi*x/nph, (len(t), 1)))
+	def ref_adj(pix, spin, t):
+		if not use_port: return so.adjoint_synthesis(map=pix.reshape(pix.shape[0], -1), spin=spin, **kw(t))
+		from oracle import sht_port
+		L = np.fft.fft(pix, axis=2)[:, :, np.arange(lmax+1) % nph]*np.exp(-1j*np.arange(lmax+1)*0.1)[None, None, :]    # sum_x ring e^{-i m phi_x}
+		cols = sht_port.leg(spin, lmax, np.arange(lmax+1), t, leg=np.transpose(L, (2, 0, 1)))
+		out = np.zeros((pix.shape[0], so.nalm(lmax)), complex)
+		for m in range(lmax+1): out[:, int(ms[m])+m:int(ms[m])+lmax+1] = cols[m, :, m:]
+		return out
 	def kw(t): return dict(theta=t, nphi=np.full(len(t), nph, np.uint64), phi0=np.full(len(t), 0.1), ringstart=np.arange(len(t), dtype=np.uint64)*nph, lmax=lmax, mstart=ms)
 	rng = np.random.default_rng(1)
 	for spin in (0, 2):
 		nc = 1 if spin == 0 else 2
 		alm = so.rand_alm_simple(lmax, nc, 6, spin=(spin,))
 		out = sht.synthesis(alm=alm, spin=spin, **kw(th)).reshape(nc, nr, nph)
-		ref = so.synthesis(alm=alm, spin=spin, **kw(th[sub])).reshape(nc, len(sub), nph)
+		ref = ref_syn(alm, spin, th[sub])
 		assert rel(out[:, sub], ref) < TOL
 		pix = np.zeros((nc, nr, nph)); pix[:, sub] = rng.standard_normal((nc, len(sub), nph))
 		oa = sht.adjoint_synthesis(map=pix.reshape(nc, -1), spin=spin, **kw(th))
-		ra = so.adjoint_synthesis(map=pix[:, sub].reshape(nc, -1), spin=spin, **kw(th[sub]))
+		ra = ref_adj(pix[:, sub], spin, th[sub])
 		ra[:, :lmax+1] = ra[:, :lmax+1].real
 		assert relrms(oa, ra) < TOL
 		assert np.max(np.abs(oa-ra)) < 1e-8*np.sqrt(np.mean(np.abs(ra)**2))
 
 @pytest.mark.gpu
 def test_large_lmax_subset_gpu(): check_large_subset(2600)
+@pytest.mark.gpu
+@pytest.mark.parametrize("lmax", [4000, 10000])
+def test_large_lmax_subset_port_gpu(lmax):
+	"""the BASELINE band limits (a missing data fetch once gave 4e-2 errors at lmax 4000 that no smaller case showed)"""
+	check_large_subset(lmax, use_port=True)
+@pytest.mark.hostsim
+def test_large_subset_logic_hostsim():
+	check_large_subset(70); check_large_subset(70, use_port=True)
 
 @pytest.mark.hostsim
 def test_deep_scaling_hostsim(): check_deep_scaling(100)
