@@ -60,10 +60,11 @@ def synth_rings(alm, spin, lmax, theta_sub, mchunk=512, mstart=None):
 def pixels_on_rings(leg, phi):
 	"""leg[nm, nc, nsub], phi[nsub, npts] -> values[nc, nsub, npts] = Re F_0 + 2 Re sum_{m>0} F_m e^{i m phi}"""
 	nm, nc, ns = leg.shape
-	m = np.arange(nm)
+	m = np.arange(nm, dtype=np.longdouble); tp = 2*np.pi*np.ones(1, np.longdouble)[0]
 	out = np.zeros((nc, ns, phi.shape[1]))
 	for r in range(ns):
-		ph = np.exp(1j*np.outer(m, phi[r]))            # [nm, npts]
+		arg = np.outer(m, np.asarray(phi[r], np.longdouble)) % tp      # m phi reaches 1e5 rad: reduce in long double
+		ph = np.exp(1j*arg.astype(np.float64))            # [nm, npts]
 		ph[1:] *= 2
 		for c in range(nc):
 			out[c, r] = np.real(leg[:, c, r] @ ph)        # (F_0 enters with its real part only)

@@ -58,9 +58,9 @@ void sht_port_leg_s0(int lmax, int nmsel, const int* msel, int np, const double*
 	const double ofs = fmax(100.0, 0.01*lmax);
 #pragma omp parallel
 	{
-		double* lam1 = (double*)malloc(sizeof(double)*np*8);
+		double* lam1 = (double*)malloc(sizeof(double)*np*9);
 		double* lam2 = lam1+np; double* csq = lam2+np; double* a1r = csq+np; double* a1i = a1r+np; double* a2r = a1i+np; double* a2i = a2r+np;
-		double* gate = a2i+np;
+		double* gate = a2i+np; double* pol = gate+np;   /* pol[p] = 1: polar ring, recurrence in -sin^2 (see below) */
 		int* sc = (int*)malloc(sizeof(int)*np);
 #pragma omp for schedule(dynamic,1)
 		for (int im = 0; im < nmsel; im++) {
@@ -68,7 +68,7 @@ void sht_port_leg_s0(int lmax, int nmsel, const int* msel, int np, const double*
 			const int nk = (lmax-m)/2+1;
 			double* A = alm + (size_t)im*(lmax+1)*2;
 			/* coefficients */
-			double* ca = (double*)malloc(sizeof(double)*nk*3); double* cb = ca+nk; double* al = cb+nk;
+			double* ca = (double*)malloc(sizeof(double)*nk*4); double* cb = ca+nk; double* al = cb+nk; double* cab = al+nk;
 			{
 				long double cm = 1/sqrtl(4*3.141592653589793238462643383279502884L);
 				for (int q = 1; q <= m; q++) cm = -cm*sqrtl((long double)(2*q+1)/(long double)(2*q));
@@ -78,14 +78,18 @@ void sht_port_leg_s0(int lmax, int nmsel, const int* msel, int np, const double*
 					long double e2 = epsl(lp+1, m)*epsl(lp+1, m)+epsl(lp, m)*epsl(lp, m), f = epsl(lp, m)*epsl(lp-1, m), d = epsl(lp+1, m)*epsl(lp+2, m);
 					long double an = (k == 0) ? ac/d : -f*ap/d;
 					long double ak = ac/(an*d);
-					ca[k] = (double)ak; cb[k] = (double)(-ak*e2); al[k] = (double)ac;
+					ca[k] = (double)ak; cb[k] = (double)(-ak*e2); al[k] = (double)ac; cab[k] = (double)(ak-ak*e2);
 					ap = ac; ac = an;
 				}
 			}
 			/* start values, first active pair */
 			int p0 = np;
 			for (int p = 0; p < np; p++) {
-				csq[p] = cth[p]*cth[p]; lam1[p] = 0; lam2[p] = 0; sc[p] = 0;
+				/* Near the poles x = cos(theta) rounds away the information about theta (1 - x ~ theta^2/2): rings with cos^2 > 1/2
+				 * run the recurrence in -sin^2(theta) with the constant a+b (rounded from long double) instead of b:
+				 * a x^2 + b = (a+b) - a sin^2.  Same measure as the HIP kernels take (legendre.hip, leg_wave_polar). */
+				pol[p] = cth[p]*cth[p] > 0.5 ? 1.0 : 0.0;
+				csq[p] = pol[p] != 0.0 ? -sth[p]*sth[p] : cth[p]*cth[p]; lam1[p] = 0; lam2[p] = 0; sc[p] = 0;
 				a1r[p] = a1i[p] = a2r[p] = a2i[p] = 0;
 				if ((double)m <= lmax*sth[p]+ofs) { double mt; int e; pow_scaled(sth[p], m, &mt, &e); to_scaled(mt, e, &lam2[p], &sc[p]); if (p < p0) p0 = p; }
 				if (dir == 1) {
@@ -113,7 +117,7 @@ void sht_port_leg_s0(int lmax, int nmsel, const int* msel, int np, const double*
 				for (int p = pb; p < pe; p++) { if (sc[p] < 0) nscaled++; if (lam2[p] != 0.0) anylive = 1; }
 				if (!anylive) continue;
 				for (int k = 0; k < nk; k++) {
-					const double a = ca[k], b = cb[k];
+					const double a = ca[k], b = cb[k], ab = cab[k];
 					if (nscaled > 0) for (int p = pb; p < pe; p++) gate[p] = sc[p] == 0 ? lam2[p] : 0.0;
 					const double* g = nscaled > 0 ? gate : lam2;
 					if (dir == 0) {
@@ -127,7 +131,7 @@ void sht_port_leg_s0(int lmax, int nmsel, const int* msel, int np, const double*
 						M[4*k] += t0; M[4*k+1] += t1; M[4*k+2] += t2; M[4*k+3] += t3;
 					}
 #pragma omp simd
-					for (int p = pb; p < pe; p++) { double t = (a*csq[p]+b)*lam2[p]+lam1[p]; lam1[p] = lam2[p]; lam2[p] = t; }
+					for (int p = pb; p < pe; p++) { double t = (a*csq[p]+(pol[p] != 0.0 ? ab : b))*lam2[p]+lam1[p]; lam1[p] = lam2[p]; lam2[p] = t; }
 					if (nscaled > 0) {
 						for (int p = pb; p < pe; p++) if (sc[p] < 0 && fabs(lam2[p]) > BIG) { lam1[p] *= SMALL; lam2[p] *= SMALL; sc[p]++; if (sc[p] == 0) nscaled--; }
 					}
@@ -164,9 +168,9 @@ void sht_port_leg_spin(int spin, int lmax, int nmsel, const int* msel, int np, c
 	const long double PIl = 3.141592653589793238462643383279502884L;
 #pragma omp parallel
 	{
-		double* buf = (double*)malloc(sizeof(double)*np*14);
+		double* buf = (double*)malloc(sizeof(double)*np*16);
 		double *gp1 = buf, *gp2 = gp1+np, *gm1 = gp2+np, *gm2 = gm1+np, *pnr = gm2+np, *pni = pnr+np, *mnr = pni+np, *mni = mnr+np,
-			*psr = mni+np, *psi = psr+np, *msr = psi+np, *msi = msr+np, *ggp = msi+np, *ggm = ggp+np;
+			*psr = mni+np, *psi = psr+np, *msr = psi+np, *msi = msr+np, *ggp = msi+np, *ggm = ggp+np, *xv = ggm+np, *pol = xv+np;
 		int* scp = (int*)malloc(sizeof(int)*np*2); int* scm = scp+np;
 #pragma omp for schedule(dynamic,1)
 		for (int im = 0; im < nmsel; im++) {
@@ -175,7 +179,7 @@ void sht_port_leg_spin(int spin, int lmax, int nmsel, const int* msel, int np, c
 			const int nl = lmax-l0+1;
 			double* E = alm + (size_t)im*2*(lmax+1)*2; double* B = E + (size_t)(lmax+1)*2;
 			if (nl <= 0) continue;
-			double* ca = (double*)malloc(sizeof(double)*nl*3); double* cb = ca+nl; double* be = cb+nl;
+			double* ca = (double*)malloc(sizeof(double)*nl*5); double* cb = ca+nl; double* be = cb+nl; double* cpb = be+nl; double* cmb = cpb+nl;
 			{
 				long double nrm;
 				if (m < s) { long double h = 2*s+1; for (int i = 1; i <= s; i++) h = h*(long double)(s+i)/(long double)i;
@@ -190,12 +194,16 @@ void sht_port_leg_spin(int spin, int lmax, int nmsel, const int* msel, int np, c
 					long double A_ = q*(L+1)/S1, B_ = q*Mm*Sp/(L*S1), C_ = l > l0 ? sqrtl((2*L+3)/(2*L-1))*(L+1)*S0/(L*S1) : 0;
 					long double bn = (l == l0) ? A_*bc : C_*bp;
 					ca[l-l0] = (double)(A_*bc/bn); cb[l-l0] = (double)(B_*bc/bn); be[l-l0] = (double)bc;
+					cpb[l-l0] = (double)(A_*bc/bn+B_*bc/bn); cmb[l-l0] = (double)(A_*bc/bn-B_*bc/bn);
 					bp = bc; bc = bn;
 				}
 			}
 			int p0 = np;
 			for (int p = 0; p < np; p++) {
 				gp1[p] = gm1[p] = gp2[p] = gm2[p] = 0; scp[p] = scm[p] = 0;
+				/* polar rings: a x +- b = a u + (a +- b) with u = cos(theta) - 1 = -2 sin^2(theta/2) (cf. the spin-0 routine) */
+				pol[p] = cth[p]*cth[p] > 0.5 ? 1.0 : 0.0;
+				xv[p] = pol[p] != 0.0 ? -2.0*sh2[p]*sh2[p] : cth[p];
 				pnr[p] = pni[p] = mnr[p] = mni[p] = psr[p] = psi[p] = msr[p] = msi[p] = 0;
 				double t1 = lmax*sth[p]+ofs, b = -2.0*s*fabs(cth[p]), c = (double)s*s-t1*t1, discr = b*b-4*c;
 				double mlim = discr <= 0 ? lmax : fmin((double)lmax, 0.5*(-b+sqrt(discr)));
@@ -228,7 +236,7 @@ void sht_port_leg_spin(int spin, int lmax, int nmsel, const int* msel, int np, c
 				double sgn = ((l0+m) & 1) ? -1.0 : 1.0;
 				for (int j = 0; j < nl; j++, sgn = -sgn) {
 					const int l = l0+j;
-					const double a = ca[j], b = cb[j];
+					const double a = ca[j], b = cb[j], apb = cpb[j], amb = cmb[j];
 					const double* Gp = gp2; const double* Gm = gm2;
 					if (nscaled > 0) { for (int p = pb; p < pe; p++) { ggp[p] = scp[p] == 0 ? gp2[p] : 0; ggm[p] = scm[p] == 0 ? gm2[p] : 0; } Gp = ggp; Gm = ggm; }
 					if (dir == 0) {
@@ -251,7 +259,7 @@ void sht_port_leg_spin(int spin, int lmax, int nmsel, const int* msel, int np, c
 					}
 #pragma omp simd
 					for (int p = pb; p < pe; p++) {
-						double tp = a*cth[p]+b, tm = a*cth[p]-b;
+						double tp = a*xv[p]+(pol[p] != 0.0 ? apb : b), tm = a*xv[p]+(pol[p] != 0.0 ? amb : -b);
 						double n1 = tp*gp2[p]-gp1[p], n2 = tm*gm2[p]-gm1[p];
 						gp1[p] = gp2[p]; gp2[p] = n1; gm1[p] = gm2[p]; gm2[p] = n2;
 					}
