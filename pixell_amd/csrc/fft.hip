@@ -8,16 +8,11 @@
 // the four-step split N = n1*n2 (pass A strided + twiddle, pass B contiguous), with the
 // intermediate processed in chunks of `temp_budget` bytes (see the constructor).
 #include "fft.hpp"
+#include "fft_dev.hpp"
 #include <cmath>
 #include <algorithm>
 
 namespace pxs {
-
-static constexpr int FFT_NLOC_MAX = 2048;   // longest line done in one LDS pass
-static constexpr int FFT_LDS_PTS  = 4096;   // complex points of LDS per workgroup (64 KiB)
-static constexpr int FFT_MAXFAC   = 16;
-
-struct PassDesc { int R; int L; int tws; FastDiv dL; FastDiv dnb; };
 
 struct KArgs {
 	int n, nfac, T, generic, mode, forward, n1, n2;
@@ -33,16 +28,6 @@ struct KArgs {
 	double2* temp; const double2* bigtw;
 	int load_inner_fast, store_inner_fast, tile_i;
 };
-
-// LDS line buffer addressing hook (see below)
-#define LPAD(i) (i)   /* padding ((i)+((i)>>4)) measured neutral-to-slower on MI355X: global latency, not LDS banks, bounds this kernel */
-
-__device__ __forceinline__ uint32_t fdiv(uint32_t x, FastDiv f) { return f.d <= 1 ? x : __umulhi(x, f.mul); }
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x); }
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x+b.x, a.y+b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x-b.x, a.y-b.y); }
-__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
-__device__ __forceinline__ double2 mulmi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
 
 __device__ __forceinline__ double2 read_elem(const void* p, int dtype, long off) {
 	switch (dtype) {
@@ -191,39 +176,6 @@ __device__ __forceinline__ void store_functor(const KArgs& a, long i, long o1, l
 	write_elem(st.ptr, st.dtype, off, v);
 }
 
-template<int R> __device__ __forceinline__ void butterfly(double2* v);
-template<> __device__ __forceinline__ void butterfly<2>(double2* v) {
-	double2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b);
-}
-template<> __device__ __forceinline__ void butterfly<3>(double2* v) {
-	const double s = 0.86602540378443864676;
-	double2 t1 = cadd(v[1], v[2]);
-	double2 t2 = make_double2(v[0].x - 0.5*t1.x, v[0].y - 0.5*t1.y);
-	double2 d = csub(v[1], v[2]);
-	double2 t3 = make_double2(s*d.y, -s*d.x);   // -i*s*d
-	v[0] = cadd(v[0], t1); v[1] = cadd(t2, t3); v[2] = csub(t2, t3);
-}
-template<> __device__ __forceinline__ void butterfly<4>(double2* v) {
-	double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-	double2 t2 = cadd(v[1], v[3]), t3 = mulmi(csub(v[1], v[3]));
-	v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
-}
-template<> __device__ __forceinline__ void butterfly<5>(double2* v) {
-	const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
-	const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
-	double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
-	double2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-	double2 a = v[0];
-	double2 m1 = make_double2(a.x + c1*t1.x + c2*t2.x, a.y + c1*t1.y + c2*t2.y);
-	double2 m2 = make_double2(a.x + c2*t1.x + c1*t2.x, a.y + c2*t1.y + c1*t2.y);
-	double2 u1 = make_double2(s1*t3.x + s2*t4.x, s1*t3.y + s2*t4.y);
-	double2 u2 = make_double2(s2*t3.x - s1*t4.x, s2*t3.y - s1*t4.y);
-	double2 iu1 = mulmi(u1), iu2 = mulmi(u2);   // -i*u
-	v[0] = make_double2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
-	v[1] = cadd(m1, iu1); v[4] = csub(m1, iu1);
-	v[2] = cadd(m2, iu2); v[3] = csub(m2, iu2);
-}
-
 // (Tried: radix 6/8/9 butterflies (216 = 8.9.3 in 3 passes instead of 5).  Per-length gain <= 4 %, but the larger
 // kernel ran every length slower (n = 200: 0.200 -> 0.238 ms, config 3 FFT stages +10 %); removed.  With the passes
 // skipped altogether the kernel moves data at 3.4-3.9 TB/s versus 2.5-2.7 TB/s with them.)
@@ -275,14 +227,6 @@ template<int NT> __device__ __forceinline__ void generic_pass(const double2* src
 		dst[LPAD(t*a.ns + j)] = acc;
 	}
 }
-
-// workgroup barrier that only waits for LDS traffic: __syncthreads() also drains vmcnt, which would stall on the
-// global loads the pipelined kernel keeps in flight for its next tile
-#ifdef PXS_HOST_SIM
-#define PXS_LDS_BARRIER() __syncthreads()
-#else
-#define PXS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
 
 // block -> (tile, other, o1, o2).  mode 0: tile over lines i.  modes 1/2 (four-step): sub-lines are (i, s) with
 // s = j2 (pass A) or k1 (pass B); tile_i selects which one is tiled.
@@ -549,6 +493,13 @@ std::shared_ptr<FftSub> FftContext::sub(long n) {
 	s->d_pass = upload(std::vector<PassDesc>(s->pass, s->pass + FFT_MAXFAC));
 	subs_[n] = s;
 	return s;
+}
+
+FftContext::SubView FftContext::view(long n) {
+	auto s = sub(n);
+	SubView v; v.n = s->n; v.nfac = s->nfac; v.ns = s->n | 1; v.generic = s->generic ? 1 : 0;
+	v.pass = s->d_pass.p; v.perm = s->perm.as<int>(); v.tw = s->tw.as<double2>();
+	return v;
 }
 
 const double2* FftContext::bigtw(long n) {

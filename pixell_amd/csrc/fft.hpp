@@ -58,6 +58,11 @@ public:
 	void exec(hipStream_t st, long n, bool forward, const FftDims& d, const FftLoad& ld, const FftStore& stf);
 	static long good_size(long n);          // smallest 2^a 3^b 5^c >= n that the engine can factor
 	static bool supported(long n, std::string* why = nullptr);
+	// views for the fused chain kernels (fftchain.hip): LDS sub-transform tables of length n (radices 2,3,4,5 only:
+	// `ok` false otherwise) and the four-step twiddle table e^{-2 pi i k/n}, k < n
+	struct SubView { int n, nfac, ns, generic; const void* pass; const int* perm; const double2* tw; };
+	SubView view(long n);
+	const double2* twiddle_table(long n) { return bigtw(n); }
 	size_t temp_budget = size_t(4) << 30;   // bytes of four-step scratch per stream (set from the free memory in the constructor)
 	int nt_override = 0;                    // 0: automatic; 128/256/512: threads per workgroup for the launches that follow (experiments)
 private:

@@ -1,0 +1,110 @@
+// Device-side building blocks of the LDS FFT kernels (shared by fft.hip and fftchain.hip).
+#pragma once
+#include "common.hpp"
+
+namespace pxs {
+
+static constexpr int FFT_NLOC_MAX = 2048;   // longest line done in one LDS pass
+static constexpr int FFT_LDS_PTS  = 4096;   // complex points of LDS per workgroup (64 KiB)
+static constexpr int FFT_MAXFAC   = 16;
+
+struct PassDesc { int R; int L; int tws; FastDiv dL; FastDiv dnb; };
+
+// LDS line buffer addressing hook (see below)
+#define LPAD(i) (i)   /* padding ((i)+((i)>>4)) measured neutral-to-slower on MI355X: global latency, not LDS banks, bounds this kernel */
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, FastDiv f) { return f.d <= 1 ? x : __umulhi(x, f.mul); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x+b.x, a.y+b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x-b.x, a.y-b.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 mulmi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+
+template<int R> __device__ __forceinline__ void butterfly(double2* v);
+template<> __device__ __forceinline__ void butterfly<2>(double2* v) {
+	double2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b);
+}
+template<> __device__ __forceinline__ void butterfly<3>(double2* v) {
+	const double s = 0.86602540378443864676;
+	double2 t1 = cadd(v[1], v[2]);
+	double2 t2 = make_double2(v[0].x - 0.5*t1.x, v[0].y - 0.5*t1.y);
+	double2 d = csub(v[1], v[2]);
+	double2 t3 = make_double2(s*d.y, -s*d.x);   // -i*s*d
+	v[0] = cadd(v[0], t1); v[1] = cadd(t2, t3); v[2] = csub(t2, t3);
+}
+template<> __device__ __forceinline__ void butterfly<4>(double2* v) {
+	double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+	double2 t2 = cadd(v[1], v[3]), t3 = mulmi(csub(v[1], v[3]));
+	v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+}
+template<> __device__ __forceinline__ void butterfly<5>(double2* v) {
+	const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+	const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+	double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+	double2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+	double2 a = v[0];
+	double2 m1 = make_double2(a.x + c1*t1.x + c2*t2.x, a.y + c1*t1.y + c2*t2.y);
+	double2 m2 = make_double2(a.x + c2*t1.x + c1*t2.x, a.y + c2*t1.y + c1*t2.y);
+	double2 u1 = make_double2(s1*t3.x + s2*t4.x, s1*t3.y + s2*t4.y);
+	double2 u2 = make_double2(s2*t3.x - s1*t4.x, s2*t3.y - s1*t4.y);
+	double2 iu1 = mulmi(u1), iu2 = mulmi(u2);   // -i*u
+	v[0] = make_double2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
+	v[1] = cadd(m1, iu1); v[4] = csub(m1, iu1);
+	v[2] = cadd(m2, iu2); v[3] = csub(m2, iu2);
+}
+
+// workgroup barrier that only waits for LDS traffic: __syncthreads() also drains vmcnt, which would stall on the
+// global loads the pipelined kernel keeps in flight for its next tile
+#ifdef PXS_HOST_SIM
+#define PXS_LDS_BARRIER() __syncthreads()
+#else
+#define PXS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+
+// Sub-transform view used by the chain kernels (fftchain.hip): one in-place mixed-radix DIT FFT of T lines of n points
+// (line stride ns) held in LDS; input must sit at its digit-reversed slot perm[j].
+struct LdsFft {
+	int n, nfac, ns, generic;
+	const PassDesc* pass; const int* perm; const double2* tw;   // device tables of the engine (FftSub)
+	FastDiv dn;
+};
+
+template<int R, int NT> __device__ __forceinline__ void radix_pass_t(double2* buf, const double2* tw, int n, int ns, int T, const PassDesc& ps) {
+	const int nb = n / R;
+	const int total = T*nb;
+	for (int b = threadIdx.x; b < total; b += NT) {
+		const uint32_t t = fdiv(b, ps.dnb);
+		const uint32_t bb = b - t*nb;
+		const uint32_t blk = fdiv(bb, ps.dL);
+		const uint32_t q = bb - blk*ps.L;
+		const uint32_t p0 = t*ns + blk*ps.L*R + q;
+		double2 v[R];
+#pragma unroll
+		for (int i = 0; i < R; i++) v[i] = buf[p0 + i*ps.L];
+		if (ps.L > 1) {
+			const int step = q*ps.tws;
+#pragma unroll
+			for (int i = 1; i < R; i++) v[i] = cmul(v[i], tw[i*step]);
+		}
+		butterfly<R>(v);
+#pragma unroll
+		for (int i = 0; i < R; i++) buf[p0 + i*ps.L] = v[i];
+	}
+}
+
+// all passes of f on T lines (radices 2,3,4,5 only); ends with a barrier
+template<int NT> __device__ __forceinline__ void lds_fft(double2* buf, const double2* tw, const LdsFft& f, int T) {
+	for (int p = 0; p < f.nfac; p++) {
+		const PassDesc ps = f.pass[p];
+		switch (ps.R) {
+			case 2: radix_pass_t<2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 3: radix_pass_t<3, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 4: radix_pass_t<4, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			default: radix_pass_t<5, NT>(buf, tw, f.n, f.ns, T, ps); break;
+		}
+		PXS_LDS_BARRIER();
+	}
+}
+
+} // namespace pxs

@@ -1,0 +1,647 @@
+// Fused FFT chains of the SHT for gfx950.
+//
+// Every long transform (ring FFT of nphi points, theta FFTs of N, M, Ncc points) is a four-step transform
+// X = a*b: pass 1 runs a-point transforms over the residues mod b, pass 2 b-point transforms that produce the residues
+// mod a.  When two consecutive transforms share the modulus g (N = g*bN, M = g*g2, Ncc = ac*g) the residue class that
+// pass 2 of one transform produces is exactly the class pass 1 of the next one consumes -- the spectrum resize between
+// them maps class r to class r -- so both passes run back to back on the same lines in LDS:
+//
+//   analysis  (leg on the map's rings -> weighted leg on the CC grid), per pair of columns (m, m+1):
+//     RA1  mirror-pair extension, FFT_g           -> Y1      RA2  FFT_bN, shift/pad to M, IFFT_g2     -> Z2
+//     RA3  IFFT_g, x |sin| series, FFT_g          -> V3      RA4  FFT_g2, keep |k| <= lmax, IFFT_ac   -> U4
+//     RA5  IFFT_g, separate the pair, weights     -> leg_cc
+//   synthesis (leg on the CC grid -> ring spectra h[ring][m]):
+//     RS1  mirror-pair extension, FFT_gs -> Y    RS2  FFT_bs, keep |k| <= lmax, shift, IFFT_aNs -> Z    RS3  IFFT_gs, separate, transpose -> h
+//   ring FFTs: MA1/MA2 (two real rings per complex line; pass 2 unpacks the pair and writes leg[m][ring] directly),
+//              MS1/MS2 (Hermitian pair load straight from h[ring][m]; pass 2 writes the two rings).
+//
+// Every intermediate array is written once and read once; one side of each access is fully contiguous, the other
+// side moves runs of T*16 bytes (T = lines per tile, a multiple of 8: whole 128-byte lines, measured at copy speed
+// on MI355X with tools/stride_bw.hip).  All global loads of a tile are issued before the first LDS write.
+// Replaces ducc0's ring FFTs / resample_theta inside synthesis_2d / analysis_2d (pixell/curvedsky.py:907-924, 1032-1046).
+#include "fftchain.hpp"
+#include "fft_dev.hpp"
+#include <algorithm>
+#include <cmath>
+
+namespace pxs {
+
+#ifdef PXS_HOST_SIM
+static constexpr int CH_NT = 1, CH_MAXE = 2560;
+#else
+#ifndef PXS_CH_NT
+#define PXS_CH_NT 512      /* threads per workgroup: measured at config 3 (ring FFT + theta resampling, one stream) 256: 129 ms, 512: 115 ms */
+#endif
+static constexpr int CH_NT = PXS_CH_NT, CH_MAXE = (2560 + PXS_CH_NT - 1)/PXS_CH_NT;
+#endif
+static constexpr int CH_TILE_PTS = 2560;
+static constexpr int CH_NMAX = 512;           // longest LDS sub-transform of a chain stage      // points per tile = CH_NT * CH_MAXE on the device
+
+struct TileC { int outer, t0, nl, comp, q0; };
+
+struct StageBase {
+	LdsFft fa, fb;
+	int T; int ntile;
+	FastDiv dT, dna, dnb, dnt;
+	// four-step twiddle of the stage's output, W_X^{(t0 + li) e} = W_X^{t0 e} * W_X^{li e}: the first factor is gathered once per tile
+	// from the full table btw (into LDS), the second comes from a small table tws[e][li] shared by all tiles (coalesced reads).
+	// (One gather per point from the full table made every wave instruction touch 64 cache lines.)
+	const double2* btw; const double2* tws;
+};
+
+__device__ __forceinline__ double2 cscale(double2 a, double f) { return make_double2(a.x*f, a.y*f); }
+__device__ __forceinline__ double2 rd_real(const void* p, int dtype, long off) {
+	return dtype == PX_F32 ? make_double2((double)((const float*)p)[off], 0.0) : make_double2(((const double*)p)[off], 0.0);
+}
+__device__ __forceinline__ void wr_real(void* p, int dtype, long off, double v) {
+	if (dtype == PX_F32) ((float*)p)[off] = (float)v; else ((double*)p)[off] = v;
+}
+
+// (Tried: persistent workgroups that issue the global loads of their NEXT tile into registers before the LDS passes of the current
+// one.  The prefetch registers pushed the single-transform stages to 151-169 VGPRs and the two-transform stages to 256 (172 with
+// 512-thread workgroups), and config 3 got slower: ring FFT 58 -> 67 ms, theta resampling 71 -> 129 ms (102 ms with 512 threads).
+// One tile per workgroup, many workgroups per CU in different phases, stays.)
+template<class S, int NT, int MAXE> __global__ __launch_bounds__(NT) void chain_kernel(const S s)
+{
+	PXS_SHARED(double2, lds);
+	const int na = s.fa.n, nb = s.fb.n;
+	const int nlast = S::TWO ? nb : na, nslast = S::TWO ? s.fb.ns : s.fa.ns;
+	double2* twa = lds; double2* twb = lds + na; double2* twx = twb + nb; double2* buf = twx + (S::HAS_TW ? nlast : 0);
+	TileC c;
+	if (!s.decode((int)blockIdx.x, c)) return;
+	const bool have_tw = S::HAS_TW && s.btw != nullptr;
+	const int T = s.T;
+	{	// ---- load: every global load of the tile is in flight before the first LDS write
+		const int total = T*na;
+		double2 v[MAXE]; int pos[MAXE];
+#pragma unroll
+		for (int u = 0; u < MAXE; u++) {
+			const int idx = threadIdx.x + u*NT; pos[u] = -1;
+			if (idx < total) {
+				uint32_t li, e;
+				if (S::LOAD_LINE_FAST) { e = fdiv(idx, s.dT); li = idx - e*T; } else { li = fdiv(idx, s.dna); e = idx - li*na; }
+				v[u] = s.load(c, (int)li, (int)e);
+				if (S::INV_A) v[u].y = -v[u].y;
+				pos[u] = (int)li*s.fa.ns + s.fa.perm[e];
+			}
+		}
+		for (int k = threadIdx.x; k < na; k += NT) twa[k] = s.fa.tw[k];
+		for (int k = threadIdx.x; k < nb; k += NT) twb[k] = s.fb.tw[k];
+		if (have_tw) for (int k = threadIdx.x; k < nlast; k += NT) twx[k] = s.btw[(long)c.t0*k];
+#pragma unroll
+		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
+	}
+	PXS_LDS_BARRIER();
+	lds_fft<NT>(buf, twa, s.fa, T);
+	if (S::TWO) {	// ---- second transform on the same lines: pull its inputs out of the first one's output (lines fastest across lanes)
+		const int total = T*nb;
+		double2 v[MAXE]; int pos[MAXE];
+#pragma unroll
+		for (int u = 0; u < MAXE; u++) {
+			const int idx = threadIdx.x + u*NT; pos[u] = -1;
+			if (idx < total) {
+				const uint32_t e = fdiv(idx, s.dT), li = idx - e*T;
+				v[u] = s.mid(c, (int)li, (int)e, buf + li*s.fa.ns);
+				if (S::INV_B) v[u].y = -v[u].y;
+				pos[u] = (int)li*s.fb.ns + s.fb.perm[e];
+			}
+		}
+		PXS_LDS_BARRIER();
+#pragma unroll
+		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
+		PXS_LDS_BARRIER();
+		lds_fft<NT>(buf, twb, s.fb, T);
+	}
+	{	// ---- store
+		const int total = T*nlast;
+		const FastDiv dl = S::TWO ? s.dnb : s.dna;
+		for (int idx = threadIdx.x; idx < total; idx += NT) {
+			uint32_t li, e;
+			if (S::STORE_LINE_FAST) { e = fdiv(idx, s.dT); li = idx - e*T; } else { li = fdiv(idx, dl); e = idx - li*nlast; }
+			double2 w = make_double2(1, 0);
+			if (have_tw) w = cmul(twx[e], s.tws[e*T + li]);
+			s.store(c, (int)li, (int)e, buf, nslast, w);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// theta chains
+// ---------------------------------------------------------------------------------------------------------------
+// value of circle sample j of the packed pair of columns (2p, 2p+1): even + odd extension (cf. LD_MIRROR_PAIR in fft.hip)
+struct PairSrc {
+	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol;
+	__device__ __forceinline__ double2 get(int p, int j) const {
+		int src = j; bool mir = false;
+		if (j >= nr) { src = N - j - mir_c; if (src < 0) src += N; mir = true; }
+		const int tj = 2*j + mir_c;
+		const bool selfm = tj == 0 || tj == N || tj == 2*N;       // the sample is its own mirror image
+		const int ca = 2*p;
+		double2 va = leg[(long)ca*ld + src];
+		double2 vb = (ca + 1 < ncol) ? leg[(long)(ca + 1)*ld + src] : make_double2(0, 0);
+		double2& vo = a_odd ? va : vb;
+		if (selfm) vo = make_double2(0, 0);
+		else if (mir) { vo.x = -vo.x; vo.y = -vo.y; }
+		return cadd(va, vb);
+	}
+};
+
+// pass 1 of the first transform of a chain: circle index j = b*j1 + j2, line = j2, a-point FFT over j1, four-step twiddle
+struct StFirst : StageBase {
+	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
+	PairSrc src; int b; double2* Y; long ldY;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0); return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		return src.get(c.outer, b*e + c.t0 + li); }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+		if (li >= c.nl) return;
+		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(buf[li*ns + e], w); }
+};
+
+// pass 2 of transform X1 (forward, b1 points) + spectrum resize + pass 1 of transform X2 (backward, a2 points); shared modulus g.
+// in: Y[outer][k1 < g][j2 < b1]; out: Z[outer][k1' < a2][k1 < g] (row stride ldZ).
+// resize rule: signed frequency kappa of the X2 slot; zero beyond kmax (or beyond X1/2); Nyquist bin of X1 halved when nyq;
+// optional phase table ph[|kappa|], conjugated for kappa < 0.
+struct StResize : StageBase {
+	static constexpr bool TWO = true, INV_A = false, INV_B = true, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
+	const double2* Y; long ldY; double2* Z; long ldZ;
+	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g - c.t0); return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		return Y[((long)c.outer*g + c.t0 + li)*ldY + e]; }
+	__device__ __forceinline__ double2 mid(const TileC& c, int li, int e, const double2* A) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		const int k1 = c.t0 + li;
+		const int jp = g*e + k1;
+		const int kap = (2*jp <= X2) ? jp : jp - X2;
+		const int ak = kap < 0 ? -kap : kap;
+		if ((kmax >= 0 && ak > kmax) || 2*ak > X1) return make_double2(0, 0);
+		const int k = kap >= 0 ? kap : kap + X1;
+		const uint32_t k2 = fdiv((uint32_t)(k - k1), dg);
+		double2 v = A[k2];
+		if (nyq && 2*ak == X1) v = cscale(v, 0.5);
+		if (ph) { double2 t = ph[ak]; if (kap < 0) t.y = -t.y; v = cmul(v, t); }
+		return v; }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+		if (li >= c.nl) return;
+		Z[((long)c.outer*fb.n + e)*ldZ + c.t0 + li] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
+};
+
+// pass 2 of IFFT_M (g points), pointwise product with the |sin| series samples, pass 1 of FFT_M (g points)
+// in: Z[outer][k1' < g2][r < g]; out: V[outer][k1'' < g][k1' < g2]
+struct StSigma : StageBase {
+	static constexpr bool TWO = true, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
+	const double2* Z; long ldZ; double2* V; long ldV; int g, g2; const double2* sigma;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g2 - c.t0); return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		return Z[((long)c.outer*g2 + c.t0 + li)*ldZ + e]; }
+	__device__ __forceinline__ double2 mid(const TileC& c, int li, int e, const double2* A) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		return cmul(cconj(A[e]), sigma[(c.t0 + li) + g2*e]); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+		if (li >= c.nl) return;
+		V[((long)c.outer*g + e)*ldV + c.t0 + li] = cmul(buf[li*ns + e], w); }
+};
+
+// last pass of a backward chain (IFFT over r < g for the lines k1 < a, circle index t = k1 + a*k2) + separation of the packed pair
+// by reflection symmetry.
+// MODE 0: a tile holds TH primary lines and their mirror lines (slots li and li + TH) of one pair;
+//         out = leg[(col)*ld + t] * w[t] * scale, rings t < nr_out          (analysis: CC grid, weights)
+// MODE 1: a tile holds T/2 pairs x (line, mirror line), slot = 2*pi + which;
+//         out = h[t*ld + col] * conj(tab[col]) * scale                      (synthesis: ring-major rows for the ring FFT)
+template<int MODE> struct StSplit : StageBase {
+	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
+	double2* out; long ld; const double2* w; const double2* tab; double scale; int TH; FastDiv da;
+	__device__ __forceinline__ int mirror_line(int k) const { int m = a - k - mir_c; if (m >= a) m -= a; if (m < 0) m += a; return m; }
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*(MODE == 0 ? TH : 1); c.nl = T;
+		if (MODE == 1) { if (mirror_line(c.t0) < c.t0) return false; }      // the tile of the mirror line does this one
+		return true; }
+	// line and pair of LDS slot li (line < 0: unused slot)
+	__device__ __forceinline__ void slot(const TileC& c, int li, int& line, int& pair) const {
+		if (MODE == 0) {
+			pair = c.outer;
+			const int prim = c.t0 + (li < TH ? li : li - TH);
+			line = -1;
+			if (prim < a) {
+				const int m = mirror_line(prim);
+				if (li < TH) { if (prim <= m) line = prim; }                   // primary lines: the smaller of (line, mirror)
+				else if (prim < m) line = m;
+			}
+		} else {
+			pair = c.outer*(T/2) + (li >> 1);
+			const int m = mirror_line(c.t0);
+			line = (li & 1) ? (m != c.t0 ? m : -1) : c.t0;
+			if (pair >= npair) line = -1;
+		}
+	}
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		int line, pair; slot(c, li, line, pair);
+		if (line < 0) return make_double2(0, 0);
+		return U[((long)pair*a + line)*ldU + e]; }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+		int line, pair; slot(c, li, line, pair);
+		if (line < 0) return;
+		const int t = line + a*e;
+		if (t >= nr_out) return;
+		int tm = X - t - mir_c; if (tm >= X) tm -= X; if (tm < 0) tm += X;
+		const double2 z = cconj(buf[li*ns + e]);
+		double2 ev, od;
+		if (tm == t) { ev = z; od = make_double2(0, 0); }
+		else {
+			const int ml = mirror_line(line);
+			const int lp = (ml == line) ? li : (MODE == 0 ? (li < TH ? li + TH : li - TH) : (li ^ 1));
+			const int e2 = (int)fdiv((uint32_t)(tm - ml), da);
+			const double2 y = cconj(buf[lp*ns + e2]);
+			ev = make_double2(0.5*(z.x + y.x), 0.5*(z.y + y.y)); od = make_double2(0.5*(z.x - y.x), 0.5*(z.y - y.y));
+		}
+		const int ca = 2*pair;
+		double2 va = a_odd ? od : ev, vb = a_odd ? ev : od;
+		if (MODE == 0) {
+			const double f = scale*(w ? w[t].x : 1.0);
+			out[(long)ca*ld + t] = cscale(va, f);
+			if (ca + 1 < ncol) out[(long)(ca + 1)*ld + t] = cscale(vb, f);
+		} else {
+			out[(long)t*ld + ca] = cscale(cmul(va, cconj(tab[ca])), scale);
+			if (ca + 1 < ncol) out[(long)t*ld + ca + 1] = cscale(cmul(vb, cconj(tab[ca + 1])), scale);
+		}
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// ring FFTs
+// ---------------------------------------------------------------------------------------------------------------
+struct MapAddr { void* ptr; int dtype; long cstride, off0, rstride, pstride; int nring; };
+
+// MA1: two real rings as one complex line z = ring(2q) + i ring(2q+1); pixel x = b*j1 + j2, line = j2, a-point FFT over j1
+struct StRingA1 : StageBase {
+	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
+	MapAddr m; int b, npair; double2* Y; long ldY; FastDiv dnp;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
+		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		const int x = b*e + c.t0 + li;
+		const long o = c.comp*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
+		const double re = rd_real(m.ptr, m.dtype, o).x;
+		const double im = (2*c.q0 + 1 < m.nring) ? rd_real(m.ptr, m.dtype, o + m.rstride).x : 0.0;
+		return make_double2(re, im); }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+		if (li >= c.nl) return;
+		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(buf[li*ns + e], w); }
+};
+
+// MA2: b-point FFT over j2 for the lines k1 and a - k1 of T/2 ring pairs; bin k = k1 + a*k2 <= mmax is unpacked with its
+// partner bin nphi - k (in the mirror line) into the spectra of the two rings and written as leg[m][2q], leg[m][2q+1]
+struct StRingA2 : StageBase {
+	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	const double2* Y; long ldY; int a, X, npair, groups, nring, mmax; double2* leg; long ldleg; int nm; const double2* tab; double scale; FastDiv da, dgr;
+	__device__ __forceinline__ int mirror_line(int k) const { return k == 0 ? 0 : a - k; }
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = bx - c.outer*ntile; c.nl = T;
+		c.comp = fdiv(c.outer, dgr); c.q0 = (c.outer - c.comp*groups)*(T/2);
+		return mirror_line(c.t0) >= c.t0; }
+	__device__ __forceinline__ void slot(const TileC& c, int li, int& line, int& q) const {
+		q = c.q0 + (li >> 1);
+		const int ml = mirror_line(c.t0);
+		line = (li & 1) ? (ml != c.t0 ? ml : -1) : c.t0;
+		if (q >= npair) line = -1;
+	}
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		int line, q; slot(c, li, line, q);
+		if (line < 0) return make_double2(0, 0);
+		return Y[(((long)c.comp*npair + q)*a + line)*ldY + e]; }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+		int line, q; slot(c, li, line, q);
+		if (line < 0) return;
+		const int k = line + a*e;
+		if (k > mmax) return;
+		const double2 zp = buf[li*ns + e];
+		double2 zm;
+		if (k == 0) zm = zp;
+		else {
+			const int kp = X - k, ml = mirror_line(line);
+			const int lp = (ml == line) ? li : (li ^ 1);
+			zm = buf[lp*ns + (int)fdiv((uint32_t)(kp - ml), da)];
+		}
+		// X_a = (Z[k] + conj Z[n-k])/2, X_b = -i (Z[k] - conj Z[n-k])/2
+		double2 xa = make_double2(0.5*(zp.x + zm.x), 0.5*(zp.y - zm.y));
+		const double2 d = make_double2(zp.x - zm.x, zp.y + zm.y);
+		double2 xb = make_double2(0.5*d.y, -0.5*d.x);
+		const double2 t = tab[k];
+		double2* o = leg + ((long)c.comp*nm + k)*ldleg + 2*q;
+		o[0] = cscale(cmul(xa, t), scale);
+		if (2*q + 1 < nring) o[1] = cscale(cmul(xb, t), scale);
+	}
+};
+
+// MS1: Hermitian pair load from h[comp][ring][m]: bin k = b*j1 + j2, line = j2, backward a-point transform over j1
+struct StRingS1 : StageBase {
+	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
+	const double2* h; long ldh; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
+		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		const int k = b*e + c.t0 + li;
+		int m; bool cj;
+		if (k <= mmax) { m = k; cj = false; }
+		else if (X - k <= mmax) { m = X - k; cj = true; }
+		else return make_double2(0, 0);
+		const double2* r = h + ((long)c.comp*nring + 2*c.q0)*ldh + m;
+		double2 ha = r[0];
+		double2 hb = (2*c.q0 + 1 < nring) ? r[ldh] : make_double2(0, 0);
+		if (m == 0) { ha.y = 0; hb.y = 0; }
+		if (cj) { ha.y = -ha.y; hb.y = -hb.y; }
+		return make_double2(ha.x - hb.y, ha.y + hb.x); }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+		if (li >= c.nl) return;
+		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
+};
+
+// MS2: backward b-point transform over j2 for the lines k1; pixel x = k1 + a*k2: real part -> ring 2q, imaginary part -> ring 2q+1
+struct StRingS2 : StageBase {
+	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	const double2* Y; long ldY; int a, npair; MapAddr m; FastDiv dnp;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, a - c.t0);
+		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		if (li >= c.nl) return make_double2(0, 0);
+		return Y[((long)c.outer*a + c.t0 + li)*ldY + e]; }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+		if (li >= c.nl) return;
+		const int x = c.t0 + li + a*e;
+		const double2 v = buf[li*ns + e];                     // conj of the backward transform: the imaginary part flips sign
+		const long o = c.comp*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
+		wr_real(m.ptr, m.dtype, o, v.x);
+		if (2*c.q0 + 1 < m.nring) wr_real(m.ptr, m.dtype, o + m.rstride, -v.y);
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static bool smooth235(long n) { if (n < 1) return false; for (int p : {2, 3, 5}) while (n % p == 0) n /= p; return n == 1; }
+bool FftChain::sub_ok(long n) { return n >= 2 && n <= CH_NMAX && smooth235(n); }
+
+static LdsFft mk(FftContext* fc, long n) {
+	LdsFft f; memset(&f, 0, sizeof(f));
+	if (n <= 0) return f;
+	auto v = fc->view(n);
+	static const int nofft = [] { const char* e = getenv("PXS_CH_NOFFT"); return e ? atoi(e) : 0; }();     // timing experiments only (wrong results)
+	f.n = v.n; f.nfac = nofft ? 0 : v.nfac; f.ns = v.ns; f.generic = v.generic; f.pass = (const PassDesc*)v.pass; f.perm = v.perm; f.tw = v.tw; f.dn = make_fastdiv((uint32_t)n);
+	return f;
+}
+
+// W_X^{li e}, e < n, li < T, laid out [e][li] (see StageBase)
+const double2* FftChain::small_tw(long X, int n, int T) {
+	static const int notw = [] { const char* e = getenv("PXS_CH_NOTW"); return e ? atoi(e) : 0; }();     // timing experiments only (wrong results)
+	if (notw) return nullptr;
+	std::lock_guard<std::mutex> g(mu_);
+	auto key = std::make_tuple(X, n, T);
+	auto it = stw_.find(key);
+	if (it != stw_.end()) return it->second.as<double2>();
+	std::vector<double2> t((size_t)n*T);
+	const long double tp = 6.283185307179586476925286766559L;
+	for (int e = 0; e < n; e++) for (int li = 0; li < T; li++) {
+		const long double ang = tp*(long double)(((long)li*e) % X)/(long double)X;
+		t[(size_t)e*T + li] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+	}
+	stw_[key] = upload(t);
+	return stw_[key].as<double2>();
+}
+
+// lines per tile: as many as fit CH_TILE_PTS, in multiples of `mult`
+static int tile_lines(long n_a, long n_b, long nlines, int mult) {
+	const long n = std::max(n_a, n_b);
+	long T = CH_TILE_PTS / n;
+	if (T >= mult) T -= T % mult;
+	if (T < 1) T = 1;
+	const long cap = ((nlines + mult - 1)/mult)*mult;
+	if (T > cap) T = cap;
+	return (int)T;
+}
+// tiles of T consecutive lines; X > 0: the stage applies the four-step twiddle of a length-X transform to its output
+template<class S> void FftChain::set_tiles(S& s, int T, long nlines, long X) {
+	s.T = T; s.ntile = (int)((nlines + T - 1)/T); s.dT = make_fastdiv((uint32_t)T); s.dnt = make_fastdiv((uint32_t)s.ntile);
+	s.dna = make_fastdiv((uint32_t)s.fa.n); s.dnb = make_fastdiv((uint32_t)std::max(1, s.fb.n));
+	s.btw = nullptr; s.tws = nullptr;
+	if (X > 0) { s.tws = small_tw(X, S::TWO ? s.fb.n : s.fa.n, T); s.btw = s.tws ? fc_->twiddle_table(X) : nullptr; }
+}
+template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st) {
+	if (nblk <= 0) return;
+	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= CH_TILE_PTS, "internal: chain tile too large");
+	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
+	const size_t sh = sizeof(double2)*((size_t)s.fa.n + s.fb.n + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
+#ifndef PXS_HOST_SIM
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, CH_NT, CH_MAXE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
+	(void)once;
+#endif
+	hipLaunchKernelGGL((chain_kernel<S, CH_NT, CH_MAXE>), dim3((unsigned)nblk), dim3(CH_NT), sh, st, s);
+}
+
+// balanced split n = a*b with both factors usable
+static bool split_balanced(long n, Split& s, long amax = 320) {
+	long best = 0; double bestc = 1e300;
+	for (long a = 2; a <= 1024 && a <= n/2; a++) if (n % a == 0) {
+		const long b = n/a;
+		if (!FftChain::sub_ok(a) || !FftChain::sub_ok(b)) continue;
+		double c = std::fabs(std::log((double)a/(double)b));
+		if (a > amax) c += 10;
+		if (b % 8) c += 0.3;
+		if (c < bestc) { bestc = c; best = a; }
+	}
+	if (!best) return false;
+	s.a = best; s.b = n/best; return true;
+}
+
+bool FftChain::plan_rings(long nphi) {
+	nphi_ = nphi; ra_ = Split(); rs_ = Split();
+	Split s;
+	if (!split_balanced(nphi, s)) return false;
+	// analysis: pass 1 tiles are 16 lines (128-byte runs of f64) x a points -> the smaller factor first;
+	// synthesis: pass 2 tiles are 16 lines x b points -> the smaller factor last
+	ra_.a = std::min(s.a, s.b); ra_.b = nphi/ra_.a;
+	rs_.b = std::min(s.a, s.b); rs_.a = nphi/rs_.b;
+	return true;
+}
+
+static long smooth_at_least(long n, bool even_product_with = false, long g = 1) {
+	for (long m = std::max<long>(n, 2);; m++) if (smooth235(m) && (!even_product_with || ((m*g) % 2 == 0))) return m;
+}
+
+ThetaPlan FftChain::plan_theta(long N, int lmax) {
+	ThetaPlan best; double bestc = 1e300;
+	for (long g = 2; g <= 1024 && g <= N/2; g++) if (N % g == 0 && sub_ok(g) && sub_ok(N/g)) {
+		ThetaPlan t; t.N = N; t.g = g; t.bN = N/g;
+		t.g2 = smooth_at_least((N + 2L*lmax + 2 + g - 1)/g); t.M = g*t.g2;
+		t.ac = smooth_at_least((2L*lmax + 2 + g - 1)/g, true, g); t.Ncc = g*t.ac;
+		if (!sub_ok(t.g2) || !sub_ok(t.ac)) continue;
+		// synthesis split: gs divides both Ncc and N
+		long gs_best = 0; double gsc = 1e300;
+		for (long gs = 2; gs <= 1024; gs++) if (t.Ncc % gs == 0 && N % gs == 0 && sub_ok(gs) && sub_ok(t.Ncc/gs) && sub_ok(N/gs)) {
+			const double c = std::max({(double)gs, (double)(t.Ncc/gs), (double)(N/gs)});
+			if (c < gsc) { gsc = c; gs_best = gs; }
+		}
+		if (!gs_best) continue;
+		t.gs = gs_best; t.bs = t.Ncc/gs_best; t.aNs = N/gs_best;
+		// cost: a CC ring costs far more (Legendre stage) than a point of FFT traffic; then traffic; then tile balance
+		const double lmin = 2.0*lmax + 2;
+		double c = 60.0*(t.Ncc - lmin)/lmin + (3.0*N + 4.0*t.M + 3.0*t.Ncc)/(3.0*N + 4.0*(N + lmin) + 3.0*lmin);
+		const double big = (double)std::max({t.g, t.bN, t.g2, t.ac});
+		if (big > 320) c += 0.05*(big - 320)/320;
+		if (c < bestc) { bestc = c; best = t; best.ok = true; }
+	}
+	return best;
+}
+
+static MapAddr map_addr(const FftChain::MapDesc& m) {
+	MapAddr a; a.ptr = const_cast<void*>(m.ptr); a.dtype = m.dtype; a.cstride = m.cstride; a.off0 = m.ring_off0; a.rstride = m.ring_stride; a.pstride = m.pix_stride; a.nring = m.nring;
+	return a;
+}
+
+void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale) {
+	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
+	const long npair = (m.nring + 1)/2, a = ra_.a, b = ra_.b, ldY = pad8(b);
+	s1_.ensure(sizeof(double2)*(size_t)nc*npair*a*ldY);
+	{	StRingA1 s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
+		s.m = map_addr(m); s.b = (int)b; s.npair = (int)npair; s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
+		set_tiles(s, tile_lines(a, 0, b, 16), b, nphi_);
+		launch_stage(s, (long)nc*npair*s.ntile, st);
+	}
+	{	StRingA2 s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
+		int T = tile_lines(b, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
+		set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
+		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.X = (int)nphi_; s.npair = (int)npair; s.nring = m.nring; s.mmax = mmax;
+		s.groups = (int)((npair + T/2 - 1)/(T/2)); s.da = make_fastdiv((uint32_t)a); s.dgr = make_fastdiv((uint32_t)s.groups);
+		s.leg = leg; s.ldleg = ldleg; s.nm = mmax + 1; s.tab = tab; s.scale = scale;
+		launch_stage(s, (long)nc*s.groups*a, st);
+	}
+	PXS_HIP(hipGetLastError());
+}
+
+void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax) {
+	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
+	const long npair = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
+	s1_.ensure(sizeof(double2)*(size_t)nc*npair*a*ldY);
+	{	StRingS1 s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
+		s.h = h; s.ldh = ldh; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = m.nring; s.mmax = mmax; s.Y = s1_.as<double2>(); s.ldY = ldY;
+		s.dnp = make_fastdiv((uint32_t)npair);
+		set_tiles(s, tile_lines(a, 0, b, 8), b, nphi_);
+		launch_stage(s, (long)nc*npair*s.ntile, st);
+	}
+	{	StRingS2 s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
+		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.npair = (int)npair; s.m = map_addr(m); s.dnp = make_fastdiv((uint32_t)npair);
+		set_tiles(s, tile_lines(b, 0, a, 16), a, 0);
+		launch_stage(s, (long)nc*npair*s.ntile, st);
+	}
+	PXS_HIP(hipGetLastError());
+}
+
+void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
+                     int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* wcc)
+{
+	const long npair = (nm + 1)/2;
+	const long g = tp.g, bN = tp.bN, g2 = tp.g2, ac = tp.ac;
+	const long ldY1 = pad8(bN), ldZ2 = pad8(g), ldV3 = pad8(g2), ldU4 = pad8(g);
+	const size_t need1 = (size_t)npair*std::max(g*ldY1, g*ldV3), need2 = (size_t)npair*std::max(g2*ldZ2, ac*ldU4);
+	s1_.ensure(sizeof(double2)*need1); s2_.ensure(sizeof(double2)*need2);
+	for (int c = 0; c < nc; c++) {
+		{	StFirst s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
+			s.src.leg = leg + (size_t)c*nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1;
+			set_tiles(s, tile_lines(g, 0, bN, 8), bN, tp.N);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StResize s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, bN); s.fb = mk(fc_, g2);
+			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.M; s.kmax = -1; s.nyq = 1;
+			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
+			set_tiles(s, tile_lines(bN, g2, g, 8), g, tp.M);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StSigma s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, g); s.fb = mk(fc_, g);
+			s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.V = s1_.as<double2>(); s.ldV = ldV3; s.g = (int)g; s.g2 = (int)g2; s.sigma = sigma;
+			set_tiles(s, tile_lines(g, g, g2, 8), g2, tp.M);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StResize s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, g2); s.fb = mk(fc_, ac);
+			s.Y = s1_.as<double2>(); s.ldY = ldV3; s.Z = s2_.as<double2>(); s.ldZ = ldU4; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
+			s.ph = nullptr; s.dg = make_fastdiv((uint32_t)g);
+			set_tiles(s, tile_lines(g2, ac, g, 8), g, tp.Ncc);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StSplit<0> s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
+			int T = tile_lines(g, 0, 2*ac, 8); if (T < 2) T = 2; T -= T % 2;
+			const int TH = T/2;
+			set_tiles(s, T, (long)((ac/2 + 1 + TH - 1)/TH)*T, 0);
+			s.TH = TH;
+			s.U = s2_.as<double2>(); s.ldU = ldU4; s.a = (int)ac; s.g = (int)g; s.X = (int)tp.Ncc; s.mir_c = 0; s.nr_out = ncc; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
+			s.out = leg_cc + (size_t)c*nm*ldcc; s.ld = ldcc; s.w = wcc; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
+			launch_stage(s, npair*s.ntile, st);
+		}
+	}
+	PXS_HIP(hipGetLastError());
+}
+
+void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
+                       int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale)
+{
+	const long npair = (nm + 1)/2;
+	const long gs = tp.gs, bs = tp.bs, aN = tp.aNs;
+	const long ldY = pad8(bs), ldZ = pad8(gs);
+	s1_.ensure(sizeof(double2)*(size_t)npair*gs*ldY); s2_.ensure(sizeof(double2)*(size_t)npair*aN*ldZ);
+	for (int c = 0; c < nc; c++) {
+		{	StFirst s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
+			s.src.leg = leg_cc + (size_t)c*nm*ldcc; s.src.ld = ldcc; s.src.nr = ncc; s.src.N = (int)tp.Ncc; s.src.mir_c = 0; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.b = (int)bs; s.Y = s1_.as<double2>(); s.ldY = ldY;
+			set_tiles(s, tile_lines(gs, 0, bs, 8), bs, tp.Ncc);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StResize s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, bs); s.fb = mk(fc_, aN);
+			s.Y = s1_.as<double2>(); s.ldY = ldY; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)gs; s.X1 = (int)tp.Ncc; s.X2 = (int)tp.N; s.kmax = lmax; s.nyq = 0;
+			s.ph = ph_up; s.dg = make_fastdiv((uint32_t)gs);
+			set_tiles(s, tile_lines(bs, aN, gs, 8), gs, tp.N);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StSplit<1> s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
+			int T = tile_lines(gs, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
+			set_tiles(s, T, aN*T, 0);         // one tile per line: ntile = aN
+			s.TH = 0;
+			s.U = s2_.as<double2>(); s.ldU = ldZ; s.a = (int)aN; s.g = (int)gs; s.X = (int)tp.N; s.mir_c = mir_c; s.nr_out = nr; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
+			s.out = h + (size_t)c*nr*ldh; s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)aN);
+			const long groups = (npair + T/2 - 1)/(T/2);
+			launch_stage(s, groups*aN, st);
+		}
+	}
+	PXS_HIP(hipGetLastError());
+}
+
+} // namespace pxs

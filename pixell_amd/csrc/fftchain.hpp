@@ -1,0 +1,59 @@
+// Fused FFT chains of the SHT for gfx950 (see fftchain.hip): ring FFTs (map <-> leg) and the exact theta resampling
+// between the map's rings and the minimal Clenshaw-Curtis grid, as sequences of LDS kernels in which every intermediate
+// array is written once and read once.
+#pragma once
+#include "fft.hpp"
+#include <tuple>
+#include <map>
+#include <mutex>
+
+namespace pxs {
+
+// factorisation N = a*b of a four-step transform: pass 1 = a-point transforms over the residues mod b,
+// pass 2 = b-point transforms producing the residues mod a
+struct Split { long a = 0, b = 0; };
+
+struct ThetaPlan {            // sizes of the theta chains of a grid plan
+	bool ok = false;
+	long N = 0, M = 0, Ncc = 0;      // map circle, fine circle (|sin| product), CC circle
+	long g = 0, bN = 0, g2 = 0, ac = 0;     // analysis: N = g*bN, M = g*g2 (both ways), Ncc = ac*g
+	long gs = 0, bs = 0, aNs = 0;            // synthesis: Ncc = gs*bs, N = aNs*gs
+};
+
+class FftChain {
+public:
+	explicit FftChain(FftContext* fc) : fc_(fc) {}
+	// can the engine run its LDS passes on lines of this length (radices 2,3,4,5, length <= 512)?
+	static bool sub_ok(long n);
+	static long pad8(long n) { return (n + 7) & ~7L; }
+	// ring FFT split of nphi for analysis (map -> leg) and synthesis (h -> map); false: no usable factorisation
+	bool plan_rings(long nphi);
+	// theta chain sizes for a grid with N circle samples; picks Ncc (even, > 2 lmax + 1) and M (> N + 2 lmax)
+	static ThetaPlan plan_theta(long N, int lmax);
+	bool rings_ok() const { return ra_.a > 0; }
+	std::string describe() const { return "analysis " + std::to_string(ra_.a) + "x" + std::to_string(ra_.b) + ", synthesis " + std::to_string(rs_.a) + "x" + std::to_string(rs_.b); }
+
+	struct MapDesc { const void* ptr; int dtype; long cstride, ring_off0, ring_stride, pix_stride; int nring; long nphi; };
+	// map -> leg[c][m][ring] * tab[m] * scale   (two real rings per complex transform; needs 2 mmax < nphi)
+	void map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale);
+	// h[c][ring][m] (row stride ldh) -> map
+	void h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax);
+	// leg on the map's rings -> quadrature-weighted leg on the CC grid (columns paired by parity)
+	void to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
+	           int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* wcc);
+	// band-limited leg on the CC grid -> h[c][ring][m] * conj(tab[m]) * scale on the map's rings
+	void from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
+	             int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale);
+	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
+private:
+	const double2* small_tw(long X, int n, int T);
+	template<class S> void set_tiles(S& s, int T, long nlines, long X);
+	std::mutex mu_;
+	std::map<std::tuple<long, int, int>, DevBuf> stw_;
+	FftContext* fc_;
+	Split ra_, rs_;           // ring FFT splits: analysis, synthesis
+	long nphi_ = 0;
+	DevBuf s1_, s2_;          // ping-pong scratch
+};
+
+} // namespace pxs

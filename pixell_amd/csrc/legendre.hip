@@ -59,6 +59,7 @@ __device__ __forceinline__ double4_t ldc_row(const double4_t* p, long i) {
 
 struct LegK {
 	int lmax, mmax, spin, nm, npairs, nring, nwave;
+	long ld;                            // row stride of leg[m][ring] (>= nring; rows padded to whole 128-byte lines)
 	long nrows;
 	const long* row; const double4_t* coef; const double* alpha;
 	const int* ring_n; const int* ring_s; const double* cth; const double* sth; const double* sh2; const double* ch2;
@@ -362,7 +363,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 			}
 		}
 	}
-	double2* __restrict__ out = a.leg + (long)m*a.nring;
+	double2* __restrict__ out = a.leg + (long)m*a.ld;
 #pragma unroll
 	for (int s = 0; s < K; s++) {      // ring indices and cos(theta) are re-read here rather than kept in registers through the loops
 		const int p = (wv*K + s)*64 + lane;
@@ -475,7 +476,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
 	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
-	const double2* __restrict__ in = a.leg + (long)m*a.nring;
+	const double2* __restrict__ in = a.leg + (long)m*a.ld;
 	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
 	int sc[K];
 	bool alive_any = false;
@@ -656,8 +657,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	if (!leg_block(a, wv, m)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
-	double2* __restrict__ outq = a.leg + (long)m*a.nring;
-	double2* __restrict__ outu = a.leg + ((long)a.nm + m)*a.nring;
+	double2* __restrict__ outq = a.leg + (long)m*a.ld;
+	double2* __restrict__ outu = a.leg + ((long)a.nm + m)*a.ld;
 	SpinState<K> S; int rn[K], rs[K];
 	// north: P = sum G+ a+, M = sum G- a-;  south (before the sign): qs = sum +-G- a+, ns = sum +-G+ a-
 	double pnr[K], pni[K], mnr[K], mni[K], qsr[K], qsi[K], nsr[K], nsi[K];
@@ -778,8 +779,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	const long row0 = a.row[m];
 	const double4_t* __restrict__ coef = a.coef + row0;
 	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
-	const double2* __restrict__ inq = a.leg + (long)m*a.nring;
-	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.nring;
+	const double2* __restrict__ inq = a.leg + (long)m*a.ld;
+	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.ld;
 	SpinState<K> S; int rn[K], rs[K];
 	const bool polar = leg_wave_polar(a, wv, K);
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
@@ -975,7 +976,7 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 }
 
 
-static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, double2* leg, int K) {
+static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, double2* leg, long ld, int K) {
 	LegK a; memset(&a, 0, sizeof(a));
 	a.lmax = tb.lmax; a.mmax = tb.mmax; a.spin = tb.spin; a.nm = tb.mmax+1; a.npairs = rs.npairs; a.nring = rs.nring;
 	a.nwave = (rs.npairs + 64*K - 1)/(64*K);
@@ -983,7 +984,7 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	a.ring_n = rs.d_ring_n.as<int>(); a.ring_s = rs.d_ring_s.as<int>(); a.cth = rs.d_cth.as<double>(); a.sth = rs.d_sth.as<double>();
 	a.sh2 = rs.d_sh2.as<double>(); a.ch2 = rs.d_ch2.as<double>();
 	a.almt = wk.almt.as<double>(); a.part = wk.part.as<double>(); a.mom = wk.mom.as<double>();
-	a.leg = leg;
+	a.leg = leg; a.ld = ld > 0 ? ld : rs.nring;
 	a.ofs = std::max(100.0, 0.01*tb.lmax);
 	a.nmc = a.nm; a.xcd = xcd_map();
 	return a;
@@ -999,7 +1000,7 @@ static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dty
 
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                   double2* leg, int deriv1, LegProfile* prof)
+                   double2* leg, int deriv1, LegProfile* prof, long ld)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
@@ -1009,7 +1010,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		const int nkmax = tb.lmax/2 + 1;
 		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
 		const int K = k_syn0();
-		LegK a = make_legk(rs, tb, wk, leg, K);
+		LegK a = make_legk(rs, tb, wk, leg, ld, K);
 		if (prof) prof->begin(st, 0);
 		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
 		else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
@@ -1018,7 +1019,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		const int nlmax = tb.lmax + 1;
 		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
 		const int K = k_syns();
-		LegK a = make_legk(rs, tb, wk, leg, K);
+		LegK a = make_legk(rs, tb, wk, leg, ld, K);
 		if (prof) prof->begin(st, 0);
 		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
 		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
@@ -1030,7 +1031,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                  int deriv1, LegProfile* prof)
+                  int deriv1, LegProfile* prof, long ld)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	const int K = tb.spin == 0 ? k_ana0() : k_anas();
@@ -1054,7 +1055,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		const int m0 = cuts[c], m1 = cuts[c+1];
 		const long rows = tb.row[m1]-tb.row[m0];
 		if (rows <= 0) continue;
-		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), K);
+		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K);
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0;
 		wk.first.ensure(sizeof(int)*(size_t)nwave*(m1-m0));
 		PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));

@@ -15,6 +15,7 @@
 #include "../../include/pxsht.h"
 #include "fft.hpp"
 #include "legendre.hpp"
+#include "fftchain.hpp"
 #include <map>
 #include <memory>
 #include <cmath>
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void transpose_mul(const double2* __restrict__
 }
 // out[b][r][c] = in[b][c][r] * tab[c]: same kernel with roles swapped is enough (tab indexed by the OUTPUT column)
 __global__ __launch_bounds__(256) void transpose_mul_outcol(const double2* __restrict__ in, double2* __restrict__ out,
-		int nr, int nc, long in_bstride, long out_bstride, const double2* __restrict__ tab, int conj_tab, double scale)
+		int nr, int nc, long in_bstride, long out_bstride, const double2* __restrict__ tab, int conj_tab, double scale, long ldin, long ldout)
 {
 	// in[b][c][r] (nc rows of length nr) -> out[b][r][c]
 	PXS_SHARED(double2, tile);
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void transpose_mul_outcol(const double2* __res
 	in += (long)b*in_bstride; out += (long)b*out_bstride;
 	for (int j = ty; j < 32; j += 8) {
 		const int c = c0 + j, r = r0 + tx;
-		if (r < nr && c < nc) tile[j*33 + tx] = in[(long)c*nr + r];
+		if (r < nr && c < nc) tile[j*33 + tx] = in[(long)c*ldin + r];
 	}
 	__syncthreads();
 	for (int j = ty; j < 32; j += 8) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void transpose_mul_outcol(const double2* __res
 			double2 v = tile[tx*33 + j];
 			if (tab) { double2 t = tab[c]; if (conj_tab) t.y = -t.y; v = make_double2(v.x*t.x - v.y*t.y, v.x*t.y + v.y*t.x); }
 			v.x *= scale; v.y *= scale;
-			out[(long)r*nc + c] = v;
+			out[(long)r*ldout + c] = v;
 		}
 	}
 }
@@ -245,6 +246,17 @@ struct pxs_plan {
 	bool syn_via_cc = false;
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
+	// fused FFT chains (fftchain.hip).  chain_rings: ring FFTs through MA1/MA2, MS1/MS2; tp.ok: theta resampling through RA1-5 / RS1-3.
+	// The chain paths use row strides padded to whole 128-byte lines for leg / leg_cc / h; the older unfused paths (kept for
+	// aliased rings, lengths without a usable factorisation, the adjoint of the analysis) use dense rows.  A stride is chosen per call.
+	std::unique_ptr<FftChain> chain; ThetaPlan tp; bool chain_rings = false;
+	bool chain_theta() const { return chain_rings && tp.ok; }
+	long ld_map() const { return chain_rings ? FftChain::pad8(nring) : nring; }
+	long ld_cc()  const { return chain_theta() ? FftChain::pad8(ncc) : ncc; }
+	long ld_h()   const { return chain_rings ? FftChain::pad8(mmax + 1) : mmax + 1; }
+	FftChain::MapDesc map_desc(const void* map, int dtype, long cstride) const {
+		FftChain::MapDesc m; m.ptr = map; m.dtype = dtype; m.cstride = cstride; m.ring_off0 = ring_off0; m.ring_stride = ring_stride; m.pix_stride = pix_stride; m.nring = nring; m.nphi = nphi;
+		return m; }
 	LegProfile prof;
 	// stage events for chaining two plans that run on different streams (pxs_plan_chain): recorded by every call
 	hipEvent_t ev_before_leg = nullptr, ev_after_leg = nullptr;
@@ -286,6 +298,11 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 	std::vector<double2> ph(mmax+1);
 	for (int m = 0; m <= mmax; m++) { LDb a = (LDb)m*(LDb)p->phi0; ph[m] = make_double2((double)cosl(a), (double)(-sinl(a))); }
 	p->phase = upload(ph);
+	{	static const bool use = [] { const char* e = getenv("PXS_CHAIN"); return e ? atoi(e) != 0 : true; }();
+		p->chain.reset(new FftChain(p->fc));
+		p->chain_rings = use && p->ring_pairs && 2L*mmax < p->nphi && p->chain->plan_rings(p->nphi);
+		if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] ring chain nphi=%d mmax=%d: %s\n", p->nphi, mmax, p->chain_rings ? p->chain->describe().c_str() : "off");
+	}
 }
 
 void setup_resampling(pxs_plan* p) {
@@ -295,9 +312,15 @@ void setup_resampling(pxs_plan* p) {
 	p->Ncc = FftContext::good_size(std::max<long>(2L*lmax + 2, 4));
 	if (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
 	while (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
-	p->ncc = (int)(p->Ncc/2 + 1);
 	p->M = FftContext::good_size(p->N + 2L*lmax + 2);
 	{ const char* e = getenv("PXS_M_FINE"); if (e && atol(e) >= p->M && FftContext::supported(atol(e))) p->M = atol(e); }   // experiments: a larger fine grid with friendlier factors
+	if (p->chain_rings) {	// the fused theta chains need N, M and Ncc to share a modulus: let their planner pick M and Ncc
+		p->tp = FftChain::plan_theta(p->N, lmax);
+		if (p->tp.ok) { p->Ncc = p->tp.Ncc; p->M = p->tp.M; }
+		if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] theta chain N=%ld lmax=%d: ok=%d g=%ld bN=%ld g2=%ld (M=%ld) ac=%ld (Ncc=%ld) | syn gs=%ld bs=%ld aNs=%ld\n",
+			p->N, lmax, (int)p->tp.ok, p->tp.g, p->tp.bN, p->tp.g2, p->tp.M, p->tp.ac, p->tp.Ncc, p->tp.gs, p->tp.bs, p->tp.aNs);
+	}
+	p->ncc = (int)(p->Ncc/2 + 1);
 	std::string why;
 	if (!FftContext::supported(p->N, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
 	// CC ring set
@@ -339,9 +362,16 @@ int ncomp_of(int spin, int mode, bool alm_side) {
 }
 
 // ring FFT: user map -> hbuf[c][ring][m] -> leg[c][m][ring] * e^{-i m phi0} * scale
-void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale) {
+// (ld: row stride of leg; the unfused path below only writes dense rows, ld == nring)
+void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale, long ldl) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
+	if (p->chain_rings) {
+		p->chain->map2leg(st, p->map_desc(map, map_dtype, map_cstride), nc, p->mmax, leg, ldl, p->phase.as<double2>(), scale);
+		p->prof.end(st, PXS_STAGE_RING_FFT);
+		return;
+	}
+	PXS_REQUIRE(ldl == nr, "internal: unfused ring FFT needs dense rows");
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	if (2L*p->mmax < p->nphi && p->ring_pairs) {
 		// two real rings per complex transform; the pruned two-sided spectrum (|k| <= mmax) is unpacked in the transpose
@@ -380,14 +410,21 @@ void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long m
 }
 
 // leg[c][m][ring] * e^{+i m phi0} -> hbuf[c][ring][m] -> c2r ring FFT -> user map
-void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, void* map, int map_dtype, long map_cstride, int nc, bool have_h = false) {
+// (ldleg: row stride of leg; hbuf rows are ld_h() long)
+void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* map, int map_dtype, long map_cstride, int nc, bool have_h = false) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
-	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*nm);
-	if (!have_h) {      // (the CC synthesis path has written hbuf already, see resample_from_cc)
+	const long ldh = p->ld_h();
+	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*ldh);
+	if (!have_h) {      // (the CC synthesis path has written hbuf already, see resample_from_cc / FftChain::from_cc)
 		dim3 grid((nm+31)/32, (nr+31)/32, nc);
 		hipLaunchKernelGGL(transpose_mul_outcol, grid, dim3(256), sizeof(double2)*32*33, st, leg, (double2*)p->hbuf.p, nr, nm,
-			(long)nr*nm, (long)nr*nm, (const double2*)p->phase.p, 1, 1.0);
+			(long)nm*ldleg, (long)nr*ldh, (const double2*)p->phase.p, 1, 1.0, ldleg, ldh);
+	}
+	if (p->chain_rings) {
+		p->chain->h2map(st, p->hbuf.as<double2>(), ldh, p->map_desc(map, map_dtype, map_cstride), nc, p->mmax);
+		p->prof.end(st, PXS_STAGE_RING_FFT);
+		return;
 	}
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	if (2L*p->mmax < p->nphi && p->ring_pairs) {
@@ -651,6 +688,14 @@ int pxs_plan_chain(pxs_plan* p, int at, pxs_plan* other, int which) {
 	PXS_CATCH
 }
 
+/* planner of the fused theta chains (diagnostics / tests): out = {ok, g, bN, g2, M, ac, Ncc, gs, bs, aNs} */
+int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out) {
+	const ThetaPlan t = FftChain::plan_theta(N, lmax);
+	const int64_t v[10] = {t.ok, t.g, t.bN, t.g2, t.M, t.ac, t.Ncc, t.gs, t.bs, t.aNs};
+	for (int i = 0; i < 10; i++) out[i] = v[i];
+	return 0;
+}
+
 int pxs_plan_option(pxs_plan* p, const char* key, int64_t value) {
 	PXS_TRY
 	PXS_REQUIRE(p && key, "pxs_plan_option: null argument");
@@ -680,30 +725,43 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
 	const int ncm = ncomp_of(spin, mode, false);
-	const int nm = p->mmax+1;
+	const int nm = p->mmax+1, nr = p->nring;
 	LegTables& tb = p->table(spin);
-	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*p->nring);
+	const bool th = p->chain_theta();
+	const long ldm = p->chain_rings ? FftChain::pad8(nr) : nr;
+	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*ldm);
 	hook_start(p, st);
-	bool via_h = false;
 	if (!adjoint) {
 		hook_before_leg(p, st);
 		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
-			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*p->ncc);
-			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+			const long ldc = p->ld_cc();
+			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*ldc);
+			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldc);
 			hook_after_leg(p, st);
-			static const bool fuse = [] { const char* e = getenv("PXS_FUSE_SPLIT"); return e ? atoi(e) != 0 : true; }();
-			via_h = fuse;
-			if (via_h) p->hbuf.ensure(sizeof(double2)*(size_t)ncm*p->nring*nm);
-			resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin, via_h ? p->hbuf.as<double2>() : nullptr);
+			if (th) {	// fused chain: CC grid -> ring spectra of the map's rings, written ring-major for the ring FFT
+				const long ldh = p->ld_h();
+				p->hbuf.ensure(sizeof(double2)*(size_t)ncm*nr*ldh);
+				p->prof.begin(st, PXS_STAGE_RESAMPLE);
+				p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, ncm, nm, spin, p->lmax,
+					p->ph_up.as<double2>(), p->phase.as<double2>(), 1.0/(double)p->Ncc);
+				p->prof.end(st, PXS_STAGE_RESAMPLE);
+				leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, ncm, true);
+			} else {
+				static const bool fuse = [] { const char* e = getenv("PXS_FUSE_SPLIT"); return e ? atoi(e) != 0 : true; }();
+				const bool via_h = fuse && !p->chain_rings;     // (the unfused transposing split writes dense h rows)
+				if (via_h) p->hbuf.ensure(sizeof(double2)*(size_t)ncm*nr*nm);
+				resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin, via_h ? p->hbuf.as<double2>() : nullptr);
+				leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, ncm, via_h);
+			}
 		} else {
-			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof);
+			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldm);
 			hook_after_leg(p, st);
+			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, ncm);
 		}
-		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, ncm, via_h);
 	} else {
-		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0);
+		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0, ldm);
 		hook_before_leg(p, st);
-		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1, &p->prof);
+		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1, &p->prof, ldm);
 		hook_after_leg(p, st);
 	}
 	PXS_CATCH
@@ -721,24 +779,31 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint,
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
 	const int nc = spin == 0 ? 1 : 2;
-	const int nm = p->mmax+1;
+	const int nm = p->mmax+1, nr = p->nring;
 	LegTables& tb = p->table(spin);
-	p->leg.ensure(sizeof(double2)*(size_t)nc*nm*p->nring);
-	p->leg2.ensure(sizeof(double2)*(size_t)nc*nm*p->ncc);
+	const bool th = p->chain_theta() && !adjoint;       // (the adjoint of the analysis runs the unfused chain, dense rows)
+	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
+	p->leg.ensure(sizeof(double2)*(size_t)nc*nm*ldm);
+	p->leg2.ensure(sizeof(double2)*(size_t)nc*nm*ldc);
 	hook_start(p, st);
 	if (!adjoint) {
-		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0);
-		resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
+		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0, ldm);
+		if (th) {
+			p->prof.begin(st, PXS_STAGE_RESAMPLE);
+			p->chain->to_cc(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>());
+			p->prof.end(st, PXS_STAGE_RESAMPLE);
+		} else resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
 		hook_before_leg(p, st);
-		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof);
+		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc);
 		hook_after_leg(p, st);
 	} else {
 		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
 		hook_before_leg(p, st);
-		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof);
+		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof, ldc);
 		hook_after_leg(p, st);
 		resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin);
-		leg2map(p, st, p->leg.as<double2>(), map, map_dtype, map_cstride, nc);
+		leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, nc);
 	}
 	PXS_CATCH
 }
