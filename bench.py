@@ -1,15 +1,22 @@
 #!/usr/bin/env python
 """bench.py -- map2alm + alm2map round trips/s on MI355X (BASELINE.json metric).
 
-One step = curvedsky.map2alm(map, lmax, spin=[0,2]) followed by curvedsky.alm2map(alm, map, spin=[0,2])
-on a device-resident T/Q/U CAR (Fejer-1) map.  Inputs are synthetic band-limited Gaussian maps made
-on the GPU before the timed region.  With N>1 every rank transforms its own map (weak
-scaling, no data-path collective) and the per-step alm are all-gathered over RCCL on a side stream,
-overlapped with the next step.
+One step = curvedsky.map2alm(map, lmax, spin) followed by curvedsky.alm2map(alm, map, spin) on device-resident
+float64 data.  Inputs are synthetic band-limited Gaussian maps made on the GPU before the timed region.
 
-Prints ONE JSON line on rank 0 (see the driver contract); human-readable detail goes to stderr.
-  --config c3 (default): 3x(21600x43200), lmax=10000   -- the configuration the metric is quoted on
-  --config c2: 3x(5400x10800), lmax=4000;  c1: 1x(1024x2048), lmax=512;  ref: 1x(900x1800), lmax=750
+  --config c3 (default)  3x(21600x43200) T/Q/U, lmax 10000: the configuration the metric is quoted on.  With N > 1 every
+                         rank transforms its own map (weak scaling, no data-path collective) and the alm of each step are
+                         all-gathered over RCCL on a side stream, overlapped with the synthesis.
+  --config c4            BASELINE config 4: 64 independent 1x(5400x10800) maps, lmax 4000, sharded contiguously over the
+                         ranks (strong scaling: 64/N maps per GPU, one batched call per direction), RCCL all-gather of the alm.
+  --config c2 / c1 / ref 3x(5400x10800) lmax 4000 / 1x(1024x2048) lmax 512 / the reference's benchmark shape 1x(900x1800) lmax 750
+
+Prints ONE JSON line on rank 0 (driver contract); human-readable detail goes to stderr.  Besides the contract fields:
+  roofline      the dominant kernel family (Legendre, FP64 FMA) from hipEvent stage timers inside the library
+  fft_chain     the HBM-bound kernel family of the step (ring FFTs + theta resampling): algorithmic bytes / time / 8 TB/s
+  fft           enmap.fft / ifft of one map component on the GPU with numpy.fft.fftn on the host cores beside it (N = 1)
+  h2d_inclusive the round trip with the PCIe transfers of map and alm added (measured pinned-memory rate; never `value`)
+  cpu_baseline  oracle/sht_port.c (+ scipy.fft) on a bounded sample on the host cores, or ducc0 itself when importable
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -21,6 +28,7 @@ CONFIGS = {
 	"c1":  dict(ncomp=1, shape=(1024, 2048),   lmax=512,   spin=[0],    name="C1 1x(1024x2048) lmax=512 spin0"),
 	"c2":  dict(ncomp=3, shape=(5400, 10800),  lmax=4000,  spin=[0, 2], name="C2 3x(5400x10800) T/Q/U lmax=4000 spin0/2"),
 	"c3":  dict(ncomp=3, shape=(21600, 43200), lmax=10000, spin=[0, 2], name="C3 3x(21600x43200) T/Q/U lmax=10000 spin0/2"),
+	"c4":  dict(ncomp=1, shape=(5400, 10800),  lmax=4000,  spin=[0],    name="C4 64x[1x(5400x10800)] independent maps, lmax=4000 spin0", nbatch_total=64),
 	"ref": dict(ncomp=1, shape=(900, 1800),    lmax=750,   spin=[0],    name="reference benchmark shape 1x(900x1800) lmax=750"),
 }
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
@@ -31,46 +39,85 @@ def log(*a):
 
 def nalm(lmax): return (lmax+1)*(lmax+2)//2
 
-def alg_flops_direction(cfg, R):
-	"""F_alg = (4 n0 + 12 n2) R nalm per direction"""
+def alg_flops_direction(cfg, R, nmaps=1):
+	"""F_alg = (4 n0 + 12 n2) R nalm per direction (per map)"""
 	n0 = sum(1 for s in cfg["spin"] if s == 0); n2 = sum(1 for s in cfg["spin"] if s != 0)
-	return (4*n0+12*n2)*R*nalm(cfg["lmax"])
+	return nmaps*(4*n0+12*n2)*R*nalm(cfg["lmax"])
 
-def make_alm(cfg, seed, device):
+def chain_alg_bytes(cfg, ncc, nmaps=1):
+	"""algorithmic bytes of the FFT stages per direction (complex128 ring spectra): ring FFT = map + leg on the map's rings,
+	theta resampling = leg on the map's rings + leg on the CC grid (when the plan resamples)"""
+	ny, nx = cfg["shape"]; nm = cfg["lmax"]+1; nc = cfg["ncomp"]*nmaps
+	ring = nc*(ny*nx*8+nm*ny*16)
+	theta = nc*(nm*ny*16+nm*ncc*16) if ncc < ny else 0
+	return ring+theta
+
+def make_alm(cfg, seed, device, ncomp=None):
 	"""white Gaussian alm with C_l = 1/(l+1)^2 (T), 0.01 C_l (E,B); m=0 real (SURVEY 8d recipe), on the GPU"""
 	import torch
-	lmax = cfg["lmax"]; n = nalm(lmax)
+	lmax = cfg["lmax"]; n = nalm(lmax); ncomp = cfg["ncomp"] if ncomp is None else ncomp
 	g = torch.Generator(device=device); g.manual_seed(seed)
-	re = torch.randn((cfg["ncomp"], n), generator=g, device=device, dtype=torch.float64)
-	im = torch.randn((cfg["ncomp"], n), generator=g, device=device, dtype=torch.float64)
+	re = torch.randn((ncomp, n), generator=g, device=device, dtype=torch.float64)
+	im = torch.randn((ncomp, n), generator=g, device=device, dtype=torch.float64)
 	alm = torch.complex(re, im)/np.sqrt(2)
-	# l of each element in the triangular layout
 	m_of = torch.repeat_interleave(torch.arange(lmax+1, device=device), torch.arange(lmax+1, 0, -1, device=device))
-	mstart = (m_of*(2*lmax+1-m_of))//2
-	l_of = torch.arange(n, device=device)-mstart
+	l_of = torch.arange(n, device=device)-(m_of*(2*lmax+1-m_of))//2
 	alm = alm/(l_of+1.0)
 	alm[:, :lmax+1] = alm[:, :lmax+1].real*np.sqrt(2)+0j
-	if cfg["ncomp"] == 3:
+	if len(cfg["spin"]) > 1 and ncomp == 3:
 		alm[1:] *= 0.1
 		alm[1:, l_of < 2] = 0
 	return alm
 
+def probe_ducc0():
+	"""say whether the real reference kernel library is on the box"""
+	try:
+		import ducc0
+		return dict(available=True, version=getattr(ducc0, "__version__", "?"))
+	except Exception as e:
+		return dict(available=False, reason="%s: %s" % (type(e).__name__, e))
+
+def ducc0_baseline(cfg, budget_s=30.0):
+	"""ducc0.sht.experimental.analysis_2d + synthesis_2d on all host cores (only when ducc0 imports and one round trip fits the budget)"""
+	import ducc0
+	ny, nx = cfg["shape"]; lmax = cfg["lmax"]
+	if 1e-9*cfg["ncomp"]*ny*lmax*lmax > 50*budget_s: return None          # rough flop estimate: skip configs that would take minutes
+	rng = np.random.default_rng(0); nthr = os.cpu_count()
+	t_tot = 0.0
+	for s in cfg["spin"]:
+		nc = 1 if s == 0 else 2
+		alm = (rng.standard_normal((nc, nalm(lmax)))+1j*rng.standard_normal((nc, nalm(lmax))))
+		alm[:, :lmax+1] = alm[:, :lmax+1].real
+		m = np.zeros((nc, ny, nx))
+		t0 = time.perf_counter()
+		ducc0.sht.experimental.synthesis_2d(alm=alm, map=m, spin=s, lmax=lmax, geometry="F1", nthreads=nthr)
+		ducc0.sht.experimental.analysis_2d(alm=alm, map=m, spin=s, lmax=lmax, geometry="F1", nthreads=nthr)
+		t_tot += time.perf_counter()-t0
+	return dict(value=round(1.0/t_tot, 6), unit="round-trips/s", cores=nthr, kind="reference", seconds_per_round_trip=round(t_tot, 3),
+		sample="ducc0 %s synthesis_2d + analysis_2d, full workload, nthreads=%d" % (getattr(ducc0, "__version__", "?"), nthr))
+
 def cpu_baseline(cfg, budget_s=20.0):
-	"""CPU port (the oracle) timed on a bounded sample of the same workload on the host cores."""
+	"""ducc0 when it is importable (kind 'reference'), otherwise the CPU port (the oracle, kind 'port') on a bounded sample"""
+	if probe_ducc0()["available"]:
+		try:
+			r = ducc0_baseline(cfg)
+			if r is not None: return r
+		except Exception as e: log("ducc0 baseline failed: %r" % (e,))
 	from oracle import sht_port
 	return sht_port.time_sample(cfg, budget_s)
 
 def measured_traffic(config, dom):
-	"""HBM bytes of the dominant Legendre direction per step, from the committed PMC passes
-	(tools/pmc_traffic.sh -> profiles/r01_traffic_<config>.json; FETCH_SIZE doubled per the gfx950 note in
-	MI355X_MICROARCH.md, WRITE_SIZE as reported).  Counters cannot be read from inside this process, so this
-	is the figure of the profiled run of the same command, or null when no profile of this config is committed."""
-	path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_%s.json" % config)
-	if not os.path.exists(path): return dict(traffic=None)
+	"""HBM bytes of a kernel family per step from the committed PMC passes of this bench command (tools/pmc_traffic.sh ->
+	profiles/r02_traffic_<config>.json; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported).
+	Counters cannot be read from inside this process: null when no profile of this config is committed."""
+	for tag in ("r02", "r01"):
+		path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config))
+		if os.path.exists(path): break
+	else: return dict(traffic=None)
 	try:
 		d = json.load(open(path)); tot = 0.0; raw = 0.0
 		for k, v in d["kernels"].items():
-			if not k.startswith("pxs::"+dom): continue
+			if not any(k.startswith("pxs::"+p) for p in dom): continue
 			n = v["launches_per_round_trip"]
 			tot += n*(v["fetch_MB_per_launch_x2"]+v["write_MB_per_launch"]); raw += n*(v["fetch_MB_per_launch_raw"]+v["write_MB_per_launch"])
 		return dict(traffic=round(tot*2**20), traffic_unit="bytes per step, all launches of the kernel family",
@@ -78,14 +125,52 @@ def measured_traffic(config, dom):
 	except Exception as e:
 		log("traffic profile unreadable: %r" % (e,)); return dict(traffic=None)
 
+def fft_block(dmap_comp, enmap, torch, reps=3):
+	"""enmap.fft / ifft (2-D, last two axes) of one map component on the GPU; numpy.fft.fftn (the reference's always-available
+	numpy engine, pixell/fft.py:8-31) on a bounded sample on the host beside it.  B = bytes of the user arrays read + written."""
+	ny, nx = dmap_comp.shape[-2:]
+	def timed(fn):
+		out = fn(); torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		for _ in range(reps): out = fn()
+		torch.cuda.synchronize()
+		return (time.perf_counter()-t0)/reps, out
+	fbuf = enmap.dmap(torch.empty(dmap_comp.shape, dtype=torch.complex128, device=dmap_comp.tensor.device), dmap_comp.wcs)
+	gbuf = enmap.dmap(torch.empty_like(fbuf.tensor), dmap_comp.wcs)     # outputs preallocated: the timing is the transform, not hipMalloc
+	t_r2c, f = timed(lambda: enmap.fft(dmap_comp, omap=fbuf))
+	b_r2c = ny*nx*(8+16)
+	t_c2c, g = timed(lambda: enmap.ifft(f, omap=gbuf))
+	b_c2c = ny*nx*32
+	err = float((g.tensor.real-dmap_comp.tensor).abs().max()/dmap_comp.tensor.abs().max())
+	del f, g, fbuf, gbuf
+	# host: numpy.fft.fftn of a block of the same aspect ratio (a few seconds of work at most)
+	sy, sx = max(8, ny//8), max(16, nx//8)
+	x = np.random.default_rng(0).standard_normal((sy, sx))
+	t0 = time.perf_counter(); np.fft.fftn(x, axes=(-2, -1)); t_np = time.perf_counter()-t0
+	return dict(shape=[ny, nx], real_to_complex_ms=round(t_r2c*1e3, 3), real_to_complex_GBps=round(b_r2c/t_r2c/1e9, 1),
+		complex_to_complex_ms=round(t_c2c*1e3, 3), complex_to_complex_GBps=round(b_c2c/t_c2c/1e9, 1),
+		frac_of_8TBps=round(b_c2c/t_c2c/1e9/HBM_PEAK_GBS, 4), roundtrip_max_error=err,
+		note="both axes exceed the LDS (160 KiB = 10240 complex128 points): each axis is a two-pass four-step transform, i.e. 4 reads + 4 writes of the array per 2-D transform against the 1 + 1 the algorithmic byte count credits",
+		cpu_baseline=dict(kind="reference", engine="numpy.fft.fftn (pixell.fft numpy engine)", cores=1, sample="%dx%d float64 block" % (sy, sx),
+			seconds=round(t_np, 4), GBps=round(sy*sx*24/t_np/1e9, 3)))
+
+def pcie_rates(torch, device, nbytes=1 << 31):
+	"""pinned host <-> device copy rates in GB/s"""
+	host = torch.empty(nbytes//8, dtype=torch.float64).pin_memory()
+	dev = torch.empty(nbytes//8, dtype=torch.float64, device=device)
+	dev.copy_(host, non_blocking=True); torch.cuda.synchronize()
+	t0 = time.perf_counter(); dev.copy_(host, non_blocking=True); torch.cuda.synchronize(); h2d = nbytes/(time.perf_counter()-t0)/1e9
+	t0 = time.perf_counter(); host.copy_(dev, non_blocking=True); torch.cuda.synchronize(); d2h = nbytes/(time.perf_counter()-t0)/1e9
+	return h2d, d2h
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-	ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-	ap.add_argument("--no-gather", action="store_true", help="skip the final alm all-gather (N>1)")
+	ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / fft / h2d legs")
+	ap.add_argument("--no-gather", action="store_true", help="skip the alm all-gather (N>1)")
 	args = ap.parse_args()
 	import torch
 	import torch.distributed as dist
@@ -100,59 +185,59 @@ def main():
 	if world > 1:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 		dist.init_process_group(backend)
-	from pixell_amd import curvedsky, enmap, sht
+	from pixell_amd import curvedsky, enmap, sht, dist as pdist
 	cfg = CONFIGS[args.config]
-	lmax = cfg["lmax"]; ny, nx = cfg["shape"]; ncomp = cfg["ncomp"]
+	batched = "nbatch_total" in cfg
+	ntot = int(os.environ.get("PXS_BENCH_NBATCH", cfg.get("nbatch_total", 0))) if batched else 0     # (smaller batches for rehearsals)
 	# memory check: fall back to the largest configuration that fits
 	free, total = torch.cuda.mem_get_info()
-	need = {"c3": 150e9, "c2": 12e9, "c1": 1e9, "ref": 1e9}[args.config]
+	need = {"c3": 130e9, "c4": 1.5e9*max(1, ntot//world)+12e9, "c2": 12e9, "c1": 1e9, "ref": 1e9}[args.config]
 	if free < need:
 		log("config %s needs ~%.0f GB, only %.0f GB free: falling back to c2" % (args.config, need/1e9, free/1e9))
-		cfg = CONFIGS["c2"]; args.config = "c2"; lmax = cfg["lmax"]; ny, nx = cfg["shape"]; ncomp = cfg["ncomp"]
+		cfg = CONFIGS["c2"]; args.config = "c2"; batched = False
+	lmax = cfg["lmax"]; ny, nx = cfg["shape"]; ncomp = cfg["ncomp"]
+	if batched:
+		lo, hi = pdist.shard_range(ntot, rank, world)       # contiguous shard of the batch axis
+		nmaps = hi-lo
+	else: lo, nmaps = rank, 1
 	shape, wcs = enmap.fullsky_geometry(shape=(ny, nx))
 	ainfo = curvedsky.alm_info(lmax)
 	t0 = time.time()
-	alm_in = make_alm(cfg, 1000+rank, device)
-	dmap = enmap.dmap(torch.zeros((ncomp, ny, nx), dtype=torch.float64, device=device), wcs)
+	ncomp_all = ncomp*nmaps
+	alm_in = torch.cat([make_alm(cfg, 1000+lo+i, device) for i in range(nmaps)], 0) if batched else make_alm(cfg, 1000+rank, device)
+	dmap = enmap.dmap(torch.zeros((ncomp_all, ny, nx), dtype=torch.float64, device=device), wcs)
 	curvedsky.alm2map(alm_in, dmap, spin=cfg["spin"], ainfo=ainfo)      # synthetic band-limited input (also builds plans)
 	alm_out = torch.zeros_like(alm_in)
 	curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo)
 	torch.cuda.synchronize()
 	rt_err = float((alm_out-alm_in).abs().pow(2).mean().sqrt()/alm_in.abs().pow(2).mean().sqrt())
-	log("[rank %d] setup %.1fs; round-trip rms error %.2e" % (rank, time.time()-t0, rt_err))
+	log("[rank %d] setup %.1fs; %d map(s); round-trip rms error %.2e" % (rank, time.time()-t0, nmaps, rt_err))
 	# north_star: alm must come back to < 1e-8 relative rms.  A throughput number of a transform that does not is worthless.
 	if not (rt_err < 1e-8) and not os.environ.get("PXS_BENCH_NOCHECK"): raise SystemExit("bench.py: round-trip rms error %.3e exceeds 1e-8 -- refusing to time a wrong transform" % rt_err)
 	minfo = curvedsky.analyse_geometry(dmap.shape, wcs)
-	# curvedsky runs the spin groups of a map on two streams with a plan each ("lanes"): stage timers are summed over both
-	nlanes = 2 if (len(list(enmap.spin_helper(cfg["spin"], ncomp))) > 1 and os.environ.get("PIXELL_AMD_LANES", "1") != "0") else 1
-	plans = [sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1, lane=l) for l in range(nlanes)]   # (lane 1: scalar group, lane 0: spin group)
-	plan = plans[0]
+	plan = sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1)
 	info = plan.info()
-	gather_buf = None; side = None
+	gather = None; side = None; ranks_seen = None
 	if world > 1 and not args.no_gather:
-		gather_buf = torch.empty((world,)+tuple(alm_out.shape), dtype=alm_out.dtype, device=device)
+		rows = [ncomp*(pdist.shard_range(ntot, r, world)[1]-pdist.shard_range(ntot, r, world)[0]) for r in range(world)] if batched else [ncomp]*world
+		gather = pdist.AlmGather(alm_out, rows, device, backend)
 		side = torch.cuda.Stream(device=device)
+		seen = [None]*world; dist.all_gather_object(seen, (rank, torch.cuda.get_device_name(local)))
+		ranks_seen = len({r for r, _ in seen})
 
 	def step():
 		curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo)
-		if gather_buf is not None:
+		if gather is not None:
 			ev = torch.cuda.Event(); ev.record()
 			side.wait_event(ev)
-			with torch.cuda.stream(side):
-				if backend == "nccl":
-					dist.all_gather_into_tensor(gather_buf.view(torch.float64).view(world, -1), alm_out.view(torch.float64).view(-1))
-				else:   # rehearsal: gloo has no device all-gather
-					side.synchronize()
-					host = [torch.empty(alm_out.shape, dtype=alm_out.dtype) for _ in range(world)]
-					dist.all_gather(host, alm_out.cpu())
-					for r in range(world): gather_buf[r].copy_(host[r])
+			with torch.cuda.stream(side): gather.run(alm_out, side)
 		curvedsky.alm2map(alm_out, dmap, spin=cfg["spin"], ainfo=ainfo)
-		if gather_buf is not None: torch.cuda.current_stream().wait_stream(side)   # alm_out is rewritten by the next step
+		if gather is not None: torch.cuda.current_stream().wait_stream(side)   # alm_out is rewritten by the next step
 
 	for _ in range(args.warmup): step()
 	torch.cuda.synchronize()
 	if world > 1: dist.barrier()
-	for p_ in plans: p_.profile(True)
+	plan.profile(True)
 	torch.cuda.synchronize()
 	t0 = time.perf_counter()
 	for _ in range(args.steps): step()
@@ -160,51 +245,64 @@ def main():
 	if world > 1: dist.barrier()
 	torch.cuda.synchronize()
 	dt = time.perf_counter()-t0
-	prof = {}
-	for p_ in plans:
-		for k_, v_ in p_.profile_read(reset=True).items():
-			a_ = prof.get(k_, (0.0, 0)); prof[k_] = (a_[0]+v_[0], a_[1]+v_[1])
-		p_.profile(False)
+	prof = plan.profile_read(reset=True); plan.profile(False)
 	if world > 1:
 		t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 	ms_step = dt/args.steps*1e3
-	value = world*args.steps/dt
+	maps_total = ntot if batched else world
+	value = maps_total*args.steps/dt
 
-	# ---- roofline of the dominant kernel (Legendre; FP64 FMA bound) ----
+	# ---- roofline of the dominant kernel family (Legendre; FP64 FMA bound) ----
 	R_syn, R_ana = info["nring_syn"], info["nring_ana"]
 	R_alg = min(ny, lmax+2)
-	stages = {k: (v[0]/max(v[1], 1), v[1], v[0]) for k, v in prof.items()}
-	# per launch algorithmic flops: a Legendre launch handles one spin group (1 comp spin 0 / 2 comps spin s)
-	n_launch_per_step = len(cfg["spin"])
 	dom = "leg_ana" if prof["leg_ana"][0] >= prof["leg_syn"][0] else "leg_syn"
-	dom_ms_total = prof[dom][0]
-	flops_dir = alg_flops_direction(cfg, R_alg)                 # all spin groups of one direction
-	dom_ms_per_step = dom_ms_total/args.steps
+	flops_dir = alg_flops_direction(cfg, R_alg, nmaps)             # all spin groups / maps of one direction on this rank
+	dom_ms_per_step = prof[dom][0]/args.steps
 	achieved = flops_dir/(dom_ms_per_step*1e-3)/1e12 if dom_ms_per_step > 0 else 0.0
-	roof = dict(bound="mfma", pipe="fp64 vector FMA (f64 MFMA dense peak is the same 78.6 TF; kernel uses v_fma_f64)",
-		kernel="leg_ana_* (Legendre analysis, all spin groups of a step)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis, all spin groups of a step)",
+	roof = dict(bound="mfma", pipe="FP64 vector FMA (v_fma_f64): the contraction is 4 right-hand sides wide per map, too narrow for the 16x16x4 f64 MFMA, whose dense peak equals the vector peak",
+		kernel="leg_ana_* (Legendre analysis, all launches of a step)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis, all launches of a step)",
 		achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved/FP64_PEAK_TFLOPS, 4), traffic=None,
 		algorithmic_flops_per_step_direction=flops_dir, kernel_ms_per_step=round(dom_ms_per_step, 3),
 		launches_per_step=prof[dom][1]//max(args.steps, 1), R_algorithmic=R_alg, R_actual_syn=R_syn, R_actual_ana=R_ana)
-	roof.update(measured_traffic(args.config, dom))
-	map_bytes = ncomp*ny*nx*8; alm_bytes = ncomp*nalm(lmax)*16
-	hbm_gbs = 2*(map_bytes+alm_bytes)/(ms_step*1e-3)/1e9
+	roof.update(measured_traffic(args.config, [dom]))
+	# ---- the HBM-bound family: ring FFTs + theta resampling (fused chains, csrc/fftchain.hip) ----
+	chain_ms = (prof["ring_fft"][0]+prof["resample"][0])/args.steps
+	chain_bytes = 2*chain_alg_bytes(cfg, R_ana, nmaps)           # both directions
+	chain = dict(bound="hbm", kernel="chain_kernel<*> (ring FFTs map<->leg and theta resampling leg<->leg_cc, both directions)",
+		achieved=round(chain_bytes/(chain_ms*1e-3)/1e9, 1) if chain_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
+		algorithmic_bytes_per_step=chain_bytes, kernel_ms_per_step=round(chain_ms, 3))
+	chain["frac"] = round(chain["achieved"]/HBM_PEAK_GBS, 4)
+	chain.update(measured_traffic(args.config, ["chain_kernel", "transpose", "fft_lds", "split_pair", "unpack", "fold"]))
+	map_bytes = ncomp_all*ny*nx*8; alm_bytes = ncomp_all*nalm(lmax)*16
+	tot_bytes = (ntot*ncomp*(ny*nx*8+nalm(lmax)*16)) if batched else world*(map_bytes+alm_bytes)
+	hbm_gbs = 2*tot_bytes/(ms_step*1e-3)/1e9
 	res = dict(metric="map2alm+alm2map round-trips/sec", value=round(value, 4), unit="round-trips/s", n_gpus=world, steps=args.steps,
-		warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
-		data="synthetic", config=dict(workload=cfg["name"], geometry="CAR fejer1 %dx%d" % (ny, nx), lmax=lmax, spin=cfg["spin"],
-			maps_per_gpu=1, parallelism="independent maps per GPU; RCCL all-gather of alm" if world > 1 else "single GPU"),
-		roofline=roof,
-		stage_ms_per_step={k: round(v[2]/args.steps, 3) for k, v in stages.items()},
-		stage_note=("the scalar and the spin group of the map run on two streams: event-bracketed stage times overlap and add up to more than ms_per_step"
-			if nlanes > 1 else "stages run back to back on one stream"),
+		warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="strong" if batched else "weak", vs_baseline=None, dtype="f64",
+		data="synthetic", config=dict(workload=cfg["name"] if not batched or ntot == cfg["nbatch_total"] else cfg["name"].replace("64x", "%dx" % ntot),
+			geometry="CAR fejer1 %dx%d" % (ny, nx), lmax=lmax, spin=cfg["spin"], maps_per_gpu=nmaps, maps_total=maps_total,
+			parallelism=("independent maps sharded contiguously over the ranks; RCCL all-gather of alm" if world > 1 else "single GPU")),
+		roofline=roof, fft_chain=chain,
+		stage_ms_per_step={k: round(v[0]/args.steps, 3) for k, v in prof.items()},
+		stage_note="stages run back to back on one stream (hipEvent-bracketed inside the library)",
 		hbm_algorithmic_GBps=round(hbm_gbs, 1), hbm_frac_of_8TBps=round(hbm_gbs/HBM_PEAK_GBS, 5),
-		roundtrip_rms_error=rt_err)
+		roundtrip_rms_error=rt_err, ducc0=probe_ducc0())
+	if ranks_seen is not None: res["rccl_ranks_seen"] = ranks_seen; res["collective"] = gather.describe()
 	if rank == 0:
 		log("stage ms/step:", res["stage_ms_per_step"], " total %.1f ms/step" % ms_step)
 		if not args.no_cpu and world == 1:
 			try:
-				res["cpu_baseline"] = cpu_baseline(cfg)
+				h2d, d2h = pcie_rates(torch, device)
+				t_io = (map_bytes+alm_bytes)/(h2d*1e9)+(map_bytes+alm_bytes)/(d2h*1e9)    # map in + alm out, alm in + map out
+				res["h2d_inclusive"] = dict(ms_per_step=round(ms_step+t_io*1e3, 1), value=round(maps_total/((ms_step*1e-3)+t_io), 4), unit="round-trips/s",
+					pcie_h2d_GBps=round(h2d, 1), pcie_d2h_GBps=round(d2h, 1), note="GPU step + (map + alm bytes) in each direction at the pinned-memory copy rate measured on 2 GiB; host-buffer callers pay this, it is never `value`")
+			except Exception as e: log("pcie probe failed: %r" % (e,))
+			try:
+				del alm_in; torch.cuda.empty_cache()
+				res["fft"] = fft_block(enmap.dmap(dmap.tensor[:1], wcs), enmap, torch)
+			except Exception as e: log("fft block failed: %r" % (e,)); res["fft"] = None
+			try:
+				res["cpu_baseline"] = cpu_baseline(dict(cfg, ncomp=ncomp))
 			except Exception as e:   # the baseline must never take the GPU number down with it
 				log("cpu_baseline failed: %r" % (e,)); res["cpu_baseline"] = None
 		print(json.dumps(res), flush=True)

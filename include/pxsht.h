@@ -80,21 +80,17 @@ int pxs_grid_maxlmax(const char* geometry, int ntheta);
 /* number of Legendre rings the plan iterates (R_actual of SURVEY 8d) for synthesis / analysis */
 int pxs_plan_info(const pxs_plan* plan, int* nring_legendre_syn, int* nring_legendre_ana, int64_t* scratch_bytes);
 
+/* Sizes the planner of the fused FFT chains picks for a theta circle of N samples and band limit lmax (diagnostics, tests):
+ * out[10] = {ok, g, bN, g2, M, ac, Ncc, gs, bs, aNs} with N = g*bN, M = g*g2 (fine circle of the |sin| product), Ncc = ac*g
+ * (Clenshaw-Curtis circle: Ncc/2+1 rings in the Legendre stage), synthesis: Ncc = gs*bs, N = aNs*gs.  See csrc/fftchain.hip. */
+int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out);
+
 /* Optional device-side stage timers (hipEvents recorded on the launch stream around each stage):
  * used by bench.py to time the dominant kernel live.  ms[PXS_NSTAGE], counts[PXS_NSTAGE]. */
 #define PXS_STAGE_LEG_SYN  0   /* Legendre synthesis kernel (alm2leg) */
 #define PXS_STAGE_LEG_ANA  1   /* Legendre analysis kernel (leg2alm) */
 #define PXS_STAGE_RING_FFT 2   /* ring FFTs + transposes (map2leg / leg2map) */
-#define PXS_STAGE_RESAMPLE 3   /* Ordering between two plans whose transforms are issued on DIFFERENT streams (one plan per stream; a plan owns its scratch).
- * Every pxs_synthesis / pxs_analysis call records two events of its plan on its stream: "before the Legendre stage" (which 0)
- * and "after the Legendre stage" (which 1).  pxs_plan_chain makes the NEXT call on `plan` wait for `other`'s event, either at
- * its start (at 0) or just before its own Legendre stage (at 1).  Issue the call on `other` first.  Used to run the memory-bound
- * stages (ring FFT, theta resampling) of one spin group while the FP64-bound Legendre stage of another one runs. */
-int pxs_plan_chain(pxs_plan* plan, int at, pxs_plan* other, int which);
-/* tuning knobs of a plan: "fft_threads" = 0 (automatic), 128, 256 or 512 threads per FFT workgroup for this plan's transforms */
-int pxs_plan_option(pxs_plan* plan, const char* key, int64_t value);
-
-/* theta resampling FFT chain */
+#define PXS_STAGE_RESAMPLE 3   /* theta resampling between the map's rings and the Clenshaw-Curtis grid */
 #define PXS_NSTAGE 4
 int pxs_profile(pxs_plan* plan, int enable);
 int pxs_profile_read(pxs_plan* plan, double* ms, int* counts, int reset);

@@ -70,7 +70,7 @@ def pixels_on_rings(leg, phi):
 			out[c, r] = np.real(leg[:, c, r] @ ph)        # (F_0 enters with its real part only)
 	return out
 
-def theta_resample(L, par, geometry, ntheta, lmax):
+def theta_resample(L, par, geometry, ntheta, lmax, workers=None):
 	"""Exact |sin|-weighted integration of the theta-interpolant, as samples on a CC grid.
 
 	L[ncol, ntheta]: ring values of one m column each (any complex numbers: NOT required to be band limited);
@@ -81,6 +81,11 @@ def theta_resample(L, par, geometry, ntheta, lmax):
 	about theta0, as sht_oracle._interp_matrix has it) and f_par its part of parity `par`."""
 	L = np.atleast_2d(np.asarray(L, np.complex128)); ncol = L.shape[0]
 	par = np.asarray(par, int).reshape(ncol)
+	if workers:          # threaded pocketfft (bench.py's cpu_baseline); numpy's otherwise
+		import scipy.fft as sfft
+		fft = lambda a, n=None, axis=-1: sfft.fft(a, n=n, axis=axis, workers=workers)
+		ifft = lambda a, n=None, axis=-1: sfft.ifft(a, n=n, axis=axis, workers=workers)
+	else: fft, ifft = np.fft.fft, np.fft.ifft
 	g = so.grid_info(geometry, ntheta); N, c = g["N"], g["c"]; th0 = float(g["theta0"])
 	# parity extension to the N full-circle samples
 	ring = np.array([so._ring_of(jp, N, c, ntheta) for jp in range(N)])
@@ -88,7 +93,7 @@ def theta_resample(L, par, geometry, ntheta, lmax):
 	sign = np.where(mirrored[None, :] & (par[:, None] == 1), -1.0, 1.0)
 	f = L[:, ring]*sign                                             # [ncol, N]
 	# interpolant spectrum c_k, |k| <= N/2 (index k + K2)
-	F = np.fft.fft(f, axis=1)/N
+	F = fft(f, axis=1)/N
 	K2 = N//2
 	k = np.arange(-K2, K2+1)
 	cspec = F[:, k % N]*np.exp(-1j*k*th0)[None, :]
@@ -103,7 +108,7 @@ def theta_resample(L, par, geometry, ntheta, lmax):
 	# full convolution via zero-padded FFTs
 	nconv = cspec.shape[1]+len(s)-1
 	nf = _good_even(nconv)
-	H = np.fft.ifft(np.fft.fft(cspec, nf, axis=1)*np.fft.fft(s, nf)[None, :], axis=1)[:, :nconv]
+	H = ifft(fft(cspec, nf, axis=1)*np.fft.fft(s, nf)[None, :], axis=1)[:, :nconv]
 	# index i of H <-> k = i - K2 - Q
 	h = H[:, (np.arange(-lmax, lmax+1)+K2+Q)]                       # [ncol, 2 lmax + 1]
 	# evaluate g(theta) = sum_{|k|<=lmax} h_k e^{ik theta} on the CC circle of Ncc > 2 lmax points
@@ -111,7 +116,7 @@ def theta_resample(L, par, geometry, ntheta, lmax):
 	spec = np.zeros((ncol, Ncc), np.complex128)
 	kk = np.arange(-lmax, lmax+1)
 	spec[:, kk % Ncc] = h
-	gcirc = np.fft.ifft(spec, axis=1)*Ncc                           # g(2 pi j / Ncc)
+	gcirc = ifft(spec, axis=1)*Ncc                           # g(2 pi j / Ncc)
 	ncc = Ncc//2+1
 	psgn = np.where(par == 1, -1.0, 1.0)[:, None]
 	gpar = 0.5*(gcirc[:, :ncc]+psgn*gcirc[:, (-np.arange(ncc)) % Ncc])

@@ -215,7 +215,7 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 	}
 	PXS_HIP(hipSetDevice(device));
 	FftContext& fc = fft_context(device);
-	fc.nt_override = 0; g_fft_device = device;
+	g_fft_device = device;
 	hipStream_t st = (hipStream_t)stream;
 	const int last = axes.back();
 	const long nlast = shape[last], nh = nlast/2 + 1;

@@ -560,7 +560,7 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		k.store_inner_fast = (std::abs(d.os_i) < std::abs(d.os_e)) ? 1 : 0;
 		long nblk = k.ntile*d.n_o1*d.n_o2;
 		size_t sh = lds_bytes(k);
-		launch_tiles(k, nblk, sh, st, nt_override);
+		launch_tiles(k, nblk, sh, st);
 		PXS_HIP(hipGetLastError());
 		return;
 	}
@@ -599,13 +599,13 @@ void FftContext::exec(hipStream_t st, long n, bool forward, const FftDims& d, co
 		pa.ntile = ((tile_i ? ni : n2) + pa.T - 1)/pa.T;
 		pa.load_inner_fast = 1; pa.store_inner_fast = 1;
 		long nblkA = pa.ntile*(tile_i ? n2 : ni)*no1;
-		launch_tiles(pa, nblkA, lds_bytes(pa), st, nt_override);
+		launch_tiles(pa, nblkA, lds_bytes(pa), st);
 		// pass B: n2-point FFTs over j2 for each (i, k1)
 		KArgs pb = a; fill_sub(pb, *s2, tile_i ? ni : n1); pb.mode = 2; pb.tile_i = tile_i;
 		pb.ntile = ((tile_i ? ni : n1) + pb.T - 1)/pb.T;
 		pb.load_inner_fast = tile_i ? 1 : 0; pb.store_inner_fast = 1;
 		long nblkB = pb.ntile*(tile_i ? n1 : ni)*no1;
-		launch_tiles(pb, nblkB, lds_bytes(pb), st, nt_override);
+		launch_tiles(pb, nblkB, lds_bytes(pb), st);
 		PXS_HIP(hipGetLastError());
 	}
 }

@@ -64,7 +64,6 @@ public:
 	SubView view(long n);
 	const double2* twiddle_table(long n) { return bigtw(n); }
 	size_t temp_budget = size_t(4) << 30;   // bytes of four-step scratch per stream (set from the free memory in the constructor)
-	int nt_override = 0;                    // 0: automatic; 128/256/512: threads per workgroup for the launches that follow (experiments)
 private:
 	int device_;
 	std::mutex mu_;

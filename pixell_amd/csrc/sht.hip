@@ -258,11 +258,6 @@ struct pxs_plan {
 		FftChain::MapDesc m; m.ptr = map; m.dtype = dtype; m.cstride = cstride; m.ring_off0 = ring_off0; m.ring_stride = ring_stride; m.pix_stride = pix_stride; m.nring = nring; m.nphi = nphi;
 		return m; }
 	LegProfile prof;
-	// stage events for chaining two plans that run on different streams (pxs_plan_chain): recorded by every call
-	hipEvent_t ev_before_leg = nullptr, ev_after_leg = nullptr;
-	int fft_nt = 0;                                  // threads per FFT workgroup for this plan's launches (0: automatic)
-	hipEvent_t wait_at[2] = {nullptr, nullptr};     // one-shot: [0] at the start of the next call, [1] before its Legendre stage
-	~pxs_plan() { if (ev_before_leg) (void)hipEventDestroy(ev_before_leg); if (ev_after_leg) (void)hipEventDestroy(ev_after_leg); }
 	size_t resample_chunk_bytes = size_t(1) << 40;    // per intermediate buffer of the theta-FFT chain (chunking to stay in the
 	                                                  // Infinity Cache was measured slower: 22.4 -> 26.2 ms at config 2; PXS_RESAMPLE_MB re-enables it)
 
@@ -581,22 +576,6 @@ void resample_from_cc(pxs_plan* p, hipStream_t st, const double2* leg_cc, double
 
 } // namespace
 
-namespace {
-void plan_events(pxs_plan* p) {
-	if (!p->ev_before_leg) { PXS_HIP(hipEventCreateWithFlags(&p->ev_before_leg, hipEventDisableTiming)); PXS_HIP(hipEventCreateWithFlags(&p->ev_after_leg, hipEventDisableTiming)); }
-}
-void hook_start(pxs_plan* p, hipStream_t st) {
-	plan_events(p);
-	p->fc->nt_override = p->fft_nt;
-	if (p->wait_at[0]) { PXS_HIP(hipStreamWaitEvent(st, p->wait_at[0], 0)); p->wait_at[0] = nullptr; }
-}
-void hook_before_leg(pxs_plan* p, hipStream_t st) {
-	PXS_HIP(hipEventRecord(p->ev_before_leg, st));
-	if (p->wait_at[1]) { PXS_HIP(hipStreamWaitEvent(st, p->wait_at[1], 0)); p->wait_at[1] = nullptr; }
-}
-void hook_after_leg(pxs_plan* p, hipStream_t st) { PXS_HIP(hipEventRecord(p->ev_after_leg, st)); }
-}
-
 #define PXS_TRY try {
 #define PXS_CATCH } catch (const pxs::Error& e) { pxs::set_last_error(e.what()); return e.code; } \
 	catch (const std::exception& e) { pxs::set_last_error(e.what()); return pxs::PXS_ERR_ARG; } return 0;
@@ -679,29 +658,12 @@ int pxs_plan_info(const pxs_plan* p, int* nsyn, int* nana, int64_t* scratch) {
 	return 0;
 }
 
-int pxs_plan_chain(pxs_plan* p, int at, pxs_plan* other, int which) {
-	PXS_TRY
-	PXS_REQUIRE(p && other && p != other && (at == 0 || at == 1) && (which == 0 || which == 1), "pxs_plan_chain: bad arguments");
-	PXS_HIP(hipSetDevice(other->device));
-	plan_events(other);
-	p->wait_at[at] = which == 0 ? other->ev_before_leg : other->ev_after_leg;
-	PXS_CATCH
-}
-
 /* planner of the fused theta chains (diagnostics / tests): out = {ok, g, bN, g2, M, ac, Ncc, gs, bs, aNs} */
 int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out) {
 	const ThetaPlan t = FftChain::plan_theta(N, lmax);
 	const int64_t v[10] = {t.ok, t.g, t.bN, t.g2, t.M, t.ac, t.Ncc, t.gs, t.bs, t.aNs};
 	for (int i = 0; i < 10; i++) out[i] = v[i];
 	return 0;
-}
-
-int pxs_plan_option(pxs_plan* p, const char* key, int64_t value) {
-	PXS_TRY
-	PXS_REQUIRE(p && key, "pxs_plan_option: null argument");
-	if (std::string(key) == "fft_threads") { PXS_REQUIRE(value == 0 || value == 128 || value == 256 || value == 512, "fft_threads must be 0, 128, 256 or 512"); p->fft_nt = (int)value; }
-	else throw Error(PXS_ERR_ARG, std::string("pxs_plan_option: unknown key ") + key);
-	PXS_CATCH
 }
 
 int pxs_profile(pxs_plan* p, int enable) { if (!p) return PXS_ERR_ARG; p->prof.enabled = enable != 0; return 0; }
@@ -730,14 +692,11 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 	const bool th = p->chain_theta();
 	const long ldm = p->chain_rings ? FftChain::pad8(nr) : nr;
 	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*ldm);
-	hook_start(p, st);
 	if (!adjoint) {
-		hook_before_leg(p, st);
 		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
 			const long ldc = p->ld_cc();
 			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*ldc);
 			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldc);
-			hook_after_leg(p, st);
 			if (th) {	// fused chain: CC grid -> ring spectra of the map's rings, written ring-major for the ring FFT
 				const long ldh = p->ld_h();
 				p->hbuf.ensure(sizeof(double2)*(size_t)ncm*nr*ldh);
@@ -755,14 +714,11 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 			}
 		} else {
 			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldm);
-			hook_after_leg(p, st);
 			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, ncm);
 		}
 	} else {
 		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0, ldm);
-		hook_before_leg(p, st);
 		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1, &p->prof, ldm);
-		hook_after_leg(p, st);
 	}
 	PXS_CATCH
 }
@@ -785,7 +741,6 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint,
 	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
 	p->leg.ensure(sizeof(double2)*(size_t)nc*nm*ldm);
 	p->leg2.ensure(sizeof(double2)*(size_t)nc*nm*ldc);
-	hook_start(p, st);
 	if (!adjoint) {
 		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0, ldm);
 		if (th) {
@@ -794,14 +749,10 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint,
 				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>());
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
 		} else resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
-		hook_before_leg(p, st);
 		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc);
-		hook_after_leg(p, st);
 	} else {
 		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
-		hook_before_leg(p, st);
 		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof, ldc);
-		hook_after_leg(p, st);
 		resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin);
 		leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, nc);
 	}

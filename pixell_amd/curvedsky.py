@@ -293,8 +293,6 @@ def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=
 	_check_shapes(alm_full, map_full, deriv)
 	func = sht.adjoint_synthesis_2d if adjoint else sht.synthesis_2d
 	kwargs = dict(phi0=minfo.phi0, lmax=ainfo.lmax, mmax=ainfo.mmax, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart, lstride=ainfo.stride, flip=minfo.flip)
-	# device-resident data: the spin groups of a map are independent transforms; they go to two streams with a plan each
-	lanes = sht.Lanes(_is_tensor(mdata) and _is_tensor(alm))
 	for I in nditer(map_full.shape[:-3]):
 		if deriv:
 			a = _contig(alm_full[I][None]); m = map_full[I]
@@ -302,20 +300,11 @@ def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=
 			if adjoint: alm_full[I] = a[0]
 			else: map_full[I+(0,)] *= -1       # theta derivative -> dec derivative (curvedsky.py:919)
 		else:
-			# Stage order of a call: synthesis = Legendre, then theta resampling and ring FFT; its adjoint the reverse.  The groups
-			# are chained so that the memory-bound stages of one run under the FP64-bound Legendre stage of the other.
-			groups = list(enmap.spin_helper(spin, alm_full.shape[-2])); lanes.mixed([int(g[0]) for g in groups])
-			if adjoint: groups, at, which = groups[::-1], 0, 0     # heavy group first; the next one starts when it reaches its Legendre stage
-			else:       at, which = 1, 1                            # the next group's Legendre stage waits for this one's to finish
-			prev = None
-			for gi, (s, j1, j2) in enumerate(groups):
+			for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
 				Ij = I+(slice(j1, j2),)
-				ln = lanes.lane(gi, int(s))
-				with lanes.stream(ln):
-					a = _contig(alm_full[Ij]); m = map_full[Ij]
-					prev = func(alm=a, map=m, spin=int(s), lane=ln, return_plan=True, after=(prev, at, which) if (lanes.enabled and prev is not None) else None, **kwargs)
-					if adjoint and a is not alm_full[Ij]: alm_full[Ij] = a
-	lanes.join()
+				v = alm_full[Ij]; a = _contig(v)
+				func(alm=a, map=map_full[Ij], spin=int(s), **kwargs)
+				if adjoint and a is not v: v[...] = a           # (only when the view was not contiguous)
 	if adjoint: return alm
 	else:       return map
 
@@ -345,21 +334,12 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 	m = min(ainfo.mmax, l)
 	func = sht.adjoint_analysis_2d if adjoint else sht.analysis_2d
 	kwargs = dict(phi0=minfo.phi0, lmax=l, mmax=m, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart[:m+1], lstride=ainfo.stride, flip=minfo.flip)
-	lanes = sht.Lanes(_is_tensor(mdata) and _is_tensor(alm))
 	for I in nditer(map_full.shape[:-3]):
-		# analysis = ring FFT and theta resampling, then Legendre (its adjoint the reverse): see alm2map_2d for the chaining
-		groups = list(enmap.spin_helper(spin, alm_full.shape[-2])); lanes.mixed([int(g[0]) for g in groups])
-		if adjoint: at, which = 1, 1
-		else:       groups, at, which = groups[::-1], 0, 0
-		prev = None
-		for gi, (s, j1, j2) in enumerate(groups):
+		for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
 			Ij = I+(slice(j1, j2),)
-			ln = lanes.lane(gi, int(s))
-			with lanes.stream(ln):
-				a = _contig(alm_full[Ij]); mm = map_full[Ij]
-				prev = func(alm=a, map=mm, spin=int(s), lane=ln, return_plan=True, after=(prev, at, which) if (lanes.enabled and prev is not None) else None, **kwargs)
-				if not adjoint and a is not alm_full[Ij]: alm_full[Ij] = a
-	lanes.join()
+			v = alm_full[Ij]; a = _contig(v)
+			func(alm=a, map=map_full[Ij], spin=int(s), **kwargs)
+			if not adjoint and a is not v: v[...] = a
 	if adjoint: return map
 	else:       return alm
 
@@ -400,7 +380,6 @@ def alm2map_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy
 	map_full = _atleast(mdata, 4)
 	_check_shapes(alm_full, map_full, deriv)
 	func = sht.adjoint_synthesis if adjoint else sht.synthesis
-	lanes = sht.Lanes(_is_tensor(mdata) and _is_tensor(alm))
 	for I in nditer(map_full.shape[:-3]):
 		if deriv:
 			a = _contig(alm_full[I][None]); m = _flat(map_full[I])
@@ -408,20 +387,11 @@ def alm2map_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy
 			if adjoint: alm_full[I] = a[0]
 			else: map_full[I+(0,)] *= -1
 		else:
-			# spin groups on two streams, chained as in alm2map_2d
-			groups = list(enmap.spin_helper(spin, alm_full.shape[-2])); lanes.mixed([int(g[0]) for g in groups])
-			if adjoint: groups, at, which = groups[::-1], 0, 0
-			else:       at, which = 1, 1
-			prev = None
-			for gi, (s, j1, j2) in enumerate(groups):
+			for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
 				Ij = I+(slice(j1, j2),)
-				ln = lanes.lane(gi, int(s))
-				with lanes.stream(ln):
-					a = _contig(alm_full[Ij]); m = _flat(map_full[Ij])
-					func(alm=a, map=m, spin=int(s), lane=ln, after=(prev, at, which) if (lanes.enabled and prev is not None) else None, **kwargs)
-					prev = func.last_plan
-					if adjoint and a is not alm_full[Ij]: alm_full[Ij] = a
-	lanes.join()
+				v = alm_full[Ij]; a = _contig(v)
+				func(alm=a, map=_flat(map_full[Ij]), spin=int(s), **kwargs)
+				if adjoint and a is not v: v[...] = a
 	if adjoint: return alm
 	else:       return map
 

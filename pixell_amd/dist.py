@@ -42,3 +42,32 @@ def map2alm_sharded(maps, wcs, lmax, spin, transform, group=None):
 	local = torch.stack(local, 0) if local else None
 	if local is None: raise ValueError("more ranks than maps")
 	return allgather_alm(local, len(maps), group=group)
+
+class AlmGather:
+	"""Preallocated all-gather of the per-rank alm block [rows_r, nelem] (complex128) into one [world, rows_max, nelem] buffer on
+	every rank: ONE all_gather_into_tensor over RCCL per step (direct schedule on the fully connected xGMI mesh), issued on a side
+	stream so that it runs under the next transform.  Uneven shards are padded to the largest one (the pad rows are never read).
+	backend "gloo" is the CPU / rehearsal path (no device collective: staged through host memory)."""
+	def __init__(self, local, rows_per_rank, device, backend="nccl"):
+		import torch
+		self.rows = list(rows_per_rank); self.world = len(self.rows); self.rmax = max(self.rows); self.backend = backend
+		self.nelem = local.shape[-1]
+		self.buf = torch.empty((self.world, self.rmax, self.nelem), dtype=local.dtype, device=device)
+		self.pad = torch.zeros((self.rmax, self.nelem), dtype=local.dtype, device=device) if min(self.rows) < self.rmax else None
+	def run(self, local, stream=None):
+		import torch, torch.distributed as dist
+		src = local
+		if self.pad is not None:
+			self.pad[:local.shape[0]] = local; src = self.pad
+		if self.backend == "nccl":
+			dist.all_gather_into_tensor(torch.view_as_real(self.buf).view(self.world, -1), torch.view_as_real(src.contiguous()).view(-1))
+		else:
+			if stream is not None: stream.synchronize()
+			host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.world)]
+			dist.all_gather(host, src.cpu())
+			for r in range(self.world): self.buf[r].copy_(host[r])
+	def result(self):
+		"""list of the per-rank blocks (views into the gather buffer)"""
+		return [self.buf[r, :self.rows[r]] for r in range(self.world)]
+	def describe(self):
+		return "all_gather_into_tensor (%s), %d ranks x %.3f GB per step" % ("RCCL" if self.backend == "nccl" else self.backend, self.world, self.rmax*self.nelem*16/1e9)

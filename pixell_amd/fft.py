@@ -156,8 +156,17 @@ class HipFFTW:
 	"""engine protocol object: plan = engines["hip"].FFTW(a, b, axes=..., direction=...); plan()"""
 	def __init__(self, a, b, axes=(-1,), direction="FFTW_FORWARD", threads=1, flags=None, *args, **kwargs):
 		self.a, self.b, self.axes, self.direction = a, b, astuple(axes), direction
-		if not isinstance(direction, str): raise NotImplementedError("r2r (DCT/DST) transforms are outside the accelerated path")
+		self.r2r = 0
+		if not isinstance(direction, str):
+			# FFTW r2r: one kind per transformed axis (pixell/fft.py:211-267); like the reference's ducc engine only homogeneous lists
+			kinds = [_dct_type(d) for d in direction]
+			if any(k != kinds[0] for k in kinds): raise ValueError("only homogeneous r2r transforms are supported")
+			self.r2r = _r2r_kind[kinds[0]]
+		elif direction not in ("FFTW_FORWARD", "FFTW_BACKWARD"): raise ValueError("unknown direction %s" % str(direction))
 	def __call__(self, normalise_idft=False):
+		if self.r2r:
+			_exec(self.a, self.b, self.axes, True, 1.0, r2r=self.r2r)
+			return self.b
 		fwd = self.direction == "FFTW_FORWARD"
 		scale = 1.0
 		if not fwd and normalise_idft:

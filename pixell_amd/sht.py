@@ -82,10 +82,6 @@ class Plan:
 		_lib.check(_lib.load().pxs_profile_read(self.handle, ms, cnt, int(bool(reset))))
 		names = ["leg_syn", "leg_ana", "ring_fft", "resample"]
 		return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
-	def chain(self, at, other, which):
-		"""next call on this plan waits (at 0: at its start, 1: before its Legendre stage) for `other`'s last call to reach
-		its Legendre stage (which 0) / finish it (which 1); see pxs_plan_chain in include/pxsht.h"""
-		_lib.check(_lib.load().pxs_plan_chain(self.handle, int(at), other.handle, int(which)))
 	def info(self):
 		a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
 		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
@@ -94,66 +90,28 @@ class Plan:
 _plans = {}
 def clear_plans(): _plans.clear()
 
-class Lanes:
-	"""Runs independent transforms (the spin groups of one map) on two HIP streams: lane 0 is the caller's stream, lane 1 a
-	side stream that starts after everything already queued on the caller's stream; join() makes the caller's stream wait
-	for it.  Measured on MI355X: T on one stream and Q/U on the other, each with its own plan, 431 -> 412 ms per
-	round trip at config 3 (the FFT stages of one group fill VGPR / issue slots the spin-2 Legendre kernels leave free)."""
-	def __init__(self, enabled):
-		self.enabled = bool(enabled) and not _lib.is_hostsim() and os.environ.get("PIXELL_AMD_LANES", "1") != "0"
-		self.side = None; self._mixed = None
-		if self.enabled:
-			# fork now: the side stream must wait for what is queued on the caller's stream at this point, not for the
-			# lane-0 transforms that are queued later (which is what it should overlap with)
-			self.side = _side_stream()
-			self.side.wait_stream(_torch().cuda.current_stream())
-	def lane(self, i, spin=None):
-		"""lane of the i-th group: scalar groups go to the side stream (lane 1), spin groups stay on the caller's (lane 0), so that
-		the light group is the one whose FFT stages run under the other's Legendre stage; equal kinds alternate"""
-		if not self.enabled: return 0
-		if spin is None or self._mixed is False: return i % 2
-		return 1 if spin == 0 else 0
-	def mixed(self, spins):
-		self._mixed = (0 in spins) and any(s != 0 for s in spins) and len(spins) == 2
-	def stream(self, lane):
-		import contextlib
-		if not self.enabled or lane == 0: return contextlib.nullcontext()
-		return _torch().cuda.stream(self.side)
-	def join(self):
-		if self.side is not None: _torch().cuda.current_stream().wait_stream(self.side)
-_side = {}
-def _side_stream():
-	torch = _torch(); d = torch.cuda.current_device()
-	if d not in _side:
-		prio = int(os.environ.get("PIXELL_AMD_LANE_PRIORITY", "-1"))      # -1: high (its memory-bound stages should grab freed slots first)
-		_side[d] = torch.cuda.Stream(device=d, priority=prio)
-	return _side[d]
-
 def tri_mstart(lmax, mmax=None):
 	if mmax is None: mmax = lmax
 	m = np.arange(mmax+1, dtype=np.int64)
 	return (m*(2*lmax+1-m)//2).astype(np.uint64)
 
-def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1, lane=0):
-	"""cached pxs_plan; plans of different `lane` are separate objects with their own device scratch, so that transforms
-	issued on different streams (curvedsky runs the spin groups of a map on two) never share a buffer"""
+def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1):
+	"""cached pxs_plan (a plan owns its device scratch: one call at a time per plan)"""
 	ms = np.ascontiguousarray(np.asarray(mstart)[:mmax+1], dtype=np.uint64)
-	key = ("g", geometry, int(ntheta), int(nphi), float(phi0), bool(flip[0]), bool(flip[1]), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index(), int(lane))
+	key = ("g", geometry, int(ntheta), int(nphi), float(phi0), bool(flip[0]), bool(flip[1]), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index())
 	p = _plans.get(key)
 	if p is None:
 		h = ctypes.c_void_p()
 		_lib.check(_lib.load().pxs_plan_grid2d(ctypes.byref(h), geometry.encode(), int(ntheta), int(nphi), float(phi0),
 			int(bool(flip[0])), int(bool(flip[1])), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
 		p = _plans[key] = Plan(h)
-		nt = int(os.environ.get("PIXELL_AMD_LANE1_FFT_THREADS", "0"))
-		if lane == 1 and nt: _lib.check(_lib.load().pxs_plan_option(h, b"fft_threads", nt))
 	return p
 
-def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1, lane=0):
+def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
 	th = np.ascontiguousarray(theta, dtype=np.float64); nph = np.ascontiguousarray(nphi, dtype=np.uint64)
 	p0 = np.ascontiguousarray(phi0, dtype=np.float64); rs = np.ascontiguousarray(ringstart, dtype=np.uint64)
 	ms = np.ascontiguousarray(np.asarray(mstart)[:mmax+1], dtype=np.uint64)
-	key = ("r", th.tobytes(), nph.tobytes(), p0.tobytes(), rs.tobytes(), int(pixstride), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index(), int(lane))
+	key = ("r", th.tobytes(), nph.tobytes(), p0.tobytes(), rs.tobytes(), int(pixstride), int(lmax), int(mmax), ms.tobytes(), int(lstride), device_index())
 	p = _plans.get(key)
 	if p is None:
 		h = ctypes.c_void_p()
@@ -190,48 +148,43 @@ def _run_ana(plan, map, alm, spin, adjoint):
 	_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), mb.ptr, _DT[md], mcs, ab.ptr, _DT[ad], acs, current_stream()))
 	ab.finish(); mb.finish()
 
-def _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip, lane=0):
+def _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip):
 	_check_pair(alm, map, spin, mode, 2)
 	if mmax is None: mmax = lmax
 	if mstart is None: mstart = tri_mstart(lmax, mmax)
 	nt, nph = map.shape[-2:]
-	return grid_plan(geometry, nt, nph, phi0, flip, lmax, mmax, mstart, lstride, lane)
+	return grid_plan(geometry, nt, nph, phi0, flip, lmax, mmax, mstart, lstride)
 
-def synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False), lane=0, after=None, return_plan=False):
+def synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False), return_plan=False):
 	"""ducc0.sht.experimental.synthesis_2d as called at curvedsky.py:907-924"""
-	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip, lane)
-	if after is not None: plan.chain(after[1], after[0], after[2])
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip)
 	_run_syn(plan, alm, map, spin, mode, False)
 	return plan if return_plan else map
 
-def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False), lane=0, after=None, return_plan=False):
-	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip, lane)
-	if after is not None: plan.chain(after[1], after[0], after[2])
+def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False), return_plan=False):
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip)
 	_run_syn(plan, alm, map, spin, mode, True)
 	return plan if return_plan else alm
 
-def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), lane=0, after=None, return_plan=False):
+def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False):
 	"""ducc0.sht.experimental.analysis_2d as called at curvedsky.py:1032-1046"""
-	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip, lane)
-	if after is not None: plan.chain(after[1], after[0], after[2])
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
 	_run_ana(plan, map, alm, spin, False)
 	return plan if return_plan else alm
 
-def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), lane=0, after=None, return_plan=False):
-	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip, lane)
-	if after is not None: plan.chain(after[1], after[0], after[2])
+def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False):
+	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
 	_run_ana(plan, map, alm, spin, True)
 	return plan if return_plan else map
 
-def _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode, lane=0):
+def _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode):
 	if mmax is None: mmax = lmax
 	if mstart is None: mstart = tri_mstart(lmax, mmax)
-	return ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride, pixstride, lane), mmax, mstart
+	return ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride, pixstride), mmax, mstart
 
-def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, map=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD", lane=0, after=None):
+def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, map=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD"):
 	"""ducc0.sht.experimental.synthesis as called at curvedsky.py:936-960 (map[nc, npix])"""
-	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode, lane)
-	if after is not None: plan.chain(after[1], after[0], after[2])
+	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
 	nca, ncm = _ncomp(spin, mode)
 	if map is None:
 		rs_ = np.asarray(ringstart).astype(np.int64); last_ = rs_+(np.asarray(nphi).astype(np.int64)-1)*pixstride
@@ -243,10 +196,9 @@ def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None
 	synthesis.last_plan = plan
 	return map
 
-def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, alm=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD", lane=0, after=None):
+def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0, alm=None, lstride=1, pixstride=1, nthreads=0, mode="STANDARD"):
 	"""ducc0.sht.experimental.adjoint_synthesis as called at curvedsky.py:1068-1084"""
-	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode, lane)
-	if after is not None: plan.chain(after[1], after[0], after[2])
+	plan, mmax, mstart = _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode)
 	nca, ncm = _ncomp(spin, mode)
 	if alm is None:
 		nelem = int(np.max(np.asarray(mstart).astype(np.int64))+lmax*lstride+1)
