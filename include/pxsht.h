@@ -60,16 +60,19 @@ void pxs_plan_destroy(pxs_plan* plan);
 
 /* alm -> map (adjoint = 0: synthesis[_2d]) or map -> alm (adjoint = 1: adjoint_synthesis[_2d]).
  * spin 0: 1 alm component, 1 map component; spin > 0: 2 and 2; mode DERIV1: 1 and 2 (spin must be 1).
- * alm_cstride / map_cstride: distance between components in elements of the respective dtype. */
-int pxs_synthesis(pxs_plan* plan, int spin, int mode, int adjoint,
-                  void* alm, int alm_dtype, int64_t alm_cstride,
-                  void* map, int map_dtype, int64_t map_cstride, void* stream);
+ * alm_cstride / map_cstride: distance between components in elements of the respective dtype.
+ * nbatch independent maps per call (the loop over pre-dimensions at curvedsky.py:763-765, 910-924): map b starts at
+ * map + b*map_bstride, its alm at alm + b*alm_bstride (elements); nbatch = 1 ignores the batch strides.  The ring FFTs of a
+ * batch run as one launch per pass; the plan's scratch bounds the maps per pass (PXS_BATCH_GB, default 32). */
+int pxs_synthesis(pxs_plan* plan, int spin, int mode, int adjoint, int nbatch,
+                  void* alm, int alm_dtype, int64_t alm_cstride, int64_t alm_bstride,
+                  void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride, void* stream);
 
 /* map -> alm (adjoint = 0: analysis_2d) or alm -> map (adjoint = 1: adjoint_analysis_2d).
- * Only for grid2d plans: exact quadrature of the theta-interpolant (curvedsky.py:1018-1048). */
-int pxs_analysis(pxs_plan* plan, int spin, int adjoint,
-                 void* map, int map_dtype, int64_t map_cstride,
-                 void* alm, int alm_dtype, int64_t alm_cstride, void* stream);
+ * Only for grid2d plans: exact quadrature of the theta-interpolant (curvedsky.py:1018-1048; batch loop :1038-1046). */
+int pxs_analysis(pxs_plan* plan, int spin, int adjoint, int nbatch,
+                 void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride,
+                 void* alm, int alm_dtype, int64_t alm_cstride, int64_t alm_bstride, void* stream);
 
 /* ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855): out[ntheta], sum = 4 pi. Host memory. */
 int pxs_gridweights(const char* geometry, int ntheta, double* out);

@@ -22,8 +22,8 @@ def _declare(lib):
 	lib.pxs_plan_rings.argtypes = [c.POINTER(vp), i32, vp, vp, vp, vp, i64, i32, i32, vp, i64, i32]
 	lib.pxs_plan_grid2d.argtypes = [c.POINTER(vp), c.c_char_p, i32, i32, dbl, i32, i32, i32, i32, vp, i64, i32]
 	lib.pxs_plan_destroy.argtypes = [vp]; lib.pxs_plan_destroy.restype = None
-	lib.pxs_synthesis.argtypes = [vp, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp]
-	lib.pxs_analysis.argtypes = [vp, i32, i32, vp, i32, i64, vp, i32, i64, vp]
+	lib.pxs_synthesis.argtypes = [vp, i32, i32, i32, i32, vp, i32, i64, i64, vp, i32, i64, i64, vp]
+	lib.pxs_analysis.argtypes = [vp, i32, i32, i32, vp, i32, i64, i64, vp, i32, i64, i64, vp]
 	lib.pxs_gridweights.argtypes = [c.c_char_p, i32, vp]
 	lib.pxs_grid_maxlmax.argtypes = [c.c_char_p, i32]
 	lib.pxs_plan_info.argtypes = [vp, c.POINTER(i32), c.POINTER(i32), c.POINTER(i64)]

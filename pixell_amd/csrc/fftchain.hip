@@ -280,7 +280,7 @@ template<int MODE> struct StSplit : StageBase {
 // ---------------------------------------------------------------------------------------------------------------
 // ring FFTs
 // ---------------------------------------------------------------------------------------------------------------
-struct MapAddr { void* ptr; int dtype; long cstride, off0, rstride, pstride; int nring; };
+struct MapAddr { void* ptr; int dtype; long cstride, bstride, off0, rstride, pstride; int nring, ncb; FastDiv dncb; };   // "component" index = b*ncb + c
 
 // MA1: two real rings as one complex line z = ring(2q) + i ring(2q+1); pixel x = b*j1 + j2, line = j2, a-point FFT over j1
 struct StRingA1 : StageBase {
@@ -292,7 +292,8 @@ struct StRingA1 : StageBase {
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		const int x = b*e + c.t0 + li;
-		const long o = c.comp*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
+		const int bi = (int)fdiv(c.comp, m.dncb);
+		const long o = bi*m.bstride + (c.comp - bi*m.ncb)*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
 		const double re = rd_real(m.ptr, m.dtype, o).x;
 		const double im = (2*c.q0 + 1 < m.nring) ? rd_real(m.ptr, m.dtype, o + m.rstride).x : 0.0;
 		return make_double2(re, im); }
@@ -388,7 +389,8 @@ struct StRingS2 : StageBase {
 		if (li >= c.nl) return;
 		const int x = c.t0 + li + a*e;
 		const double2 v = buf[li*ns + e];                     // conj of the backward transform: the imaginary part flips sign
-		const long o = c.comp*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
+		const int bi = (int)fdiv(c.comp, m.dncb);
+		const long o = bi*m.bstride + (c.comp - bi*m.ncb)*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
 		wr_real(m.ptr, m.dtype, o, v.x);
 		if (2*c.q0 + 1 < m.nring) wr_real(m.ptr, m.dtype, o + m.rstride, -v.y);
 	}
@@ -512,7 +514,8 @@ ThetaPlan FftChain::plan_theta(long N, int lmax) {
 }
 
 static MapAddr map_addr(const FftChain::MapDesc& m) {
-	MapAddr a; a.ptr = const_cast<void*>(m.ptr); a.dtype = m.dtype; a.cstride = m.cstride; a.off0 = m.ring_off0; a.rstride = m.ring_stride; a.pstride = m.pix_stride; a.nring = m.nring;
+	MapAddr a; a.ptr = const_cast<void*>(m.ptr); a.dtype = m.dtype; a.cstride = m.cstride; a.bstride = m.bstride; a.off0 = m.ring_off0; a.rstride = m.ring_stride; a.pstride = m.pix_stride; a.nring = m.nring;
+	a.ncb = m.ncb > 0 ? m.ncb : (1 << 30); a.dncb = make_fastdiv((uint32_t)a.ncb);
 	return a;
 }
 

@@ -33,7 +33,8 @@ public:
 	bool rings_ok() const { return ra_.a > 0; }
 	std::string describe() const { return "analysis " + std::to_string(ra_.a) + "x" + std::to_string(ra_.b) + ", synthesis " + std::to_string(rs_.a) + "x" + std::to_string(rs_.b); }
 
-	struct MapDesc { const void* ptr; int dtype; long cstride, ring_off0, ring_stride, pix_stride; int nring; long nphi; };
+	struct MapDesc { const void* ptr; int dtype; long cstride, ring_off0, ring_stride, pix_stride; int nring; long nphi;
+	                 long bstride = 0; int ncb = 0; };   // batches: component index k of a call = b*ncb + c lives at b*bstride + c*cstride (ncb = 0: no batch axis)
 	// map -> leg[c][m][ring] * tab[m] * scale   (two real rings per complex transform; needs 2 mmax < nphi)
 	void map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale);
 	// h[c][ring][m] (row stride ldh) -> map

@@ -1050,6 +1050,12 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	size_t maxrows = 1;
 	for (size_t c = 0; c+1 < cuts.size(); c++) maxrows = std::max<size_t>(maxrows, (size_t)(tb.row[cuts[c+1]]-tb.row[cuts[c]]));
 	wk.part.ensure(sizeof(double)*4*maxrows*nwave);
+	{	// sized once, before the first launch: growing a buffer inside the chunk loop would free memory that kernels of the
+		// previous chunk may still use (and hipFree synchronises the device)
+		size_t maxm = 1;
+		for (size_t c = 0; c+1 < cuts.size(); c++) maxm = std::max<size_t>(maxm, (size_t)(cuts[c+1]-cuts[c]));
+		wk.first.ensure(sizeof(int)*(size_t)nwave*maxm);
+	}
 	const size_t sh = sizeof(double)*16*LEG_RED_STRIDE;
 	for (size_t c = 0; c+1 < cuts.size(); c++) {
 		const int m0 = cuts[c], m1 = cuts[c+1];
@@ -1057,7 +1063,6 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		if (rows <= 0) continue;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K);
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0;
-		wk.first.ensure(sizeof(int)*(size_t)nwave*(m1-m0));
 		PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));
 		a.first = wk.first.as<int>();
 		if (prof) prof->begin(st, 1);

@@ -254,8 +254,9 @@ struct pxs_plan {
 	long ld_map() const { return chain_rings ? FftChain::pad8(nring) : nring; }
 	long ld_cc()  const { return chain_theta() ? FftChain::pad8(ncc) : ncc; }
 	long ld_h()   const { return chain_rings ? FftChain::pad8(mmax + 1) : mmax + 1; }
-	FftChain::MapDesc map_desc(const void* map, int dtype, long cstride) const {
+	FftChain::MapDesc map_desc(const void* map, int dtype, long cstride, long bstride = 0, int ncb = 0) const {
 		FftChain::MapDesc m; m.ptr = map; m.dtype = dtype; m.cstride = cstride; m.ring_off0 = ring_off0; m.ring_stride = ring_stride; m.pix_stride = pix_stride; m.nring = nring; m.nphi = nphi;
+		m.bstride = bstride; m.ncb = ncb;
 		return m; }
 	LegProfile prof;
 	size_t resample_chunk_bytes = size_t(1) << 40;    // per intermediate buffer of the theta-FFT chain (chunking to stay in the
@@ -358,15 +359,15 @@ int ncomp_of(int spin, int mode, bool alm_side) {
 
 // ring FFT: user map -> hbuf[c][ring][m] -> leg[c][m][ring] * e^{-i m phi0} * scale
 // (ld: row stride of leg; the unfused path below only writes dense rows, ld == nring)
-void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale, long ldl) {
+void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale, long ldl, long map_bstride = 0, int ncb = 0) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
 	if (p->chain_rings) {
-		p->chain->map2leg(st, p->map_desc(map, map_dtype, map_cstride), nc, p->mmax, leg, ldl, p->phase.as<double2>(), scale);
+		p->chain->map2leg(st, p->map_desc(map, map_dtype, map_cstride, map_bstride, ncb), nc, p->mmax, leg, ldl, p->phase.as<double2>(), scale);
 		p->prof.end(st, PXS_STAGE_RING_FFT);
 		return;
 	}
-	PXS_REQUIRE(ldl == nr, "internal: unfused ring FFT needs dense rows");
+	PXS_REQUIRE(ldl == nr && ncb == 0, "internal: unfused ring FFT needs dense rows and single maps");
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	if (2L*p->mmax < p->nphi && p->ring_pairs) {
 		// two real rings per complex transform; the pruned two-sided spectrum (|k| <= mmax) is unpacked in the transpose
@@ -406,7 +407,7 @@ void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long m
 
 // leg[c][m][ring] * e^{+i m phi0} -> hbuf[c][ring][m] -> c2r ring FFT -> user map
 // (ldleg: row stride of leg; hbuf rows are ld_h() long)
-void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* map, int map_dtype, long map_cstride, int nc, bool have_h = false) {
+void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* map, int map_dtype, long map_cstride, int nc, bool have_h = false, long map_bstride = 0, int ncb = 0) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
 	const long ldh = p->ld_h();
@@ -417,10 +418,11 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* 
 			(long)nm*ldleg, (long)nr*ldh, (const double2*)p->phase.p, 1, 1.0, ldleg, ldh);
 	}
 	if (p->chain_rings) {
-		p->chain->h2map(st, p->hbuf.as<double2>(), ldh, p->map_desc(map, map_dtype, map_cstride), nc, p->mmax);
+		p->chain->h2map(st, p->hbuf.as<double2>(), ldh, p->map_desc(map, map_dtype, map_cstride, map_bstride, ncb), nc, p->mmax);
 		p->prof.end(st, PXS_STAGE_RING_FFT);
 		return;
 	}
+	PXS_REQUIRE(ncb == 0, "internal: unfused ring FFT handles single maps");
 	auto esz = [](int dt) { return dt == PX_F32 ? 4 : 8; };
 	if (2L*p->mmax < p->nphi && p->ring_pairs) {
 		// two rings per complex transform: Z = X_a + i X_b, real part -> ring 2q, imaginary part -> ring 2q+1
@@ -675,37 +677,38 @@ int pxs_profile_read(pxs_plan* p, double* ms, int* counts, int reset) {
 	PXS_CATCH
 }
 
-int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
-                  void* alm, int alm_dtype, int64_t alm_cstride,
-                  void* map, int map_dtype, int64_t map_cstride, void* stream)
+// nb maps of one call (nb > 1 only on the fused-chain paths): ring FFTs of all maps in one launch each, theta chains and
+// Legendre kernels map by map on the plan's scratch
+static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb, void* alm, int alm_dtype, long alm_cstride, long alm_bstride,
+                           void* map, int map_dtype, long map_cstride, long map_bstride, hipStream_t st)
 {
-	PXS_TRY
-	PXS_REQUIRE(p && alm && map, "pxs_synthesis: null argument");
-	PXS_REQUIRE(spin >= 0 && spin <= p->lmax + 1, "pxs_synthesis: bad spin");
-	PXS_REQUIRE(mode == PXS_MODE_STANDARD || (mode == PXS_MODE_DERIV1 && spin == 1), "DERIV1 needs spin 1");
-	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
-	PXS_HIP(hipSetDevice(p->device));
-	hipStream_t st = (hipStream_t)stream;
-	const int ncm = ncomp_of(spin, mode, false);
+	const int ncm = ncomp_of(spin, mode, false), nca = ncomp_of(spin, mode, true), nct = nb*ncm;
 	const int nm = p->mmax+1, nr = p->nring;
 	LegTables& tb = p->table(spin);
 	const bool th = p->chain_theta();
 	const long ldm = p->chain_rings ? FftChain::pad8(nr) : nr;
-	p->leg.ensure(sizeof(double2)*(size_t)ncm*nm*ldm);
+	const int ncb = nb > 1 ? ncm : 0;
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+	auto alm_of = [&](int b) { return (void*)((char*)alm + aesz*(size_t)b*alm_bstride); };
+	(void)nca;
+	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
 	if (!adjoint) {
 		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
 			const long ldc = p->ld_cc();
-			p->leg2.ensure(sizeof(double2)*(size_t)ncm*nm*ldc);
-			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldc);
+			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
+			for (int b = 0; b < nb; b++)
+				leg_synthesis(st, p->rs_cc, tb, p->wk, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+					p->leg2.as<double2>() + (size_t)b*ncm*nm*ldc, mode == PXS_MODE_DERIV1, &p->prof, ldc);
 			if (th) {	// fused chain: CC grid -> ring spectra of the map's rings, written ring-major for the ring FFT
 				const long ldh = p->ld_h();
-				p->hbuf.ensure(sizeof(double2)*(size_t)ncm*nr*ldh);
+				p->hbuf.ensure(sizeof(double2)*(size_t)nct*nr*ldh);
 				p->prof.begin(st, PXS_STAGE_RESAMPLE);
-				p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, ncm, nm, spin, p->lmax,
+				p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
 					p->ph_up.as<double2>(), p->phase.as<double2>(), 1.0/(double)p->Ncc);
 				p->prof.end(st, PXS_STAGE_RESAMPLE);
-				leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, ncm, true);
+				leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, ncb);
 			} else {
+				PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path");
 				static const bool fuse = [] { const char* e = getenv("PXS_FUSE_SPLIT"); return e ? atoi(e) != 0 : true; }();
 				const bool via_h = fuse && !p->chain_rings;     // (the unfused transposing split writes dense h rows)
 				if (via_h) p->hbuf.ensure(sizeof(double2)*(size_t)ncm*nr*nm);
@@ -713,48 +716,99 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint,
 				leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, ncm, via_h);
 			}
 		} else {
-			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldm);
-			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, ncm);
+			for (int b = 0; b < nb; b++)
+				leg_synthesis(st, p->rs_map, tb, p->wk, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+					p->leg.as<double2>() + (size_t)b*ncm*nm*ldm, mode == PXS_MODE_DERIV1, &p->prof, ldm);
+			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, nct, false, map_bstride, ncb);
 		}
 	} else {
-		map2leg(p, st, map, map_dtype, map_cstride, ncm, p->leg.as<double2>(), 1.0, ldm);
-		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, mode == PXS_MODE_DERIV1, &p->prof, ldm);
+		map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
+		for (int b = 0; b < nb; b++)
+			leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>() + (size_t)b*ncm*nm*ldm, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				mode == PXS_MODE_DERIV1, &p->prof, ldm);
+	}
+}
+
+// maps per pass of a batched call: bounded by the scratch the plan may hold (leg + leg_cc + h per map, and the chain scratch)
+static int batch_chunk(const pxs_plan* p, int nbatch, int ncm) {
+	if (nbatch <= 1 || !p->chain_rings) return 1;           // the unfused paths take one map at a time
+	const size_t per_map = sizeof(double2)*(size_t)ncm*((size_t)(p->mmax+1)*(p->nring + (p->ncc > 0 ? p->ncc : 0))*2 + (size_t)p->nring*p->nphi);
+	static const size_t budget = [] { const char* e = getenv("PXS_BATCH_GB"); return (size_t)(e ? atol(e) : 32) << 30; }();
+	return (int)std::max<size_t>(1, std::min<size_t>((size_t)nbatch, budget/std::max<size_t>(per_map, 1)));
+}
+
+int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint, int nbatch,
+                  void* alm, int alm_dtype, int64_t alm_cstride, int64_t alm_bstride,
+                  void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(p && alm && map, "pxs_synthesis: null argument");
+	PXS_REQUIRE(spin >= 0 && spin <= p->lmax + 1, "pxs_synthesis: bad spin");
+	PXS_REQUIRE(mode == PXS_MODE_STANDARD || (mode == PXS_MODE_DERIV1 && spin == 1), "DERIV1 needs spin 1");
+	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
+	PXS_REQUIRE(nbatch >= 1, "pxs_synthesis: nbatch must be >= 1");
+	PXS_HIP(hipSetDevice(p->device));
+	hipStream_t st = (hipStream_t)stream;
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
+	const int chunk = batch_chunk(p, nbatch, ncomp_of(spin, mode, false));
+	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
+		const int nb = std::min(chunk, nbatch - b0);
+		synthesis_core(p, spin, mode, adjoint, nb, (char*)alm + aesz*(size_t)b0*alm_bstride, alm_dtype, alm_cstride, alm_bstride,
+			(char*)map + mesz*(size_t)b0*map_bstride, map_dtype, map_cstride, map_bstride, st);
 	}
 	PXS_CATCH
 }
 
-int pxs_analysis(pxs_plan* p, int spin, int adjoint,
-                 void* map, int map_dtype, int64_t map_cstride,
-                 void* alm, int alm_dtype, int64_t alm_cstride, void* stream)
+static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map, int map_dtype, long map_cstride, long map_bstride,
+                          void* alm, int alm_dtype, long alm_cstride, long alm_bstride, hipStream_t st)
+{
+	const int nc = spin == 0 ? 1 : 2, nct = nb*nc;
+	const int nm = p->mmax+1, nr = p->nring;
+	LegTables& tb = p->table(spin);
+	const bool th = p->chain_theta() && !adjoint;       // (the adjoint of the analysis runs the unfused chain, dense rows)
+	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
+	const int ncb = nb > 1 ? nc : 0;
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+	auto alm_of = [&](int b) { return (void*)((char*)alm + aesz*(size_t)b*alm_bstride); };
+	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
+	p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
+	if (!adjoint) {
+		map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
+		if (th) {
+			p->prof.begin(st, PXS_STAGE_RESAMPLE);
+			p->chain->to_cc(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>());
+			p->prof.end(st, PXS_STAGE_RESAMPLE);
+		} else { PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path"); resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin); }
+		for (int b = 0; b < nb; b++)
+			leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>() + (size_t)b*nc*nm*ldc, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc);
+	} else {
+		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
+		PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path");
+		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof, ldc);
+		resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin);
+		leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, nc);
+	}
+}
+
+int pxs_analysis(pxs_plan* p, int spin, int adjoint, int nbatch,
+                 void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride,
+                 void* alm, int alm_dtype, int64_t alm_cstride, int64_t alm_bstride, void* stream)
 {
 	PXS_TRY
 	PXS_REQUIRE(p && alm && map, "pxs_analysis: null argument");
 	PXS_REQUIRE(p->is_grid, "pxs_analysis needs a grid2d plan");
 	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
+	PXS_REQUIRE(nbatch >= 1, "pxs_analysis: nbatch must be >= 1");
 	if (p->lmax > grid_maxlmax(p->geometry, p->nring)) throw Error(PXS_ERR_ARG, "too few rings for analysis up to requested lmax");
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
-	const int nc = spin == 0 ? 1 : 2;
-	const int nm = p->mmax+1, nr = p->nring;
-	LegTables& tb = p->table(spin);
-	const bool th = p->chain_theta() && !adjoint;       // (the adjoint of the analysis runs the unfused chain, dense rows)
-	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
-	p->leg.ensure(sizeof(double2)*(size_t)nc*nm*ldm);
-	p->leg2.ensure(sizeof(double2)*(size_t)nc*nm*ldc);
-	if (!adjoint) {
-		map2leg(p, st, map, map_dtype, map_cstride, nc, p->leg.as<double2>(), 1.0, ldm);
-		if (th) {
-			p->prof.begin(st, PXS_STAGE_RESAMPLE);
-			p->chain->to_cc(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, nm, spin, p->lmax,
-				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>());
-			p->prof.end(st, PXS_STAGE_RESAMPLE);
-		} else resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin);
-		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc);
-	} else {
-		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
-		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof, ldc);
-		resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin);
-		leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, nc);
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
+	const int chunk = (adjoint || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
+	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
+		const int nb = std::min(chunk, nbatch - b0);
+		analysis_core(p, spin, adjoint, nb, (char*)map + mesz*(size_t)b0*map_bstride, map_dtype, map_cstride, map_bstride,
+			(char*)alm + aesz*(size_t)b0*alm_bstride, alm_dtype, alm_cstride, alm_bstride, st);
 	}
 	PXS_CATCH
 }

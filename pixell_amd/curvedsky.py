@@ -14,15 +14,8 @@ import numpy as np
 from . import enmap, sht, wcs as wcsutils
 from .sht import _is_tensor, _np_dtype, _torch
 
-class Bunch(dict):
-	def __getattr__(self, k):
-		try: return self[k]
-		except KeyError: raise AttributeError(k)
-	def __setattr__(self, k, v): self[k] = v
+from .geometry import Bunch, degree
 
-degree = np.pi/180
-
-def hasoff(val, off, tol=1e-6): return np.abs((val-off+0.5) % 1-0.5) < tol
 def nint(a): return np.round(a).astype(int)
 def complex_dtype(dtype): return np.result_type(dtype, 0j)
 def real_dtype(dtype): return np.zeros([0], dtype).real.dtype
@@ -30,42 +23,47 @@ def nditer(shape):
 	for I in np.ndindex(*shape): yield tuple(I)
 
 def nalm2lmax(nalm):
-	return int((-1+(1+8*nalm)**0.5)/2)-1
+	"""band limit of a full triangular layout with nalm = (lmax+1)(lmax+2)/2 elements"""
+	return int((np.sqrt(8.0*nalm+1)-1)/2)-1
+
+# ---------------------------------------------------------------------------------------
+# alm layout
+# ---------------------------------------------------------------------------------------
+def _mstart_triangular(lmax, mmax, stride):
+	m = np.arange(mmax+1, dtype=np.int64)
+	return stride*((m*(2*lmax+1-m))//2)           # column m starts where l = 0 WOULD be: element (l, m) sits at mstart[m] + l stride
+def _mstart_rectangular(lmax, mmax, stride):
+	return stride*(lmax+1)*np.arange(mmax+1, dtype=np.int64)
+_LAYOUTS = {"triangular": (_mstart_triangular, nalm2lmax), "tri": (_mstart_triangular, nalm2lmax),
+	"rectangular": (_mstart_rectangular, lambda nalm: int(np.sqrt(nalm))-1), "rect": (_mstart_rectangular, lambda nalm: int(np.sqrt(nalm))-1)}
 
 class alm_info:
-	"""alm layout (curvedsky.alm_info, curvedsky.py:409-476)"""
+	"""Where element (l, m) of a spherical-harmonic coefficient array lives: index = mstart[m] + l*stride (the contract of
+	pixell's curvedsky.alm_info, curvedsky.py:409-476, which the C ABI takes over as `mstart` / `lstride`).
+	layout: "triangular" (m-major, no padding; the default), "rectangular" (every m has lmax+1 slots) or an explicit mstart array.
+	Either lmax or the element count nalm fixes the size; mmax defaults to lmax."""
 	def __init__(self, lmax=None, mmax=None, nalm=None, stride=1, layout="triangular"):
-		if lmax is not None: lmax = int(lmax)
-		if mmax is not None: mmax = int(mmax)
-		if nalm is not None: nalm = int(nalm)
+		lmax, mmax, nalm = (None if v is None else int(v) for v in (lmax, mmax, nalm))
 		if isinstance(layout, str):
-			if layout == "triangular" or layout == "tri":
-				if lmax is None: lmax = nalm2lmax(nalm)
-				if mmax is None: mmax = lmax
-				m = np.arange(mmax+1)
-				mstart = stride*(m*(2*lmax+1-m)//2)
-			elif layout == "rectangular" or layout == "rect":
-				if lmax is None: lmax = int(nalm**0.5)-1
-				if mmax is None: mmax = lmax
-				mstart = np.arange(mmax+1)*(lmax+1)*stride
-			else:
-				raise ValueError("unkonwn layout: %s" % layout)
+			if layout not in _LAYOUTS: raise ValueError("unknown alm layout: %s" % layout)
+			build, lmax_from_count = _LAYOUTS[layout]
+			if lmax is None:
+				if nalm is None: raise ValueError("alm_info needs lmax or nalm")
+				lmax = lmax_from_count(nalm)
+			if mmax is None: mmax = lmax
+			mstart = build(lmax, mmax, int(stride))
 		else:
 			mstart = np.asarray(layout)
-		self.lmax  = lmax
-		self.mmax  = mmax
-		self.stride= int(stride)
-		self.nelem = int(np.max(mstart) + (lmax+1)*stride)
-		self.nreal = lmax**2+2*lmax+2
-		if nalm is not None:
-			assert self.nelem == nalm, "lmax must be explicitly specified when lmax != mmax"
-		self.mstart= mstart.astype(np.uint64, copy=False)
-	@property
-	def nl(self): return self.lmax+1
-	@property
-	def nm(self): return self.mmax+1
+			if lmax is None or mmax is None: raise ValueError("an explicit mstart needs lmax and mmax")
+		self.lmax, self.mmax, self.stride = lmax, mmax, int(stride)
+		self.nelem = int(np.max(mstart))+(lmax+1)*self.stride
+		self.nreal = lmax*lmax+2*lmax+2
+		assert nalm is None or self.nelem == nalm, "lmax must be explicitly specified when lmax != mmax"
+		self.mstart = mstart.astype(np.uint64, copy=False)
+	nl = property(lambda self: self.lmax+1)
+	nm = property(lambda self: self.mmax+1)
 	def lm2ind(self, l, m):
-		return (self.mstart[m].astype(int, copy=False)+l*self.stride).astype(int, copy=False)
+		return (self.mstart[m].astype(int, copy=False)+np.asarray(l)*self.stride).astype(int, copy=False)
 	def get_map(self):
 		raise NotImplementedError
 	def alm2cl(self, alm, alm2=None, dtype=None):
@@ -81,87 +79,16 @@ class alm_info:
 		return "alm_info(lmax=%s,mmax=%s,mstart=%s)" % (str(self.lmax), str(self.mmax), str(self.mstart))
 
 # ---------------------------------------------------------------------------------------
-# geometry analysis (curvedsky.py:1252-1353)
+# geometry analysis: thin names over pixell_amd/geometry.py (the reference's function names, curvedsky.py:478-505, 1170-1353)
 # ---------------------------------------------------------------------------------------
-def get_ducc_maxlmax(name, ny):
-	if   name == "CC": return ny-2
-	elif name == "DH": return (ny-2)//2
-	elif name == "F2": return (ny-1)//2
-	else:              return ny-1
-
-def get_ducc_geo(wcs, shape=None, tol=1e-6):
-	"""curvedsky.get_ducc_geo (curvedsky.py:1308-1347): which named ducc grid the (flipped) geometry is"""
-	def near(a, b): return np.abs(a-b) < tol
-	flip = [wcs.wcs.cdelt[1] > 0, wcs.wcs.cdelt[0] < 0]
-	_, w = wcsutils.flipped(shape or (1, 1), wcs, flip)
-	nx = 360/w.wcs.cdelt[0]
-	if not hasoff(nx, 0, tol): return None
-	phi0 = wcsutils.pix2world(w, 0, 0)[0]*degree
-	y1 = wcsutils.world2pix(w, 0,  90)[1]
-	y2 = wcsutils.world2pix(w, 0, -90)[1]
-	Ny = shape[-2] if shape is not None else nint(y2)+1
-	if   hasoff(y1, 0.0, tol) and hasoff(y2, 0.0, tol):
-		if   near(y1, -1) and near(y2, Ny): name, o1, o2 = "F2", 1, 1
-		elif near(y1,  0) and near(y2, Ny): name, o1, o2 = "DH", 1, 0
-		else: name, o1, o2 = "CC", 0, 0
-	elif hasoff(y1, 0.5, tol) and hasoff(y2, 0.5, tol): name, o1, o2 = "F1", 0.5, 0.5
-	elif hasoff(y1, 0.5, tol) and hasoff(y2, 0.0, tol): name, o1, o2 = "MW", 0.5, 0.0
-	elif hasoff(y1, 0.0, tol) and hasoff(y2, 0.5, tol): name, o1, o2 = "MWflip", 0.0, 0.5
-	else: return None
-	ny   = nint(y2-y1+1-o1-o2)
-	yoff = nint(-y1-o1)
-	lmax = get_ducc_maxlmax(name, ny)
-	return Bunch(name=name, nx=nint(nx), ny=ny, pole_offs=[o1, o2], phi0=phi0, yoff=yoff, lmax=lmax)
-
-def analyse_geometry(shape, wcs, tol=1e-6):
-	"""curvedsky.analyse_geometry (curvedsky.py:1252-1306)"""
-	separable = wcsutils.is_separable(wcs)
-	divides   = hasoff(360/np.abs(wcs.wcs.cdelt[0]), 0, tol=tol)
-	if not separable or not divides:
-		return Bunch(case="general", flip=[False, False], ducc_geo=None, ypad=(0, 0), xpad=(0, 0), phi0=0)
-	flip = [bool(wcs.wcs.cdelt[1] > 0), bool(wcs.wcs.cdelt[0] < 0)]
-	wshape, wwcs = wcsutils.flipped(shape, wcs, flip)
-	phi0 = wcsutils.pix2world(wwcs, 0, wshape[-2]//2)[0]*degree
-	ducc_geo = get_ducc_geo(wwcs, shape=wshape, tol=tol)
-	if ducc_geo is not None and shape[-2] == ducc_geo.ny and shape[-1] == ducc_geo.nx and np.abs(ducc_geo.yoff) < tol:
-		return Bunch(case="2d", flip=flip, ducc_geo=ducc_geo, ypad=(0, 0), xpad=(0, 0), phi0=phi0)
-	else:
-		if ducc_geo is not None: ypad = (ducc_geo.yoff, ducc_geo.ny-ducc_geo.yoff-shape[-2])
-		else: ypad = (0, 0)
-		nx = nint(360/wwcs.wcs.cdelt[0])
-		if shape[-1] == nx:
-			return Bunch(case="cyl", flip=flip, ducc_geo=ducc_geo, ypad=ypad, xpad=(0, 0), phi0=phi0)
-		else:
-			return Bunch(case="partial", flip=flip, ducc_geo=ducc_geo, ypad=ypad, xpad=(0, nx-shape[-1]), phi0=phi0)
-
+from . import geometry as _geo
+get_ducc_maxlmax = _geo.grid_maxlmax
+def get_ducc_geo(wcs, shape=None, tol=1e-6): return _geo.classify_grid(wcs, shape=shape, tol=tol)
+def analyse_geometry(shape, wcs, tol=1e-6): return _geo.analyse(shape, wcs, tol=tol)
 def get_method(shape, wcs, minfo=None, pix_tol=1e-6):
-	if minfo is None: minfo = analyse_geometry(shape, wcs, tol=pix_tol)
-	if   minfo.case == "general": return "general"
-	elif minfo.case == "2d":      return "2d"
-	else:                         return "cyl"
-
-def get_ring_info(shape, wcs, dtype=np.float64):
-	"""curvedsky.get_ring_info (curvedsky.py:1170-1190)"""
-	y = np.arange(shape[-2])
-	dec, ra = enmap.pix2sky(shape, wcs, [y, y*0])
-	theta = np.asarray(np.pi/2-dec, dtype=dtype)
-	ntheta = len(theta)
-	nphi = np.zeros(ntheta, dtype=np.uint64)+shape[-1]
-	phi0 = np.asarray(ra, dtype=dtype)
-	offsets = (np.arange(ntheta)*shape[-1]).astype(np.uint64)
-	stride = np.zeros(ntheta, dtype=np.int32)+1
-	return Bunch(theta=theta, nphi=nphi, phi0=phi0, offsets=offsets, stride=stride, npix=int(np.sum(nphi)), nrow=ntheta)
-
-def quad_weights(shape, wcs, pix_tol=1e-6):
-	"""curvedsky.quad_weights (curvedsky.py:492-505)"""
-	minfo = analyse_geometry(shape, wcs, tol=pix_tol)
-	if minfo.ducc_geo is None or minfo.ducc_geo.name is None:
-		raise ValueError("Quadrature weights not available for geometry %s,%s" % (str(shape), str(wcs)))
-	ny = shape[-2]+int(np.sum(minfo.ypad))
-	weights = sht.get_gridweights(minfo.ducc_geo.name, ny)
-	weights = weights[minfo.ypad[0]:len(weights)-minfo.ypad[1]]
-	if minfo.flip[0]: weights = weights[::-1]
-	return weights/minfo.ducc_geo.nx
+	return _geo.method_of((minfo if minfo is not None else _geo.analyse(shape, wcs, tol=pix_tol)).case)
+def get_ring_info(shape, wcs, dtype=np.float64): return _geo.ring_tables(shape, wcs, dtype=dtype)
+def quad_weights(shape, wcs, pix_tol=1e-6): return _geo.ring_weights(shape, wcs, sht.get_gridweights, tol=pix_tol)
 
 # ---------------------------------------------------------------------------------------
 # array plumbing
@@ -176,20 +103,19 @@ def _zeros_like_kind(shape, dtype, like):
 	return np.zeros(shape, dtype)
 
 def prepare_alm(alm=None, ainfo=None, lmax=None, pre=(), dtype=np.float64, convert=False, like=None):
-	"""curvedsky.prepare_alm (curvedsky.py:1413-1427)"""
-	ctype = complex_dtype(dtype)
+	"""(alm, ainfo) ready for a transform of maps of real type `dtype` (the contract of curvedsky.prepare_alm, curvedsky.py:1413-1427):
+	a missing alm is allocated (zeros, next to `like`) for ainfo or lmax; an alm of the wrong precision is converted when
+	`convert`, refused with ValueError otherwise; a missing ainfo is the triangular layout of the alm's length."""
+	want = complex_dtype(dtype)
 	if alm is None:
-		if ainfo is None:
-			if lmax is None:
-				raise ValueError("prepare_alm needs either alm, ainfo or lmax to be specified")
-			ainfo = alm_info(lmax)
-		alm = _zeros_like_kind(tuple(pre)+(ainfo.nelem,), ctype, like)
-	if ainfo is None:
-		ainfo = alm_info(nalm=alm.shape[-1])
-	if not convert and _np_dtype(alm) != ctype:
-		raise ValueError("alm had dtype '%s', but expected '%s'" % (str(_np_dtype(alm)), str(ctype)))
-	if _np_dtype(alm) != ctype:
-		alm = alm.to(getattr(_torch(), np.dtype(ctype).name)) if _is_tensor(alm) else alm.astype(ctype)
+		if ainfo is None and lmax is None: raise ValueError("prepare_alm needs either alm, ainfo or lmax to be specified")
+		ainfo = ainfo if ainfo is not None else alm_info(lmax)
+		return _zeros_like_kind(tuple(pre)+(ainfo.nelem,), want, like), ainfo
+	ainfo = ainfo if ainfo is not None else alm_info(nalm=alm.shape[-1])
+	have = _np_dtype(alm)
+	if have != want:
+		if not convert: raise ValueError("alm had dtype '%s', but expected '%s'" % (str(have), str(want)))
+		alm = alm.to(getattr(_torch(), np.dtype(want).name)) if _is_tensor(alm) else alm.astype(want)
 	return alm, ainfo
 
 def _atleast(x, n):
@@ -199,6 +125,28 @@ def _atleast(x, n):
 def _contig(x):
 	if _is_tensor(x): return x if x.is_contiguous() else x.contiguous()
 	return x
+
+def _batched_jobs(spin, alm_full, map_full):
+	"""[(spin, alm [nb, nca, nelem], map [nb, ncm, ny, nx])]: the reference loops over the pre-dimensions and the spin groups
+	(curvedsky.py:910-924, 1038-1046) with one ducc call each; here every spin group is ONE library call over all pre-dimension
+	entries, and a stack of scalar maps (every component a spin-0 group) is one call over its components."""
+	nelem = alm_full.shape[-1]; ncomp = alm_full.shape[-2]; ny, nx = map_full.shape[-2:]
+	groups = [(int(s), j1, j2) for s, j1, j2 in enmap.spin_helper(spin, ncomp)]
+	if int(np.prod(map_full.shape[:-3], dtype=int)) == 0: return []       # empty pre-dimension: nothing to transform
+	a3 = _as_view(alm_full, (-1, ncomp, nelem)); m4 = _as_view(map_full, (-1, ncomp, ny, nx))
+	if a3 is None or m4 is None:
+		# pre-dimensions that cannot be merged without a copy (exotic strides): one call per entry, as the reference does
+		return [(s, alm_full[I+(slice(j1, j2),)][None], map_full[I+(slice(j1, j2),)][None]) for I in nditer(map_full.shape[:-3]) for s, j1, j2 in groups]
+	if all(s == 0 for s, _, _ in groups) and ncomp > 1:
+		return [(0, a3.reshape((-1, 1, nelem)), m4.reshape((-1, 1, ny, nx)))]
+	return [(s, a3[:, j1:j2], m4[:, j1:j2]) for s, j1, j2 in groups]
+
+def _as_view(x, shape):
+	"""x reshaped WITHOUT copying (results are written through these views), or None"""
+	try:
+		if _is_tensor(x): return x.view(shape)
+		v = x.view(); v.shape = tuple(int(np.prod(x.shape[:x.ndim-len(shape)+1], dtype=int)) if n == -1 else n for n in shape); return v
+	except (RuntimeError, AttributeError): return None
 
 # ---------------------------------------------------------------------------------------
 # public API
@@ -293,18 +241,14 @@ def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=
 	_check_shapes(alm_full, map_full, deriv)
 	func = sht.adjoint_synthesis_2d if adjoint else sht.synthesis_2d
 	kwargs = dict(phi0=minfo.phi0, lmax=ainfo.lmax, mmax=ainfo.mmax, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart, lstride=ainfo.stride, flip=minfo.flip)
-	for I in nditer(map_full.shape[:-3]):
-		if deriv:
+	if deriv:
+		for I in nditer(map_full.shape[:-3]):
 			a = _contig(alm_full[I][None]); m = map_full[I]
 			func(alm=a, map=m, mode="DERIV1", spin=1, **kwargs)
 			if adjoint: alm_full[I] = a[0]
 			else: map_full[I+(0,)] *= -1       # theta derivative -> dec derivative (curvedsky.py:919)
-		else:
-			for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
-				Ij = I+(slice(j1, j2),)
-				v = alm_full[Ij]; a = _contig(v)
-				func(alm=a, map=map_full[Ij], spin=int(s), **kwargs)
-				if adjoint and a is not v: v[...] = a           # (only when the view was not contiguous)
+	else:
+		for s, a, m in _batched_jobs(spin, alm_full, map_full): func(alm=a, map=m, spin=s, **kwargs)
 	if adjoint: return alm
 	else:       return map
 
@@ -334,12 +278,7 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 	m = min(ainfo.mmax, l)
 	func = sht.adjoint_analysis_2d if adjoint else sht.analysis_2d
 	kwargs = dict(phi0=minfo.phi0, lmax=l, mmax=m, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart[:m+1], lstride=ainfo.stride, flip=minfo.flip)
-	for I in nditer(map_full.shape[:-3]):
-		for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
-			Ij = I+(slice(j1, j2),)
-			v = alm_full[Ij]; a = _contig(v)
-			func(alm=a, map=map_full[Ij], spin=int(s), **kwargs)
-			if not adjoint and a is not v: v[...] = a
+	for s, a, m in _batched_jobs(spin, alm_full, map_full): func(alm=a, map=m, spin=s, **kwargs)
 	if adjoint: return map
 	else:       return alm
 
@@ -396,10 +335,11 @@ def alm2map_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy
 	else:       return map
 
 def jacobi_inverse(forward, approx_backward, y, niter=0):
-	"""curvedsky.jacobi_inverse (curvedsky.py:1122-1136)"""
+	"""Solve forward(x) = y given an approximate inverse B: x_0 = B y, x_{k+1} = x_k + B (y - forward(x_k))
+	(Jacobi / Richardson refinement; what curvedsky.jacobi_inverse, curvedsky.py:1122-1136, does around the ring transforms)"""
 	x = approx_backward(y)
-	for i in range(niter):
-		x -= approx_backward(forward(x)-y)
+	for _ in range(int(niter)):
+		x = x+approx_backward(y-forward(x))
 	return x
 
 def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], weights=None, deriv=False, copy=False, verbose=False, adjoint=False, nthread=None, pix_tol=1e-6, niter=0):
@@ -553,28 +493,27 @@ def transpose_alm(ainfo, alm, out=None):
 alm_info.transpose_alm = lambda self, alm, out=None: transpose_alm(self, alm, out=out)
 
 def rand_alm_white(ainfo, pre=None, alm=None, seed=None, dtype=np.complex128, m_major=True):
+	"""unit-variance complex Gaussian numbers for every alm slot.  To give the same alm as pixell for a seed (curvedsky.py:602-628)
+	the numbers come from numpy's legacy global RNG, are drawn in l-major order ((l,m) = (0,0), (1,0), (1,1), ...) and are
+	then moved to the m-major layout unless m_major is False."""
 	if seed is not None: np.random.seed(seed)
-	if alm is None:
-		if pre is None: alm = np.empty(ainfo.nelem, dtype)
-		else:           alm = np.empty(tuple(pre)+(ainfo.nelem,), dtype)
+	if alm is None: alm = np.empty((tuple(pre) if pre is not None else ())+(ainfo.nelem,), dtype)
 	fill_gauss(alm)
-	if m_major: ainfo.transpose_alm(alm, alm)
-	return alm
+	return ainfo.transpose_alm(alm, alm) if m_major else alm
 
 def rand_alm(ps, ainfo=None, lmax=None, seed=None, dtype=np.complex128, m_major=True, return_ainfo=False):
-	"""Gaussian alm with (cross) spectrum ps (curvedsky.py:61-79): white numbers drawn in l-major order
-	from numpy's legacy RNG, then coloured with sqrt(ps) on the GPU (alm_info.lmul)."""
+	"""Gaussian alm with (cross) spectrum ps [nl], [nspec,nl] or [ncomp,ncomp,nl] (curvedsky.rand_alm, curvedsky.py:61-79):
+	white numbers (rand_alm_white), coloured by the matrix square root of the spectrum on the GPU (alm_info.lmul); the factor
+	1/sqrt(2) shares the variance between real and imaginary parts, m = 0 is made real with the full variance."""
 	ps = np.asarray(ps)
-	rtype = real_dtype(dtype)
 	wps, ainfo = prepare_ps(ps, ainfo=ainfo, lmax=lmax)
-	alm = rand_alm_white(ainfo, pre=[wps.shape[0]], seed=seed, dtype=dtype, m_major=m_major)
-	ps12 = _multi_sqrt(wps)
-	alm = ainfo.lmul(alm, (ps12/2**0.5).astype(rtype, copy=False))
-	alm[:, :ainfo.lmax+1].imag  = 0
-	alm[:, :ainfo.lmax+1].real *= 2**0.5
-	if ps.ndim == 1: alm = alm[0]
-	if return_ainfo: return alm, ainfo
-	else: return alm
+	white = rand_alm_white(ainfo, pre=[wps.shape[0]], seed=seed, dtype=dtype, m_major=m_major)
+	colour = (_multi_sqrt(wps)/np.sqrt(2.0)).astype(real_dtype(dtype), copy=False)
+	alm = ainfo.lmul(white, colour)
+	m0 = alm[:, :ainfo.lmax+1]                        # the m = 0 column comes first in the m-major layout
+	m0.imag = 0; m0.real *= np.sqrt(2.0)
+	alm = alm[0] if ps.ndim == 1 else alm
+	return (alm, ainfo) if return_ainfo else alm
 
 def transfer_alm(iainfo, ialm, oainfo, oalm=None, op=lambda a, b: b):
 	"""Copy alm between layouts / band limits (curvedsky.py:744-750 -> cmisc.pyx:131-151): for every (l,m) both

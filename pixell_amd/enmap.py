@@ -20,6 +20,11 @@ class ndmap(np.ndarray):
 		if obj is None: return
 		self.wcs = getattr(obj, "wcs", None)
 	def copy(self, order="C"): return ndmap(np.copy(self, order), self.wcs)
+	def __getitem__(self, sel):
+		"""slicing the two pixel axes moves the wcs with the data (enmap.ndmap.__getitem__, enmap.py:140-163); anything that
+		removes or fancy-indexes a pixel axis returns a plain array, which has no geometry"""
+		res = np.ndarray.__getitem__(self, sel)
+		return _sliced(self, res, sel)
 	@property
 	def geometry(self): return self.shape, self.wcs
 	def pixsize(self): return pixsize(self.shape, self.wcs)
@@ -36,9 +41,31 @@ class dmap:
 	def dtype(self):
 		from .sht import _np_dtype
 		return _np_dtype(self.tensor)
-	def __getitem__(self, sel): return dmap(self.tensor[sel], self.wcs)
+	def __getitem__(self, sel):
+		res = _sliced(self, self.tensor[sel], sel)
+		if not isinstance(res, dmap): raise IndexError("indexing a pixel axis of a dmap leaves no map geometry: slice the tensor itself")
+		return res
 	def copy(self): return dmap(self.tensor.clone(), self.wcs)
 	def pixsize(self): return pixsize(self.shape, self.wcs)
+
+def _sliced(parent, res, sel):
+	"""wrap the result of parent[sel] with the geometry it now has (None axes / Ellipsis / leading-axis indexing allowed)"""
+	nd = parent.ndim
+	sel = sel if isinstance(sel, tuple) else (sel,)
+	if any(isinstance(x, (list, np.ndarray)) or hasattr(x, "data_ptr") for x in sel):
+		return np.asarray(res) if isinstance(parent, ndmap) else res          # fancy indexing: no geometry
+	nreal = sum(1 for x in sel if x is not None and x is not Ellipsis)
+	full = []
+	for x in sel:
+		if x is Ellipsis: full += [slice(None)]*(nd-nreal)
+		elif x is not None: full.append(x)
+	full += [slice(None)]*(nd-len(full))
+	ysel, xsel = full[nd-2], full[nd-1]
+	if not (isinstance(ysel, slice) and isinstance(xsel, slice)):
+		return np.asarray(res) if isinstance(parent, ndmap) else res          # a pixel axis was indexed away
+	if ysel == slice(None) and xsel == slice(None): wcs = parent.wcs
+	else: _, wcs = wcsutils.slice_geometry(parent.shape, parent.wcs, (ysel, xsel))
+	return dmap(res, wcs) if isinstance(parent, dmap) else ndmap(res, wcs)
 
 def enmap(arr, wcs=None, dtype=None, copy=True):
 	if wcs is None: wcs = getattr(arr, "wcs", None)
@@ -52,45 +79,51 @@ def zeros(shape, wcs=None, dtype=None): return ndmap(np.zeros(shape, dtype=dtype
 def empty(shape, wcs=None, dtype=None): return ndmap(np.empty(shape, dtype=dtype), wcs)
 def ones(shape, wcs=None, dtype=None): return ndmap(np.ones(shape, dtype=dtype), wcs)
 
+# rows a full-sky CAR grid spends ON the poles: Clenshaw-Curtis has a ring on each pole (ny - 1 intervals span pi),
+# Fejer-1 keeps half a pixel away from both (ny intervals)
+_POLE_ROWS = {"cc": 1, "fejer1": 0}
+
 def fullsky_geometry(res=None, shape=None, dims=(), proj="car", variant="fejer1"):
-	"""enmap.fullsky_geometry (enmap.py:1713-1740)"""
+	"""(shape, wcs) of a CAR map covering the whole sky, from a resolution in radians or a pixel shape (ny, nx): the
+	geometry contract of enmap.fullsky_geometry (enmap.py:1713-1740).  Columns run east to west (cdelt_ra < 0) with pixel
+	centres half a pixel off RA = 0; rows run south to north with the equator on the row lattice."""
 	assert proj == "car", "Only CAR fullsky geometry implemented"
-	if   variant.lower() == "cc":     yo = 1
-	elif variant.lower() == "fejer1": yo = 0
-	else: raise ValueError("Unrecognized CAR variant '%s'" % str(variant))
+	key = str(variant).lower()
+	if key not in _POLE_ROWS: raise ValueError("Unrecognized CAR variant '%s'" % str(variant))
+	extra = _POLE_ROWS[key]
 	if shape is None:
-		res   = np.zeros(2)+res
-		shape = np.round(([1*np.pi, 2*np.pi]/res)+(yo, 0)).astype(int)
+		dy, dx = np.broadcast_to(np.asarray(res, float), (2,)) if np.ndim(res) else (float(res), float(res))
+		ny, nx = int(round(np.pi/dy))+extra, int(round(2*np.pi/dx))
 	else:
-		res = np.array([1*np.pi, 2*np.pi])/(np.array(shape)-(yo, 0))
-	ny, nx = int(shape[0]), int(shape[1])
-	assert abs(res[0]*(ny-yo)-np.pi) < 1e-8, "Vertical resolution does not evenly divide the sky; this is required for SHTs."
-	assert abs(res[1]*nx-2*np.pi) < 1e-8, "Horizontal resolution does not evenly divide the sky; this is required for SHTs."
-	wcs = CarWCS(cdelt=[-360./nx, 180./(ny-yo)], crval=[res[1]/2/degree, 0], crpix=[nx//2+0.5, (ny+1)/2])
+		ny, nx = int(shape[-2]), int(shape[-1])
+		dy, dx = np.pi/(ny-extra), 2*np.pi/nx
+	assert abs(dy*(ny-extra)-np.pi) < 1e-8, "Vertical resolution does not evenly divide the sky; this is required for SHTs."
+	assert abs(dx*nx-2*np.pi) < 1e-8, "Horizontal resolution does not evenly divide the sky; this is required for SHTs."
+	wcs = CarWCS(cdelt=[-360.0/nx, 180.0/(ny-extra)], crval=[0.5*dx/degree, 0.0], crpix=[nx//2+0.5, 0.5*(ny+1)])
 	return tuple(dims)+(ny, nx), wcs
 
 def band_geometry(dec_cut, res=None, shape=None, dims=(), proj="car", variant="fejer1"):
-	"""rows of the full-sky geometry whose centres lie within the declination cut (enmap.py:1742-1772)"""
-	dec_cut = np.atleast_1d(dec_cut)
-	dmin, dmax = (-dec_cut[0], dec_cut[0]) if dec_cut.size == 1 else dec_cut
+	"""the rows of the full-sky geometry whose centres lie within |dec| <= dec_cut (or within [dec_cut[0], dec_cut[1]]), all
+	columns kept (enmap.band_geometry, enmap.py:1742-1772)"""
+	cut = np.atleast_1d(np.asarray(dec_cut, float))
+	lo, hi = (-cut[0], cut[0]) if cut.size == 1 else (cut[0], cut[1])
 	fshape, fwcs = fullsky_geometry(res=res, shape=shape, dims=dims, proj=proj, variant=variant)
-	y1 = wcsutils.world2pix(fwcs, 0, dmin/degree)[1]; y2 = wcsutils.world2pix(fwcs, 0, dmax/degree)[1]
-	start = max(int(np.round(min(y1, y2))), 0); stop = min(int(np.round(max(y1, y2))), fshape[-2])
-	w = fwcs.deepcopy(); w.wcs.crpix[1] -= start
-	return tuple(dims)+(stop-start, fshape[-1]), w
+	rows = [float(wcsutils.world2pix(fwcs, 0, d/degree)[1]) for d in (lo, hi)]
+	first, last = max(int(np.round(min(rows))), 0), min(int(np.round(max(rows))), fshape[-2])
+	w = fwcs.deepcopy(); w.wcs.crpix[1] -= first
+	return tuple(dims)+(last-first, fshape[-1]), w
 
 def spin_helper(spin, n):
-	"""enmap.spin_helper (enmap.py:3378-3388)"""
-	spin  = np.array(spin).reshape(-1)
-	scomp = 1+(spin != 0)
-	ci, i1 = 0, 0
-	while True:
-		i2 = min(i1+scomp[ci], n)
-		if i2-i1 != scomp[ci]: raise IndexError("Unpaired component in spin transform")
-		yield spin[ci], i1, i2
-		if i2 == n: break
-		i1 = i2
-		ci = (ci+1) % len(spin)
+	"""Walk the n components of a map / alm stack in spin groups: yields (spin, first, last+1); spin 0 takes one component,
+	any other spin a pair; the spin list is cycled (enmap.spin_helper, enmap.py:3378-3388).  IndexError if a pair is cut."""
+	import itertools
+	first = 0
+	for s in itertools.cycle(np.atleast_1d(spin).reshape(-1)):
+		if first >= n: return
+		width = 1 if s == 0 else 2
+		if first+width > n: raise IndexError("Unpaired component in spin transform")
+		yield s, first, first+width
+		first += width
 
 def pix2sky(shape, wcs, pix):
 	"""[{y,x},...] -> [{dec,ra},...] in radians (enmap.pix2sky, enmap.py:483-494, linear CAR)"""
@@ -99,12 +132,10 @@ def pix2sky(shape, wcs, pix):
 	return np.array([dec*degree, ra*degree])
 
 def area(shape, wcs):
-	"""enmap.area_cyl (enmap.py:1032-1036)"""
+	"""solid angle of a separable cylindrical map: (sin dec_hi - sin dec_lo) * RA range (enmap.area_cyl, enmap.py:1032-1036)"""
 	if not wcsutils.is_separable(wcs): raise NotImplementedError("area: only separable cylindrical geometries")
-	d = pix2sky(shape, wcs, [[-0.5, shape[-2]-1+0.5], [0, 0]])[0]
-	dec1, dec2 = np.sort(d)
-	dec1, dec2 = max(-np.pi/2, dec1), min(np.pi/2, dec2)
-	return (np.sin(dec2)-np.sin(dec1))*abs(wcs.wcs.cdelt[0])*shape[-1]*degree
+	lo, hi, _ = _dec_span(shape, wcs)
+	return (np.sin(hi)-np.sin(lo))*abs(wcs.wcs.cdelt[0])*degree*shape[-1]
 def pixsize(shape, wcs): return area(shape, wcs)/np.prod(shape[-2:])
 
 def _norm(emap, normalize, sign, dct=False):
@@ -146,57 +177,58 @@ def _wrap(res, like):
 # flat-sky harmonic helpers around fft/ifft (SURVEY 8 f3).  Geometry arithmetic is host numpy; everything
 # that touches an [ny,nx] array runs on the GPU (include/pxsht.h pxm_*).
 # ---------------------------------------------------------------------------------------
+def _dec_span(shape, wcs):
+	"""declinations of the lower and upper map edge (pixel edges, not centres), clipped to the sphere, and the row direction"""
+	edges = pix2sky(shape, wcs, [[-0.5, shape[-2]-0.5], [0, 0]])[0]
+	sign = 1 if edges[0] <= edges[1] else -1
+	lo, hi = np.clip(np.sort(edges), -np.pi/2, np.pi/2)
+	return lo, hi, sign
+
 def extent(shape, wcs, signed=False, method="auto"):
-	"""[height, width] of the patch in radians (enmap.extent / extent_cyl / extent_intermediate, enmap.py:917-1014)"""
+	"""[height, width] of the patch in radians (enmap.extent, enmap.py:917-1014).  "cylindrical" (separable geometries): the
+	width is the RA range times the mean of cos(dec) over the patch, so that area = height * width holds exactly;
+	"intermediate": pixel counts times the WCS increments."""
 	if method == "auto": method = "cylindrical" if wcsutils.is_separable(wcs) else "intermediate"
 	if method in ("inter", "intermediate"):
-		res = np.array(wcs.wcs.cdelt[::-1], float)*np.array(shape[-2:], float)*degree
-		return res if signed else np.abs(res)
-	if method not in ("cyl", "cylindrical"): raise NotImplementedError("extent: only the cylindrical and intermediate methods")
-	dec1, dec2 = pix2sky(shape, wcs, [[-0.5, shape[-2]-1+0.5], [0, 0]])[0]
-	if dec1 <= dec2: ysign = 1
-	else: dec1, dec2, ysign = dec2, dec1, -1
-	dec1, dec2 = max(-np.pi/2, dec1), min(np.pi/2, dec2)
-	mean_cos = (np.sin(dec2)-np.sin(dec1))/(dec2-dec1)
-	ext = np.array([(dec2-dec1)*ysign, shape[-1]*wcs.wcs.cdelt[0]*mean_cos*degree])
+		ext = np.array([wcs.wcs.cdelt[1]*shape[-2], wcs.wcs.cdelt[0]*shape[-1]], float)*degree
+	elif method in ("cyl", "cylindrical"):
+		lo, hi, sign = _dec_span(shape, wcs)
+		ext = np.array([sign*(hi-lo), shape[-1]*wcs.wcs.cdelt[0]*degree*(np.sin(hi)-np.sin(lo))/(hi-lo)])
+	else: raise NotImplementedError("extent: only the cylindrical and intermediate methods")
 	return ext if signed else np.abs(ext)
 
 def laxes(shape, wcs, oversample=1, method="auto", broadcastable=False):
-	"""wavenumber axes ly[ny], lx[nx] of the 2-D FFT of a map (enmap.laxes, enmap.py:1275-1294)"""
-	oversample = int(oversample)
-	step = extent(shape, wcs, signed=True, method=method)/np.array(shape[-2:], float)
-	ly = np.fft.fftfreq(shape[-2]*oversample, step[0])*2*np.pi
-	lx = np.fft.fftfreq(shape[-1]*oversample, step[1])*2*np.pi
-	if oversample > 1:
-		def shift(l, a, n): return l+a/2*(-1+1./n)
-		ly = shift(ly, ly[oversample], oversample)
-		lx = shift(lx, lx[oversample], oversample)
-	if broadcastable: ly, lx = ly[:, None], lx[None, :]
-	return ly, lx
+	"""the multipoles (ly[ny], lx[nx]) of the bins of the map's 2-D FFT: 2 pi times the FFT frequencies for the pixel pitch
+	extent/shape (enmap.laxes, enmap.py:1275-1294); oversample > 1 describes the finer lattice of a zero-padded transform"""
+	os_ = int(oversample)
+	pitch = extent(shape, wcs, signed=True, method=method)/np.array(shape[-2:], float)
+	axes = [2*np.pi*np.fft.fftfreq(n*os_, d) for n, d in zip(shape[-2:], pitch)]
+	if os_ > 1: axes = [l+0.5*l[os_]*(1.0/os_-1) for l in axes]
+	ly, lx = axes
+	return (ly[:, None], lx[None, :]) if broadcastable else (ly, lx)
 
 def lmap(shape, wcs, oversample=1, method="auto"):
-	ly, lx = laxes(shape, wcs, oversample=oversample, method=method)
-	data = np.empty((2, ly.size, lx.size))
-	data[0] = ly[:, None]; data[1] = lx[None, :]
-	return ndmap(data, wcs)
+	"""[{ly,lx},ny,nx] multipole of every 2-D FFT bin"""
+	ly, lx = laxes(shape, wcs, oversample=oversample, method=method, broadcastable=True)
+	return ndmap(np.stack(np.broadcast_arrays(ly, lx)).astype(float), wcs)
 
 def modlmap(shape, wcs, oversample=1, method="auto", min=0):
-	slmap = lmap(shape, wcs, oversample=oversample, method=method)
-	l = np.sum(np.asarray(slmap)**2, 0)**0.5
-	if min > 0: l = np.maximum(l, min)
-	return ndmap(l, wcs)
+	"""|l| of every 2-D FFT bin (floored at `min`)"""
+	ly, lx = laxes(shape, wcs, oversample=oversample, method=method, broadcastable=True)
+	l = np.hypot(ly, lx)
+	return ndmap(np.maximum(l, min) if min > 0 else l, wcs)
 
 def lpixshape(shape, wcs, signed=False, method="auto"): return 2*np.pi/extent(shape, wcs, signed=signed, method=method)
-def lpixsize(shape, wcs, signed=False, method="auto"): return np.prod(lpixshape(shape, wcs, signed=signed, method=method))
+def lpixsize(shape, wcs, signed=False, method="auto"): return float(np.prod(lpixshape(shape, wcs, signed=signed, method=method)))
 
 def queb_rotmat(lmap, inverse=False, iau=False, spin=2, wcs=None):
-	"""host version of the rotation matrix (enmap.py:1391-1400); the transforms below never build it"""
-	sign = 1
-	if iau: sign = -sign
-	if inverse: sign = -sign
-	a = spin*np.arctan2(sign*np.asarray(lmap[1]), np.asarray(lmap[0]))
-	c, s = np.cos(a), np.sin(a)
-	return samewcs(np.array([[c, -s], [s, c]]), lmap)
+	"""host version of the [2,2,ny,nx] rotation between (Q,U) and (E,B) in flat-sky harmonic space: angle = spin * atan2(+-lx, ly),
+	sign flipped by `iau` and by `inverse` (enmap.queb_rotmat, enmap.py:1391-1400).  The transforms below never build it: they rotate
+	in place on the GPU (pxm_rotate_queb)."""
+	sign = (-1 if iau else 1)*(-1 if inverse else 1)
+	ang = spin*np.arctan2(sign*np.asarray(lmap[1]), np.asarray(lmap[0]))
+	c, s_ = np.cos(ang), np.sin(ang)
+	return samewcs(np.array([[c, -s_], [s_, c]]), lmap)
 
 def _torch():
 	import torch

@@ -87,7 +87,24 @@ class Plan:
 		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
 		return dict(nring_syn=a.value, nring_ana=b.value, scratch_bytes=c.value)
 
-_plans = {}
+class _PlanCache:
+	"""least-recently-used cache of pxs_plan handles: a plan owns device scratch (tens of GB at the largest configurations), so a
+	sweep over geometries or band limits must not keep every plan alive.  PIXELL_AMD_MAX_PLANS (default 4) bounds the count; an
+	evicted plan is destroyed (its kernels are stream-ordered before the free)."""
+	def __init__(self):
+		import collections
+		self.d = collections.OrderedDict()
+		self.cap = max(1, int(os.environ.get("PIXELL_AMD_MAX_PLANS", "4")))
+	def get(self, key):
+		p = self.d.get(key)
+		if p is not None: self.d.move_to_end(key)
+		return p
+	def __setitem__(self, key, plan):
+		self.d[key] = plan; self.d.move_to_end(key)
+		while len(self.d) > self.cap: self.d.popitem(last=False)
+	def clear(self): self.d.clear()
+	def __len__(self): return len(self.d)
+_plans = _PlanCache()
 def clear_plans(): _plans.clear()
 
 def tri_mstart(lmax, mmax=None):
@@ -104,7 +121,7 @@ def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1)
 		h = ctypes.c_void_p()
 		_lib.check(_lib.load().pxs_plan_grid2d(ctypes.byref(h), geometry.encode(), int(ntheta), int(nphi), float(phi0),
 			int(bool(flip[0])), int(bool(flip[1])), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
-		p = _plans[key] = Plan(h)
+		p = Plan(h); _plans[key] = p
 	return p
 
 def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
@@ -117,7 +134,7 @@ def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixst
 		h = ctypes.c_void_p()
 		_lib.check(_lib.load().pxs_plan_rings(ctypes.byref(h), len(th), th.ctypes.data, nph.ctypes.data, p0.ctypes.data, rs.ctypes.data,
 			int(pixstride), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
-		p = _plans[key] = Plan(h)
+		p = Plan(h); _plans[key] = p
 	return p
 
 def _ncomp(spin, mode):
@@ -127,26 +144,52 @@ def _ncomp(spin, mode):
 def _check_pair(alm, map, spin, mode, pixdims):
 	nca, ncm = _ncomp(spin, mode)
 	if mode not in ("STANDARD", "DERIV1"): raise ValueError("unknown mode '%s'" % str(mode))
+	if alm.ndim == 3 and map.ndim == 2+pixdims:          # a batch of independent maps (ours; ducc takes one map per call)
+		if alm.shape[0] != map.shape[0]: raise ValueError("batched call: alm and map disagree on the batch size")
+		alm, map = alm[0], map[0]
 	if alm.ndim != 2 or alm.shape[0] != nca: raise ValueError("alm must have shape [%d,nelem] for spin %d mode %s" % (nca, spin, mode))
 	if map.ndim != 1+pixdims or map.shape[0] != ncm: raise ValueError("map must have %d components" % ncm)
 	ad, md = _np_dtype(alm), _np_dtype(map)
 	if ad not in (np.complex64, np.complex128) or md not in (np.float32, np.float64): raise TypeError("alm must be complex, map real")
 	return ad, md
 
+class _View:
+	"""device pointer + (batch, component) strides of alm [nb?, nc, nelem] / map [nb?, nc, pixels...].  CUDA tensors are used in
+	place whenever their inner axes are contiguous (the batch and component axes may be strided views, e.g. one spin group of
+	many maps); numpy arrays and other tensors are staged contiguously (and written back for outputs)."""
+	def __init__(self, arr, inner_ndim, batched, writeback):
+		self.buf = None
+		if _is_tensor(arr) and (arr.is_cuda or _lib.is_hostsim()):
+			st = list(arr.stride()); sh = list(arr.shape)
+			inner_ok = all(st[-k] == int(np.prod(sh[len(sh)-k+1:], dtype=np.int64)) for k in range(1, inner_ndim+1))
+			if inner_ok:
+				self.keep = arr; self.ptr = arr.data_ptr()
+				self.cstride = st[-inner_ndim-1]; self.bstride = st[0] if batched else 0
+				return
+		self.buf = _Buf(arr, writeback=writeback); self.ptr = self.buf.ptr
+		inner = int(np.prod(arr.shape[arr.ndim-inner_ndim:], dtype=np.int64))
+		self.cstride = inner; self.bstride = inner*arr.shape[-inner_ndim-1] if batched else 0
+	def finish(self):
+		if self.buf is not None: self.buf.finish()
+
 def _run_syn(plan, alm, map, spin, mode, adjoint):
+	"""alm [nca, nelem], map [ncm, ...] -- or a batch of independent maps alm [nb, nca, nelem], map [nb, ncm, ...] in ONE library call"""
 	ad, md = _np_dtype(alm), _np_dtype(map)
-	ab = _Buf(alm, writeback=bool(adjoint)); mb = _Buf(map, writeback=not adjoint)
-	acs = alm.shape[-1]; mcs = int(np.prod(map.shape[1:]))
-	_lib.check(_lib.load().pxs_synthesis(plan.handle, int(spin), 1 if mode == "DERIV1" else 0, int(bool(adjoint)),
-		ab.ptr, _DT[ad], acs, mb.ptr, _DT[md], mcs, current_stream()))
-	ab.finish(); mb.finish()
+	batched = alm.ndim == 3
+	nb = alm.shape[0] if batched else 1
+	av = _View(alm, 1, batched, bool(adjoint)); mv = _View(map, map.ndim-(2 if batched else 1), batched, not adjoint)
+	_lib.check(_lib.load().pxs_synthesis(plan.handle, int(spin), 1 if mode == "DERIV1" else 0, int(bool(adjoint)), int(nb),
+		av.ptr, _DT[ad], av.cstride, av.bstride, mv.ptr, _DT[md], mv.cstride, mv.bstride, current_stream()))
+	av.finish(); mv.finish()
 
 def _run_ana(plan, map, alm, spin, adjoint):
 	ad, md = _np_dtype(alm), _np_dtype(map)
-	ab = _Buf(alm, writeback=not adjoint); mb = _Buf(map, writeback=bool(adjoint))
-	acs = alm.shape[-1]; mcs = int(np.prod(map.shape[1:]))
-	_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), mb.ptr, _DT[md], mcs, ab.ptr, _DT[ad], acs, current_stream()))
-	ab.finish(); mb.finish()
+	batched = alm.ndim == 3
+	nb = alm.shape[0] if batched else 1
+	av = _View(alm, 1, batched, not adjoint); mv = _View(map, map.ndim-(2 if batched else 1), batched, bool(adjoint))
+	_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), int(nb), mv.ptr, _DT[md], mv.cstride, mv.bstride,
+		av.ptr, _DT[ad], av.cstride, av.bstride, current_stream()))
+	av.finish(); mv.finish()
 
 def _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip):
 	_check_pair(alm, map, spin, mode, 2)

@@ -58,3 +58,19 @@ def flipped(shape, wcs, flip):
 	if flip[0]: w.wcs.cdelt[1] = -w.wcs.cdelt[1]; w.wcs.crpix[1] = ny+1-w.wcs.crpix[1]
 	if flip[1]: w.wcs.cdelt[0] = -w.wcs.cdelt[0]; w.wcs.crpix[0] = nx+1-w.wcs.crpix[0]
 	return tuple(shape), w
+
+def slice_geometry(shape, wcs, sel):
+	"""geometry of map[..., sel_y, sel_x] for two slice objects (any start / stop / step, negative steps included): the
+	first selected pixel becomes pixel 0 and the increments are multiplied by the step (what enmap.slice_geometry does,
+	enmap.py:264-285)"""
+	w = wcs.deepcopy()
+	oshape = list(shape)
+	for axis, sl in zip((-2, -1), sel):                   # y is the second WCS axis, x the first
+		n = shape[axis]; start, stop, step = sl.indices(n)
+		count = len(range(start, stop, step))
+		k = 1 if axis == -2 else 0
+		# 0-based pixel p of the new map is pixel start + p*step of the old one
+		w.wcs.crpix[k] = (w.wcs.crpix[k]-1-start)/step+1
+		w.wcs.cdelt[k] = w.wcs.cdelt[k]*step
+		oshape[axis] = count
+	return tuple(oshape), w

@@ -78,3 +78,35 @@ def test_prepare_alm_errors():
 		curvedsky.prepare_alm(alm=np.zeros(21, np.complex64), dtype=np.float64)
 	alm, ai = curvedsky.prepare_alm(alm=np.zeros(21, np.complex64), dtype=np.float64, convert=True)
 	assert alm.dtype == np.complex128
+
+def test_slicing_moves_the_geometry():
+	"""ndmap[..., y-slice, x-slice] carries the wcs of the slice (enmap.ndmap.__getitem__ / slice_geometry, enmap.py:140-163, 264-285)"""
+	shape, wcs = enmap.fullsky_geometry(shape=(12, 24))
+	m = enmap.ndmap(np.arange(3*12*24, dtype=float).reshape(3, 12, 24), wcs)
+	for sel in [(Ellipsis, slice(2, 9), slice(4, 20)), (slice(None), slice(None, None, -1), slice(None)), (1, slice(3, None, 2), slice(None, None, -3)), (Ellipsis, slice(5, 7))]:
+		sub = m[sel]
+		assert isinstance(sub, enmap.ndmap) and np.array_equal(np.asarray(sub), np.asarray(m)[sel])
+		# the sky position of every pixel of the slice is that of the pixel it came from
+		yy, xx = np.mgrid[:12, :24]
+		src_y = np.broadcast_to(yy, m.shape)[sel]; src_x = np.broadcast_to(xx, m.shape)[sel]
+		src_y = src_y.reshape((-1,)+src_y.shape[-2:])[0]; src_x = src_x.reshape((-1,)+src_x.shape[-2:])[0]
+		py, px = np.mgrid[:sub.shape[-2], :sub.shape[-1]]
+		assert np.allclose(enmap.pix2sky(sub.shape, sub.wcs, [py, px]), enmap.pix2sky(m.shape, m.wcs, [src_y, src_x]), atol=1e-13)
+	assert not isinstance(m[0, 3], enmap.ndmap)               # a pixel axis indexed away: plain array
+	assert m[1].wcs is m.wcs
+	# a flipped full-sky map is still a "2d" geometry, with the flips reversed
+	mi = curvedsky.analyse_geometry(m[..., ::-1, ::-1].shape, m[..., ::-1, ::-1].wcs)
+	assert mi.case == "2d" and [bool(f) for f in mi.flip] == [False, False]
+
+def test_non_car_cylindrical_is_general():
+	"""CEA / MER maps are not transformed with CAR ring positions"""
+	shape, wcs = enmap.fullsky_geometry(shape=(12, 24))
+	w = wcs.deepcopy(); w.wcs.ctype = ["RA---CEA", "DEC--CEA"]
+	assert curvedsky.analyse_geometry(shape, w).case == "general" and curvedsky.get_method(shape, w) == "general"
+
+def test_plan_cache_is_bounded():
+	from pixell_amd import sht
+	assert sht._plans.cap >= 1
+	c = sht._PlanCache(); c.cap = 2
+	for k in "abc": c[k] = object()
+	assert len(c) == 2 and c.get("a") is None and c.get("c") is not None

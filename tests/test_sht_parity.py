@@ -215,3 +215,45 @@ def test_errors():
 		sht.synthesis_2d(alm=np.zeros((1, n), complex), map=np.zeros((1, 30, 64)), spin=0, lmax=lmax, mstart=ms, geometry="GL")
 	with pytest.raises(ValueError):
 		sht.synthesis_2d(alm=np.zeros((1, n), complex), map=np.zeros((1, 30, 64)), spin=2, lmax=lmax, mstart=ms, geometry="F1")
+
+def check_batched(nb=3, geometry="F1", nt=24, nph=48, lmax=20):
+	"""nbatch > 1 at the C ABI (pxs_synthesis / pxs_analysis with batch strides): alm [nb, nc, nelem], map [nb, nc, nt, nph] in one
+	call equals nb single calls (bit for bit) and the oracle; strided batches (one spin group out of T/Q/U stacks) included"""
+	ms = so._tri_mstart(lmax, lmax)
+	for spin in (0, 2):
+		nc = 1 if spin == 0 else 2
+		alm = np.stack([so.rand_alm_simple(lmax, nc, 20+i, spin=(spin,)) for i in range(nb)])
+		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.2)
+		out = np.zeros((nb, nc, nt, nph)); sht.synthesis_2d(alm=alm, map=out, **kw)
+		for i in range(nb):
+			one = np.zeros((nc, nt, nph)); sht.synthesis_2d(alm=alm[i], map=one, **kw)
+			assert np.array_equal(one, out[i])
+			ref = np.zeros((nc, nt, nph)); so.synthesis_2d(alm=alm[i], map=ref, **kw)
+			assert rel(out[i], ref) < TOL
+		back = np.zeros_like(alm); sht.analysis_2d(alm=back, map=out, **kw)
+		assert relrms(back, alm) < TOL
+		adj = np.zeros_like(alm); sht.adjoint_synthesis_2d(alm=adj, map=out, **kw)
+		one = np.zeros_like(alm[0]); sht.adjoint_synthesis_2d(alm=one, map=out[1], **kw)
+		assert np.array_equal(one, adj[1])
+		aa = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=aa, **kw)       # (runs map by map inside the library)
+		one = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm[2], map=one, **kw)
+		assert np.array_equal(one, aa[2])
+
+@pytest.mark.hostsim
+def test_batched_hostsim(): check_batched()
+@pytest.mark.gpu
+def test_batched_gpu():
+	check_batched(); check_batched(5, "CC", 130, 300, 128)
+	# device-resident strided batch: the Q/U group of a stack of T/Q/U maps, in place
+	import torch
+	from pixell_amd import curvedsky, enmap
+	lmax = 64; shape, wcs = enmap.fullsky_geometry(shape=(70, 140))
+	alm = torch.from_numpy(np.stack([so.rand_alm_simple(lmax, 3, 40+i, spin=(0, 2)) for i in range(4)])).cuda()
+	m = enmap.dmap(torch.zeros((4, 3)+tuple(shape), dtype=torch.float64, device="cuda"), wcs)
+	curvedsky.alm2map(alm, m, spin=[0, 2])
+	for i in range(4):
+		one = enmap.dmap(torch.zeros((3,)+tuple(shape), dtype=torch.float64, device="cuda"), wcs)
+		curvedsky.alm2map(alm[i], one, spin=[0, 2])
+		assert torch.equal(one.tensor, m.tensor[i])
+	back = torch.zeros_like(alm); curvedsky.map2alm(m, alm=back, spin=[0, 2])
+	assert float((back-alm).abs().max()) < 1e-11
