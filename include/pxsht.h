@@ -45,7 +45,7 @@ int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64
                    const double* phi0, const uint64_t* ringstart, int64_t pixstride,
                    int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device);
 
-/* Plan for a named full-sky equiangular grid ("CC","F1","MW","MWflip"), map[ntheta][nphi].
+/* Plan for a named full-sky equiangular grid ("CC","F1","MW","MWflip","DH","F2"; curvedsky.py:1329-1342), map[ntheta][nphi].
  * Replaces the geometry arguments of ducc0.sht.experimental.{synthesis_2d, adjoint_synthesis_2d,
  * analysis_2d, adjoint_analysis_2d} (curvedsky.py:907-924, 1032-1046).
  * flip_y / flip_x fold curvedsky.map2buffer / buffer2map (curvedsky.py:1384-1411) into the kernels'

@@ -90,7 +90,16 @@ def get_gridweights(name, n):
 	trigonometric interpolant on the grid.  Mirrors ducc0.sht.experimental.get_gridweights
 	as used at curvedsky.py:501,855."""
 	if name in ("DH", "F2"):
-		raise NotImplementedError("gridweights for %s: grid does not carry its own mirror images" % name)
+		# Fejer's second rule on the interior nodes theta_j = j pi/(K+1), j = 1..K (classical closed form, exact for polynomials
+		# in cos(theta) of degree <= K-1, which is where get_ducc_maxlmax's (n-1)/2 and (n-2)/2 come from):
+		#   w_j = 4 sin(theta_j)/(K+1) * sum_{k=1}^{floor((K+1)/2)} sin((2k-1) theta_j)/(2k-1)      (sum over the ring = 2)
+		# F2 is exactly that grid (K = n); DH is the north pole (weight 0) followed by the K = n-1 interior nodes of spacing pi/n.
+		K = n if name == "F2" else n-1
+		j = np.arange(1, K+1, dtype=LD); th = j*PI/(K+1)
+		acc = np.zeros(K, LD)
+		for k in range(1, (K+1)//2+1): acc += np.sin((2*k-1)*th)/(2*k-1)
+		w = np.asarray(4*np.sin(th)/(K+1)*acc, np.float64)*2*np.pi
+		return w if name == "F2" else np.concatenate([[0.0], w])
 	g = grid_info(name, n); N, c = g["N"], g["c"]
 	th = np.asarray(g["theta0"] + 2*PI*np.arange(N, dtype=LD)/N, dtype=np.float64)
 	K = (N-1)//2

@@ -5,6 +5,8 @@
 // along l so that loads of one m-column are contiguous (lstride 1).
 #include "../../include/pxsht.h"
 #include "common.hpp"
+#include <map>
+#include <mutex>
 
 namespace pxs {
 const char* get_last_error();
@@ -49,6 +51,41 @@ __global__ __launch_bounds__(256) void alm2cl_kernel(int lmax, int mmax, const u
 		const double2 x = ld_c(a1, dtype, i), y = ld_c(a2, dtype, i);
 		s += x.x*y.x + x.y*y.y;
 	}
+	s *= 2.0/(2*l+1);
+	if (cl_dtype == PX_F32) ((float*)cl)[l] = (float)s; else ((double*)cl)[l] = s;
+}
+
+// double-accumulating variants, split over m: block (l tile, m chunk) -> part[chunk][l]; a second kernel adds the chunks in a fixed
+// order (deterministic) and applies 2/(2l+1).  The one-thread-per-l kernel above walks 10^4 dependent loads per thread with only
+// lmax+1 threads on the chip; this one exposes (lmax+1)(mmax+1)/MCH-fold parallelism and streams the alm once.
+static constexpr int ALM2CL_MCH = 32;
+__global__ __launch_bounds__(256) void alm2cl_part_kernel(int lmax, int mmax, const uint64_t* __restrict__ mstart, long lstride,
+		const void* __restrict__ a1, const void* __restrict__ a2, int dtype, double* __restrict__ part)
+{
+	const int l = blockIdx.x*blockDim.x + threadIdx.x;
+	const int m0 = blockIdx.y*ALM2CL_MCH;
+	if (l > lmax) return;
+	const int m1 = min(min(l, mmax), m0 + ALM2CL_MCH - 1);
+	double s = 0;
+	for (int m = m0; m <= m1; m++) {
+		const long i = (long)mstart[m] + l*lstride;
+		if (dtype == PX_C64) {     // terms formed in float as the reference does (cmisc_core.c:58,64), summed in double
+			const float2 x = ((const float2*)a1)[i], y = ((const float2*)a2)[i];
+			s += (m == 0) ? (double)(__fmul_rn(x.x, y.x)/2) : (double)__fadd_rn(__fmul_rn(x.x, y.x), __fmul_rn(x.y, y.y));
+		} else {
+			const double2 x = ((const double2*)a1)[i], y = ((const double2*)a2)[i];
+			s += (m == 0) ? x.x*y.x/2 : x.x*y.x + x.y*y.y;
+		}
+	}
+	part[(long)blockIdx.y*(lmax+1) + l] = s;
+}
+__global__ __launch_bounds__(256) void alm2cl_sum_kernel(int lmax, int mmax, const double* __restrict__ part, void* __restrict__ cl, int cl_dtype)
+{
+	const int l = blockIdx.x*blockDim.x + threadIdx.x;
+	if (l > lmax) return;
+	const int nch = min(l, mmax)/ALM2CL_MCH + 1;          // chunks beyond m = l hold nothing for this l
+	double s = 0;
+	for (int c = 0; c < nch; c++) s += part[(long)c*(lmax+1) + l];
 	s *= 2.0/(2*l+1);
 	if (cl_dtype == PX_F32) ((float*)cl)[l] = (float)s; else ((double*)cl)[l] = s;
 }
@@ -108,8 +145,20 @@ int pxa_alm2cl(int lmax, int mmax, const uint64_t* d_mstart, int64_t lstride, co
 	PXS_REQUIRE(cl_dtype == PX_F32 || cl_dtype == PX_F64, "pxa_alm2cl: cl must be float32 or float64");
 	PXS_REQUIRE(!(alm_dtype == PX_C128 && cl_dtype == PX_F32), "pxa_alm2cl: float32 spectrum of double precision alm is not supported");
 	PXS_HIP(hipSetDevice(device));
-	hipLaunchKernelGGL(alm2cl_kernel, dim3((lmax+256)/256), dim3(256), 0, (hipStream_t)stream, lmax, mmax, d_mstart, (long)lstride,
-		alm1, alm2, alm_dtype, cl, cl_dtype, (alm_dtype == PX_C64 && cl_dtype == PX_F32) ? 1 : 0);
+	const bool acc_f32 = alm_dtype == PX_C64 && cl_dtype == PX_F32;
+	if (acc_f32 || lmax < 256) {
+		// float running sum in the reference's order (alm2cl_sp), or a spectrum too short to be worth two launches
+		hipLaunchKernelGGL(alm2cl_kernel, dim3((lmax+256)/256), dim3(256), 0, (hipStream_t)stream, lmax, mmax, d_mstart, (long)lstride,
+			alm1, alm2, alm_dtype, cl, cl_dtype, acc_f32 ? 1 : 0);
+	} else {
+		static std::mutex mu; static std::map<int, DevBuf> scratch;
+		const int nch = mmax/ALM2CL_MCH + 1;
+		double* part;
+		{ std::lock_guard<std::mutex> g(mu); DevBuf& b = scratch[device]; b.ensure(sizeof(double)*(size_t)nch*(lmax+1)); part = b.as<double>(); }
+		hipLaunchKernelGGL(alm2cl_part_kernel, dim3((lmax+256)/256, nch), dim3(256), 0, (hipStream_t)stream, lmax, mmax, d_mstart, (long)lstride,
+			alm1, alm2, alm_dtype, part);
+		hipLaunchKernelGGL(alm2cl_sum_kernel, dim3((lmax+256)/256), dim3(256), 0, (hipStream_t)stream, lmax, mmax, (const double*)part, cl, cl_dtype);
+	}
 	PXS_HIP(hipGetLastError());
 	PXS_CATCH
 }

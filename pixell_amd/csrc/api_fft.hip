@@ -66,7 +66,8 @@ static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::
 
 static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
                            FftLoad ld, FftStore stf) {
-	if (ld.mode != LD_PLAIN || ld.mul || stf.mul) throw Error(PXS_ERR_UNSUPPORTED, "FFT length " + std::to_string(n) + " has a prime factor > 2048: only c2c and r2c transforms are available for it (Bluestein)");
+	const bool c2r = ld.mode == LD_HERM && !ld.herm_fold;      // Hermitian half spectrum in, real line out
+	if ((ld.mode != LD_PLAIN && !c2r) || ld.mul || stf.mul) throw Error(PXS_ERR_UNSUPPORTED, "FFT length " + std::to_string(n) + " has a prime factor > 2048: only plain c2c / r2c / c2r transforms are available for it (Bluestein)");
 	const BluePlan& bp = blue_plan(fc, device, st, n, forward);
 	const long M = bp.M;
 	// dense scratch [lines][M]
@@ -75,7 +76,9 @@ static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, b
 	for (size_t k = dims.size(); k-- > 0;) { d1[k].os = lines*M; d2[k].is = lines*M; lines *= dims[k].n; }
 	DevBuf scratch; scratch.alloc(sizeof(double2)*(size_t)lines*M);
 	{	// y = FFT_M(x w, zero padded)
-		FftLoad l1 = ld; l1.mul = bp.w.as<double2>(); l1.ne = (ld.ne >= 0 && ld.ne < n) ? ld.ne : n;
+		FftLoad l1 = ld; l1.mul = bp.w.as<double2>();
+		if (c2r) l1.herm_n = n;                                   // Hermitian extension of n points (times the chirp), zero padded to M
+		else l1.ne = (ld.ne >= 0 && ld.ne < n) ? ld.ne : n;
 		FftStore s1; s1.ptr = scratch.p; s1.dtype = PX_C128;
 		fft_axis(fc, st, M, true, d1, is_e, 1, l1, s1);
 	}
@@ -211,7 +214,7 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 			const long N = r2r_length(kind, shape[a]);
 			if (N < 2) throw Error(PXS_ERR_ARG, "DCT-I needs at least 2 points along each axis");
 			if (!FftContext::supported(N, &why)) throw Error(PXS_ERR_UNSUPPORTED, "DCT/DST of " + std::to_string(shape[a]) + " points: " + why);
-		} else if (!FftContext::supported(shape[a], &why) && kind == 2 && a == axes.back()) throw Error(PXS_ERR_UNSUPPORTED, why + " (c2r along such an axis is not implemented)");
+		}
 	}
 	PXS_HIP(hipSetDevice(device));
 	FftContext& fc = fft_context(device);

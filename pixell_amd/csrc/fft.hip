@@ -61,9 +61,14 @@ template<int LM> __device__ __forceinline__ double2 load_functor(const KArgs& a,
 	case LD_HERM: {
 		if (!ld.herm_fold) {
 			// plain c2r (numpy.fft.irfft semantics): X[e] = h[e] for e < nh, conj(h[N-e]) otherwise
-			if (e < ld.ne) return read_elem(ld.ptr, ld.dtype, base + e*a.d.is_e);
-			if (N - e < ld.ne) return cconj(read_elem(ld.ptr, ld.dtype, base + (N-e)*a.d.is_e));
-			return make_double2(0, 0);
+			const long Nh = ld.herm_n > 0 ? ld.herm_n : N;
+			if (e >= Nh) return make_double2(0, 0);
+			double2 v;
+			if (e < ld.ne) v = read_elem(ld.ptr, ld.dtype, base + e*a.d.is_e);
+			else if (Nh - e < ld.ne) v = cconj(read_elem(ld.ptr, ld.dtype, base + (Nh-e)*a.d.is_e));
+			else return make_double2(0, 0);
+			if (ld.mul) v = cmul(v, ld.mul[e]);
+			return v;
 		}
 		// SHT ring synthesis: ring(x) = Re h[0] + 2 Re sum_{m>=1} h[m] e^{i m phi_x}, i.e.
 		// X[e] = sum_{m = e (mod N)} h[m] + sum_{m = -e (mod N), m > 0} conj(h[m]); only Re h[0] counts.

@@ -33,6 +33,8 @@ struct FftLoad {
 	int nyq_half = 0;           // SPEC: source Nyquist bin (Ns even) is split 1/2,1/2 onto +-Ns/2
 	long pair_lines = 0;        // MIRROR_PAIR: number of source lines (line i packs source lines 2i [parity par0] and 2i+1 [opposite parity])
 	int herm_fold = 0;          // HERM: 1 = SHT ring semantics (2 Re sum over m, with aliasing folds), 0 = plain c2r
+	long herm_n = 0;            // HERM, plain c2r: logical length of the Hermitian extension when it differs from the transform length
+	                            // (Bluestein: the extension of n points, times mul[e], zero padded to the chirp length); 0: the transform length
 };
 
 struct FftStore {

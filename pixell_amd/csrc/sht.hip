@@ -35,7 +35,25 @@ static GridInfo grid_info(const std::string& g, int n) {
 	if (g == "F1")     return {2L*n,   1, true};
 	if (g == "MW")     return {2L*n-1, 1, true};
 	if (g == "MWflip") return {2L*n-1, 0, true};
+	// Driscoll-Healy (north pole + n-1 interior rings of spacing pi/n) and Fejer-2 (n interior rings of spacing pi/(n+1)): the
+	// circle has sample points without a ring (a pole), so there is no interpolant to integrate: analysis on these grids is plain
+	// quadrature with Fejer's second rule, exact up to get_ducc_maxlmax (curvedsky.py:1349-1353)
+	if (g == "DH")     return {2L*n,   0, true};
+	if (g == "F2")     return {2L*n+2, 2, true};
 	return {0, 0, false};
+}
+static bool grid_weights_only(const std::string& g) { return g == "DH" || g == "F2"; }
+// Fejer's second rule on K interior nodes theta_j = j pi/(K+1): w_j = 4 sin(theta_j)/(K+1) sum_{k=1}^{(K+1)/2} sin((2k-1) theta_j)/(2k-1)
+// (ring weights, sum 2); the inner sum by the Chebyshev recurrence sin((2k+1)t) = 2 cos(2t) sin((2k-1)t) - sin((2k-3)t)
+static std::vector<LDb> fejer2_weights(int K) {
+	std::vector<LDb> w(K);
+	for (int j = 1; j <= K; j++) {
+		const LDb t = (LDb)j*PIl/(K+1), c2 = 2*cosl(2*t);
+		LDb sm = -sinl(t), s0 = sinl(t), acc = 0;          // sin(-t), sin(t)
+		for (int k = 1; k <= (K+1)/2; k++) { acc += s0/(2*k-1); const LDb sn = c2*s0 - sm; sm = s0; s0 = sn; }
+		w[j-1] = 4*sinl(t)/(K+1)*acc;
+	}
+	return w;
 }
 static int grid_maxlmax(const std::string& g, int n) {
 	if (g == "CC") return n-2;
@@ -154,6 +172,16 @@ __global__ __launch_bounds__(256) void gather_alias(const double2* __restrict__ 
 	out[(long)b*out_bstride + idx] = v;
 }
 
+// leg[line][ring] *= w[ring] (DH / F2 analysis: plain quadrature weights)
+__global__ __launch_bounds__(256) void scale_rings(double2* __restrict__ leg, long nlines, int nr, long ld, const double2* __restrict__ w)
+{
+	const long idx = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (idx >= nlines*nr) return;
+	const long line = idx / nr; const int j = (int)(idx - line*nr);
+	double2& v = leg[line*ld + j]; const double f = w[j].x;
+	v.x *= f; v.y *= f;
+}
+
 // transpose of the parity mirror extension: out[line][j] = in[line][j] + sgn * in[line][mirror(j)], j < nr
 // (self-mirrored samples -- pole rings -- are kept for even parity and dropped for odd parity)
 __global__ __launch_bounds__(256) void fold_mirror(const double2* __restrict__ in, double2* __restrict__ out,
@@ -243,6 +271,7 @@ struct pxs_plan {
 	// analysis resampling (grid plans)
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
 	DevBuf ph_shift, ph_up, sigma, wcc, b1, b2;
+	DevBuf wring;                // DH / F2 grids: per-ring quadrature weight / nphi (analysis = weighted adjoint synthesis)
 	bool syn_via_cc = false;
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
@@ -590,7 +619,14 @@ int pxs_gridweights(const char* geometry, int ntheta, double* out) {
 	PXS_TRY
 	PXS_REQUIRE(geometry && out && ntheta > 0, "pxs_gridweights: bad arguments");
 	GridInfo gi = grid_info(geometry, ntheta);
-	if (!gi.ok) throw Error(PXS_ERR_UNSUPPORTED, std::string("gridweights: unsupported geometry '") + geometry + "' (CC, F1, MW, MWflip)");
+	if (!gi.ok) throw Error(PXS_ERR_UNSUPPORTED, std::string("gridweights: unsupported geometry '") + geometry + "' (CC, F1, MW, MWflip, DH, F2)");
+	if (grid_weights_only(geometry)) {
+		const bool dh = std::string(geometry) == "DH";
+		const std::vector<LDb> w = fejer2_weights(dh ? ntheta-1 : ntheta);
+		if (dh) out[0] = 0;
+		for (size_t j = 0; j < w.size(); j++) out[j + (dh ? 1 : 0)] = (double)(w[j]*2*PIl);
+		return 0;
+	}
 	const long N = gi.N; const int n = ntheta;
 	const LDb th0 = (LDb)gi.c*PIl/N;
 	std::vector<LDb> v(N);
@@ -612,7 +648,7 @@ int pxs_plan_grid2d(pxs_plan** plan, const char* geometry, int ntheta, int nphi,
 	PXS_TRY
 	PXS_REQUIRE(plan && geometry && ntheta > 0 && nphi > 0, "pxs_plan_grid2d: bad arguments");
 	GridInfo gi = grid_info(geometry, ntheta);
-	if (!gi.ok) throw Error(PXS_ERR_UNSUPPORTED, std::string("unsupported 2d geometry '") + geometry + "' (supported: CC, F1, MW, MWflip)");
+	if (!gi.ok) throw Error(PXS_ERR_UNSUPPORTED, std::string("unsupported 2d geometry '") + geometry + "' (supported: CC, F1, MW, MWflip, DH, F2)");
 	std::unique_ptr<pxs_plan> p(new pxs_plan());
 	p->is_grid = true; p->geometry = geometry; p->nring = ntheta; p->nphi = nphi; p->phi0 = phi0;
 	p->ring_stride = flip_y ? -(long)nphi : (long)nphi;
@@ -620,7 +656,13 @@ int pxs_plan_grid2d(pxs_plan** plan, const char* geometry, int ntheta, int nphi,
 	p->ring_off0 = (flip_y ? (long)(ntheta-1)*nphi : 0) + (flip_x ? (long)nphi-1 : 0);
 	plan_common(p.get(), lmax, mmax, mstart, lstride, device);
 	p->rs_map.build(grid_theta(geometry, ntheta)); p->rs_map.upload_all();
-	if (lmax <= grid_maxlmax(geometry, ntheta)) setup_resampling(p.get());
+	if (grid_weights_only(geometry)) {	// quadrature weights per pixel for the analysis (pxs_analysis)
+		std::vector<double> w(ntheta);
+		if (pxs_gridweights(geometry, ntheta, w.data()) != 0) throw Error(PXS_ERR_ARG, get_last_error());
+		std::vector<double2> wd(ntheta);
+		for (int j = 0; j < ntheta; j++) wd[j] = make_double2(w[j]/nphi, 0.0);
+		p->wring = upload(wd);
+	} else if (lmax <= grid_maxlmax(geometry, ntheta)) setup_resampling(p.get());
 	*plan = p.release();
 	PXS_CATCH
 }
@@ -765,6 +807,28 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 	const int nc = spin == 0 ? 1 : 2, nct = nb*nc;
 	const int nm = p->mmax+1, nr = p->nring;
 	LegTables& tb = p->table(spin);
+	if (p->wring.p) {	// DH / F2: analysis = adjoint synthesis of the weighted map (its adjoint: synthesis, then the weights)
+		const long ldw = p->chain_rings ? FftChain::pad8(nr) : nr;
+		const int ncbw = nb > 1 ? nc : 0;
+		const size_t aeszw = alm_dtype == PX_C64 ? 8 : 16;
+		p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldw);
+		const long tot = (long)nct*nm*nr;
+		if (!adjoint) {
+			map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldw, map_bstride, ncbw);
+			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, p->wring.as<double2>());
+			for (int b = 0; b < nb; b++)
+				leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>() + (size_t)b*nc*nm*ldw, (char*)alm + aeszw*(size_t)b*alm_bstride, alm_dtype, alm_cstride,
+					p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldw);
+		} else {
+			for (int b = 0; b < nb; b++)
+				leg_synthesis(st, p->rs_map, tb, p->wk, (char*)alm + aeszw*(size_t)b*alm_bstride, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+					p->leg.as<double2>() + (size_t)b*nc*nm*ldw, 0, &p->prof, ldw);
+			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, p->wring.as<double2>());
+			leg2map(p, st, p->leg.as<double2>(), ldw, map, map_dtype, map_cstride, nct, false, map_bstride, ncbw);
+		}
+		PXS_HIP(hipGetLastError());
+		return;
+	}
 	const bool th = p->chain_theta() && !adjoint;       // (the adjoint of the analysis runs the unfused chain, dense rows)
 	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
 	const int ncb = nb > 1 ? nc : 0;
@@ -804,7 +868,7 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint, int nbatch,
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
-	const int chunk = (adjoint || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
+	const int chunk = p->wring.p ? batch_chunk(p, nbatch, spin == 0 ? 1 : 2) : (adjoint || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
 	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
 		const int nb = std::min(chunk, nbatch - b0);
 		analysis_core(p, spin, adjoint, nb, (char*)map + mesz*(size_t)b0*map_bstride, map_dtype, map_cstride, map_bstride,

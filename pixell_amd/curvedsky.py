@@ -354,7 +354,7 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, lmax=lmax, pre=map.shape[:-3] if deriv else map.shape[:-2], dtype=_np_dtype(mdata), convert=adjoint, like=mdata)
 	if minfo is None: minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
 	if weights is None:
-		if minfo.ducc_geo is not None and minfo.ducc_geo.name in ("CC", "F1", "MW", "MWflip"):
+		if minfo.ducc_geo is not None and minfo.ducc_geo.name in _geo.WEIGHTED_GRIDS:
 			weights = quad_weights(map.shape, map.wcs, pix_tol=pix_tol)
 		else:
 			# pixel area of each row (enmap.pixsizemap separable; curvedsky.py:858-860)

@@ -107,8 +107,12 @@ def check_bluestein():
 	assert rel(pfft.fft(a+0j, axes=[-2]), np.fft.fft(a, axis=-2)) < 1e-12
 	assert rel(pfft.fft(a+0j, axes=[-2, -1]), np.fft.fft2(a)) < 1e-12
 	assert rel(pfft.rfft(a.transpose(0, 2, 1).copy(), axes=[-2, -1]), np.fft.rfft2(a.transpose(0, 2, 1))) < 1e-12
-	with pytest.raises(PxsError):
-		pfft.irfft(np.zeros((1, 2053//2+1), complex), n=2053)       # c2r along such an axis is not implemented
+	for n in (2053, 2*4099):                                     # c2r along such an axis: Hermitian extension inside the chirp transform
+		r = rng.standard_normal((3, n)); h = np.fft.rfft(r, axis=-1)
+		assert rel(pfft.irfft(h, n=n, normalize=True), r) < 1e-12
+		assert rel(pfft.irfft(h, n=n), np.fft.irfft(h, n=n, axis=-1)*n) < 1e-12
+	r2 = rng.standard_normal((2, 12, 2053)); h2 = np.fft.rfftn(r2, axes=(-2, -1))
+	assert rel(pfft.irfft(h2, n=2053, axes=[-2, -1], normalize=True), r2) < 1e-12
 	assert pfft.fft_len(4099, "above") >= 4099
 
 @pytest.mark.hostsim

@@ -200,7 +200,7 @@ def test_rings_hostsim(): check_rings()
 def test_rings_gpu(): check_rings()
 
 def check_gridweights():
-	for g in ["CC", "F1", "MW", "MWflip"]:
+	for g in ["CC", "F1", "MW", "MWflip", "DH", "F2"]:
 		for n in [7, 12, 33, 100]:
 			assert np.max(np.abs(sht.get_gridweights(g, n)-so.get_gridweights(g, n))) < 1e-13
 def test_gridweights(): check_gridweights()
@@ -257,3 +257,20 @@ def test_batched_gpu():
 		assert torch.equal(one.tensor, m.tensor[i])
 	back = torch.zeros_like(alm); curvedsky.map2alm(m, alm=back, spin=[0, 2])
 	assert float((back-alm).abs().max()) < 1e-11
+
+
+def check_dh_f2():
+	"""Driscoll-Healy and Fejer-2 grids (get_ducc_geo can return them, curvedsky.py:1329-1342): synthesis on their rings, analysis
+	by Fejer's second rule, exact up to get_ducc_maxlmax = (n-2)//2 resp. (n-1)//2; adjoints; error beyond the limit"""
+	from pixell_amd._lib import PxsError
+	for g, nt in [("DH", 22), ("F2", 21), ("DH", 41), ("F2", 40)]:
+		lmax = so.grid_maxlmax(g, nt); assert sht.grid_maxlmax(g, nt) == lmax
+		for spin in (0, 2):
+			check_grid(g, nt, 2*lmax+3, lmax, spin)
+		with pytest.raises(PxsError):
+			sht.analysis_2d(alm=np.zeros((1, so.nalm(lmax+1)), complex), map=np.zeros((1, nt, 64)), spin=0, lmax=lmax+1, mstart=so._tri_mstart(lmax+1, lmax+1), geometry=g)
+
+@pytest.mark.hostsim
+def test_dh_f2_hostsim(): check_dh_f2()
+@pytest.mark.gpu
+def test_dh_f2_gpu(): check_dh_f2()
