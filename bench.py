@@ -108,7 +108,8 @@ def cpu_baseline(cfg, budget_s=20.0):
 
 def measured_traffic(config, dom):
 	"""HBM bytes of a kernel family per step from the committed PMC passes of this bench command (tools/pmc_traffic.sh ->
-	profiles/r02_traffic_<config>.json; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported).
+	profiles/r02_traffic_<config>.json; FETCH_SIZE corrected per access pattern -- x2 for 16-byte-per-lane row reads as the gfx950 note
+	of MI355X_MICROARCH.md prescribes, x1 where the known array sizes of the chain kernels show full counting -- WRITE_SIZE as reported).
 	Counters cannot be read from inside this process: null when no profile of this config is committed."""
 	for tag in ("r02", "r01"):
 		path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config))
@@ -119,7 +120,7 @@ def measured_traffic(config, dom):
 		for k, v in d["kernels"].items():
 			if not any(k.startswith("pxs::"+p) for p in dom): continue
 			n = v["launches_per_round_trip"]
-			tot += n*(v["fetch_MB_per_launch_x2"]+v["write_MB_per_launch"]); raw += n*(v["fetch_MB_per_launch_raw"]+v["write_MB_per_launch"])
+			tot += n*(v.get("fetch_MB_per_launch_calibrated", v["fetch_MB_per_launch_x2"])+v["write_MB_per_launch"]); raw += n*(v["fetch_MB_per_launch_raw"]+v["write_MB_per_launch"])
 		return dict(traffic=round(tot*2**20), traffic_unit="bytes per step, all launches of the kernel family",
 			traffic_uncorrected=round(raw*2**20), traffic_source=os.path.basename(path))
 	except Exception as e:

@@ -44,3 +44,16 @@ def test_product_package_does_not_import_oracle():
 	for f in glob.glob(os.path.join(ROOT, "pixell_amd", "*.py")):
 		src = open(f).read()
 		assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_docs_agree_with_the_header():
+	"""the entry-point count quoted in INTEGRATION.md / DESIGN.md / README.md is the number of declarations in include/pxsht.h,
+	and every declared symbol is in the loader's export list"""
+	import re
+	hdr = open(os.path.join(ROOT, "include", "pxsht.h")).read()
+	names = re.findall(r"^(?:int|void|int64_t|const char\*)\s+(px[a-z]_\w+)\s*\(", hdr, re.M)
+	assert len(names) == len(set(names)) and set(names) == set(_lib.EXPORTS), sorted(set(names) ^ set(_lib.EXPORTS))
+	for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+		txt = open(os.path.join(ROOT, doc)).read()
+		counts = set(int(n) for n in re.findall(r"(\d+) entry points", txt))
+		assert counts == {len(names)}, (doc, counts, len(names))
