@@ -50,6 +50,7 @@ def test_docs_agree_with_the_header():
 	"""the entry-point count quoted in INTEGRATION.md / DESIGN.md / README.md is the number of declarations in include/pxsht.h,
 	and every declared symbol is in the loader's export list"""
 	import re
+	from pixell_amd import _lib
 	hdr = open(os.path.join(ROOT, "include", "pxsht.h")).read()
 	names = re.findall(r"^(?:int|void|int64_t|const char\*)\s+(px[a-z]_\w+)\s*\(", hdr, re.M)
 	assert len(names) == len(set(names)) and set(names) == set(_lib.EXPORTS), sorted(set(names) ^ set(_lib.EXPORTS))
