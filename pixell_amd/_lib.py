@@ -49,7 +49,8 @@ EXPORTS = ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_plan_destroy", "pxs_synthes
 	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxs_debug_theta_plan", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]
 
 def lib_path():
-	return os.path.join(HERE, "libpxsht.so")
+	# PIXELL_AMD_LIB: another build of the same library (kernel A/B experiments, tools/chain_exp*.sh)
+	return os.environ.get("PIXELL_AMD_LIB") or os.path.join(HERE, "libpxsht.so")
 
 def load():
 	"""Return the loaded library, loading it on first use.  Raises if it is absent."""

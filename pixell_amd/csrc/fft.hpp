@@ -72,7 +72,7 @@ private:
 	std::map<long, std::shared_ptr<FftSub>> subs_;
 	std::map<long, DevBuf> bigtw_;
 	std::map<hipStream_t, DevBuf> temps_;
-	std::shared_ptr<FftSub> sub(long n);
+	std::shared_ptr<FftSub> sub(long n, bool comp = false);   // comp: factorisation with the composite register radices (chain kernels)
 	const double2* bigtw(long n);
 };
 

@@ -1,6 +1,7 @@
 // Device-side building blocks of the LDS FFT kernels (shared by fft.hip and fftchain.hip).
 #pragma once
 #include "common.hpp"
+#include "fft_radix_tw.hpp"
 
 namespace pxs {
 
@@ -93,7 +94,64 @@ template<int R, int NT> __device__ __forceinline__ void radix_pass_t(double2* bu
 	}
 }
 
-// all passes of f on T lines (radices 2,3,4,5 only); ends with a barrier
+// Composite radices R = A*B (6, 8, 9, 10, 12, 15, 16) done in registers: B butterflies of radix A over stride B, the constant
+// twiddles W_R^{n2 k1}, A butterflies of radix B.  Output X[k1 + A k2] ends up in v[B k1 + k2].  One LDS round trip (and one
+// barrier) then does the work of two passes of the plain radices.
+// Only radices up to PXS_COMP_MAXR are compiled in.  Measured on MI355X (C3 bench, FFT stages of a round trip, same box):
+// plain radices 112.5 ms (48-54 VGPRs), up to 8: 108.4 ms (62-67 VGPRs), up to 10: 107.9 ms (75-79 VGPRs), up to 16: 139 ms --
+// at 107-112 VGPRs a 512-thread workgroup fits only twice on a CU and even tiles that never take the radix-16 path slow
+// down by a third.  9 keeps every chain kernel at <= 69 VGPRs.
+#ifndef PXS_COMP_MAXR
+#define PXS_COMP_MAXR 9
+#endif
+template<int R> struct RadixTw;
+template<> struct RadixTw<6>  { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW6[2*j],  PXS_RTW6[2*j+1]); } };
+template<> struct RadixTw<8>  { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW8[2*j],  PXS_RTW8[2*j+1]); } };
+template<> struct RadixTw<9>  { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW9[2*j],  PXS_RTW9[2*j+1]); } };
+template<> struct RadixTw<10> { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW10[2*j], PXS_RTW10[2*j+1]); } };
+template<> struct RadixTw<12> { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW12[2*j], PXS_RTW12[2*j+1]); } };
+template<> struct RadixTw<15> { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW15[2*j], PXS_RTW15[2*j+1]); } };
+template<> struct RadixTw<16> { static __device__ __forceinline__ double2 w(int j) { return make_double2(PXS_RTW16[2*j], PXS_RTW16[2*j+1]); } };
+
+template<int A, int B> __device__ __forceinline__ void butterfly_comp(double2* v) {
+#pragma unroll
+	for (int n2 = 0; n2 < B; n2++) {
+		double2 t[A];
+#pragma unroll
+		for (int n1 = 0; n1 < A; n1++) t[n1] = v[B*n1 + n2];
+		butterfly<A>(t);
+#pragma unroll
+		for (int k1 = 0; k1 < A; k1++) v[B*k1 + n2] = (n2*k1 == 0) ? t[k1] : cmul(t[k1], RadixTw<A*B>::w(n2*k1));
+	}
+#pragma unroll
+	for (int k1 = 0; k1 < A; k1++) butterfly<B>(v + B*k1);
+}
+
+template<int A, int B, int NT> __device__ __forceinline__ void radix_pass_comp(double2* buf, const double2* tw, int n, int ns, int T, const PassDesc& ps) {
+	constexpr int R = A*B;
+	const int nb = n / R;
+	const int total = T*nb;
+	for (int b = threadIdx.x; b < total; b += NT) {
+		const uint32_t t = fdiv(b, ps.dnb);
+		const uint32_t bb = b - t*nb;
+		const uint32_t blk = fdiv(bb, ps.dL);
+		const uint32_t q = bb - blk*ps.L;
+		const uint32_t p0 = t*ns + blk*ps.L*R + q;
+		double2 v[R];
+#pragma unroll
+		for (int i = 0; i < R; i++) v[i] = buf[p0 + i*ps.L];
+		if (ps.L > 1) {
+			const int step = q*ps.tws;
+#pragma unroll
+			for (int i = 1; i < R; i++) v[i] = cmul(v[i], tw[i*step]);
+		}
+		butterfly_comp<A, B>(v);
+#pragma unroll
+		for (int k = 0; k < R; k++) buf[p0 + k*ps.L] = v[B*(k % A) + k/A];
+	}
+}
+
+// all passes of f on T lines (radices 2,3,4,5 and the composite ones); ends with a barrier
 template<int NT> __device__ __forceinline__ void lds_fft(double2* buf, const double2* tw, const LdsFft& f, int T) {
 	for (int p = 0; p < f.nfac; p++) {
 		const PassDesc ps = f.pass[p];
@@ -101,7 +159,29 @@ template<int NT> __device__ __forceinline__ void lds_fft(double2* buf, const dou
 			case 2: radix_pass_t<2, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 3: radix_pass_t<3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 4: radix_pass_t<4, NT>(buf, tw, f.n, f.ns, T, ps); break;
-			default: radix_pass_t<5, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 5: radix_pass_t<5, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#if PXS_COMP_MAXR >= 6
+			case 6: radix_pass_comp<3, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+#if PXS_COMP_MAXR >= 8
+			case 8: radix_pass_comp<4, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+#if PXS_COMP_MAXR >= 9
+			case 9: radix_pass_comp<3, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+#if PXS_COMP_MAXR >= 10
+			case 10: radix_pass_comp<5, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+#if PXS_COMP_MAXR >= 12
+			case 12: radix_pass_comp<4, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+#if PXS_COMP_MAXR >= 15
+			case 15: radix_pass_comp<5, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+#if PXS_COMP_MAXR >= 16
+			case 16: radix_pass_comp<4, 4, NT>(buf, tw, f.n, f.ns, T, ps); break;
+#endif
+			default: break;
 		}
 		PXS_LDS_BARRIER();
 	}

@@ -75,25 +75,30 @@ template<class F> void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
 	const int nt = block.x*block.y*block.z;
 	const int nw = (nt + 63)/64;
 	std::vector<char> sh(shmem + 64);
-	for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
-		Barrier bar(nt);
-		std::vector<Barrier*> wb; for (int w = 0; w < nw; w++) wb.push_back(new Barrier(std::min(64, nt - 64*w)));
-		std::vector<uint64_t> slots((size_t)nw*64*2);
-		BlockCtx ctx{sh.data(), &bar, wb, &slots, nt};
-		if (nt == 1) {
-			t_threadIdx = {0, 0, 0}; t_blockIdx = {bx, by, bz}; t_blockDim = {block.x, block.y, block.z}; t_gridDim = {grid.x, grid.y, grid.z};
-			t_ctx = &ctx; body();
-		} else {
-			std::vector<std::thread> th;
-			for (int t = 0; t < nt; t++) th.emplace_back([&, t] {
-				t_threadIdx = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x*block.y))};
-				t_blockIdx = {bx, by, bz}; t_blockDim = {block.x, block.y, block.z}; t_gridDim = {grid.x, grid.y, grid.z};
-				t_ctx = &ctx; body();
-			});
-			for (auto& x : th) x.join();
+	Barrier bar(nt);
+	std::vector<Barrier*> wb; for (int w = 0; w < nw; w++) wb.push_back(new Barrier(std::min(64, nt - 64*w)));
+	std::vector<uint64_t> slots((size_t)nw*64*2);
+	BlockCtx ctx{sh.data(), &bar, wb, &slots, nt};
+	// the lanes of a workgroup are OS threads created ONCE per launch; they walk over the blocks of the grid together
+	// (a rendezvous between blocks: the shared-memory buffer and the barriers are reused)
+	Barrier between(nt);
+	auto lane = [&](int t) {
+		t_threadIdx = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x*block.y))};
+		t_blockDim = {block.x, block.y, block.z}; t_gridDim = {grid.x, grid.y, grid.z};
+		t_ctx = &ctx;
+		for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+			t_blockIdx = {bx, by, bz};
+			body();
+			if (nt > 1) between.wait();
 		}
-		for (auto b : wb) delete b;
+	};
+	if (nt == 1) lane(0);
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; t++) th.emplace_back(lane, t);
+		for (auto& x : th) x.join();
 	}
+	for (auto b : wb) delete b;
 }
 static inline int lane_id() { return (t_threadIdx.x + t_threadIdx.y*t_blockDim.x) & 63; }
 static inline int wave_id() { return (t_threadIdx.x + t_threadIdx.y*t_blockDim.x) >> 6; }
