@@ -69,6 +69,7 @@ struct LegK {
 	int m0; long rowbase, rows_chunk;   // analysis processes m in chunks to bound the partial-moment scratch
 	int nmc, xcd;                       // m count of this launch; XCD-aware block order on/off
 	int* first;                         // analysis: see LegWork::first
+	int atomic;                         // analysis: waves add their sums into mom (part = mom) instead of writing per-wave partial moments
 };
 
 // Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
@@ -250,8 +251,6 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 #define PXS_VCOPY(dst, src) double dst; asm("v_mov_b64 %0, %1" : "=v"(dst) : "s"(src))
 #endif
 
-#define LEG_RED_STRIDE 66
-
 // (An L2 prefetch of the coefficient streams via global_load_lds into an LDS sink was tried to hide SMEM
 // miss latency and measured SLOWER on MI355X: leg_syn 10.8 -> 12.4 ms at config 2; removed.)
 
@@ -381,26 +380,28 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 // of the previous flush.
 #ifdef PXS_HOST_SIM
 #define PXS_WAVE_LDS_SYNC() __syncthreads()
+#elif defined(PXS_LDS_NOWAIT)
+#define PXS_WAVE_LDS_SYNC() asm volatile("" ::: "memory")
 #else
 #define PXS_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
-#if defined(PXS_HOST_SIM) || defined(PXS_LDS_REDUCE)
-// simulator path: transpose the per-lane partial sums through a 16x66 LDS tile.  (-DPXS_LDS_REDUCE compiles it for the device:
-// re-measured with the final kernels at config 3, leg_ana 142.2 ms against 139.2 ms for the lane-swap reduction below.)
-__device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk) {
-	PXS_WAVE_LDS_SYNC();
-	const int rowi = lane >> 2, part = lane & 3;
+// The sums over the rings of a wave (4 values per recurrence step) are collected for LEG_FSTEPS steps in an LDS tile and
+// flushed together: output j = 4*step + row of the tile is then owned by lane j, which adds up its partial sums and
+// contributes ONE value to a contiguous 512-byte store (or atomic add).  Measured on MI355X at config 3 (leg_ana per round
+// trip, same box): no reduction at all 105.5 ms, lane swaps + LDS writes +22.7 ms, and the former flush (every 4 steps, 4
+// lanes per output, two shuffles, 128-byte stores) +14 ms.
+#define LEG_FSTEPS 16
+#ifdef PXS_HOST_SIM
+// simulator path: every lane writes its 4 sums, lane j adds row j over the 64 lanes
+#define LEG_RED_STRIDE 66
+#define LEG_RED_DOUBLES (4*LEG_FSTEPS*LEG_RED_STRIDE)
+__device__ __forceinline__ double leg_flush_sum(const double* red, int lane) {
+	const double* r = red + lane*LEG_RED_STRIDE;
 	double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-	if (rowi < 4*nkk) {
-		const double* r = red + rowi*LEG_RED_STRIDE + part;
-		for (int i = 0; i < 16; i += 4) { s0 += r[i*4]; s1 += r[(i+1)*4]; s2 += r[(i+2)*4]; s3 += r[(i+3)*4]; }
-	}
-	double sum = (s0 + s1) + (s2 + s3);
-	sum += __shfl_xor(sum, 1);
-	sum += __shfl_xor(sum, 2);
-	if (part == 0 && rowi < 4*nkk) dst[rowi] = sum;
-	PXS_WAVE_LDS_SYNC();
+	for (int i = 0; i < 64; i += 4) { s0 += r[i]; s1 += r[i+1]; s2 += r[i+2]; s3 += r[i+3]; }
+	return (s0 + s1) + (s2 + s3);
 }
+__device__ __forceinline__ int leg_flush_col(int lane) { return lane; }
 #define LEG_RED_PUT(kk, t0, t1, t2, t3) \
 	red[((kk)*4+0)*LEG_RED_STRIDE + lane] = t0; red[((kk)*4+1)*LEG_RED_STRIDE + lane] = t1; \
 	red[((kk)*4+2)*LEG_RED_STRIDE + lane] = t2; red[((kk)*4+3)*LEG_RED_STRIDE + lane] = t3;
@@ -408,11 +409,13 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 // MI355X path: reduce-scatter across lanes with the gfx950 lane-swap instructions.  Stage 1
 // (v_permlane32_swap on the pairs (t0,t1), (t2,t3)) leaves sum(t0|t2) in lanes 0-31 and sum(t1|t3) in
 // lanes 32-63; stage 2 (v_permlane16_swap) leaves ONE value per lane, already summed over the 4 lanes
-// {l, l+16, l+32, l+48}: rows 0..3 of the wave hold t0, t2, t1, t3.  One ds_write_b64 per step (4x fewer
-// LDS bytes than transposing all partial sums; the LDS write port was the limiter), and every 4 steps
-// 4 lanes per output add the remaining 16 partials.  (Tried and rejected: v_mfma_f64_4x4x4 with B = 1 as
-// a lane adder -- layout in tools/mfma_probe.hip -- correct, but 8 dependent f64 MFMAs per step made the
-// kernel matrix-pipe bound.)
+// {l, l+16, l+32, l+48}: the four 16-lane rows of the wave hold t0, t2, t1, t3.  One ds_write_b64 per step (4x fewer
+// LDS bytes than transposing all partial sums; the LDS write port was the limiter); row r of step kk goes to
+// red[(4 kk + r)*18 .. +16], so that lane j = 4 kk + r reads its 16 partial sums as 8 aligned 16-byte words.
+// (Tried and rejected: v_mfma_f64_4x4x4 with B = 1 as a lane adder: correct, but 8 dependent f64 MFMAs per step made the
+// kernel matrix-pipe bound; transposing all four sums through LDS: 145.1 against 142.1 ms.)
+#define LEG_RED_STRIDE 18
+#define LEG_RED_DOUBLES (4*LEG_FSTEPS*LEG_RED_STRIDE)
 __device__ __forceinline__ void leg_swap32(double& a, double& b) {
 	const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
 	const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
@@ -425,28 +428,49 @@ __device__ __forceinline__ void leg_swap16(double& a, double& b) {
 	const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
 	a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
 }
-__device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk) {
-	PXS_WAVE_LDS_SYNC();
-	const int rowi = lane >> 2, part = lane & 3;
-	const int kk = rowi >> 2, c = rowi & 3;
-	const int block = (c == 1) ? 2 : (c == 2) ? 1 : c;          // wave rows hold t0, t2, t1, t3
+__device__ __forceinline__ double leg_flush_sum(const double* red, int lane) {
+	const double2* r = reinterpret_cast<const double2*>(red + lane*LEG_RED_STRIDE);
+	// two rounds of 4 loads, not unrolled: all 16 values at once cost 16-20 more VGPRs at the point where every chain is live
+	// (leg_ana_s0<8> 174 VGPRs = 2 waves per SIMD instead of 3)
 	double sum = 0;
-	if (rowi < 4*nkk) {
-		const double* r = red + kk*64 + block*16 + part*4;
-		sum = (r[0] + r[1]) + (r[2] + r[3]);
+#pragma unroll 1
+	for (int h = 0; h < 8; h += 4) {
+		const double2 a = r[h], b = r[h+1], c = r[h+2], d = r[h+3];
+		sum += ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
 	}
-	sum += __shfl_xor(sum, 1);
-	sum += __shfl_xor(sum, 2);
-	if (part == 0 && rowi < 4*nkk) dst[rowi] = sum;
-	PXS_WAVE_LDS_SYNC();
+	return sum;
 }
+// lane j = 4 kk + r holds row r of step kk: rows are t0, t2, t1, t3
+__device__ __forceinline__ int leg_flush_col(int lane) { const int r = lane & 3; return (lane & ~3) | ((r == 1) ? 2 : (r == 2) ? 1 : r); }
+#ifdef PXS_EXP_NORED
+#define LEG_RED_PUT(kk, t0, t1, t2, t3) { asm volatile("" :: "v"(t0), "v"(t1), "v"(t2), "v"(t3)); }     // timing experiment (wrong results)
+#else
 #define LEG_RED_PUT(kk, t0, t1, t2, t3) { \
 	double a_ = t0, b_ = t1, c_ = t2, d_ = t3; \
 	leg_swap32(a_, b_); leg_swap32(c_, d_); \
 	double u_ = a_ + b_, v_ = c_ + d_; \
 	leg_swap16(u_, v_); \
-	red[(kk)*64 + lane] = u_ + v_; }
+	red[((kk)*4 + (lane >> 4))*LEG_RED_STRIDE + (lane & 15)] = u_ + v_; }
 #endif
+#endif
+// nkk steps of the tile -> dst[4 step + c] (c = 0..3: the sums t0..t3 of the step).  atomic: several waves add into the same
+// rows (dst pre-zeroed); otherwise dst belongs to this wave alone
+__device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk, int atomic) {
+#if defined(PXS_EXP_NORED) || defined(PXS_EXP_NOFLUSH)
+	return;      // timing experiments (wrong results)
+#endif
+	PXS_WAVE_LDS_SYNC();
+	if (lane < 4*nkk) {
+		const double sum = leg_flush_sum(red, lane);
+		double* q = dst + leg_flush_col(lane);
+#ifdef PXS_HOST_SIM
+		if (atomic) atomicAdd(q, sum); else *q = sum;
+#else
+		if (atomic) unsafeAtomicAdd(q, sum); else *q = sum;
+#endif
+	}
+	PXS_WAVE_LDS_SYNC();
+}
 
 // two fast steps of the spin-0 analysis: 2 x 4 lane sums into the LDS reduction tile, flush every 4 steps
 #define S0_ANA_PAIR(c0, c1) { \
@@ -461,11 +485,11 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 		u0 = fma(lam1[s], d1r[s], u0); u1 = fma(lam1[s], d1i[s], u1); u2 = fma(lam1[s], d2r[s], u2); u3 = fma(lam1[s], d2i[s], u3); \
 		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
 	} \
-	/* steps come in aligned pairs (phase A advances by 4, phases B and C by 2): kk is 0 or 2 here */ \
+	/* steps come in aligned pairs (phase A advances by 4, phases B and C by 2): kk is even here */ \
 	LEG_RED_PUT(kk, t0, t1, t2, t3) \
 	LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
 	kk += 2; \
-	if (kk == 4) { leg_flush(red, pout + 4*kbase, lane, 4); kk = 0; kbase = k+2; } }
+	if (kk == LEG_FSTEPS) { leg_flush(red, pout + 4*kbase, lane, LEG_FSTEPS, a.atomic); kk = 0; kbase = k+2; } }
 
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
@@ -509,7 +533,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
 	int k = 0;
 	S0_PHASE_A
-	if (lane == 0) a.first[wv*a.nmc + (m - a.m0)] = k + 1;      // rows before k are not written (reduce_partials skips them)
+	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = k + 1;      // rows before k are not written (reduce_partials skips them)
 	// ring data of the lanes that start at scale 0 or reached it during phase A (rings without signal have lam = 0)
 #pragma unroll
 	for (int s = 0; s < K; s++) if (sc[s] == 0) load_data(s);
@@ -546,7 +570,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 		LEG_RED_PUT(kk, t0, t1, t2, t3)
 		kk++;
 	}
-	if (kk > 0) leg_flush(red, pout + 4*kbase, lane, kk);
+	if (kk > 0) leg_flush(red, pout + 4*kbase, lane, kk, a.atomic);
 }
 
 // ---------------------------------------------------------------------------------
@@ -762,11 +786,11 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 			S.gp2[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp2[s]); S.gm2[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm2[s]); \
 		} \
 	} \
-	/* steps come in aligned pairs: kk is 0 or 2 here */ \
+	/* steps come in aligned pairs: kk is even here */ \
 	LEG_RED_PUT(kk, t0, t1, t2, t3) \
 	LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
 	kk += 2; \
-	if (kk == 4) { leg_flush(red, pout + 4*jbase, lane, 4); kk = 0; jbase = j+2; } }
+	if (kk == LEG_FSTEPS) { leg_flush(red, pout + 4*jbase, lane, LEG_FSTEPS, a.atomic); kk = 0; jbase = j+2; } }
 
 template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 {
@@ -803,7 +827,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	for (int s = 0; s < K; s++) tpnr[s] = tpni[s] = tmnr[s] = tmni[s] = tpsr[s] = tpsi[s] = tmsr[s] = tmsi[s] = 0;
 	int j = 0;
 	SPIN_PHASE_A
-	if (lane == 0) a.first[wv*a.nmc + (m - a.m0)] = j + 1;      // rows before j are not written (reduce_partials skips them)
+	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = j + 1;      // rows before j are not written (reduce_partials skips them)
 	// ring data of the lanes whose chains start at scale 0 or both reached it during phase A
 #pragma unroll
 	for (int s = 0; s < K; s++) if (S.scp[s] == 0 && S.scm[s] == 0) load_data(s);
@@ -847,7 +871,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 		LEG_RED_PUT(kk, t0, t1, t2, t3)
 		kk++;
 	}
-	if (kk > 0) leg_flush(red, pout + 4*jbase, lane, kk);
+	if (kk > 0) leg_flush(red, pout + 4*jbase, lane, kk, a.atomic);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1039,32 +1063,45 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = 4*std::max<long>(tb.nrows, 1);
 	wk.mom.ensure(sizeof(double)*n4);
-	// chunk m so that the per-wave partial moments stay below part_budget bytes
-	const size_t budget = wk.part_budget;
+	// Default: the waves of one m add their sums straight into mom with global_atomic_add_f64 -- the blocks of one m run back
+	// to back on one XCD (leg_block), so the row they share sits in that XCD's L2 while they do.  The order of those additions
+	// is not fixed: results repeat to rounding, not bit for bit.  PXS_DETERMINISTIC=1 selects the former scheme instead
+	// (per-wave partial moments in scratch, summed in wave order by reduce_partials), for callers that need bitwise repeats.
+	const char* det = getenv("PXS_DETERMINISTIC");
+	const bool atomic = !(det && atoi(det) != 0);
 	std::vector<int> cuts; cuts.push_back(0);
-	for (int m = 0; m < nm;) {
-		int m1 = m+1;
-		while (m1 < nm && (size_t)(tb.row[m1+1]-tb.row[m])*32*nwave <= budget) m1++;
-		cuts.push_back(m1); m = m1;
-	}
-	size_t maxrows = 1;
-	for (size_t c = 0; c+1 < cuts.size(); c++) maxrows = std::max<size_t>(maxrows, (size_t)(tb.row[cuts[c+1]]-tb.row[cuts[c]]));
-	wk.part.ensure(sizeof(double)*4*maxrows*nwave);
-	{	// sized once, before the first launch: growing a buffer inside the chunk loop would free memory that kernels of the
+	if (atomic) {
+		cuts.push_back(nm);
+		PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*n4, st));
+	} else {
+		// chunk m so that the per-wave partial moments stay below part_budget bytes
+		const size_t budget = wk.part_budget;
+		for (int m = 0; m < nm;) {
+			int m1 = m+1;
+			while (m1 < nm && (size_t)(tb.row[m1+1]-tb.row[m])*32*nwave <= budget) m1++;
+			cuts.push_back(m1); m = m1;
+		}
+		size_t maxrows = 1;
+		for (size_t c = 0; c+1 < cuts.size(); c++) maxrows = std::max<size_t>(maxrows, (size_t)(tb.row[cuts[c+1]]-tb.row[cuts[c]]));
+		wk.part.ensure(sizeof(double)*4*maxrows*nwave);
+		// sized once, before the first launch: growing a buffer inside the chunk loop would free memory that kernels of the
 		// previous chunk may still use (and hipFree synchronises the device)
 		size_t maxm = 1;
 		for (size_t c = 0; c+1 < cuts.size(); c++) maxm = std::max<size_t>(maxm, (size_t)(cuts[c+1]-cuts[c]));
 		wk.first.ensure(sizeof(int)*(size_t)nwave*maxm);
 	}
-	const size_t sh = sizeof(double)*16*LEG_RED_STRIDE;
+	const size_t sh = sizeof(double)*LEG_RED_DOUBLES;
 	for (size_t c = 0; c+1 < cuts.size(); c++) {
 		const int m0 = cuts[c], m1 = cuts[c+1];
 		const long rows = tb.row[m1]-tb.row[m0];
 		if (rows <= 0) continue;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K);
-		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0;
-		PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));
-		a.first = wk.first.as<int>();
+		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0; a.atomic = atomic ? 1 : 0;
+		if (atomic) { a.part = (double*)wk.mom.p; a.rowbase = 0; a.rows_chunk = 0; a.first = nullptr; }
+		else {
+			PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));
+			a.first = wk.first.as<int>();
+		}
 		if (prof) prof->begin(st, 1);
 		const dim3 grid = leg_grid(a);
 		if (tb.spin == 0) {
@@ -1079,6 +1116,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 			else             hipLaunchKernelGGL(leg_ana_spin<2>, grid, dim3(64), sh, st, a);
 		}
 		if (prof) prof->end(st, 1);
+		if (atomic) continue;
 		const long maxrow = tb.row[m0+1] - tb.row[m0];       // rows per m shrink with m
 		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*maxrow+255)/256), m1-m0), dim3(256), 0, st, (const double*)wk.part.p,
 			(double*)wk.mom.p, tb.d_row.as<long>(), (const int*)wk.first.p, m0, m1-m0, tb.row[m0], rows, a.nwave);

@@ -55,6 +55,31 @@ def test_grid_small_hostsim(geometry, nt, nph, lmax, spin):
 	check_grid(geometry, nt, nph, lmax, spin)
 
 @pytest.mark.hostsim
+@pytest.mark.parametrize("spin", [0, 2])
+def test_deterministic_mode_hostsim(monkeypatch, spin):
+	"""PXS_DETERMINISTIC=1: per-wave partial moments + ordered sum instead of atomic adds into the moments (legendre.hip, leg_analysis)"""
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1")
+	check_grid("F1", 20, 41, 19, spin)
+
+@pytest.mark.gpu
+def test_deterministic_mode_gpu(monkeypatch):
+	"""several waves per m: the ordered scheme against the oracle (the default one is what every other test runs), the two
+	schemes against each other at a size with 3-6 waves per m, and the ordered one repeats bit for bit"""
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1")
+	check_grid("CC", 514, 1200, 512, 2, random_map=False)
+	nt, nph, lmax = 1500, 3000, 1400
+	rng = np.random.default_rng(5); ms = so._tri_mstart(lmax, lmax)
+	for spin, nc in ((0, 1), (2, 2)):
+		pix = rng.standard_normal((nc, nt, nph))
+		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry="F1", phi0=0.1)
+		res = []
+		for det in ("1", "1", "0", "0"):
+			monkeypatch.setenv("PXS_DETERMINISTIC", det)
+			oa = np.zeros((nc, int(ms[-1])+lmax+1), complex); sht.analysis_2d(alm=oa, map=pix, **kw); res.append(oa)
+		assert np.array_equal(res[0], res[1])
+		assert relrms(res[2], res[0]) < 1e-14 and relrms(res[3], res[2]) < 1e-14
+
+@pytest.mark.hostsim
 def test_scaled_recurrence_hostsim():
 	"""large enough that sin^m(theta) needs the extended exponent near the poles (spin 0 and 2)"""
 	check_grid("F1", 100, 200, 96, 0, random_map=False)      # (spin 2 with scaling: test_deep_scaling)

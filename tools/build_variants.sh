@@ -1,8 +1,11 @@
-# builds libpxsht variants with different composite-radix sets compiled in -> variants/libpxsht_r<MAXR>.so
+# builds a variant of libpxsht.so for same-box kernel A/B runs (selected with PIXELL_AMD_LIB=variants/libpxsht_<name>.so)
+# usage: tools/build_variants.sh <name> "<extra hipcc flags>" <source stems to recompile...>     e.g.  r10 "-DPXS_COMP_MAXR=10" fftchain fft
 set -e
 cd "$(dirname "$0")/.."; mkdir -p variants/obj
-for r in "$@"; do
-  for f in fftchain fft; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPXS_COMP_MAXR=$r -c pixell_amd/csrc/$f.hip -o variants/obj/$f.$r.o & done; wait
-  objs=$(ls pixell_amd/build/*.o | grep -v -E '/(fftchain|fft)\.hip\.o'); /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libpxsht_r$r.so $objs variants/obj/fftchain.$r.o variants/obj/fft.$r.o
-done
-ls -la variants/*.so
+name=$1; flags=$2; shift; shift
+ex=""
+for f in "$@"; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c pixell_amd/csrc/$f.hip -o variants/obj/$f.$name.o & ex="$ex|$f"; done; wait
+objs=$(ls pixell_amd/build/*.o | grep -v -E "/(${ex#|})\.hip\.o")
+vobjs=""; for f in "$@"; do vobjs="$vobjs variants/obj/$f.$name.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libpxsht_$name.so $objs $vobjs
+ls -la variants/libpxsht_$name.so
