@@ -389,7 +389,9 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 // flushed together: output j = 4*step + row of the tile is then owned by lane j, which adds up its partial sums and
 // contributes ONE value to a contiguous 512-byte store (or atomic add).  Measured on MI355X at config 3 (leg_ana per round
 // trip, same box): no reduction at all 105.5 ms, lane swaps + LDS writes +22.7 ms, and the former flush (every 4 steps, 4
-// lanes per output, two shuffles, 128-byte stores) +14 ms.
+// lanes per output, two shuffles, 128-byte stores) +14 ms; this flush +3.3 ms.  What remains is the lane-swap stage: 6 swaps,
+// 3 adds and a ds_write per step next to 48 FMAs, every one of them a 4-cycle VALU issue for a wave64 (10/58 = the measured
+// share).  More ring pairs per lane would amortise it, but the kernels sit at the 3-waves-per-SIMD VGPR line already.
 #define LEG_FSTEPS 16
 #ifdef PXS_HOST_SIM
 // simulator path: every lane writes its 4 sums, lane j adds row j over the 64 lanes
