@@ -371,11 +371,16 @@ def synthesis(*, alm, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None
 	if mstart is None: mstart = _tri_mstart(lmax, mmax)
 	nca, ncm = _ncomp(spin, mode)
 	assert alm.shape[0] == nca
-	npix = int(np.max(np.asarray(ringstart).astype(np.int64)+(np.asarray(nphi).astype(np.int64)-1)*pixstride)+1)
+	rs_ = np.asarray(ringstart).astype(np.int64); np_ = np.asarray(nphi).astype(np.int64)
+	npix = int(max(np.max(rs_), np.max(rs_+(np_-1)*pixstride))+1)
+	if map is not None: npix = max(npix, map.shape[-1])
 	leg = alm2leg(alm, spin, lmax, mmax, mstart, np.asarray(theta, LD), lstride, mode)
 	res = leg2map(leg, nphi, phi0, ringstart, npix, pixstride)
 	if map is None: return res
-	map[...] = res.astype(map.dtype)
+	# only the pixels of the rings are written (a ring subset of a larger map leaves the rest alone, curvedsky.py:333-335)
+	hit = np.zeros(npix, bool)
+	for r in range(len(rs_)): hit[rs_[r]+pixstride*np.arange(np_[r])] = True
+	map[..., hit] = res[..., hit].astype(map.dtype)
 	return map
 
 def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mstart=None, spin=0,

@@ -125,6 +125,18 @@ static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::
 	}
 }
 
+// nlines dense complex lines of n points each, in -> out (may alias), any n (Bluestein where the mixed-radix engine has no
+// factorisation): the ring FFTs of ring sets with per-ring lengths (sht.hip, general rings)
+void fft_dense_lines(int device, hipStream_t st, long n, bool forward, long nlines, const double2* in, double2* out) {
+	if (nlines <= 0 || n <= 0) return;
+	if (n == 1) { if (in != out) PXS_HIP(hipMemcpyAsync(out, in, sizeof(double2)*(size_t)nlines, hipMemcpyDeviceToDevice, st)); return; }
+	FftContext& fc = fft_context(device);
+	g_fft_device = device;
+	std::vector<AxisDim> dims; dims.push_back(AxisDim{nlines, n, n});
+	FftLoad ld; ld.ptr = in; FftStore sf; sf.ptr = out;
+	fft_axis(fc, st, n, forward, dims, 1, 1, ld, sf);
+}
+
 // ---- r2r (DCT / DST) as functor-wrapped complex FFTs ---------------------------------------------------------------
 struct R2RPlan { long N = 0; bool forward = true, mirror = false; int mir_c = 0; long ld_shift = 0, st_shift = 0; double scale = 1.0; DevBuf ld_mul, st_mul; };
 long r2r_length(int kind, long n) {

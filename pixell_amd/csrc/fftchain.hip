@@ -450,7 +450,8 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	if (nblk <= 0) return;
 	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= CH_TILE_PTS, "internal: chain tile too large");
 	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
-	const size_t sh = sizeof(double2)*((size_t)s.fa.n + s.fb.n + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
+	size_t sh = sizeof(double2)*((size_t)s.fa.n + s.fb.n + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
+	{ static const size_t pad = [] { const char* e = getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
 #ifndef PXS_HOST_SIM
 	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, CH_NT, CH_MAXE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
 	(void)once;

@@ -24,6 +24,7 @@
 namespace pxs {
 
 FftContext& fft_context(int device);
+void fft_dense_lines(int device, hipStream_t st, long n, bool forward, long nlines, const double2* in, double2* out);   // api_fft.hip
 const char* get_last_error();
 
 typedef long double LDb;
@@ -172,6 +173,59 @@ __global__ __launch_bounds__(256) void gather_alias(const double2* __restrict__ 
 	out[(long)b*out_bstride + idx] = v;
 }
 
+// ---- general ring sets (per-ring nphi, phi0, ringstart: healpix, profile rings; ducc's synthesis / adjoint_synthesis contract,
+// curvedsky.py:328-349, 396-403, 537, 553, 936-960) ---------------------------------------------------------------------
+// Rings are grouped by length; z holds one complex line per ring, group after group, so that every group is a dense
+// [rings][n] block for one batched FFT.  A block of 256 threads works on 256 consecutive elements of one ring (blk_ring, blk_k0).
+struct GenK {
+	int nring, nm, nc; long ldleg, leg_cstride, zc, map_cstride, pix_stride;
+	const int* blk_ring; const int* blk_k0; const int* nphi; const long* zoff; const long* rstart; const double* phi0;
+	double scale;
+};
+// ring spectrum with aliasing: H[k] = sum_{m = k mod n, m <= mmax} f_m leg[m][r] e^{i m phi0_r}, f_0 = 1, f_m = 2: the real ring is
+// Re of the backward DFT of H
+__global__ __launch_bounds__(256) void gen_fold(const GenK g, const double2* __restrict__ leg, double2* __restrict__ z)
+{
+	const int r = g.blk_ring[blockIdx.x], k = g.blk_k0[blockIdx.x] + (int)threadIdx.x, c = blockIdx.y;
+	const int n = g.nphi[r];
+	if (k >= n) return;
+	const double ph = g.phi0[r];
+	const double2* col = leg + (long)c*g.leg_cstride + r;
+	double ar = 0, ai = 0;
+	for (int m = k; m < g.nm; m += n) {
+		const double2 a = col[(long)m*g.ldleg];
+		double sn, cs; sincos((double)m*ph, &sn, &cs);
+		const double f = m ? 2.0 : 1.0;
+		ar += f*(a.x*cs - a.y*sn); ai += f*(a.x*sn + a.y*cs);
+	}
+	z[(long)c*g.zc + g.zoff[r] + k] = make_double2(ar, ai);
+}
+template<class T> __global__ __launch_bounds__(256) void gen_scatter(const GenK g, const double2* __restrict__ z, T* __restrict__ map)
+{
+	const int r = g.blk_ring[blockIdx.x], j = g.blk_k0[blockIdx.x] + (int)threadIdx.x, c = blockIdx.y;
+	if (j >= g.nphi[r]) return;
+	map[(long)c*g.map_cstride + g.rstart[r] + (long)j*g.pix_stride] = (T)z[(long)c*g.zc + g.zoff[r] + j].x;
+}
+template<class T> __global__ __launch_bounds__(256) void gen_gather(const GenK g, const T* __restrict__ map, double2* __restrict__ z)
+{
+	const int r = g.blk_ring[blockIdx.x], j = g.blk_k0[blockIdx.x] + (int)threadIdx.x, c = blockIdx.y;
+	if (j >= g.nphi[r]) return;
+	z[(long)c*g.zc + g.zoff[r] + j] = make_double2((double)map[(long)c*g.map_cstride + g.rstart[r] + (long)j*g.pix_stride], 0.0);
+}
+// leg[m][r] = scale e^{-i m phi0_r} F_r[m mod n_r]
+__global__ __launch_bounds__(256) void gen_unfold(const GenK g, const double2* __restrict__ z, double2* __restrict__ leg)
+{
+	const int r = blockIdx.x*256 + (int)threadIdx.x, c = blockIdx.z;
+	if (r >= g.nring) return;
+	const int n = g.nphi[r]; const double ph = g.phi0[r];
+	const double2* line = z + (long)c*g.zc + g.zoff[r];
+	for (int m = blockIdx.y; m < g.nm; m += gridDim.y) {
+		const double2 a = line[m % n];
+		double sn, cs; sincos((double)m*ph, &sn, &cs);
+		leg[(long)c*g.leg_cstride + (long)m*g.ldleg + r] = make_double2(g.scale*(a.x*cs + a.y*sn), g.scale*(a.y*cs - a.x*sn));
+	}
+}
+
 // leg[line][ring] *= w[ring] (DH / F2 analysis: plain quadrature weights)
 __global__ __launch_bounds__(256) void scale_rings(double2* __restrict__ leg, long nlines, int nr, long ld, const double2* __restrict__ w)
 {
@@ -271,6 +325,10 @@ struct pxs_plan {
 	// analysis resampling (grid plans)
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
 	DevBuf ph_shift, ph_up, sigma, wcc, b1, b2;
+	// general ring sets (gen_* kernels): rings of equal length are one dense block of z
+	struct GenGroup { long n, count, zoff; };
+	bool general = false; std::vector<GenGroup> groups; long npixz = 0;
+	DevBuf g_blk_ring, g_blk_k0, g_nphi, g_zoff, g_rstart, g_phi0, gz; long g_nblk = 0;
 	DevBuf wring;                // DH / F2 grids: per-ring quadrature weight / nphi (analysis = weighted adjoint synthesis)
 	bool syn_via_cc = false;
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
@@ -317,6 +375,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 		const char* e = getenv("PXS_PART_GB"); if (e) p->wk.part_budget = (size_t)atol(e) << 30;
 	}
 	{ const char* e = getenv("PXS_RESAMPLE_MB"); if (e) p->resample_chunk_bytes = (size_t)atol(e) << 20; }
+	if (p->general) return;      // per-ring lengths and phases: see setup_general
 	std::string why;
 	if (!FftContext::supported(p->nphi, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
 	// e^{-i m phi0}
@@ -381,6 +440,41 @@ void setup_resampling(pxs_plan* p) {
 	p->wcc = upload(w);
 }
 
+// tables of a general ring set: groups of equal length, z offsets, the block table of the gen_* kernels
+void setup_general(pxs_plan* p, int nring, const uint64_t* nphi, const double* phi0, const uint64_t* ringstart) {
+	std::vector<int> order(nring);
+	for (int r = 0; r < nring; r++) { order[r] = r; PXS_REQUIRE(nphi[r] >= 1 && nphi[r] < (1ull << 31), "pxs_plan_rings: bad nphi"); }
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nphi[a] < nphi[b]; });
+	std::vector<int> np(nring), blk_ring, blk_k0; std::vector<long> zoff(nring), rstart(nring); std::vector<double> ph(phi0, phi0 + nring);
+	long off = 0;
+	p->groups.clear();
+	for (int i = 0; i < nring; i++) {
+		const int r = order[i];
+		np[r] = (int)nphi[r]; rstart[r] = (long)ringstart[r]; zoff[r] = off;
+		if (p->groups.empty() || p->groups.back().n != (long)nphi[r]) p->groups.push_back(pxs_plan::GenGroup{(long)nphi[r], 0, off});
+		p->groups.back().count++;
+		for (long k0 = 0; k0 < (long)nphi[r]; k0 += 256) { blk_ring.push_back(r); blk_k0.push_back((int)k0); }
+		off += (long)nphi[r];
+	}
+	p->npixz = off; p->g_nblk = (long)blk_ring.size();
+	p->g_blk_ring = upload(blk_ring); p->g_blk_k0 = upload(blk_k0); p->g_nphi = upload(np); p->g_zoff = upload(zoff);
+	p->g_rstart = upload(rstart); p->g_phi0 = upload(ph);
+}
+static GenK gen_args(pxs_plan* p, int nc, long ldleg, long map_cstride, double scale) {
+	GenK g; g.nring = p->nring; g.nm = p->mmax + 1; g.nc = nc; g.ldleg = ldleg; g.leg_cstride = (long)(p->mmax + 1)*ldleg; g.zc = p->npixz;
+	g.map_cstride = map_cstride; g.pix_stride = p->pix_stride;
+	g.blk_ring = p->g_blk_ring.as<int>(); g.blk_k0 = p->g_blk_k0.as<int>(); g.nphi = p->g_nphi.as<int>(); g.zoff = p->g_zoff.as<long>();
+	g.rstart = p->g_rstart.as<long>(); g.phi0 = p->g_phi0.as<double>(); g.scale = scale;
+	return g;
+}
+static void gen_ffts(pxs_plan* p, hipStream_t st, int nc, bool forward) {
+	for (int c = 0; c < nc; c++)
+		for (const auto& gr : p->groups) {
+			double2* zl = p->gz.as<double2>() + (size_t)c*p->npixz + gr.zoff;
+			fft_dense_lines(p->device, st, gr.n, forward, gr.count, zl, zl);
+		}
+}
+
 int ncomp_of(int spin, int mode, bool alm_side) {
 	if (mode == PXS_MODE_DERIV1) return alm_side ? 1 : 2;
 	return spin == 0 ? 1 : 2;
@@ -391,6 +485,19 @@ int ncomp_of(int spin, int mode, bool alm_side) {
 void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long map_cstride, int nc, double2* leg, double scale, long ldl, long map_bstride = 0, int ncb = 0) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
+	if (p->general) {
+		PXS_REQUIRE(ncb == 0, "internal: general ring sets take one map per call");
+		p->gz.ensure(sizeof(double2)*(size_t)nc*p->npixz);
+		const GenK g = gen_args(p, nc, ldl, map_cstride, scale);
+		const dim3 grid((unsigned)p->g_nblk, nc);
+		if (map_dtype == PX_F32) hipLaunchKernelGGL(gen_gather<float>, grid, dim3(256), 0, st, g, (const float*)map, p->gz.as<double2>());
+		else                     hipLaunchKernelGGL(gen_gather<double>, grid, dim3(256), 0, st, g, (const double*)map, p->gz.as<double2>());
+		gen_ffts(p, st, nc, true);
+		hipLaunchKernelGGL(gen_unfold, dim3((nr + 255)/256, std::min(nm, 4096), nc), dim3(256), 0, st, g, (const double2*)p->gz.p, leg);
+		p->prof.end(st, PXS_STAGE_RING_FFT);
+		PXS_HIP(hipGetLastError());
+		return;
+	}
 	if (p->chain_rings) {
 		p->chain->map2leg(st, p->map_desc(map, map_dtype, map_cstride, map_bstride, ncb), nc, p->mmax, leg, ldl, p->phase.as<double2>(), scale);
 		p->prof.end(st, PXS_STAGE_RING_FFT);
@@ -439,6 +546,20 @@ void map2leg(pxs_plan* p, hipStream_t st, const void* map, int map_dtype, long m
 void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* map, int map_dtype, long map_cstride, int nc, bool have_h = false, long map_bstride = 0, int ncb = 0) {
 	p->prof.begin(st, PXS_STAGE_RING_FFT);
 	const int nm = p->mmax+1, nr = p->nring;
+	if (p->general) {
+		PXS_REQUIRE(ncb == 0 && !have_h, "internal: general ring sets take one map per call");
+		p->gz.ensure(sizeof(double2)*(size_t)nc*p->npixz);
+		const GenK g = gen_args(p, nc, ldleg, map_cstride, 1.0);
+		const dim3 grid((unsigned)p->g_nblk, nc);
+		hipLaunchKernelGGL(gen_fold, grid, dim3(256), 0, st, g, leg, p->gz.as<double2>());
+		gen_ffts(p, st, nc, false);
+		if (map_dtype == PX_F32) hipLaunchKernelGGL(gen_scatter<float>, grid, dim3(256), 0, st, g, (const double2*)p->gz.p, (float*)map);
+		else                     hipLaunchKernelGGL(gen_scatter<double>, grid, dim3(256), 0, st, g, (const double2*)p->gz.p, (double*)map);
+		p->prof.end(st, PXS_STAGE_RING_FFT);
+		PXS_HIP(hipGetLastError());
+		(void)nm;
+		return;
+	}
 	const long ldh = p->ld_h();
 	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*ldh);
 	if (!have_h) {      // (the CC synthesis path has written hbuf already, see resample_from_cc / FftChain::from_cc)
@@ -675,16 +796,16 @@ int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64
 	PXS_REQUIRE(plan && nring > 0 && theta && nphi && phi0 && ringstart, "pxs_plan_rings: bad arguments");
 	std::unique_ptr<pxs_plan> p(new pxs_plan());
 	p->is_grid = false; p->nring = nring; p->nphi = (int)nphi[0]; p->phi0 = phi0[0];
-	for (int r = 0; r < nring; r++) {
-		if ((long)nphi[r] != p->nphi) throw Error(PXS_ERR_UNSUPPORTED, "rings with varying nphi (e.g. healpix) are not supported yet");
-		if (std::fabs(phi0[r] - phi0[0]) > 1e-13) throw Error(PXS_ERR_UNSUPPORTED, "rings with varying phi0 are not supported yet");
-	}
 	p->ring_off0 = (long)ringstart[0];
 	p->ring_stride = nring > 1 ? (long)ringstart[1] - (long)ringstart[0] : (long)nphi[0];
+	// equal rings at equal spacing (every CAR map) take the fused / paired ring FFTs; anything else (healpix, profile rings,
+	// masked ring subsets) the general path: per-ring length, phase and offset
 	for (int r = 0; r < nring; r++)
-		if ((long)ringstart[r] != p->ring_off0 + r*p->ring_stride) throw Error(PXS_ERR_UNSUPPORTED, "ringstart must be an arithmetic progression");
+		if ((long)nphi[r] != p->nphi || std::fabs(phi0[r] - phi0[0]) > 1e-13 || (long)ringstart[r] != p->ring_off0 + r*p->ring_stride) p->general = true;
+	{ const char* e = getenv("PXS_GENERAL_RINGS"); if (e && atoi(e) != 0) p->general = true; }      // (tests: the general path on uniform rings)
 	p->pix_stride = pixstride;
 	plan_common(p.get(), lmax, mmax, mstart, lstride, device);
+	if (p->general) setup_general(p.get(), nring, nphi, phi0, ringstart);
 	std::vector<LDb> th(nring);
 	for (int r = 0; r < nring; r++) th[r] = theta[r];
 	p->rs_map.build(th); p->rs_map.upload_all();

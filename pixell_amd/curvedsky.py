@@ -404,6 +404,77 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 	else:       return alm
 
 # ---------------------------------------------------------------------------------------
+# healpix maps: the same ring transforms on ring tables with per-ring nphi / phi0 (the general ring path of sht.hip)
+# ---------------------------------------------------------------------------------------
+def npix2nside(npix): return nint((npix/12)**0.5)
+def get_ring_info_healpix(nside, rings=None): return _geo.healpix_rings(nside, rings)
+def get_ring_info_radial(r): return _geo.radial_rings(r)
+def apply_minfo_theta_lim(minfo, theta_min=None, theta_max=None): return _geo.theta_window(minfo, theta_min, theta_max)
+def prepare_healmap(healmap, nside=None, pre=(), dtype=np.float64, like=None):
+	if healmap is not None: return healmap
+	return _zeros_like_kind(tuple(pre)+(12*int(nside)**2,), dtype, like)
+
+def _healpix_kwargs(npix, ainfo, theta_min, theta_max):
+	rinfo = apply_minfo_theta_lim(get_ring_info_healpix(npix2nside(npix)), theta_min, theta_max)
+	return rinfo, dict(theta=rinfo.theta, nphi=rinfo.nphi, phi0=rinfo.phi0, ringstart=rinfo.offsets, lmax=ainfo.lmax, mmax=ainfo.mmax,
+		mstart=ainfo.mstart, lstride=ainfo.stride)
+
+def alm2map_healpix(alm, healmap=None, spin=[0, 2], deriv=False, adjoint=False, copy=False, ainfo=None, nside=None, theta_min=None, theta_max=None, nthread=None):
+	"""alm[..., ncomp, nelem] -> healpix map[..., ncomp, 12 nside^2] in RING order (curvedsky.alm2map_healpix, curvedsky.py:312-351);
+	adjoint: the transpose, map -> alm.  With deriv the map is [..., 2, npix] = (d/ddec, d/dra / cos dec)."""
+	if copy:
+		if adjoint and alm is not None: alm = alm.clone() if _is_tensor(alm) else alm.copy()
+		elif not adjoint and healmap is not None: healmap = healmap.clone() if _is_tensor(healmap) else healmap.copy()
+	rdt = real_dtype(_np_dtype(alm))
+	alm, ainfo = prepare_alm(alm, ainfo, dtype=rdt, convert=not adjoint, like=alm)
+	healmap = prepare_healmap(healmap, nside, alm.shape[:-2]+(2,) if deriv else alm.shape[:-1], rdt, like=alm)
+	alm_full = _atleast(alm, 2 if deriv else 3); map_full = _atleast(healmap, 3)
+	if deriv and (tuple(alm_full.shape[:-1]) != tuple(map_full.shape[:-2]) or map_full.shape[-2] != 2):
+		raise ValueError("When deriv is True, alm must have shape [...,nelem] and map shape [...,2,npix]")
+	if not deriv and tuple(alm_full.shape[:-1]) != tuple(map_full.shape[:-1]):
+		raise ValueError("alm must have shape [...,[ncomp,]nelem] and map shape [...,[ncomp,]npix]")
+	rinfo, kwargs = _healpix_kwargs(map_full.shape[-1], ainfo, theta_min, theta_max)
+	if (theta_min is not None or theta_max is not None) and not adjoint: map_full[...] = 0     # rings outside the window are not written
+	func = sht.adjoint_synthesis if adjoint else sht.synthesis
+	for I in nditer(map_full.shape[:-2]):
+		if deriv:
+			a = _contig(alm_full[I][None])
+			func(alm=a, map=map_full[I], mode="DERIV1", spin=1, **kwargs)
+			if adjoint: alm_full[I] = a[0]
+			else: map_full[I+(0,)] *= -1                   # d/dtheta -> d/ddec
+		else:
+			for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
+				Ij = I+(slice(j1, j2),)
+				v = alm_full[Ij]; a = _contig(v)
+				func(alm=a, map=map_full[Ij], spin=int(s), **kwargs)
+				if adjoint and a is not v: v[...] = a
+	return alm if adjoint else healmap
+
+def map2alm_healpix(healmap, alm=None, ainfo=None, lmax=None, spin=[0, 2], weights=None, deriv=False, copy=False, verbose=False, adjoint=False, niter=0, theta_min=None, theta_max=None, nthread=None):
+	"""healpix map -> alm with pixel-area weights 4 pi / npix (or `weights`) and `niter` Jacobi refinements
+	(curvedsky.map2alm_healpix, curvedsky.py:353-403; like healpy.map2alm).  adjoint: the transpose of that operator, alm -> map."""
+	if copy:
+		if adjoint and healmap is not None: healmap = healmap.clone() if _is_tensor(healmap) else healmap.copy()
+		elif not adjoint and alm is not None: alm = alm.clone() if _is_tensor(alm) else alm.copy()
+	if deriv: raise NotImplementedError("map2alm_healpix with deriv=True is broken")          # (as in the reference, curvedsky.py:378)
+	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, lmax=lmax, pre=healmap.shape[:-1], dtype=_np_dtype(healmap), convert=adjoint, like=healmap)
+	alm_full = _atleast(alm, 3); map_full = _atleast(healmap, 3)
+	rinfo, kwargs = _healpix_kwargs(map_full.shape[-1], ainfo, theta_min, theta_max)
+	if weights is None: weights = 4*np.pi/rinfo.npix
+	if _is_tensor(healmap) and not np.isscalar(weights): weights = _torch().as_tensor(np.asarray(weights), device=healmap.device)
+	for I in nditer(map_full.shape[:-2]):
+		for s, j1, j2 in enmap.spin_helper(spin, alm_full.shape[-2]):
+			Ij = I+(slice(j1, j2),)
+			like = map_full[Ij]
+			def Y(a):   return sht.synthesis(alm=_contig(a), map=_zeros_like_kind(tuple(like.shape), _np_dtype(like), like), spin=int(s), **kwargs)
+			def YT(m):  return sht.adjoint_synthesis(map=_contig(m), spin=int(s), **kwargs)
+			def YTW(m): return YT(m*weights)
+			def WY(a):  return Y(a)*weights
+			if adjoint: map_full[Ij] = jacobi_inverse(YT, WY, _contig(alm_full[Ij]), niter=niter)
+			else:       alm_full[Ij] = jacobi_inverse(Y, YTW, map_full[Ij], niter=niter)
+	return healmap if adjoint else alm
+
+# ---------------------------------------------------------------------------------------
 # alm post-processing either side of the transforms (SURVEY 8 f1): almxfl, alm2cl, rand_alm.
 # The per-element arithmetic (lmul, alm2cl) runs on the GPU (almops.py -> pxa_*); the random
 # numbers come from numpy's legacy global RNG exactly as in the reference, so that a seed gives the

@@ -1,0 +1,45 @@
+"""Fixtures for the healpix layer (pixell_amd.curvedsky.{get_ring_info_healpix, alm2map_healpix, map2alm_healpix}), made by
+running the REFERENCE's own functions (pixell/curvedsky.py:312-403, 1192-1234) in this container with the long-double oracle
+mounted as ducc0.sht.experimental.
+
+Run:  python tests/golden/make_healpix.py      (needs /root/reference; never run on the GPU box)
+
+Saved to healpix.npz: the ring tables of nside 1, 2, 8, 5 and of a ring subset; alm2map_healpix / its adjoint / deriv /
+map2alm_healpix (niter 0 and 2, a theta window) outputs for seeded inputs.  Only arrays; no reference code."""
+import sys, os, types
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..")); sys.path.insert(0, HERE)
+from oracle import sht_oracle as so
+import _ref_harness as H
+
+def main():
+	back = types.ModuleType("ducc0.sht.experimental")
+	for n in ["synthesis_2d", "adjoint_synthesis_2d", "analysis_2d", "adjoint_analysis_2d", "synthesis", "adjoint_synthesis", "get_gridweights"]: setattr(back, n, getattr(so, n))
+	ns = H.load_reference(back); cs = ns.curvedsky
+	out = {}
+	for nside in (1, 2, 5, 8):
+		r = cs.get_ring_info_healpix(nside)
+		for k in ("theta", "nphi", "phi0", "offsets"): out["rings%d_%s" % (nside, k)] = np.asarray(r[k])
+	sub = np.array([0, 3, 4, 9, 14]); r = cs.get_ring_info_healpix(4, sub)
+	out["sub_rings"] = sub
+	for k in ("theta", "nphi", "phi0", "offsets"): out["sub_%s" % k] = np.asarray(r[k])
+	rad = cs.get_ring_info_radial(np.array([0.1, 0.5, 2.0]))
+	for k in ("theta", "nphi", "phi0", "offsets"): out["rad_%s" % k] = np.asarray(rad[k])
+	nside, lmax = 4, 9
+	rng = np.random.default_rng(21)
+	alm = so.rand_alm_simple(lmax, 3, 8, spin=(0, 2)); out["alm"] = alm
+	m = cs.alm2map_healpix(alm.copy(), nside=nside, spin=[0, 2]); out["alm2map"] = np.array(m)
+	pix = rng.standard_normal((3, 12*nside**2)); out["pix"] = pix
+	at = cs.alm2map_healpix(np.zeros_like(alm), pix.copy(), spin=[0, 2], adjoint=True); out["alm2map_adjoint"] = np.array(at)
+	d = cs.alm2map_healpix(alm[0].copy(), np.zeros((2, 12*nside**2)), deriv=True); out["deriv"] = np.array(d)
+	w = cs.alm2map_healpix(alm.copy(), nside=nside, spin=[0, 2], theta_min=0.6, theta_max=2.2); out["alm2map_window"] = np.array(w)
+	for niter in (0, 2):
+		a = cs.map2alm_healpix(pix.copy(), lmax=lmax, spin=[0, 2], niter=niter); out["map2alm_niter%d" % niter] = np.array(a)
+	a = cs.map2alm_healpix(m.copy(), lmax=lmax, spin=[0, 2], niter=3); out["map2alm_roundtrip"] = np.array(a)
+	ma = cs.map2alm_healpix(np.zeros((3, 12*nside**2)), alm=alm.copy(), spin=[0, 2], adjoint=True, niter=1); out["map2alm_adjoint"] = np.array(ma)
+	out["meta"] = np.array([nside, lmax])
+	np.savez_compressed(os.path.join(HERE, "healpix.npz"), **out)
+	print("healpix.npz: %d arrays; round trip error after 3 Jacobi steps %.2e" % (len(out), np.max(np.abs(a-alm))/np.max(np.abs(alm))))
+
+if __name__ == "__main__": main()

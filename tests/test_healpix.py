@@ -1,0 +1,75 @@
+"""The healpix layer of pixell_amd.curvedsky (ring tables with per-ring nphi / phi0 through the general ring path of sht.hip)
+against tests/golden/healpix.npz, which tests/golden/make_healpix.py recorded from the REFERENCE's own
+get_ring_info_healpix / get_ring_info_radial / alm2map_healpix / map2alm_healpix (pixell/curvedsky.py:312-403, 1192-1234) over the
+long-double oracle."""
+import os
+import numpy as np
+import pytest
+from pixell_amd import curvedsky
+
+def _real_m0(a, lmax):
+	a = np.array(a); a[..., :lmax+1] = a[..., :lmax+1].real; return a
+
+def test_ring_tables(golden_dir):
+	d = np.load(os.path.join(golden_dir, "healpix.npz"))
+	for nside in (1, 2, 5, 8):
+		r = curvedsky.get_ring_info_healpix(nside)
+		assert r.npix == 12*nside**2 and r.nrow == 4*nside-1 and int(np.sum(r.nphi)) == r.npix
+		for k in ("theta", "phi0"): np.testing.assert_allclose(r[k], d["rings%d_%s" % (nside, k)], rtol=0, atol=2e-15)
+		for k in ("nphi", "offsets"): assert r[k].dtype == np.uint64 and np.array_equal(r[k], d["rings%d_%s" % (nside, k)])
+	r = curvedsky.get_ring_info_healpix(4, d["sub_rings"])
+	for k in ("theta", "phi0"): np.testing.assert_allclose(r[k], d["sub_%s" % k], rtol=0, atol=2e-15)
+	for k in ("nphi", "offsets"): assert np.array_equal(r[k], d["sub_%s" % k])
+	r = curvedsky.get_ring_info_radial(np.array([0.1, 0.5, 2.0]))
+	for k in ("theta", "nphi", "phi0", "offsets"): assert np.array_equal(r[k], d["rad_%s" % k])
+	assert curvedsky.npix2nside(12*64**2) == 64
+	w = curvedsky.apply_minfo_theta_lim(curvedsky.get_ring_info_healpix(4), 0.6, 2.2)
+	assert len(w.theta) == len(w.nphi) == len(w.offsets) < 15 and w.theta.min() >= 0.6 and w.theta.max() <= 2.2
+
+def healpix_body(golden_dir, to_dev=lambda x: x, to_host=np.asarray):
+	d = np.load(os.path.join(golden_dir, "healpix.npz"))
+	nside, lmax = (int(v) for v in d["meta"]); npix = 12*nside**2
+	alm, pix = np.array(d["alm"]), np.array(d["pix"])
+	def close(a, b, tol=1e-11): assert a.shape == b.shape and np.max(np.abs(a-b)) < tol*np.max(np.abs(b))
+	close(to_host(curvedsky.alm2map_healpix(to_dev(alm.copy()), nside=nside, spin=[0, 2])), d["alm2map"])
+	close(to_host(curvedsky.alm2map_healpix(to_dev(alm.copy()), to_dev(np.full((3, npix), 7.0)), spin=[0, 2])), d["alm2map"])      # overwrites a given map
+	at = curvedsky.alm2map_healpix(to_dev(np.zeros_like(alm)), to_dev(pix.copy()), spin=[0, 2], adjoint=True)
+	close(_real_m0(to_host(at), lmax), _real_m0(d["alm2map_adjoint"], lmax))
+	close(to_host(curvedsky.alm2map_healpix(to_dev(alm[0].copy()), to_dev(np.zeros((2, npix))), deriv=True)), d["deriv"])
+	w = to_host(curvedsky.alm2map_healpix(to_dev(alm.copy()), to_dev(np.full((3, npix), 7.0)), spin=[0, 2], theta_min=0.6, theta_max=2.2))
+	close(w, d["alm2map_window"]); assert np.any(w == 0)                                             # rings outside the window are zeroed
+	for niter in (0, 2):
+		a = curvedsky.map2alm_healpix(to_dev(pix.copy()), lmax=lmax, spin=[0, 2], niter=niter)
+		close(_real_m0(to_host(a), lmax), _real_m0(d["map2alm_niter%d" % niter], lmax), 1e-10)
+	a = curvedsky.map2alm_healpix(to_dev(np.array(d["alm2map"])), lmax=lmax, spin=[0, 2], niter=3)
+	close(_real_m0(to_host(a), lmax), _real_m0(d["map2alm_roundtrip"], lmax), 1e-10)
+	ma = curvedsky.map2alm_healpix(to_dev(np.zeros((3, npix))), alm=to_dev(alm.copy()), spin=[0, 2], adjoint=True, niter=1)
+	close(to_host(ma), d["map2alm_adjoint"], 1e-10)
+	with pytest.raises(NotImplementedError): curvedsky.map2alm_healpix(to_dev(np.zeros((2, npix))), lmax=lmax, deriv=True)
+	with pytest.raises(ValueError): curvedsky.alm2map_healpix(to_dev(alm.copy()), to_dev(np.zeros((2, npix))), spin=[0, 2])
+
+@pytest.mark.hostsim
+def test_healpix_hostsim(golden_dir): healpix_body(golden_dir)
+
+@pytest.mark.gpu
+def test_healpix_gpu(golden_dir):
+	healpix_body(golden_dir)
+	import torch
+	healpix_body(golden_dir, to_dev=lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda(), to_host=lambda x: x.cpu().numpy())
+
+@pytest.mark.gpu
+def test_healpix_large_gpu():
+	"""nside 256 (786 432 pixels, 1023 rings of 256 different lengths, lengths with prime factors up to 251), lmax 512: adjointness
+	<Y a, p> = <a, Y^T p> to rounding and convergence of the Jacobi iteration on a band-limited map"""
+	nside, lmax = 256, 512; npix = 12*nside**2
+	from oracle import sht_oracle as so
+	rng = np.random.default_rng(3)
+	alm = so.rand_alm_simple(lmax, 3, 2, spin=(0, 2))
+	m = curvedsky.alm2map_healpix(alm.copy(), nside=nside, spin=[0, 2])
+	pix = rng.standard_normal((3, npix))
+	at = curvedsky.alm2map_healpix(np.zeros_like(alm), pix.copy(), spin=[0, 2], adjoint=True)
+	wgt = np.full(alm.shape[-1], 2.0); wgt[:lmax+1] = 1                                             # real-field inner product on m >= 0 storage
+	lhs = np.sum(m*pix); rhs = np.sum(wgt*(alm.real*at.real+alm.imag*at.imag))
+	assert abs(lhs-rhs) < 1e-11*abs(lhs)
+	back = curvedsky.map2alm_healpix(m, lmax=lmax, spin=[0, 2], niter=3)
+	assert np.sqrt(np.mean(np.abs(back-alm)**2)/np.mean(np.abs(alm)**2)) < 2e-3

@@ -147,6 +147,55 @@ def check_rings():
 		ra[:, :lmax+1] = ra[:, :lmax+1].real
 		assert relrms(oa, ra) < TOL
 
+def healpix_rings(nside):
+	"""the standard healpix ring layout (RING order): theta, nphi, phi0, ringstart"""
+	i = np.arange(1, 4*nside); north = np.minimum(i, 4*nside-i)             # ring index counted from the nearer pole
+	cap = north < nside
+	nphi = np.where(cap, 4*north, 4*nside).astype(np.uint64)
+	z = np.where(cap, 1-north**2/(3.0*nside**2), (4*nside-2.0*north)/(3*nside))*np.where(i <= 2*nside, 1, -1)
+	phi0 = np.where(cap, np.pi/(4*north), np.where((north-nside) % 2 == 0, np.pi/(4*nside), 0.0))
+	ringstart = np.concatenate([[0], np.cumsum(nphi)[:-1]]).astype(np.uint64)
+	return np.arccos(z), nphi, phi0, ringstart
+
+def check_general_rings(nside=4, lmax=14, big=False):
+	"""ring sets with per-ring nphi / phi0 / ringstart (ducc synthesis / adjoint_synthesis as called for healpix maps and profile
+	rings, curvedsky.py:328-349, 396-403, 537, 553): healpix; ragged rings incl. nphi = 1, a prime and heavy aliasing (nphi < mmax),
+	gaps between rings, unsorted offsets, pixstride 2"""
+	rng = np.random.default_rng(4)
+	cases = [healpix_rings(nside)+(1,)]
+	th = np.array([0.2, 0.7, 1.1, np.pi/2, np.pi-0.7, 2.6, 1.9, 0.05]); nph = np.array([5, 1, 13, 32, 7, 2, 24, 3], np.uint64)
+	p0 = rng.uniform(-3, 3, len(th)); order = rng.permutation(len(th))
+	rs = np.zeros(len(th), np.uint64); off = 3
+	for r in order: rs[r] = off; off += 2*int(nph[r])+5            # pixstride 2, gaps, rings stored out of order
+	if not big: cases.append((th, nph, p0, rs, 2))
+	for th, nph, p0, rs, pstr in cases:
+		kw = dict(theta=th, nphi=nph, phi0=p0, ringstart=rs, lmax=lmax, mstart=so._tri_mstart(lmax, lmax), pixstride=pstr)
+		for spin, mode in [(0, "STANDARD"), (2, "STANDARD")]+([] if big else [(1, "DERIV1")]):
+			nca = 1 if (spin == 0 or mode == "DERIV1") else 2
+			alm = so.rand_alm_simple(lmax, nca, 5, spin=(spin if mode != "DERIV1" else 0,))
+			ref = so.synthesis(alm=alm, spin=spin, mode=mode, **kw); out = sht.synthesis(alm=alm, spin=spin, mode=mode, **kw)
+			used = np.zeros(ref.shape[-1], bool)
+			for r in range(len(th)): used[int(rs[r])+pstr*np.arange(int(nph[r]))] = True
+			assert rel(out[:, used], ref[:, used]) < TOL and np.all(out[:, ~used] == 0)
+			pix = rng.standard_normal(ref.shape)
+			ra = so.adjoint_synthesis(map=pix, spin=spin, mode=mode, **kw); oa = sht.adjoint_synthesis(map=pix, spin=spin, mode=mode, **kw)
+			ra[:, :lmax+1] = ra[:, :lmax+1].real
+			assert relrms(oa, ra) < TOL
+			o32 = sht.synthesis(alm=alm.astype(np.complex64), spin=spin, mode=mode, **kw)
+			assert o32.dtype == np.float32 and rel(o32[:, used], ref[:, used]) < 1e-5
+
+@pytest.mark.hostsim
+def test_general_rings_hostsim(): check_general_rings()
+@pytest.mark.gpu
+def test_general_rings_gpu(): check_general_rings(); check_general_rings(nside=16, lmax=40, big=True)
+
+@pytest.mark.hostsim
+def test_general_path_equals_uniform_hostsim(monkeypatch):
+	"""PXS_GENERAL_RINGS=1 sends equal rings through the general path: same numbers as the paired ring FFTs"""
+	monkeypatch.setenv("PXS_GENERAL_RINGS", "1"); sht.clear_plans()
+	try: check_rings()
+	finally: sht.clear_plans()
+
 def check_deep_scaling(lmax=260):
 	"""rings so close to the poles (1e-5 rad: sin^100 = 2^-1660) that sin^m(theta) needs two and three 2^-800 scale steps, next to equatorial rings in
 	the same wave: lanes reach scale 0 at very different l (the ungated phase-B steps, data fetch / sum reset on arrival)"""
