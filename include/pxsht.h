@@ -37,10 +37,12 @@ typedef struct pxs_plan pxs_plan;
 
 /* Plan for transforms on explicit iso-latitude rings.
  * Replaces the geometry arguments of ducc0.sht.experimental.synthesis / adjoint_synthesis
- * (curvedsky.py:936-960, 1068-1084; ring tables from get_ring_info, curvedsky.py:1170-1190).
- * theta[nring] colatitudes, nphi[nring] pixels per ring (all equal in this version),
- * phi0[nring] azimuth of pixel 0, ringstart[nring] index of pixel 0 of each ring in the flat map,
- * pixstride: stride between pixels of a ring (+1 or -1). */
+ * (curvedsky.py:936-960, 1068-1084, 328-349, 396-403; ring tables from get_ring_info, get_ring_info_healpix,
+ * get_ring_info_radial, curvedsky.py:1170-1234).
+ * theta[nring] colatitudes, nphi[nring] pixels per ring (>= 1), phi0[nring] azimuth of pixel 0,
+ * ringstart[nring] index of pixel 0 of each ring in the flat map, pixstride: stride between pixels of a ring.
+ * Rings of equal length, phase and spacing (CAR maps) take the fused ring FFTs; any other ring set (healpix, profile
+ * rings, ring subsets, nphi < mmax) the general path: one batched FFT per ring length. */
 int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64_t* nphi,
                    const double* phi0, const uint64_t* ringstart, int64_t pixstride,
                    int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device);

@@ -74,7 +74,11 @@ static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, b
 	std::vector<AxisDim> d1 = dims, d2 = dims;
 	long lines = 1;
 	for (size_t k = dims.size(); k-- > 0;) { d1[k].os = lines*M; d2[k].is = lines*M; lines *= dims[k].n; }
-	DevBuf scratch; scratch.alloc(sizeof(double2)*(size_t)lines*M);
+	// scratch per stream, grown on demand and kept (growing frees the old block: hipFree waits for the device)
+	static std::mutex smu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> scratches;
+	DevBuf* sp;
+	{ std::lock_guard<std::mutex> g(smu); auto& u = scratches[std::make_pair(device, st)]; if (!u) u.reset(new DevBuf()); sp = u.get(); }
+	DevBuf& scratch = *sp; scratch.ensure(sizeof(double2)*(size_t)lines*M);
 	{	// y = FFT_M(x w, zero padded)
 		FftLoad l1 = ld; l1.mul = bp.w.as<double2>();
 		if (c2r) l1.herm_n = n;                                   // Hermitian extension of n points (times the chirp), zero padded to M
@@ -87,13 +91,22 @@ static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, b
 		FftStore s2 = stf; s2.mul = bp.wout.as<double2>(); s2.ne = (stf.ne >= 0 && stf.ne < n) ? stf.ne : n;
 		fft_axis(fc, st, M, false, d2, 1, os_e, l2, s2);
 	}
-	PXS_HIP(hipStreamSynchronize(st));          // scratch is freed on return
 }
 
 static int g_fft_device = 0;
 static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
                      FftLoad ld, FftStore stf) {
 	if (!FftContext::supported(n)) { bluestein_axis(fc, g_fft_device, st, n, forward, dims, is_e, os_e, ld, stf); return; }
+	{	// the generic radix pass costs n*p for a prime factor p: beyond ~128 two chirp FFTs of a smooth length are cheaper
+		// (healpix ring lengths 4k: alm2map_healpix at nside 2048, lmax 4096, 3 components 270 -> 94 ms)
+		static const long pmin = [] { const char* e = getenv("PXS_BLUESTEIN_MINPRIME"); return e ? atol(e) : 128L; }();
+		const bool plain = (ld.mode == LD_PLAIN || (ld.mode == LD_HERM && !ld.herm_fold)) && !ld.mul && !stf.mul && ld.shift == 0 && stf.shift == 0 && !stf.conj_out
+			&& stf.two_sided_k < 0 && !stf.real_pair;
+		long m = n, big = 1;
+		for (long q = 2; q*q <= m; q++) while (m % q == 0) { big = std::max(big, q); m /= q; }
+		if (m > 1) big = std::max(big, m);
+		if (plain && big > pmin) { bluestein_axis(fc, g_fft_device, st, n, forward, dims, is_e, os_e, ld, stf); return; }
+	}
 	// drop singleton dims, merge mergeable neighbours (outer,inner): outer.s == inner.s*inner.n for both in and out
 	std::vector<AxisDim> d;
 	for (auto& x : dims) if (x.n > 1) d.push_back(x);

@@ -39,6 +39,9 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v,
 static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = size_t(2) << 30; *tot = size_t(2) << 30; return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static const unsigned hipStreamNonBlocking = 1;
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }

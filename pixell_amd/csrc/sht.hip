@@ -329,6 +329,12 @@ struct pxs_plan {
 	struct GenGroup { long n, count, zoff; };
 	bool general = false; std::vector<GenGroup> groups; long npixz = 0;
 	DevBuf g_blk_ring, g_blk_k0, g_nphi, g_zoff, g_rstart, g_phi0, gz; long g_nblk = 0;
+	std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gjoin; hipEvent_t gfork = nullptr;
+	~pxs_plan() {
+		for (auto s_ : gstreams) (void)hipStreamDestroy(s_);
+		for (auto e : gjoin) (void)hipEventDestroy(e);
+		if (gfork) (void)hipEventDestroy(gfork);
+	}
 	DevBuf wring;                // DH / F2 grids: per-ring quadrature weight / nphi (analysis = weighted adjoint synthesis)
 	bool syn_via_cc = false;
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
@@ -459,6 +465,12 @@ void setup_general(pxs_plan* p, int nring, const uint64_t* nphi, const double* p
 	p->npixz = off; p->g_nblk = (long)blk_ring.size();
 	p->g_blk_ring = upload(blk_ring); p->g_blk_k0 = upload(blk_k0); p->g_nphi = upload(np); p->g_zoff = upload(zoff);
 	p->g_rstart = upload(rstart); p->g_phi0 = upload(ph);
+	if (p->groups.size() >= 8) {
+		static const int ns = [] { const char* e = getenv("PXS_GEN_STREAMS"); return e ? std::max(0, atoi(e)) : 16; }();
+		p->gstreams.resize(ns); p->gjoin.resize(ns);
+		for (int i = 0; i < ns; i++) { PXS_HIP(hipStreamCreateWithFlags(&p->gstreams[i], hipStreamNonBlocking)); PXS_HIP(hipEventCreateWithFlags(&p->gjoin[i], hipEventDisableTiming)); }
+		PXS_HIP(hipEventCreateWithFlags(&p->gfork, hipEventDisableTiming));
+	}
 }
 static GenK gen_args(pxs_plan* p, int nc, long ldleg, long map_cstride, double scale) {
 	GenK g; g.nring = p->nring; g.nm = p->mmax + 1; g.nc = nc; g.ldleg = ldleg; g.leg_cstride = (long)(p->mmax + 1)*ldleg; g.zc = p->npixz;
@@ -467,12 +479,24 @@ static GenK gen_args(pxs_plan* p, int nc, long ldleg, long map_cstride, double s
 	g.rstart = p->g_rstart.as<long>(); g.phi0 = p->g_phi0.as<double>(); g.scale = scale;
 	return g;
 }
+// one batched FFT per (component, length).  A healpix map has 2 nside lengths with two to four rings each: the launches are
+// dealt round-robin to side streams that fork from / join the caller's stream, so that the many small transforms overlap
+// (nside 2048, lmax 4096, 3 components: 282 ms on one stream, 94 ms on 16)
 static void gen_ffts(pxs_plan* p, hipStream_t st, int nc, bool forward) {
+	const size_t njobs = (size_t)nc*p->groups.size();
+	const size_t ns = njobs >= 16 ? p->gstreams.size() : 0;
+	if (ns) {
+		PXS_HIP(hipEventRecord(p->gfork, st));
+		for (size_t i = 0; i < ns; i++) PXS_HIP(hipStreamWaitEvent(p->gstreams[i], p->gfork, 0));
+	}
+	size_t job = 0;
 	for (int c = 0; c < nc; c++)
 		for (const auto& gr : p->groups) {
 			double2* zl = p->gz.as<double2>() + (size_t)c*p->npixz + gr.zoff;
-			fft_dense_lines(p->device, st, gr.n, forward, gr.count, zl, zl);
+			fft_dense_lines(p->device, ns ? p->gstreams[job % ns] : st, gr.n, forward, gr.count, zl, zl);
+			job++;
 		}
+	for (size_t i = 0; i < ns; i++) { PXS_HIP(hipEventRecord(p->gjoin[i], p->gstreams[i])); PXS_HIP(hipStreamWaitEvent(st, p->gjoin[i], 0)); }
 }
 
 int ncomp_of(int spin, int mode, bool alm_side) {
