@@ -826,6 +826,7 @@ int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64
 	// masked ring subsets) the general path: per-ring length, phase and offset
 	for (int r = 0; r < nring; r++)
 		if ((long)nphi[r] != p->nphi || std::fabs(phi0[r] - phi0[0]) > 1e-13 || (long)ringstart[r] != p->ring_off0 + r*p->ring_stride) p->general = true;
+	if (!FftContext::supported(p->nphi)) p->general = true;          // equal rings of a length with a prime factor > 2048: Bluestein lives on the general path
 	{ const char* e = getenv("PXS_GENERAL_RINGS"); if (e && atoi(e) != 0) p->general = true; }      // (tests: the general path on uniform rings)
 	p->pix_stride = pixstride;
 	plan_common(p.get(), lmax, mmax, mstart, lstride, device);

@@ -475,6 +475,44 @@ def map2alm_healpix(healmap, alm=None, ainfo=None, lmax=None, spin=[0, 2], weigh
 	return healmap if adjoint else alm
 
 # ---------------------------------------------------------------------------------------
+# 1-D transforms: radial profiles <-> functions of l, as m = 0 transforms on rings of one pixel (curvedsky.py:510-554)
+# ---------------------------------------------------------------------------------------
+def _m0_kwargs(theta, lmax):
+	rinfo = get_ring_info_radial(theta)
+	return dict(theta=rinfo.theta, nphi=rinfo.nphi, phi0=rinfo.phi0, ringstart=rinfo.offsets, spin=0, lmax=int(lmax), mmax=0, mstart=np.zeros(1, np.uint64))
+
+def profile2harm(br, r, lmax=None, oversample=1, left=None, right=None):
+	"""br[..., nr] sampled at ascending radii r (radians) -> bl[..., lmax+1] with b(r) = sum_l (2l+1)/(4 pi) b_l P_l(cos r): the
+	profile is interpolated linearly onto the Clenshaw-Curtis nodes of spacing ~dr that cover [0, r_max], weighted with the CC ring
+	weights and analysed with one m = 0 adjoint synthesis (the contract of curvedsky.profile2harm, curvedsky.py:510-541)"""
+	br = np.asarray(br); r = np.asarray(r)
+	step = (r[-1]-r[0])/(len(r)-1)
+	nfull = nint(np.pi/step)+1; step = np.pi/(nfull-1)          # nodes k pi/(nfull-1) of the full circle, of which the first ncut reach r_max
+	ncut = int(np.ceil(r[-1]/step))
+	if lmax is None: lmax = int(nfull//2-1)
+	theta = np.arange(ncut)*step
+	kw = _m0_kwargs(theta, lmax)
+	w = sht.get_gridweights("CC", nfull)[:ncut]
+	norm = np.sqrt(4*np.pi/(2*np.arange(lmax+1)+1))
+	out = np.zeros(br.shape[:-1]+(lmax+1,), br.dtype)
+	for I in nditer(br.shape[:-1]):
+		ring = np.interp(theta, r, br[I], left=left, right=right)[None]*w
+		out[I] = sht.adjoint_synthesis(map=np.ascontiguousarray(ring, dtype=np.float64), **kw)[0].real*norm
+	return out
+
+def harm2profile(bl, r):
+	"""bl[..., nl] -> b(r)[..., nr] = sum_l (2l+1)/(4 pi) b_l P_l(cos r): one m = 0 synthesis on rings of one pixel at
+	colatitudes r (curvedsky.harm2profile, curvedsky.py:543-554)"""
+	bl = np.asarray(bl); r = np.asarray(r)
+	nl = bl.shape[-1]
+	kw = _m0_kwargs(r.reshape(-1), nl-1)
+	alm = bl*np.sqrt((2*np.arange(nl)+1)/(4*np.pi))+0j
+	out = np.zeros(bl.shape[:-1]+(r.size,), bl.dtype)
+	for I in nditer(bl.shape[:-1]):
+		out[I] = sht.synthesis(alm=np.ascontiguousarray(alm[I][None], dtype=np.complex128), **kw)[0]
+	return out
+
+# ---------------------------------------------------------------------------------------
 # alm post-processing either side of the transforms (SURVEY 8 f1): almxfl, alm2cl, rand_alm.
 # The per-element arithmetic (lmul, alm2cl) runs on the GPU (almops.py -> pxa_*); the random
 # numbers come from numpy's legacy global RNG exactly as in the reference, so that a seed gives the

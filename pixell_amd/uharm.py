@@ -3,8 +3,9 @@
 The method set and semantics of pixell's uharm.UHT (pixell/uharm.py:8-182) for the part of it that sits on the accelerated
 path: map2harm / harm2map and their adjoints, quad_weights, lprof2hprof, hmul, harm2powspec, sum_hprof / mean_hprof.  In "flat"
 mode the harmonic representation is a complex map of the 2-D FFT bins (enmap.map2harm, normalize="phys"); in "curved" mode it is
-an alm array.  The profile transforms (rprof2hprof, hprof2rprof: 1-D Legendre transforms of beams), hrand in flat mode and
-hprof_rpow are host-side helpers of the reference outside this path and raise NotImplementedError.
+an alm array.  The profile transforms (rprof2hprof, hprof2rprof: 1-D Legendre transforms of beams) run in curved mode as m = 0
+transforms on one-pixel rings; their flat-mode versions, hrand in flat mode and hprof_rpow in flat mode are host-side helpers of the
+reference outside this path and raise NotImplementedError.
 Maps may be numpy ndmaps (staged) or enmap.dmap (device resident, nothing leaves HBM).
 The stock pixell.uharm.UHT itself also runs on this backend unchanged through the integration routes of INTEGRATION.md
 (pixell.curvedsky over pixell_amd.sht, pixell.fft.engines["hip"]); this class is for callers that keep their data on the GPU."""
@@ -117,5 +118,18 @@ class UHT:
 		hprof = hprof.cpu().numpy() if _is_tensor(hprof) else np.asanyarray(hprof.tensor.cpu().numpy() if isinstance(hprof, enmap.dmap) else hprof)
 		return np.sum(hprof*self.nper, (-2, -1) if self.mode == "flat" else -1)
 	def mean_hprof(self, hprof): return self.sum_hprof(hprof)/self.ntot
-	def rprof2hprof(self, br, r): raise NotImplementedError("radial profile transforms are host-side helpers outside the accelerated path")
-	def hprof2rprof(self, harm, r): raise NotImplementedError("radial profile transforms are host-side helpers outside the accelerated path")
+	def rprof2hprof(self, br, r):
+		"""radial profile br[..., nr] at radii r -> harmonic profile (curved: a function of l up to lmax; uharm.py:127-132)"""
+		if self.mode == "curved": return curvedsky.profile2harm(br, r, lmax=self.lmax)
+		raise NotImplementedError("rprof2hprof in flat mode (profile2harm_flat_2d) is a host-side helper outside the accelerated path")
+	def hprof2rprof(self, harm, r):
+		if self.mode == "curved": return curvedsky.harm2profile(harm, r)
+		raise NotImplementedError("hprof2rprof in flat mode (harm2profile_flat_2d) is a host-side helper outside the accelerated path")
+	def hprof_rpow(self, hprof, power):
+		"""the harmonic profile of (the real-space profile of hprof)**power: map2harm(harm2map(hprof)**power) for profiles
+		(uharm.py:191-207).  curved: the profile is sampled at a tenth of the beam's 1/e^(1/2) scale out to 20 of them"""
+		if self.mode != "curved": raise NotImplementedError("hprof_rpow in flat mode is a host-side helper outside the accelerated path")
+		hprof = np.asarray(hprof)
+		scale = 1/max(1, np.where(hprof > np.max(hprof)*np.exp(-0.5))[0][-1])
+		r = np.arange(0, 20*scale, scale/10)
+		return self.rprof2hprof(self.hprof2rprof(hprof, r)**power, r)

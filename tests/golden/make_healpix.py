@@ -38,6 +38,21 @@ def main():
 		a = cs.map2alm_healpix(pix.copy(), lmax=lmax, spin=[0, 2], niter=niter); out["map2alm_niter%d" % niter] = np.array(a)
 	a = cs.map2alm_healpix(m.copy(), lmax=lmax, spin=[0, 2], niter=3); out["map2alm_roundtrip"] = np.array(a)
 	ma = cs.map2alm_healpix(np.zeros((3, 12*nside**2)), alm=alm.copy(), spin=[0, 2], adjoint=True, niter=1); out["map2alm_adjoint"] = np.array(ma)
+	# 1-D profile transforms (m = 0 on one-pixel rings): a Gaussian beam and a two-row stack with extrapolation values
+	sig = np.deg2rad(1.5); rr = np.linspace(0, 12*sig, 400)
+	br = np.stack([np.exp(-0.5*rr**2/sig**2), (1+rr)**-3.0])
+	out["prof_r"] = rr; out["prof_br"] = br
+	out["prof_bl"] = cs.profile2harm(br, rr, lmax=150)
+	out["prof_bl_auto"] = cs.profile2harm(br[0], rr)
+	out["prof_bl_lr"] = cs.profile2harm(br[1, 20:], rr[20:], lmax=90, left=2.0, right=0.0)
+	r2 = np.array([0.0, 0.01, 0.05, 0.3, 1.0, 2.5, np.pi]); out["prof_r2"] = r2
+	out["prof_back"] = cs.harm2profile(out["prof_bl"], r2)
+	from pixell import uharm
+	shape, wcs = ns.enmap.fullsky_geometry(shape=(46, 90))
+	uht = uharm.UHT(shape, wcs, mode="curved", lmax=40)
+	hp = np.exp(-0.5*np.arange(41.0)**2*sig**2*9)
+	out["uht_hprof"] = hp; out["uht_rpow"] = uht.hprof_rpow(hp, 2.0)
+	out["uht_rprof2hprof"] = uht.rprof2hprof(br[0], rr); out["uht_hprof2rprof"] = uht.hprof2rprof(hp, r2)
 	out["meta"] = np.array([nside, lmax])
 	np.savez_compressed(os.path.join(HERE, "healpix.npz"), **out)
 	print("healpix.npz: %d arrays; round trip error after 3 Jacobi steps %.2e" % (len(out), np.max(np.abs(a-alm))/np.max(np.abs(alm))))

@@ -5,7 +5,7 @@ long-double oracle."""
 import os
 import numpy as np
 import pytest
-from pixell_amd import curvedsky
+from pixell_amd import curvedsky, enmap, uharm
 
 def _real_m0(a, lmax):
 	a = np.array(a); a[..., :lmax+1] = a[..., :lmax+1].real; return a
@@ -48,8 +48,27 @@ def healpix_body(golden_dir, to_dev=lambda x: x, to_host=np.asarray):
 	with pytest.raises(NotImplementedError): curvedsky.map2alm_healpix(to_dev(np.zeros((2, npix))), lmax=lmax, deriv=True)
 	with pytest.raises(ValueError): curvedsky.alm2map_healpix(to_dev(alm.copy()), to_dev(np.zeros((2, npix))), spin=[0, 2])
 
+def profile_body(golden_dir):
+	"""profile2harm / harm2profile (m = 0 transforms on one-pixel rings, curvedsky.py:510-554) and the UHT profile methods
+	(uharm.py:127-138, 191-207) against the reference's outputs"""
+	d = np.load(os.path.join(golden_dir, "healpix.npz"))
+	rr, br, r2 = d["prof_r"], d["prof_br"], d["prof_r2"]
+	def close(a, b, tol=1e-11): assert a.shape == b.shape and np.max(np.abs(a-b)) < tol*np.max(np.abs(b))
+	close(curvedsky.profile2harm(br, rr, lmax=150), d["prof_bl"])
+	close(curvedsky.profile2harm(br[0], rr), d["prof_bl_auto"])
+	close(curvedsky.profile2harm(br[1, 20:], rr[20:], lmax=90, left=2.0, right=0.0), d["prof_bl_lr"])
+	close(curvedsky.harm2profile(d["prof_bl"], r2), d["prof_back"])
+	shape, wcs = enmap.fullsky_geometry(shape=(46, 90))
+	uht = uharm.UHT(shape, wcs, mode="curved", lmax=40)
+	close(uht.rprof2hprof(br[0], rr), d["uht_rprof2hprof"]); close(uht.hprof2rprof(d["uht_hprof"], r2), d["uht_hprof2rprof"])
+	close(uht.hprof_rpow(d["uht_hprof"], 2.0), d["uht_rpow"], 1e-10)
+
 @pytest.mark.hostsim
 def test_healpix_hostsim(golden_dir): healpix_body(golden_dir)
+@pytest.mark.hostsim
+def test_profiles_hostsim(golden_dir): profile_body(golden_dir)
+@pytest.mark.gpu
+def test_profiles_gpu(golden_dir): profile_body(golden_dir)
 
 @pytest.mark.gpu
 def test_healpix_gpu(golden_dir):

@@ -184,6 +184,22 @@ def check_general_rings(nside=4, lmax=14, big=False):
 			o32 = sht.synthesis(alm=alm.astype(np.complex64), spin=spin, mode=mode, **kw)
 			assert o32.dtype == np.float32 and rel(o32[:, used], ref[:, used]) < 1e-5
 
+def check_prime_rings():
+	"""equal rings whose length has a prime factor > 2048 (no mixed-radix factorisation): general path + Bluestein"""
+	th = np.array([0.4, 1.3, np.pi-1.3, 2.5]); nph = 2*2053; lmax = 12
+	kw = dict(theta=th, nphi=np.full(4, nph, np.uint64), phi0=np.full(4, 0.1), ringstart=np.arange(4, dtype=np.uint64)*nph, lmax=lmax, mstart=so._tri_mstart(lmax, lmax))
+	alm = so.rand_alm_simple(lmax, 2, 5, spin=(2,))
+	ref = so.synthesis(alm=alm, spin=2, **kw); out = sht.synthesis(alm=alm, spin=2, **kw)
+	assert rel(out, ref) < TOL
+	ra = so.adjoint_synthesis(map=ref, spin=2, **kw); oa = sht.adjoint_synthesis(map=ref, spin=2, **kw)
+	ra[:, :lmax+1] = ra[:, :lmax+1].real
+	assert relrms(oa, ra) < TOL
+
+@pytest.mark.hostsim
+def test_prime_rings_hostsim(): check_prime_rings()
+@pytest.mark.gpu
+def test_prime_rings_gpu(): check_prime_rings()
+
 @pytest.mark.hostsim
 def test_general_rings_hostsim(): check_general_rings()
 @pytest.mark.gpu
