@@ -10,6 +10,7 @@ Differences that matter for speed, not for results:
   * `map` may be an enmap.ndmap (numpy; staged through the GPU) or an enmap.dmap wrapping a torch
     CUDA tensor (transformed in place, nothing leaves HBM); `alm` likewise numpy or tensor.
 """
+import os
 import numpy as np
 from . import enmap, sht, wcs as wcsutils
 from .sht import _is_tensor, _np_dtype, _torch
@@ -402,6 +403,89 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 			else:       alm_full[Ij] = jacobi_inverse(Y, YTW, map_full[Ij], niter=niter)
 	if adjoint: return map
 	else:       return alm
+
+# ---------------------------------------------------------------------------------------
+# The reference's helper entry points around the transforms, by name (curvedsky.py:900-1086, 1236-1250, 1349-1353, 1384-1473).
+# pixell stages every map through a flipped, padded copy (map2buffer) and runs the `raw` functions on that buffer; here flips are
+# strides inside the kernels, so the `raw` functions are the plain ones restricted to what a buffer is (a complete grid / complete
+# rings), and map2buffer / buffer2map exist for callers that want the staged form.
+# ---------------------------------------------------------------------------------------
+class ShapeError(Exception): pass
+
+def get_ducc_maxlmax(name, ny): return _geo.grid_maxlmax(name, ny)
+def dangerous_dtype(dtype): return np.dtype(dtype).byteorder not in ("=", "|")
+
+def flip2slice(flips):
+	"""index expression that reverses the trailing axes whose flag is set"""
+	return (Ellipsis,)+tuple(slice(None, None, -1 if f else 1) for f in flips)
+def flip_array(arr, flips): return arr[flip2slice(flips)]
+def flip_geometry(shape, wcs, flips): return wcsutils.flipped(shape, wcs, flips)
+def pad_geometry(shape, wcs, pad):
+	"""geometry with pad[0] = (rows, columns) added before and pad[1] after"""
+	pad = np.asarray(pad)
+	w = wcs.deepcopy(); w.wcs.crpix[0] += pad[0, 1]; w.wcs.crpix[1] += pad[0, 0]
+	return tuple(shape[:-2])+(int(pad[0, 0]+shape[-2]+pad[1, 0]), int(pad[0, 1]+shape[-1]+pad[1, 1])), w
+
+def map2buffer(map, flip, pad, obuf=False):
+	"""zero-filled map of the flipped, padded geometry holding the flipped map (obuf: left empty, an output buffer)"""
+	pad = np.asarray(pad)
+	shape, wcs = pad_geometry(*flip_geometry(map.shape, map.wcs, flip), pad)
+	buf = enmap.zeros(shape, wcs, np.dtype(map.dtype).newbyteorder("="))
+	if not obuf: buf[..., pad[0, 0]:shape[-2]-pad[1, 0], pad[0, 1]:shape[-1]-pad[1, 1]] = flip_array(np.asarray(map), flip)
+	return buf
+def buffer2map(map, flip, pad):
+	"""undo map2buffer: crop the padding, flip back (a view)"""
+	pad = np.asarray(pad)
+	return flip_array(map[..., pad[0, 0]:map.shape[-2]-pad[1, 0], pad[0, 1]:map.shape[-1]-pad[1, 1]], flip)
+
+def prepare_raw(alm, map, ainfo=None, lmax=None, deriv=False, verbose=False, nthread=None, pixdims=2, convert_alm=False):
+	"""(alm_full, map_full, ainfo, nthread): alm [..., ncomp, nelem] and map [..., ncomp, pixels] with agreeing leading dimensions
+	(deriv: alm [..., nelem], map [..., 2, pixels]); AssertionError otherwise (curvedsky.py:1429-1446)"""
+	mdata = _mdata(map)
+	alm, ainfo = prepare_alm(alm, ainfo, lmax=lmax, pre=map.shape[:-pixdims], dtype=_np_dtype(mdata), convert=convert_alm, like=mdata)
+	alm_full = _atleast(alm, 2 if deriv else 3); map_full = _atleast(mdata, pixdims+2)
+	if deriv:
+		assert map_full.shape[-pixdims-1] == 2, "map must have shape [...,2,%s] when deriv is True" % ("nloc" if pixdims == 1 else "ny,nx")
+		assert tuple(map_full.shape[:-1-pixdims]) == tuple(alm_full.shape[:-1]), "map and alm must agree on pre-dimensions"
+	else:
+		assert tuple(map_full.shape[:-pixdims]) == tuple(alm_full.shape[:-1]), "map and alm must agree on pre-dimensions"
+	env = os.environ.get("OMP_NUM_THREADS")
+	return alm_full, map_full, ainfo, int(env) if env else int(nthread or 0)
+
+def _require_case(map, minfo, cases, what):
+	minfo = analyse_geometry(map.shape, map.wcs) if minfo is None else minfo
+	if minfo.case not in cases or (minfo.case == "cyl" and cases == ("2d",)): raise ValueError("%s needs %s (got case '%s'): use the function without _raw, which pads" % (what, " or ".join(cases), minfo.case))
+	return minfo
+
+def alm2map_raw_2d(alm, map, ainfo=None, spin=[0, 2], deriv=False, copy=False, verbose=False, adjoint=False, nthread=None):
+	"""synthesis_2d / adjoint_synthesis_2d on a map that IS a complete named grid (curvedsky.py:900-926)"""
+	return alm2map_2d(alm, map, ainfo=ainfo, minfo=_require_case(map, None, ("2d",), "alm2map_raw_2d"), spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread)
+def map2alm_raw_2d(map, alm=None, ainfo=None, lmax=None, spin=[0, 2], deriv=False, copy=False, verbose=False, adjoint=False, nthread=None):
+	"""analysis_2d / adjoint_analysis_2d on a map that IS a complete named grid (curvedsky.py:1018-1048)"""
+	return map2alm_2d(map, alm=alm, ainfo=ainfo, minfo=_require_case(map, None, ("2d",), "map2alm_raw_2d"), lmax=lmax, spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread)
+def alm2map_raw_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=False, verbose=False, adjoint=False, nthread=None):
+	"""synthesis / adjoint_synthesis on the rows of a map whose rings close the circle (curvedsky.py:928-962)"""
+	return alm2map_cyl(alm, map, ainfo=ainfo, minfo=_require_case(map, minfo, ("2d", "cyl"), "alm2map_raw_cyl"), spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread)
+def map2alm_raw_cyl(map, alm=None, ainfo=None, lmax=None, spin=[0, 2], weights=None, deriv=False, copy=False, verbose=False, adjoint=False, niter=0, nthread=None):
+	"""weighted adjoint_synthesis + Jacobi refinement on the rows of a map whose rings close the circle (curvedsky.py:1050-1086)"""
+	return map2alm_cyl(map, alm=alm, ainfo=ainfo, minfo=_require_case(map, None, ("2d", "cyl"), "map2alm_raw_cyl"), lmax=lmax, spin=spin, weights=weights, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread, niter=niter)
+
+def alm_complex2real(alm, ainfo=None):
+	"""complex alm (m >= 0 storage) -> real vector of the same information with unit Jacobian: the m = 0 block keeps its real
+	parts, every m > 0 coefficient becomes sqrt(2) (Re, Im) (curvedsky.py:1451-1456)"""
+	alm = np.asarray(alm)
+	ainfo = alm_info(nalm=alm.shape[-1]) if ainfo is None else ainfo
+	n0 = int(ainfo.mstart[1])+1
+	return np.concatenate([alm[..., :n0].real, np.sqrt(2.0)*np.ascontiguousarray(alm[..., n0:]).view(real_dtype(alm.dtype))], -1)
+def alm_real2complex(ralm, ainfo=None):
+	"""inverse of alm_complex2real; without ainfo the triangular layout with (lmax+1)^2 = len is assumed"""
+	ralm = np.asarray(ralm)
+	if ainfo is None: ainfo = alm_info(lmax=nint((ralm.shape[-1]-1)**0.5)-1)       # length = lmax^2 + 2 lmax + 2 (a_00's zero slot included)
+	n0 = int(ainfo.mstart[1])+1
+	out = np.zeros(ralm.shape[:-1]+(ainfo.nelem,), complex_dtype(ralm.dtype))
+	out[..., :n0] = ralm[..., :n0]
+	out[..., n0:] = np.ascontiguousarray(ralm[..., n0:]).view(out.dtype)/np.sqrt(2.0)
+	return out
 
 # ---------------------------------------------------------------------------------------
 # healpix maps: the same ring transforms on ring tables with per-ring nphi / phi0 (the general ring path of sht.hip)

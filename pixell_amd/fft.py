@@ -275,3 +275,36 @@ def resample(a, n, axes=None, nthread=0, engine="auto"):
 	out = ifft(fa, axes=axes, normalize=False)
 	out = _to_host(out, was_host)
 	return out if iscomplex else out.real
+
+# ---- the registry face of pixell.fft (fft.py:78-131, 313-338): on this backend there is one engine ---------------------------
+engines = {"hip": hip_engine}
+engine = "hip"
+alignment = 32
+def set_engine(eng):
+	"""select the default engine by name (only "hip" exists here; pixell.fft.register() installs it next to the reference's own)"""
+	global engine
+	if eng not in engines: raise KeyError("no FFT engine '%s' (available: %s)" % (eng, ", ".join(sorted(engines))))
+	engine = eng
+def get_engine(eng): return engine if eng == "auto" else eng
+def empty(shape, dtype): return engines[engine].empty_aligned(shape, dtype=dtype, n=alignment)
+def asfcarray(a):
+	"""a as an array of at least float precision (integers become float64)"""
+	a = np.asarray(a)
+	return np.asarray(a, np.result_type(a, 0.0))
+def ichebt(a, b=None, nthread=0, engine="auto"):
+	"""inverse of chebt along the last axis: halve the interior coefficients, DCT-I (fft.py:313-317)"""
+	a = asfcarray(a).copy()
+	a[..., 1:-1] *= 0.5
+	return redft00(a, b, nthread)
+# bin index <-> frequency of an n-point transform with sample spacing d
+def ind2freq(n, i, d=1.0):  return np.where(np.asarray(i) < n/2, i, np.asarray(i)-n)/(d*n)
+def int2rfreq(n, i, d=1.0): return np.asarray(i)/(n*d)
+def freq2ind(n, f, d=1.0):
+	j = np.asarray(f)*(d*n)
+	return np.where(j >= 0, j, n+j)
+def rfreq2ind(n, f, d=1.0): return np.asarray(f)*(n*d)
+def fft_flat(tod, ft, nthread=1, axes=[-1], flags=None, _direction="FFTW_FORWARD"):
+	"""pixell's work-around entry for engines that cannot take many leading dimensions (fft.py:669-683); this engine can"""
+	return fft(tod, ft, nthread=nthread, axes=axes, flags=flags, _direction=_direction)
+def ifft_flat(ft, tod, nthread=1, axes=[-1], flags=None):
+	return ifft(ft, tod, nthread=nthread, normalize=False, axes=axes, flags=flags)

@@ -53,6 +53,32 @@ def main():
 	hp = np.exp(-0.5*np.arange(41.0)**2*sig**2*9)
 	out["uht_hprof"] = hp; out["uht_rpow"] = uht.hprof_rpow(hp, 2.0)
 	out["uht_rprof2hprof"] = uht.rprof2hprof(br[0], rr); out["uht_hprof2rprof"] = uht.hprof2rprof(hp, r2)
+	# helper entry points by name: buffers, raw transforms on them, alm real <-> complex
+	enmap = ns.enmap
+	shape, wcs = enmap.fullsky_geometry(shape=(14, 24))
+	bshape, bwcs = enmap.band_geometry(np.deg2rad(50), shape=(10, 24))
+	mb = enmap.enmap(rng.standard_normal((3,)+tuple(bshape)), bwcs)
+	info = cs.analyse_geometry(mb.shape, mb.wcs)
+	pad = np.array([info.ypad, info.xpad]).T
+	buf = cs.map2buffer(mb, info.flip, pad)
+	out["buf_in"] = np.array(mb); out["buf_flip"] = np.array(info.flip); out["buf_pad"] = pad; out["buf_out"] = np.array(buf)
+	out["buf_wcs"] = np.array([buf.wcs.wcs.cdelt, buf.wcs.wcs.crval, buf.wcs.wcs.crpix]); out["buf_in_wcs"] = np.array([bwcs.wcs.cdelt, bwcs.wcs.crval, bwcs.wcs.crpix])
+	out["buf_back"] = np.array(cs.buffer2map(buf, info.flip, pad))
+	a12 = so.rand_alm_simple(12, 3, 9, spin=(0, 2)); out["raw_alm"] = a12
+	raw = cs.alm2map_raw_2d(a12.copy(), enmap.zeros((3,)+buf.shape[-2:], buf.wcs), spin=[0, 2]); out["raw_alm2map_2d"] = np.array(raw)
+	out["raw_map2alm_2d"] = np.array(cs.map2alm_raw_2d(buf.copy(), alm=np.zeros_like(a12), spin=[0, 2]))      # (without alm= the reference returns None)
+	cyl = cs.map2buffer(mb, info.flip, np.zeros((2, 2), int))
+	out["raw_cyl_in"] = np.array(cyl); out["raw_cyl_wcs"] = np.array([cyl.wcs.wcs.cdelt, cyl.wcs.wcs.crval, cyl.wcs.wcs.crpix])
+	out["raw_alm2map_cyl"] = np.array(cs.alm2map_raw_cyl(a12.copy(), enmap.zeros(cyl.shape, cyl.wcs), spin=[0, 2]))
+	wq = 4*np.pi/24*np.sin(cs.get_ring_info(cyl.shape, cyl.wcs).theta)*np.pi/15      # explicit weights: pixell's quad_weights reverses the rows of EVERY map
+	out["raw_cyl_weights"] = wq                                                     # (`if minfo.flip:` on a list, curvedsky.py:503), wrong for an asymmetric band stored north to south
+	out["raw_map2alm_cyl"] = np.array(cs.map2alm_raw_cyl(cyl.copy(), alm=np.zeros_like(a12), spin=[0, 2], niter=1, weights=wq))
+	out["c2r"] = cs.alm_complex2real(a12); out["r2c"] = cs.alm_real2complex(out["c2r"][0])
+	out["maxlmax"] = np.array([[cs.get_ducc_maxlmax(n, k) for k in (8, 9, 30)] for n in ("CC", "F1", "MW", "MWflip", "DH", "F2")])
+	from pixell import fft as rfft
+	rfft.set_engine("numpy")          # (the harness stubs ducc0: its FFT engine must not be picked)
+	xx = rng.standard_normal((3, 17)); out["cheb_in"] = xx; out["cheb"] = np.array([rfft.chebt(v.copy()) for v in xx])
+	out["icheb"] = np.array([rfft.ichebt(v.copy()) for v in out["cheb"]])
 	out["meta"] = np.array([nside, lmax])
 	np.savez_compressed(os.path.join(HERE, "healpix.npz"), **out)
 	print("healpix.npz: %d arrays; round trip error after 3 Jacobi steps %.2e" % (len(out), np.max(np.abs(a-alm))/np.max(np.abs(alm))))
