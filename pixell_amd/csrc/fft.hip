@@ -474,7 +474,7 @@ long FftContext::good_size(long n) {
 // Fewest passes with radices from {2,3,4,5} and the composite register radices {6,8,9,10,12,15,16} (fft_dev.hpp); PXS_FFT_RADICES
 // restricts the set (tuning); only those up to PXS_COMP_MAXR are compiled in (fft_dev.hpp).  Odd radices go first: in the first passes (small L) consecutive lanes are R points apart, which
 // for an even R puts them on few LDS banks.
-static std::vector<int> factorize_comp(long n) {
+static std::vector<int> factorize_comp(long n, int maxr) {
 	static const std::vector<int> allowed = [] {
 		std::vector<int> a; const char* e = getenv("PXS_FFT_RADICES");
 		std::string s = e ? e : "16,15,12,10,9,8,6,5,4,3,2";
@@ -485,7 +485,7 @@ static std::vector<int> factorize_comp(long n) {
 	std::function<void(long, size_t)> rec = [&](long m, size_t from) {
 		if (m == 1) { if (best.empty() || cur.size() < best.size()) best = cur; return; }
 		if (!best.empty() && cur.size()+1 >= best.size()) return;
-		for (size_t i = from; i < allowed.size(); i++) if (m % allowed[i] == 0) { cur.push_back(allowed[i]); rec(m/allowed[i], i); cur.pop_back(); }
+		for (size_t i = from; i < allowed.size(); i++) if (m % allowed[i] == 0 && (allowed[i] <= 5 || allowed[i] <= maxr)) { cur.push_back(allowed[i]); rec(m/allowed[i], i); cur.pop_back(); }
 	};
 	rec(n, 0);
 	if (best.empty()) return factorize(n);
@@ -493,21 +493,22 @@ static std::vector<int> factorize_comp(long n) {
 	return best;
 }
 
-std::shared_ptr<FftSub> FftContext::sub(long n, bool comp) {
+std::shared_ptr<FftSub> FftContext::sub(long n, bool comp, int maxr) {
 	std::lock_guard<std::mutex> g(mu_);
 	static const bool comp_on = [] { const char* e = getenv("PXS_FFT_COMP"); return e ? atoi(e) != 0 : true; }();
 	comp = comp && comp_on;
-	const long key = comp ? -n : n;
+	maxr = std::min(maxr, PXS_COMP_MAXR);
+	const long key = comp ? -(n + ((long)maxr << 40)) : n;
 	auto it = subs_.find(key);
 	if (it != subs_.end()) return it->second;
 	auto s = std::make_shared<FftSub>();
-	s->n = (int)n; s->fac = comp ? factorize_comp(n) : factorize(n);
+	s->n = (int)n; s->fac = comp ? factorize_comp(n, maxr) : factorize(n);
 	PXS_REQUIRE((int)s->fac.size() <= FFT_MAXFAC, "FFT: too many factors");
 	int L = 1; s->nfac = (int)s->fac.size();
 	std::vector<int> Ls(s->nfac+1); Ls[0] = 1;
 	for (int p = 0; p < s->nfac; p++) {
 		int R = s->fac[p];
-		const bool comp_r = comp && R <= PXS_COMP_MAXR && (R == 6 || R == 8 || R == 9 || R == 10 || R == 12 || R == 15 || R == 16);
+		const bool comp_r = comp && R <= maxr && (R == 6 || R == 8 || R == 9 || R == 10 || R == 12 || R == 15 || R == 16);
 		if (R != 2 && R != 3 && R != 4 && R != 5 && !comp_r) s->generic = true;
 		PassDesc& ps = s->pass[p];
 		ps.R = R; ps.L = L; ps.tws = (int)(n/((long)L*R));
@@ -527,8 +528,8 @@ std::shared_ptr<FftSub> FftContext::sub(long n, bool comp) {
 	return s;
 }
 
-FftContext::SubView FftContext::view(long n) {
-	auto s = sub(n, true);
+FftContext::SubView FftContext::view(long n, int maxr) {
+	auto s = sub(n, true, maxr);
 	SubView v; v.n = s->n; v.nfac = s->nfac; v.ns = s->n | 1; v.generic = s->generic ? 1 : 0;
 	v.pass = s->d_pass.p; v.perm = s->perm.as<int>(); v.tw = s->tw.as<double2>();
 	return v;

@@ -63,7 +63,7 @@ public:
 	// views for the fused chain kernels (fftchain.hip): LDS sub-transform tables of length n (radices 2,3,4,5 only:
 	// `ok` false otherwise) and the four-step twiddle table e^{-2 pi i k/n}, k < n
 	struct SubView { int n, nfac, ns, generic; const void* pass; const int* perm; const double2* tw; };
-	SubView view(long n);
+	SubView view(long n, int maxr = 1000);      // maxr: largest composite register radix the calling kernel has compiled in
 	const double2* twiddle_table(long n) { return bigtw(n); }
 	size_t temp_budget = size_t(4) << 30;   // bytes of four-step scratch per stream (set from the free memory in the constructor)
 private:
@@ -72,7 +72,7 @@ private:
 	std::map<long, std::shared_ptr<FftSub>> subs_;
 	std::map<long, DevBuf> bigtw_;
 	std::map<hipStream_t, DevBuf> temps_;
-	std::shared_ptr<FftSub> sub(long n, bool comp = false);   // comp: factorisation with the composite register radices (chain kernels)
+	std::shared_ptr<FftSub> sub(long n, bool comp = false, int maxr = 1000);   // comp: factorisation with the composite register radices (chain kernels)
 	const double2* bigtw(long n);
 };
 

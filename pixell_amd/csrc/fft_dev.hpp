@@ -100,7 +100,9 @@ template<int R, int NT> __device__ __forceinline__ void radix_pass_t(double2* bu
 // Only radices up to PXS_COMP_MAXR are compiled in.  Measured on MI355X (C3 bench, FFT stages of a round trip, same box):
 // plain radices 112.5 ms (48-54 VGPRs), up to 8: 108.4 ms (62-67 VGPRs), up to 10: 107.9 ms (75-79 VGPRs), up to 16: 139 ms --
 // at 107-112 VGPRs a 512-thread workgroup fits only twice on a CU and even tiles that never take the radix-16 path slow
-// down by a third.  9 keeps every chain kernel at <= 69 VGPRs.
+// down by a third.  9 keeps every chain kernel at <= 69 VGPRs.  lds_fft<NT, MAXR> lets a kernel leave out the larger ones: the
+// ring stages of fftchain.hip compile radices up to 8 only and fit 64 VGPRs (8 waves per SIMD): ring FFTs 49.3 -> 46.4 ms at C3,
+// 68.2 -> 60.8 ms at C4.
 #ifndef PXS_COMP_MAXR
 #define PXS_COMP_MAXR 9
 #endif
@@ -152,7 +154,8 @@ template<int A, int B, int NT> __device__ __forceinline__ void radix_pass_comp(d
 }
 
 // all passes of f on T lines (radices 2,3,4,5 and the composite ones); ends with a barrier
-template<int NT> __device__ __forceinline__ void lds_fft(double2* buf, const double2* tw, const LdsFft& f, int T) {
+template<int NT, int MAXR = PXS_COMP_MAXR> __device__ __forceinline__ void lds_fft(double2* buf, const double2* tw, const LdsFft& f, int T) {
+	static_assert(MAXR <= PXS_COMP_MAXR, "composite radix not compiled in");
 	for (int p = 0; p < f.nfac; p++) {
 		const PassDesc ps = f.pass[p];
 		switch (ps.R) {
@@ -160,26 +163,20 @@ template<int NT> __device__ __forceinline__ void lds_fft(double2* buf, const dou
 			case 3: radix_pass_t<3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 4: radix_pass_t<4, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 5: radix_pass_t<5, NT>(buf, tw, f.n, f.ns, T, ps); break;
-#if PXS_COMP_MAXR >= 6
-			case 6: radix_pass_comp<3, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
-#endif
-#if PXS_COMP_MAXR >= 8
-			case 8: radix_pass_comp<4, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
-#endif
-#if PXS_COMP_MAXR >= 9
-			case 9: radix_pass_comp<3, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
-#endif
+			case 6: if constexpr (MAXR >= 6) radix_pass_comp<3, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 8: if constexpr (MAXR >= 8) radix_pass_comp<4, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 9: if constexpr (MAXR >= 9) radix_pass_comp<3, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #if PXS_COMP_MAXR >= 10
-			case 10: radix_pass_comp<5, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 10: if constexpr (MAXR >= 10) radix_pass_comp<5, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #endif
 #if PXS_COMP_MAXR >= 12
-			case 12: radix_pass_comp<4, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 12: if constexpr (MAXR >= 12) radix_pass_comp<4, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #endif
 #if PXS_COMP_MAXR >= 15
-			case 15: radix_pass_comp<5, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 15: if constexpr (MAXR >= 15) radix_pass_comp<5, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #endif
 #if PXS_COMP_MAXR >= 16
-			case 16: radix_pass_comp<4, 4, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 16: if constexpr (MAXR >= 16) radix_pass_comp<4, 4, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #endif
 			default: break;
 		}

@@ -61,7 +61,14 @@ __device__ __forceinline__ void wr_real(void* p, int dtype, long off, double v) 
 // one.  The prefetch registers pushed the single-transform stages to 151-169 VGPRs and the two-transform stages to 256 (172 with
 // 512-thread workgroups), and config 3 got slower: ring FFT 58 -> 67 ms, theta resampling 71 -> 129 ms (102 ms with 512 threads).
 // One tile per workgroup, many workgroups per CU in different phases, stays.)
-template<class S, int NT, int MAXE> __global__ __launch_bounds__(NT) void chain_kernel(const S s)
+// S::MINW = 8 asks the compiler for <= 64 VGPRs (8 waves per SIMD = four 512-thread workgroups per CU where the LDS allows):
+// the ring stages, whose passes use radices up to 8 (S::MAXR), gain 6-12 % from it; with radix 9 compiled in the same bound spills.
+#ifndef PXS_HOST_SIM
+#define PXS_CH_BOUNDS __launch_bounds__(NT, S::MINW)
+#else
+#define PXS_CH_BOUNDS
+#endif
+template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(const S s)
 {
 	PXS_SHARED(double2, lds);
 	const int na = s.fa.n, nb = s.fb.n;
@@ -92,7 +99,7 @@ template<class S, int NT, int MAXE> __global__ __launch_bounds__(NT) void chain_
 		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
 	}
 	PXS_LDS_BARRIER();
-	lds_fft<NT>(buf, twa, s.fa, T);
+	lds_fft<NT, S::MAXR>(buf, twa, s.fa, T);
 	if (S::TWO) {	// ---- second transform on the same lines: pull its inputs out of the first one's output (lines fastest across lanes)
 		const int total = T*nb;
 		double2 v[MAXE]; int pos[MAXE];
@@ -110,7 +117,7 @@ template<class S, int NT, int MAXE> __global__ __launch_bounds__(NT) void chain_
 #pragma unroll
 		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
 		PXS_LDS_BARRIER();
-		lds_fft<NT>(buf, twb, s.fb, T);
+		lds_fft<NT, S::MAXR>(buf, twb, s.fb, T);
 	}
 	{	// ---- store
 		const int total = T*nlast;
@@ -149,6 +156,7 @@ struct PairSrc {
 // pass 1 of the first transform of a chain: circle index j = b*j1 + j2, line = j2, a-point FFT over j1, four-step twiddle
 struct StFirst : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
+	static constexpr int MAXR = 9, MINW = 1;
 	PairSrc src; int b; double2* Y; long ldY;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0); return true; }
@@ -167,6 +175,7 @@ struct StFirst : StageBase {
 // optional phase table ph[|kappa|], conjugated for kappa < 0.
 struct StResize : StageBase {
 	static constexpr bool TWO = true, INV_A = false, INV_B = true, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
+	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; double2* Z; long ldZ;
 	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
@@ -196,6 +205,7 @@ struct StResize : StageBase {
 // in: Z[outer][k1' < g2][r < g]; out: V[outer][k1'' < g][k1' < g2]
 struct StSigma : StageBase {
 	static constexpr bool TWO = true, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
+	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Z; long ldZ; double2* V; long ldV; int g, g2; const double2* sigma;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g2 - c.t0); return true; }
@@ -218,6 +228,7 @@ struct StSigma : StageBase {
 //         out = h[t*ld + col] * conj(tab[col]) * scale                      (synthesis: ring-major rows for the ring FFT)
 template<int MODE> struct StSplit : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	static constexpr int MAXR = 9, MINW = 1;
 	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
 	double2* out; long ld; const double2* w; const double2* tab; double scale; int TH; FastDiv da;
 	__device__ __forceinline__ int mirror_line(int k) const { int m = a - k - mir_c; if (m >= a) m -= a; if (m < 0) m += a; return m; }
@@ -285,6 +296,7 @@ struct MapAddr { void* ptr; int dtype; long cstride, bstride, off0, rstride, pst
 // MA1: two real rings as one complex line z = ring(2q) + i ring(2q+1); pixel x = b*j1 + j2, line = j2, a-point FFT over j1
 struct StRingA1 : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
+	static constexpr int MAXR = 8, MINW = 8;
 	MapAddr m; int b, npair; double2* Y; long ldY; FastDiv dnp;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
@@ -307,6 +319,7 @@ struct StRingA1 : StageBase {
 // partner bin nphi - k (in the mirror line) into the spectra of the two rings and written as leg[m][2q], leg[m][2q+1]
 struct StRingA2 : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, X, npair, groups, nring, mmax; double2* leg; long ldleg; int nm; const double2* tab; double scale; FastDiv da, dgr;
 	__device__ __forceinline__ int mirror_line(int k) const { return k == 0 ? 0 : a - k; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
@@ -351,6 +364,7 @@ struct StRingA2 : StageBase {
 // MS1: Hermitian pair load from h[comp][ring][m]: bin k = b*j1 + j2, line = j2, backward a-point transform over j1
 struct StRingS1 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
+	static constexpr int MAXR = 8, MINW = 8;
 	const double2* h; long ldh; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
@@ -377,6 +391,7 @@ struct StRingS1 : StageBase {
 // MS2: backward b-point transform over j2 for the lines k1; pixel x = k1 + a*k2: real part -> ring 2q, imaginary part -> ring 2q+1
 struct StRingS2 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, npair; MapAddr m; FastDiv dnp;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, a - c.t0);
@@ -402,10 +417,10 @@ struct StRingS2 : StageBase {
 static bool smooth235(long n) { if (n < 1) return false; for (int p : {2, 3, 5}) while (n % p == 0) n /= p; return n == 1; }
 bool FftChain::sub_ok(long n) { return n >= 2 && n <= CH_NMAX && smooth235(n); }
 
-static LdsFft mk(FftContext* fc, long n) {
+static LdsFft mk(FftContext* fc, long n, int maxr = 9) {
 	LdsFft f; memset(&f, 0, sizeof(f));
 	if (n <= 0) return f;
-	auto v = fc->view(n);
+	auto v = fc->view(n, maxr);
 	static const int nofft = [] { const char* e = getenv("PXS_CH_NOFFT"); return e ? atoi(e) : 0; }();     // timing experiments only (wrong results)
 	f.n = v.n; f.nfac = nofft ? 0 : v.nfac; f.ns = v.ns; f.generic = v.generic; f.pass = (const PassDesc*)v.pass; f.perm = v.perm; f.tw = v.tw; f.dn = make_fastdiv((uint32_t)n);
 	return f;
@@ -430,13 +445,19 @@ const double2* FftChain::small_tw(long X, int n, int T) {
 }
 
 // lines per tile: as many as fit CH_TILE_PTS, in multiples of `mult`
-static int tile_lines(long n_a, long n_b, long nlines, int mult) {
+// tab_pts >= 0 (ring stages, which run at <= 64 VGPRs) and PXS_RING_TILE_KB = k > 0: shrink the tile until tile + tab_pts table
+// entries fit k KiB of LDS (k = 39.5: four workgroups per CU).  Off by default -- measured at C3 / C4 / C2: ring FFT stages
+// 47.4 / 60.6 / 2.85 ms with 39.5 KiB tiles against 46.4 / 60.8 / 2.83 ms with the full 2560-point tiles.
+static int tile_lines(long n_a, long n_b, long nlines, int mult, long tab_pts = -1) {
 	const long n = std::max(n_a, n_b);
 	long T = CH_TILE_PTS / n;
 	if (T >= mult) T -= T % mult;
 	if (T < 1) T = 1;
 	const long cap = ((nlines + mult - 1)/mult)*mult;
 	if (T > cap) T = cap;
+	static const long limit = [] { const char* e = getenv("PXS_RING_TILE_KB"); return e ? (long)(atof(e)*1024) : 0L; }();
+	if (tab_pts >= 0 && limit > 0)
+		while (T > mult && (long)sizeof(double2)*(tab_pts + T*(n | 1) + 2) > limit) T -= mult;
 	return (int)T;
 }
 // tiles of T consecutive lines; X > 0: the stage applies the four-step twiddle of a length-X transform to its output
@@ -525,14 +546,14 @@ void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, doubl
 	const long npair = (m.nring + 1)/2, a = ra_.a, b = ra_.b, ldY = pad8(b);
 	s1_.ensure(sizeof(double2)*(size_t)nc*npair*a*ldY);
 	{	StRingA1 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
+		s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
 		s.m = map_addr(m); s.b = (int)b; s.npair = (int)npair; s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
-		set_tiles(s, tile_lines(a, 0, b, 16), b, nphi_);
+		set_tiles(s, tile_lines(a, 0, b, 16, 2*a), b, nphi_);
 		launch_stage(s, (long)nc*npair*s.ntile, st);
 	}
 	{	StRingA2 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
-		int T = tile_lines(b, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
+		s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
+		int T = tile_lines(b, 0, 2*npair, 8, b); if (T < 2) T = 2; T -= T % 2;
 		set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
 		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.X = (int)nphi_; s.npair = (int)npair; s.nring = m.nring; s.mmax = mmax;
 		s.groups = (int)((npair + T/2 - 1)/(T/2)); s.da = make_fastdiv((uint32_t)a); s.dgr = make_fastdiv((uint32_t)s.groups);
@@ -547,16 +568,16 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 	const long npair = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
 	s1_.ensure(sizeof(double2)*(size_t)nc*npair*a*ldY);
 	{	StRingS1 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
+		s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
 		s.h = h; s.ldh = ldh; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = m.nring; s.mmax = mmax; s.Y = s1_.as<double2>(); s.ldY = ldY;
 		s.dnp = make_fastdiv((uint32_t)npair);
-		set_tiles(s, tile_lines(a, 0, b, 8), b, nphi_);
+		set_tiles(s, tile_lines(a, 0, b, 8, 2*a), b, nphi_);
 		launch_stage(s, (long)nc*npair*s.ntile, st);
 	}
 	{	StRingS2 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
+		s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
 		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.npair = (int)npair; s.m = map_addr(m); s.dnp = make_fastdiv((uint32_t)npair);
-		set_tiles(s, tile_lines(b, 0, a, 16), a, 0);
+		set_tiles(s, tile_lines(b, 0, a, 16, b), a, 0);
 		launch_stage(s, (long)nc*npair*s.ntile, st);
 	}
 	PXS_HIP(hipGetLastError());
