@@ -70,6 +70,9 @@ struct LegK {
 	int nmc, xcd;                       // m count of this launch; XCD-aware block order on/off
 	int* first;                         // analysis: see LegWork::first
 	int atomic;                         // analysis: waves add their sums into mom (part = mom) instead of writing per-wave partial moments
+	// recurrence seeds: the state of every chain at the end of phase A, per (m, wave): [nd][K][64] doubles, [ni][K][64] + 64 ints
+	// (the first of the last 64: the step reached).  mode 0: off, 1: run phase A and record, 2: load instead of running it
+	int seed_mode; double* seed_d; int* seed_i;
 };
 
 // Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
@@ -254,6 +257,50 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 // (An L2 prefetch of the coefficient streams via global_load_lds into an LDS sink was tried to hide SMEM
 // miss latency and measured SLOWER on MI355X: leg_syn 10.8 -> 12.4 ms at config 2; removed.)
 
+#ifdef PXS_HOST_SIM
+#define PXS_UNIFORM_INT(x) (x)
+#define PXS_UNIFORM_LONG(x) (x)
+#else
+#define PXS_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+// (a wave-uniform table offset that the compiler keeps in VGPRs turns every coefficient row load of the loops below into a per-lane
+// global_load: seen when the seed stores entered the kernels -- leg_syn 101 -> 123 ms at config 3)
+#define PXS_UNIFORM_LONG(x) ((long)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long)(x) >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long)(x))))
+#endif
+// Recurrence seeds.  Phase A (recurrence only, no accumulation, until the first lane of the wave reaches scale 0) is the same
+// for every transform on a plan: ~18 % of the steps of a live (wave, m) at a third of the cost of an accumulating step, i.e.
+// ~5 % of the Legendre time, plus the sin^m start values.  The first launch on a ring set records the state it ends in, later
+// launches load it: K x 20 bytes (spin 0) or K x 40 bytes (spin s) per lane.
+#define S0_SEEDED_PHASE_A \
+	if (a.seed_mode == 2) { \
+		const double* sd = a.seed_d + ((long)m*a.nwave + wv)*(2*K*64); const int* si = a.seed_i + ((long)m*a.nwave + wv)*((K+1)*64); \
+		k = PXS_UNIFORM_INT(si[K*64]); \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { lam1[s] = sd[s*64 + lane]; lam2[s] = sd[(K+s)*64 + lane]; sc[s] = si[s*64 + lane]; } \
+	} else { \
+		S0_PHASE_A \
+		if (a.seed_mode == 1) { \
+			double* sd = a.seed_d + ((long)m*a.nwave + wv)*(2*K*64); int* si = a.seed_i + ((long)m*a.nwave + wv)*((K+1)*64); \
+			_Pragma("unroll") for (int s = 0; s < K; s++) { sd[s*64 + lane] = lam1[s]; sd[(K+s)*64 + lane] = lam2[s]; si[s*64 + lane] = sc[s]; } \
+			if (lane == 0) si[K*64] = k; \
+		} \
+	}
+#define SPIN_SEEDED_PHASE_A \
+	if (a.seed_mode == 2) { \
+		const double* sd = a.seed_d + ((long)m*a.nwave + wv)*(4*K*64); const int* si = a.seed_i + ((long)m*a.nwave + wv)*((2*K+1)*64); \
+		j = PXS_UNIFORM_INT(si[2*K*64]); \
+		_Pragma("unroll") for (int s = 0; s < K; s++) { \
+			S.gp1[s] = sd[s*64 + lane]; S.gp2[s] = sd[(K+s)*64 + lane]; S.gm1[s] = sd[(2*K+s)*64 + lane]; S.gm2[s] = sd[(3*K+s)*64 + lane]; \
+			S.scp[s] = si[s*64 + lane]; S.scm[s] = si[(K+s)*64 + lane]; } \
+	} else { \
+		SPIN_PHASE_A \
+		if (a.seed_mode == 1) { \
+			double* sd = a.seed_d + ((long)m*a.nwave + wv)*(4*K*64); int* si = a.seed_i + ((long)m*a.nwave + wv)*((2*K+1)*64); \
+			_Pragma("unroll") for (int s = 0; s < K; s++) { \
+				sd[s*64 + lane] = S.gp1[s]; sd[(K+s)*64 + lane] = S.gp2[s]; sd[(2*K+s)*64 + lane] = S.gm1[s]; sd[(3*K+s)*64 + lane] = S.gm2[s]; \
+				si[s*64 + lane] = S.scp[s]; si[(K+s)*64 + lane] = S.scm[s]; } \
+			if (lane == 0) si[2*K*64] = j; \
+		} \
+	}
+
 // Phase A of the spin-0 kernels: no lane of the wave has reached scale 0 yet, so nothing is
 // accumulated.  Four recurrence steps per iteration with the four coefficient rows fetched together;
 // the rescale / activity test runs once per 4 steps (a chain grows by < 2^60 in 4 steps, far from
@@ -299,7 +346,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 {
 	const int lane = threadIdx.x; int wv, m;
 	if (!leg_block(a, wv, m)) return;
-	const long row0 = a.row[m];
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
 	const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
@@ -317,14 +364,15 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 		csq[s] = polar ? -sth*sth : x[s]*x[s];
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
-		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
+		if (alive && a.seed_mode != 2) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
 		p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0;
 		alive_any |= alive;
 	}
 	int k = 0;
 	if (__any(alive_any)) {
 		// phase A: nobody at scale 0 yet -> recurrence only, 4 steps per check (S0_PHASE_A)
-		S0_PHASE_A
+		S0_SEEDED_PHASE_A
+		k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
 		// phase B: some lanes are still below scale 0.  The steps are the plain fast steps (no per-lane gating); every
 		// 4 steps the lanes below scale 0 are rescaled.  Such a lane accumulates scaled-up garbage meanwhile; its sums are
 		// reset when it reaches scale 0 (its true terms before that are < 2^-340 of the final value).
@@ -498,7 +546,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	PXS_SHARED(double, red);
 	const int lane = threadIdx.x; int wv, m;
 	if (!leg_block(a, wv, m)) return;
-	const long row0 = a.row[m];
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
 	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
@@ -527,14 +575,15 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 		csq[s] = polar ? -sth*sth : x*x;
 		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
 		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
-		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
+		if (alive && a.seed_mode != 2) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
 		// a lane below scale 0 keeps zero data until it gets there, so that it can run the ungated steps
 		d1r[s] = d1i[s] = d2r[s] = d2i[s] = 0;
 		alive_any |= alive;
 	}
 	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
 	int k = 0;
-	S0_PHASE_A
+	S0_SEEDED_PHASE_A
+	k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
 	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = k + 1;      // rows before k are not written (reduce_partials skips them)
 	// ring data of the lanes that start at scale 0 or reached it during phase A (rings without signal have lam = 0)
 #pragma unroll
@@ -605,7 +654,7 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 		const double mlim = discr <= 0 ? a.lmax : fmin((double)a.lmax, 0.5*(-b + sqrt(discr)));
 		const bool alive = valid && ((double)m <= mlim + 0.5);
 		S.gp1[s] = S.gm1[s] = 0; S.gp2[s] = S.gm2[s] = 0; S.scp[s] = S.scm[s] = 0;
-		if (alive) {
+		if (alive && a.seed_mode != 2) {
 			const double sh = shh, ch = a.ch2[p];
 			double m1, m2; int e1, e2;
 			if (m >= s_) {
@@ -694,11 +743,12 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
 	double sg0 = 1.0;
 	if (nl > 0 && __any(alive_any)) {
-		const long row0 = a.row[m];
+		const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 		const double4_t* __restrict__ coef = a.coef + row0;
 		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
 		int j = 0;
-		SPIN_PHASE_A
+		SPIN_SEEDED_PHASE_A
+		j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
 		sg0 = ((l0 + j + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m) of the first accumulated step; pairs of steps keep the parity
 		// phase B: plain fast steps; every 4 steps the chains below scale 0 are rescaled.  A lane's sums hold scaled-up
 		// garbage until both of its chains are at scale 0, when they are reset (true terms before that: < 2^-340 of the result)
@@ -802,7 +852,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	if (nl <= 0) return;
-	const long row0 = a.row[m];
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const double4_t* __restrict__ coef = a.coef + row0;
 	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
 	const double2* __restrict__ inq = a.leg + (long)m*a.ld;
@@ -828,7 +878,8 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 #pragma unroll
 	for (int s = 0; s < K; s++) tpnr[s] = tpni[s] = tmnr[s] = tmni[s] = tpsr[s] = tpsi[s] = tmsr[s] = tmsi[s] = 0;
 	int j = 0;
-	SPIN_PHASE_A
+	SPIN_SEEDED_PHASE_A
+	j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
 	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = j + 1;      // rows before j are not written (reduce_partials skips them)
 	// ring data of the lanes whose chains start at scale 0 or both reached it during phase A
 #pragma unroll
@@ -1016,6 +1067,30 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	return a;
 }
 
+// seeds of (ring set, spin, direction, K): allocate on first use if the plan's budget allows; returns the mode for this launch
+static LegWork::Seeds* seeds_for(LegWork& wk, const RingSet& rs, const LegTables& tb, int dir, int K, LegK& a) {
+	a.seed_mode = 0; a.seed_d = nullptr; a.seed_i = nullptr;
+	{ const char* e = getenv("PXS_SEED_GB"); if (e) wk.seed_budget = (size_t)atol(e) << 30; }
+	if (wk.seed_budget == 0) return nullptr;
+	// loading a seed costs 20 / 40 bytes per lane and m, running phase A ~0.09 lmax recurrence steps: measured on MI355X the seeds
+	// win at lmax 10^4 (C3 341.8 -> 327.6 ms per round trip) and for spin 2 at lmax 4000 (C2 28.7 -> 28.0 ms), and lose for spin 0
+	// at lmax 4000 (C4: leg_syn 109.1 -> 113.9 ms per 64 maps)
+	{	const char* e = getenv("PXS_SEED_MIN_LMAX");
+		const int lmin = e ? atoi(e) : (tb.spin == 0 ? 6000 : 3000);
+		if (tb.lmax < lmin) return nullptr; }
+	LegWork::Seeds& sb = wk.seeds[std::make_tuple((const void*)&rs, tb.spin, dir, K)];
+	if (sb.refused) return nullptr;
+	const int nd = tb.spin == 0 ? 2 : 4, ni = tb.spin == 0 ? 1 : 2;
+	const size_t slots = (size_t)a.nm*a.nwave;
+	if (!sb.d.p) {
+		const size_t bd = sizeof(double)*slots*nd*K*64, bi = sizeof(int)*slots*(ni*K + 1)*64;
+		if (wk.seed_bytes + bd + bi > wk.seed_budget) { sb.refused = true; return nullptr; }
+		sb.d.alloc(bd); sb.i.alloc(bi); wk.seed_bytes += bd + bi;
+	}
+	a.seed_d = sb.d.as<double>(); a.seed_i = sb.i.as<int>(); a.seed_mode = sb.ready ? 2 : 1;
+	return &sb;
+}
+
 static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dtype, long cstride, const uint64_t* d_mstart, long lstride, int deriv1) {
 	AlmK k; memset(&k, 0, sizeof(k));
 	k.lmax = tb.lmax; k.mmax = tb.mmax; k.spin = tb.spin; k.deriv1 = deriv1; k.dtype = dtype;
@@ -1037,20 +1112,24 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
 		const int K = k_syn0();
 		LegK a = make_legk(rs, tb, wk, leg, ld, K);
+		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a);
 		if (prof) prof->begin(st, 0);
 		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
 		else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
+		if (sb) sb->ready = true;
 	} else {
 		const int nlmax = tb.lmax + 1;
 		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
 		const int K = k_syns();
 		LegK a = make_legk(rs, tb, wk, leg, ld, K);
+		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a);
 		if (prof) prof->begin(st, 0);
 		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
 		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
 		else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
+		if (sb) sb->ready = true;
 	}
 	PXS_HIP(hipGetLastError());
 }
@@ -1093,12 +1172,14 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		wk.first.ensure(sizeof(int)*(size_t)nwave*maxm);
 	}
 	const size_t sh = sizeof(double)*LEG_RED_DOUBLES;
+	LegWork::Seeds* seeds = nullptr;
 	for (size_t c = 0; c+1 < cuts.size(); c++) {
 		const int m0 = cuts[c], m1 = cuts[c+1];
 		const long rows = tb.row[m1]-tb.row[m0];
 		if (rows <= 0) continue;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K);
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0; a.atomic = atomic ? 1 : 0;
+		seeds = seeds_for(wk, rs, tb, 1, K, a);
 		if (atomic) { a.part = (double*)wk.mom.p; a.rowbase = 0; a.rows_chunk = 0; a.first = nullptr; }
 		else {
 			PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));
@@ -1123,6 +1204,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*maxrow+255)/256), m1-m0), dim3(256), 0, st, (const double*)wk.part.p,
 			(double*)wk.mom.p, tb.d_row.as<long>(), (const int*)wk.first.p, m0, m1-m0, tb.row[m0], rows, a.nwave);
 	}
+	if (seeds) seeds->ready = true;
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm), dim3(256), 0, st, ak);

@@ -212,6 +212,40 @@ def test_general_path_equals_uniform_hostsim(monkeypatch):
 	try: check_rings()
 	finally: sht.clear_plans()
 
+def check_seeds(lmax, nt, nph):
+	"""recurrence seeds (legendre.hip): the first transform of a kind on a plan records the state of the recurrences where their
+	accumulation starts, later ones load it -- results must not change by a bit, and must equal those of a plan without seeds"""
+	import os
+	ms = so._tri_mstart(lmax, lmax); rng = np.random.default_rng(9)
+	for spin, nc in ((0, 1), (2, 2)):
+		alm = so.rand_alm_simple(lmax, nc, 3, spin=(spin,)); pix = rng.standard_normal((nc, nt, nph))
+		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry="F1", phi0=0.2)
+		def run():
+			out = []
+			for rep in range(3):
+				m = np.zeros((nc, nt, nph)); sht.synthesis_2d(alm=alm, map=m, **kw)
+				a = np.zeros_like(alm); sht.analysis_2d(alm=a, map=pix, **kw)
+				b = np.zeros_like(alm); sht.adjoint_synthesis_2d(alm=b, map=pix, **kw)
+				out.append((m, a, b))
+			return out
+		sht.clear_plans(); res = run()
+		for r in res[1:]:
+			for x, y in zip(res[0], r): assert np.array_equal(x, y)
+		os.environ["PXS_SEED_GB"] = "0"; sht.clear_plans()
+		try: ref = run()
+		finally: del os.environ["PXS_SEED_GB"]; sht.clear_plans()
+		for x, y in zip(res[0], ref[0]): assert np.array_equal(x, y)
+
+@pytest.mark.hostsim
+def test_seeds_hostsim(monkeypatch):
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0")
+	check_seeds(90, 96, 190)
+@pytest.mark.gpu
+def test_seeds_gpu(monkeypatch):
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1")           # (bitwise comparison of the analysis needs the ordered accumulation)
+	monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0")
+	check_seeds(1500, 1600, 3100)
+
 def check_deep_scaling(lmax=260):
 	"""rings so close to the poles (1e-5 rad: sin^100 = 2^-1660) that sin^m(theta) needs two and three 2^-800 scale steps, next to equatorial rings in
 	the same wave: lanes reach scale 0 at very different l (the ungated phase-B steps, data fetch / sum reset on arrival)"""
