@@ -286,6 +286,7 @@ def main():
 		roofline=roof, fft_chain=chain,
 		stage_ms_per_step={k: round(v[0]/args.steps, 3) for k, v in prof.items()},
 		stage_note="stages run back to back on one stream (hipEvent-bracketed inside the library)",
+		plan_state="data-independent tables built with the plan or by its first transform (untimed warm-up): recurrence coefficients, twiddles, CC quadrature, and the recurrence seeds of DESIGN.md section 4; every timed step runs the full transform on the resident map",
 		hbm_algorithmic_GBps=round(hbm_gbs, 1), hbm_frac_of_8TBps=round(hbm_gbs/HBM_PEAK_GBS, 5),
 		roundtrip_rms_error=rt_err, ducc0=probe_ducc0())
 	if ranks_seen is not None: res["rccl_ranks_seen"] = ranks_seen; res["collective"] = gather.describe()
