@@ -336,7 +336,7 @@ struct pxs_plan {
 		if (gfork) (void)hipEventDestroy(gfork);
 	}
 	DevBuf wring;                // DH / F2 grids: per-ring quadrature weight / nphi (analysis = weighted adjoint synthesis)
-	bool syn_via_cc = false;
+	bool syn_via_cc = false, syn_via_cc0 = false;      // synthesis through the CC grid: spin s / spin 0 (the recurrence of spin 0 is 4x cheaper per ring, the resampling is not)
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
 	// fused FFT chains (fftchain.hip).  chain_rings: ring FFTs through MA1/MA2, MS1/MS2; tp.ok: theta resampling through RA1-5 / RS1-3.
@@ -425,7 +425,9 @@ void setup_resampling(pxs_plan* p) {
 	p->ph_shift = upload(ps);
 	{ std::vector<double2> pu(ps.size()); for (size_t k = 0; k < ps.size(); k++) pu[k] = make_double2(ps[k].x, -ps[k].y); p->ph_up = upload(pu); }
 	// synthesis: Legendre on the minimal CC grid + exact Fourier upsampling in theta pays once the map has clearly more rings
-	{ const char* e = getenv("PXS_SYN_VIA_CC"); p->syn_via_cc = e ? atoi(e) != 0 : (p->nring > p->ncc + p->ncc/4); }
+	// (measured: at nring / ncc = 1.33 -- C2, C4 -- the detour pays for spin 2 and costs 11 ms per 64 scalar maps at C4)
+	{ const char* e = getenv("PXS_SYN_VIA_CC"); p->syn_via_cc = e ? atoi(e) != 0 : (p->nring > p->ncc + p->ncc/4);
+	  p->syn_via_cc0 = e ? atoi(e) != 0 : (p->nring > p->ncc + p->ncc/2); }
 	// sigma_i = sum_{|q|<=Ks} s_q e^{i q theta_i} on the M grid, via one device FFT
 	const long Ks = lmax + p->N/2;
 	PXS_REQUIRE(2*Ks < p->M, "internal: fine grid too small");
@@ -881,7 +883,7 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 	(void)nca;
 	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
 	if (!adjoint) {
-		if (p->is_grid && p->syn_via_cc && p->ncc > 0) {
+		if (p->is_grid && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0) {
 			const long ldc = p->ld_cc();
 			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
 			for (int b = 0; b < nb; b++)
