@@ -17,6 +17,19 @@ template<int NCH> __global__ __launch_bounds__(64) void fma_kernel(double* out, 
 	double s = 0; for (int i = 0; i < NCH; i++) s += acc[i];
 	out[blockIdx.x*64 + threadIdx.x] = s;
 }
+// the same with three per-lane operands, as in the analysis accumulation t = fma(lambda, data, t)
+template<int NCH> __global__ __launch_bounds__(64) void fma3_kernel(double* out, const double* coef, int iters) {
+	double acc[NCH], x[NCH], y[NCH];
+	for (int i = 0; i < NCH; i++) { acc[i] = threadIdx.x*1e-3 + i; x[i] = 1.0 - 1e-9*(threadIdx.x + i); y[i] = 1.0 + 1e-9*(threadIdx.x - i) + coef[0]*1e-12; }
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+#pragma unroll
+			for (int i = 0; i < NCH; i++) acc[i] = fma(x[i], y[(i + u) % NCH], acc[i]);
+	}
+	double s = 0; for (int i = 0; i < NCH; i++) s += acc[i];
+	out[blockIdx.x*64 + threadIdx.x] = s;
+}
 int main() {
 	const int nblk = 256*4*8, iters = 20000; constexpr int NCH = 16;
 	double *out, *coef; hipMalloc(&out, sizeof(double)*nblk*64); hipMalloc(&coef, 16);
@@ -27,6 +40,12 @@ int main() {
 		float ms; hipEventElapsedTime(&ms, e0, e1);
 		const double flops = 2.0*nblk*64.0*NCH*8.0*iters;
 		printf("rep %d: %.2f ms, %.1f TFLOP/s FP64 FMA (%.0f%% of 78.6)\n", rep, ms, flops/ms*1e-9, flops/ms*1e-9/78.6*100);
+	}
+	for (int rep = 0; rep < 4; rep++) {
+		hipEventRecord(e0); hipLaunchKernelGGL(fma3_kernel<NCH>, dim3(nblk), dim3(64), 0, 0, out, coef, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+		float ms; hipEventElapsedTime(&ms, e0, e1);
+		const double flops = 2.0*nblk*64.0*NCH*8.0*iters;
+		printf("3 VGPR operands, rep %d: %.2f ms, %.1f TFLOP/s (%.0f%% of 78.6)\n", rep, ms, flops/ms*1e-9, flops/ms*1e-9/78.6*100);
 	}
 	return 0;
 }
