@@ -512,7 +512,8 @@ static long smooth_at_least(long n, bool even_product_with = false, long g = 1) 
 
 ThetaPlan FftChain::plan_theta(long N, int lmax) {
 	ThetaPlan best; double bestc = 1e300;
-	for (long g = 2; g <= 1024 && g <= N/2; g++) if (N % g == 0 && sub_ok(g) && sub_ok(N/g)) {
+	static const long gforce = [] { const char* e = getenv("PXS_THETA_G"); return e ? atol(e) : 0L; }();     // experiments: force the shared modulus
+	for (long g = 2; g <= 1024 && g <= N/2; g++) if (N % g == 0 && sub_ok(g) && sub_ok(N/g) && (!gforce || g == gforce)) {
 		ThetaPlan t; t.N = N; t.g = g; t.bN = N/g;
 		t.g2 = smooth_at_least((N + 2L*lmax + 2 + g - 1)/g); t.M = g*t.g2;
 		t.ac = smooth_at_least((2L*lmax + 2 + g - 1)/g, true, g); t.Ncc = g*t.ac;
