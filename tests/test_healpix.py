@@ -117,10 +117,12 @@ def test_healpix_gpu(golden_dir):
 	healpix_body(golden_dir, to_dev=lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda(), to_host=lambda x: x.cpu().numpy())
 
 @pytest.mark.gpu
-def test_healpix_large_gpu():
-	"""nside 256 (786 432 pixels, 1023 rings of 256 different lengths, lengths with prime factors up to 251), lmax 512: adjointness
-	<Y a, p> = <a, Y^T p> to rounding and convergence of the Jacobi iteration on a band-limited map"""
-	nside, lmax = 256, 512; npix = 12*nside**2
+@pytest.mark.parametrize("nside,lmax", [(256, 512), (1024, 700)])
+def test_healpix_large_gpu(nside, lmax):
+	"""nside 256 (786 432 pixels, 1023 rings of 256 different lengths, lengths with prime factors up to 251 -> Bluestein), lmax 512,
+	and nside 1024 (ring lengths up to 4096: two-pass transforms): adjointness <Y a, p> = <a, Y^T p> to rounding and convergence of
+	the Jacobi iteration on a band-limited map"""
+	npix = 12*nside**2
 	from oracle import sht_oracle as so
 	rng = np.random.default_rng(3)
 	alm = so.rand_alm_simple(lmax, 3, 2, spin=(0, 2))
