@@ -778,11 +778,30 @@ int pxs_gridweights(const char* geometry, int ntheta, double* out) {
 	const LDb th0 = (LDb)gi.c*PIl/N;
 	std::vector<LDb> v(N);
 	const long K = (N-1)/2;
-	for (long j = 0; j < N; j++) {
-		LDb th = th0 + 2*PIl*j/N, s = (LDb)abs_sin_coef(0);
-		for (long k = 2; k <= K; k += 2) s += 2*(-(2/PIl)/((LDb)k*k-1))*cosl(k*th);
-		if (N % 2 == 0 && ((N/2) % 2) == 0) s += (-(2/PIl)/((LDb)(N/2)*(N/2)-1))*cosl((N/2)*(th-th0))*cosl((N/2)*th0);
-		v[j] = s*PIl/N;
+	if (N <= 4096) {
+		for (long j = 0; j < N; j++) {
+			LDb th = th0 + 2*PIl*j/N, s = (LDb)abs_sin_coef(0);
+			for (long k = 2; k <= K; k += 2) s += 2*(-(2/PIl)/((LDb)k*k-1))*cosl(k*th);
+			if (N % 2 == 0 && ((N/2) % 2) == 0) s += (-(2/PIl)/((LDb)(N/2)*(N/2)-1))*cosl((N/2)*(th-th0))*cosl((N/2)*th0);
+			v[j] = s*PIl/N;
+		}
+	} else {
+		// the same cosine series as one backward DFT of length N on the device (the direct sum is N^2/4 long-double cosines:
+		// 60 s for the 21600-ring grid, paid by every map2alm of a declination band through quad_weights)
+		std::vector<double2> c(N, make_double2(0, 0));
+		c[0].x = (double)abs_sin_coef(0);
+		for (long k = 2; k <= K; k += 2) {
+			const LDb sk = -(2/PIl)/((LDb)k*k-1), a = (LDb)k*th0;
+			c[k] = make_double2((double)(sk*cosl(a)), (double)(sk*sinl(a)));
+			c[N-k] = make_double2(c[k].x, -c[k].y);
+		}
+		if (N % 2 == 0 && ((N/2) % 2) == 0) c[N/2] = make_double2((double)((-(2/PIl)/((LDb)(N/2)*(N/2)-1))*cosl((N/2)*th0)), 0.0);
+		int dev = 0; PXS_HIP(hipGetDevice(&dev));
+		DevBuf dc = upload(c);
+		fft_dense_lines(dev, nullptr, N, false, 1, dc.as<double2>(), dc.as<double2>());
+		PXS_HIP(hipStreamSynchronize(nullptr));
+		PXS_HIP(hipMemcpy(c.data(), dc.p, sizeof(double2)*N, hipMemcpyDeviceToHost));
+		for (long j = 0; j < N; j++) v[j] = (LDb)c[j].x*PIl/N;
 	}
 	for (int j = 0; j < n; j++) out[j] = 0;
 	for (long jp = 0; jp < N; jp++) { long r = jp < n ? jp : ((-jp - gi.c) % N + N) % N; out[r] += (double)(v[jp]*2*PIl); }

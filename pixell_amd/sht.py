@@ -252,11 +252,18 @@ def adjoint_synthesis(*, map, theta, nphi, phi0, ringstart, lmax, mmax=None, mst
 	adjoint_synthesis.last_plan = plan
 	return alm
 
+_gridweights_cache = {}
 def get_gridweights(geometry, ntheta):
-	"""ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855); sum = 4 pi"""
-	out = np.zeros(int(ntheta), np.float64)
-	_lib.check(_lib.load().pxs_gridweights(geometry.encode(), int(ntheta), out.ctypes.data))
-	return out
+	"""ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855); sum = 4 pi.  The last few results are kept: quad_weights asks
+	for the same grid on every map2alm of a declination band"""
+	key = (str(geometry), int(ntheta))
+	out = _gridweights_cache.get(key)
+	if out is None:
+		out = np.zeros(int(ntheta), np.float64)
+		_lib.check(_lib.load().pxs_gridweights(geometry.encode(), int(ntheta), out.ctypes.data))
+		if len(_gridweights_cache) >= 8: _gridweights_cache.pop(next(iter(_gridweights_cache)))
+		_gridweights_cache[key] = out
+	return out.copy()
 
 def grid_maxlmax(geometry, ntheta):
 	return int(_lib.load().pxs_grid_maxlmax(geometry.encode(), int(ntheta)))

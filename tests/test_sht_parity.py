@@ -323,6 +323,17 @@ def test_rings_hostsim(): check_rings()
 @pytest.mark.gpu
 def test_rings_gpu(): check_rings()
 
+def check_gridweights_large(cases=(("F1", 2100), ("CC", 2161), ("MW", 2050))):
+	"""grids beyond 2048 rings take the DFT route of pxs_gridweights: same numbers as the direct series of the oracle, sum 4 pi"""
+	for geo, n in cases:
+		w = sht.get_gridweights(geo, n); ref = so.get_gridweights(geo, n)
+		assert abs(w.sum()-4*np.pi) < 1e-12 and np.max(np.abs(w-ref)) < 1e-15 and np.max(np.abs(w-ref)/ref) < 1e-9
+
+@pytest.mark.hostsim
+def test_gridweights_large_hostsim(): check_gridweights_large()
+@pytest.mark.gpu
+def test_gridweights_large_gpu(): check_gridweights_large(); check_gridweights_large((("F1", 5400), ("MWflip", 4000)))
+
 def check_gridweights():
 	for g in ["CC", "F1", "MW", "MWflip", "DH", "F2"]:
 		for n in [7, 12, 33, 100]:
