@@ -125,7 +125,7 @@ def lmul(ainfo, alm, lfun, out=None):
 	else:
 		torch = _torch()
 		dev_in = fa if tens else torch.from_numpy(fa if fa.flags.writeable else fa.copy()).cuda()
-		work = dev_in[torch.as_tensor(ia, device=dev_in.device)]          # gather = fresh contiguous copy
+		work = dev_in[torch.as_tensor(np.array(ia), device=dev_in.device)]          # gather = fresh contiguous copy (np.array: broadcast index views are read-only)
 		ptr = work.data_ptr()
 	for i in range(npre):
 		row = ptr + i*nalm*csz

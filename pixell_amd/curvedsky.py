@@ -661,25 +661,37 @@ def fill_gauss(arr, bsize=0x10000):
 	for i in range(0, arr.size, bsize):
 		arr[i:i+bsize] = np.random.standard_normal(min(bsize, arr.size-i))
 
-def _transpose_index(ainfo):
+def _transpose_index(ainfo, device=None):
 	"""Source and destination positions of alm_info.transpose_alm (cmisc_core.c:116-135): the k-th
-	element in storage order (m-major) moves to the k-th (l,m) pair in l-major order."""
+	element in storage order (m-major) moves to the k-th (l,m) pair in l-major order.  With `device` the index arrays are built
+	there with torch (50 M entries at lmax 10^4: 0.6 s with numpy on the host)."""
 	lmax, mmax = ainfo.lmax, ainfo.mmax
-	m_src = np.repeat(np.arange(mmax+1), lmax+1-np.arange(mmax+1))
-	first = np.concatenate([[0], np.cumsum(lmax+1-np.arange(mmax+1))[:-1]])
-	l_src = np.arange(len(m_src))-np.repeat(first, lmax+1-np.arange(mmax+1))+m_src
-	cnt = np.minimum(np.arange(lmax+1), mmax)+1
-	l_dst = np.repeat(np.arange(lmax+1), cnt)
-	firstl = np.concatenate([[0], np.cumsum(cnt)[:-1]])
-	m_dst = np.arange(len(l_dst))-np.repeat(firstl, cnt)
-	ms = ainfo.mstart.astype(np.int64)
+	if device is None:
+		arange, repeat, cumsum, cat, minimum = np.arange, np.repeat, np.cumsum, np.concatenate, np.minimum
+		ms = ainfo.mstart.astype(np.int64); zero = np.zeros(1, np.int64)
+	else:
+		torch = _torch()
+		arange = lambda n: torch.arange(n, device=device, dtype=torch.int64)
+		repeat, cumsum, cat = torch.repeat_interleave, (lambda x: torch.cumsum(x, 0)), torch.cat
+		minimum = lambda a, b: torch.clamp(a, max=b)
+		ms = torch.as_tensor(ainfo.mstart.astype(np.int64), device=device); zero = torch.zeros(1, device=device, dtype=torch.int64)
+	per_m = lmax+1-arange(mmax+1)                                   # number of l per m
+	m_src = repeat(arange(mmax+1), per_m)
+	l_src = arange(len(m_src))-repeat(cat([zero, cumsum(per_m)[:-1]]), per_m)+m_src
+	per_l = minimum(arange(lmax+1), mmax)+1                         # number of m per l
+	l_dst = repeat(arange(lmax+1), per_l)
+	m_dst = arange(len(l_dst))-repeat(cat([zero, cumsum(per_l)[:-1]]), per_l)
 	return ms[m_src]+l_src*ainfo.stride, ms[m_dst]+l_dst*ainfo.stride
 
 def transpose_alm(ainfo, alm, out=None):
 	"""alm_info.transpose_alm (curvedsky.py:443-451): reorder numbers generated in l-major order into
 	the m-major layout.  alm is out is allowed."""
-	src, dst = _transpose_index(ainfo)
-	if out is None: out = alm.copy()
+	if _is_tensor(alm):
+		src, dst = _transpose_index(ainfo, alm.device)
+		if out is None: out = alm.clone()
+	else:
+		src, dst = _transpose_index(ainfo)
+		if out is None: out = alm.copy()
 	vals = alm[..., src]
 	out[..., dst] = vals
 	return out
@@ -692,7 +704,13 @@ def rand_alm_white(ainfo, pre=None, alm=None, seed=None, dtype=np.complex128, m_
 	if seed is not None: np.random.seed(seed)
 	if alm is None: alm = np.empty((tuple(pre) if pre is not None else ())+(ainfo.nelem,), dtype)
 	fill_gauss(alm)
-	return ainfo.transpose_alm(alm, alm) if m_major else alm
+	if not m_major: return alm
+	from . import _lib
+	if not _lib.is_hostsim() and alm.nbytes >= (1 << 24):     # large alm: the reordering as one gather on the GPU (0.6 s of host indexing at lmax 10^4)
+		torch = _torch()
+		alm[...] = ainfo.transpose_alm(torch.from_numpy(alm).cuda()).cpu().numpy()
+		return alm
+	return ainfo.transpose_alm(alm, alm)
 
 def rand_alm(ps, ainfo=None, lmax=None, seed=None, dtype=np.complex128, m_major=True, return_ainfo=False):
 	"""Gaussian alm with (cross) spectrum ps [nl], [nspec,nl] or [ncomp,ncomp,nl] (curvedsky.rand_alm, curvedsky.py:61-79):
