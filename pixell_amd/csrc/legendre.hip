@@ -1090,6 +1090,16 @@ static LegWork::Seeds* seeds_for(LegWork& wk, const RingSet& rs, const LegTables
 	a.seed_d = sb.d.as<double>(); a.seed_i = sb.i.as<int>(); a.seed_mode = sb.ready ? 2 : 1;
 	return &sb;
 }
+// after the recording launch: later launches on OTHER streams wait for it (a plan serves one call at a time, but the next call may
+// come on another stream)
+static void seeds_written(LegWork::Seeds* sb, hipStream_t st) {
+	if (!sb || sb->ready) return;
+	if (!sb->written) PXS_HIP(hipEventCreateWithFlags(&sb->written, hipEventDisableTiming));
+	PXS_HIP(hipEventRecord(sb->written, st)); sb->wstream = st; sb->ready = true;
+}
+static void seeds_wait(LegWork::Seeds* sb, hipStream_t st) {
+	if (sb && sb->ready && sb->written && st != sb->wstream) PXS_HIP(hipStreamWaitEvent(st, sb->written, 0));
+}
 
 static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dtype, long cstride, const uint64_t* d_mstart, long lstride, int deriv1) {
 	AlmK k; memset(&k, 0, sizeof(k));
@@ -1112,24 +1122,24 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
 		const int K = k_syn0();
 		LegK a = make_legk(rs, tb, wk, leg, ld, K);
-		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a);
+		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
 		if (prof) prof->begin(st, 0);
 		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
 		else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
-		if (sb) sb->ready = true;
+		seeds_written(sb, st);
 	} else {
 		const int nlmax = tb.lmax + 1;
 		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
 		const int K = k_syns();
 		LegK a = make_legk(rs, tb, wk, leg, ld, K);
-		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a);
+		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
 		if (prof) prof->begin(st, 0);
 		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
 		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
 		else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
 		if (prof) prof->end(st, 0);
-		if (sb) sb->ready = true;
+		seeds_written(sb, st);
 	}
 	PXS_HIP(hipGetLastError());
 }
@@ -1179,7 +1189,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		if (rows <= 0) continue;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K);
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0; a.atomic = atomic ? 1 : 0;
-		seeds = seeds_for(wk, rs, tb, 1, K, a);
+		seeds = seeds_for(wk, rs, tb, 1, K, a); seeds_wait(seeds, st);
 		if (atomic) { a.part = (double*)wk.mom.p; a.rowbase = 0; a.rows_chunk = 0; a.first = nullptr; }
 		else {
 			PXS_HIP(hipMemsetAsync(wk.first.p, 0, sizeof(int)*(size_t)nwave*(m1-m0), st));
@@ -1204,7 +1214,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((4*maxrow+255)/256), m1-m0), dim3(256), 0, st, (const double*)wk.part.p,
 			(double*)wk.mom.p, tb.d_row.as<long>(), (const int*)wk.first.p, m0, m1-m0, tb.row[m0], rows, a.nwave);
 	}
-	if (seeds) seeds->ready = true;
+	seeds_written(seeds, st);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm), dim3(256), 0, st, ak);

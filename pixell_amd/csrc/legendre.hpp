@@ -44,7 +44,8 @@ struct LegWork {     // scratch owned by the SHT plan
 	DevBuf mom;      // [nrows][4] reduced moments
 	DevBuf first;    // [nwave][m chunk] int: 1 + first row a wave wrote for that m (0: the wave had no live ring and wrote nothing)
 	// recurrence seeds (legendre.hip, S0_SEEDED_PHASE_A): one set per (ring set, spin, direction, K), recorded by the first launch
-	struct Seeds { DevBuf d, i; bool ready = false, refused = false; };
+	struct Seeds { DevBuf d, i; bool ready = false, refused = false; hipEvent_t written = nullptr; hipStream_t wstream = nullptr;
+	               ~Seeds() { if (written) (void)hipEventDestroy(written); } };
 	std::map<std::tuple<const void*, int, int, int>, Seeds> seeds;
 	size_t seed_budget = size_t(16) << 30, seed_bytes = 0;     // PXS_SEED_GB; 0 turns the seeds off
 };
