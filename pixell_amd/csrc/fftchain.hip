@@ -365,7 +365,7 @@ struct StRingA2 : StageBase {
 struct StRingS1 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
-	const double2* h; long ldh; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;
+	const double2* h; long ldh, hcomp; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;      // hcomp: rows of h per component
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
 		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
@@ -376,7 +376,7 @@ struct StRingS1 : StageBase {
 		if (k <= mmax) { m = k; cj = false; }
 		else if (X - k <= mmax) { m = X - k; cj = true; }
 		else return make_double2(0, 0);
-		const double2* r = h + ((long)c.comp*nring + 2*c.q0)*ldh + m;
+		const double2* r = h + ((long)c.comp*hcomp + 2*c.q0)*ldh + m;
 		double2 ha = r[0];
 		double2 hb = (2*c.q0 + 1 < nring) ? r[ldh] : make_double2(0, 0);
 		if (m == 0) { ha.y = 0; hb.y = 0; }
@@ -542,44 +542,68 @@ static MapAddr map_addr(const FftChain::MapDesc& m) {
 	return a;
 }
 
+// ring pairs per pass of the ring-FFT stages: PXS_RING_CHUNK_MB > 0 bounds the intermediate of a pass (experiment: keeping it in
+// the 256 MB memory-side cache between the two kernels of a pass); 0 = all pairs at once.  Measured at C3 (ring FFT ms per round
+// trip): all at once 47.3, 2048 MB 46.7, 512 MB 47.6, 200 MB 50.9, 128 MB 49.3, 64 MB 55.4 -- the cache does not pay for the
+// shorter launches.
+static long ring_chunk(long npair, long bytes_per_pair, int mult) {
+	static const long mb = [] { const char* e = getenv("PXS_RING_CHUNK_MB"); return e ? atol(e) : 0L; }();
+	if (mb <= 0) return npair;
+	long q = std::max<long>(mult, ((mb << 20)/std::max<long>(bytes_per_pair, 1))/mult*mult);
+	return std::min(q, npair);
+}
+
 void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale) {
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
-	const long npair = (m.nring + 1)/2, a = ra_.a, b = ra_.b, ldY = pad8(b);
-	s1_.ensure(sizeof(double2)*(size_t)nc*npair*a*ldY);
-	{	StRingA1 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
-		s.m = map_addr(m); s.b = (int)b; s.npair = (int)npair; s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
-		set_tiles(s, tile_lines(a, 0, b, 16, 2*a), b, nphi_);
-		launch_stage(s, (long)nc*npair*s.ntile, st);
-	}
-	{	StRingA2 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
-		int T = tile_lines(b, 0, 2*npair, 8, b); if (T < 2) T = 2; T -= T % 2;
-		set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
-		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.X = (int)nphi_; s.npair = (int)npair; s.nring = m.nring; s.mmax = mmax;
-		s.groups = (int)((npair + T/2 - 1)/(T/2)); s.da = make_fastdiv((uint32_t)a); s.dgr = make_fastdiv((uint32_t)s.groups);
-		s.leg = leg; s.ldleg = ldleg; s.nm = mmax + 1; s.tab = tab; s.scale = scale;
-		launch_stage(s, (long)nc*s.groups*a, st);
+	const long npair_all = (m.nring + 1)/2, a = ra_.a, b = ra_.b, ldY = pad8(b);
+	int T2 = tile_lines(b, 0, 2*npair_all, 8, b); if (T2 < 2) T2 = 2; T2 -= T2 % 2;
+	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, T2/2);
+	s1_.ensure(sizeof(double2)*(size_t)nc*qchunk*a*ldY);
+	for (long q_lo = 0; q_lo < npair_all; q_lo += qchunk) {
+		const long npair = std::min(qchunk, npair_all - q_lo);
+		const int nring = m.nring - (int)(2*q_lo);           // rings from the first pair of this pass on (the odd-last-ring tests are local)
+		{	StRingA1 s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
+			s.m = map_addr(m); s.m.off0 += 2*q_lo*m.ring_stride; s.m.nring = nring;
+			s.b = (int)b; s.npair = (int)npair; s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
+			set_tiles(s, tile_lines(a, 0, b, 16, 2*a), b, nphi_);
+			launch_stage(s, (long)nc*npair*s.ntile, st);
+		}
+		{	StRingA2 s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
+			const int T = T2;
+			set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
+			s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
+			s.groups = (int)((npair + T/2 - 1)/(T/2)); s.da = make_fastdiv((uint32_t)a); s.dgr = make_fastdiv((uint32_t)s.groups);
+			s.leg = leg + 2*q_lo; s.ldleg = ldleg; s.nm = mmax + 1; s.tab = tab; s.scale = scale;
+			launch_stage(s, (long)nc*s.groups*a, st);
+		}
 	}
 	PXS_HIP(hipGetLastError());
 }
 
 void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax) {
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
-	const long npair = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
-	s1_.ensure(sizeof(double2)*(size_t)nc*npair*a*ldY);
-	{	StRingS1 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
-		s.h = h; s.ldh = ldh; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = m.nring; s.mmax = mmax; s.Y = s1_.as<double2>(); s.ldY = ldY;
-		s.dnp = make_fastdiv((uint32_t)npair);
-		set_tiles(s, tile_lines(a, 0, b, 8, 2*a), b, nphi_);
-		launch_stage(s, (long)nc*npair*s.ntile, st);
-	}
-	{	StRingS2 s; memset(&s, 0, sizeof(s));
-		s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
-		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.npair = (int)npair; s.m = map_addr(m); s.dnp = make_fastdiv((uint32_t)npair);
-		set_tiles(s, tile_lines(b, 0, a, 16, b), a, 0);
-		launch_stage(s, (long)nc*npair*s.ntile, st);
+	const long npair_all = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
+	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, 1);
+	s1_.ensure(sizeof(double2)*(size_t)nc*qchunk*a*ldY);
+	for (long q_lo = 0; q_lo < npair_all; q_lo += qchunk) {
+		const long npair = std::min(qchunk, npair_all - q_lo);
+		const int nring = m.nring - (int)(2*q_lo);
+		{	StRingS1 s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
+			s.h = h + 2*q_lo*ldh; s.ldh = ldh; s.hcomp = m.nring; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
+			s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
+			set_tiles(s, tile_lines(a, 0, b, 8, 2*a), b, nphi_);
+			launch_stage(s, (long)nc*npair*s.ntile, st);
+		}
+		{	StRingS2 s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
+			s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.npair = (int)npair; s.m = map_addr(m); s.m.off0 += 2*q_lo*m.ring_stride; s.m.nring = nring;
+			s.dnp = make_fastdiv((uint32_t)npair);
+			set_tiles(s, tile_lines(b, 0, a, 16, b), a, 0);
+			launch_stage(s, (long)nc*npair*s.ntile, st);
+		}
 	}
 	PXS_HIP(hipGetLastError());
 }
