@@ -658,6 +658,47 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 	PXS_HIP(hipGetLastError());
 }
 
+// exact transpose of from_cc (theta upsampling CC grid -> map rings): leg on the map's rings -> leg on the CC grid, for grids
+// without self-mirrored rings (F1).  With U = S F_N^-1 D(e^{ik theta0}) Pad F_Ncc E (E: mirror extension of the CC samples,
+// S: sampling at the rings), U^T = E^T F_Ncc^-1 Trunc D(e^{-ik theta0}) F_N S^T up to the scalar; E^T A S^T = R A E' for any
+// operator A that commutes with the reflection (E': mirror extension of the ring samples, R: restriction to the CC rings) except
+// at the CC pole rings, which E' counts twice: weight 1/2 there (w).  So: RA1, the resize N -> N_cc directly, RA5.
+void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
+                               int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w)
+{
+	const long npair = (nm + 1)/2;
+	const long g = tp.g, bN = tp.bN, ac = tp.ac;
+	const long ldY1 = pad8(bN), ldU = pad8(g);
+	s1_.ensure(sizeof(double2)*(size_t)npair*g*ldY1); s2_.ensure(sizeof(double2)*(size_t)npair*ac*ldU);
+	for (int c = 0; c < nc; c++) {
+		{	StFirst s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
+			s.src.leg = leg + (size_t)c*nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1;
+			set_tiles(s, tile_lines(g, 0, bN, 8), bN, tp.N);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StResize s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, bN); s.fb = mk(fc_, ac);
+			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldU; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
+			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
+			set_tiles(s, tile_lines(bN, ac, g, 8), g, tp.Ncc);
+			launch_stage(s, npair*s.ntile, st);
+		}
+		{	StSplit<0> s; memset(&s, 0, sizeof(s));
+			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
+			int T = tile_lines(g, 0, 2*ac, 8); if (T < 2) T = 2; T -= T % 2;
+			const int TH = T/2;
+			set_tiles(s, T, (long)((ac/2 + 1 + TH - 1)/TH)*T, 0);
+			s.TH = TH;
+			s.U = s2_.as<double2>(); s.ldU = ldU; s.a = (int)ac; s.g = (int)g; s.X = (int)tp.Ncc; s.mir_c = 0; s.nr_out = ncc; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
+			s.out = leg_cc + (size_t)c*nm*ldcc; s.ld = ldcc; s.w = w; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
+			launch_stage(s, npair*s.ntile, st);
+		}
+	}
+	PXS_HIP(hipGetLastError());
+}
+
 void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
                        int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale)
 {

@@ -45,6 +45,9 @@ public:
 	// band-limited leg on the CC grid -> h[c][ring][m] * conj(tab[m]) * scale on the map's rings
 	void from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
 	             int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale);
+	// exact transpose of from_cc for grids without self-mirrored rings: leg on the map's rings -> leg on the CC grid (w: 1/N_cc, half at the poles)
+	void from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
+	                     int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w);
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
 private:
 	const double2* small_tw(long X, int n, int T);

@@ -324,7 +324,7 @@ struct pxs_plan {
 	DevBuf leg, leg2, hbuf, phase;
 	// analysis resampling (grid plans)
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
-	DevBuf ph_shift, ph_up, sigma, wcc, b1, b2;
+	DevBuf ph_shift, ph_up, sigma, wcc, wadj, b1, b2;
 	// general ring sets (gen_* kernels): rings of equal length are one dense block of z
 	struct GenGroup { long n, count, zoff; };
 	bool general = false; std::vector<GenGroup> groups; long npixz = 0;
@@ -446,6 +446,10 @@ void setup_resampling(pxs_plan* p) {
 		w[j] = make_double2((double)((PIl/p->nphi)*(2*PIl/p->Ncc)*e/((LDb)p->N*(LDb)p->M)), 0.0);
 	}
 	p->wcc = upload(w);
+	{	// weights of the transposed theta upsampling (FftChain::from_cc_adjoint): 1/N_cc, half at the two pole rings
+		std::vector<double2> wa(p->ncc);
+		for (int j = 0; j < p->ncc; j++) wa[j] = make_double2(((j == 0 || j == p->ncc-1) ? 0.5 : 1.0)/(double)p->Ncc, 0.0);
+		p->wadj = upload(wa); }
 }
 
 // tables of a general ring set: groups of equal length, z offsets, the block table of the gen_* kernels
@@ -932,6 +936,20 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 		}
 	} else {
 		map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
+		// the transpose of the synthesis through the CC grid, where that is the cheaper synthesis: F1 grids (no self-mirrored rings)
+		static const bool adj_cc = [] { const char* e = getenv("PXS_ADJ_VIA_CC"); return e ? atoi(e) != 0 : true; }();
+		if (adj_cc && p->is_grid && th && p->geometry == "F1" && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0) {
+			const long ldc = p->ld_cc();
+			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
+			p->prof.begin(st, PXS_STAGE_RESAMPLE);
+			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), p->wadj.as<double2>());
+			p->prof.end(st, PXS_STAGE_RESAMPLE);
+			for (int b = 0; b < nb; b++)
+				leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>() + (size_t)b*ncm*nm*ldc, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+					mode == PXS_MODE_DERIV1, &p->prof, ldc);
+			return;
+		}
 		for (int b = 0; b < nb; b++)
 			leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>() + (size_t)b*ncm*nm*ldm, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
 				mode == PXS_MODE_DERIV1, &p->prof, ldm);
