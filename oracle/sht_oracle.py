@@ -339,7 +339,7 @@ def leg2map(leg, nphi, phi0, ringstart, npix, pixstride=1, dtype=np.float64):
 	for c in range(nc):
 		for r in range(nr):
 			n = int(nphi[r]); o = int(ringstart[r])
-			out[c, o:o+n*pixstride:pixstride] = leg2map_ring(leg[c, r], n, float(phi0[r]))
+			out[c, o+pixstride*np.arange(n)] = leg2map_ring(leg[c, r], n, float(phi0[r]))       # (index array: negative strides too)
 	return out
 
 def map2leg(map, nphi, phi0, ringstart, mmax, pixstride=1):
@@ -349,7 +349,7 @@ def map2leg(map, nphi, phi0, ringstart, mmax, pixstride=1):
 	for c in range(nc):
 		for r in range(nr):
 			n = int(nphi[r]); o = int(ringstart[r])
-			leg[c, r] = map2leg_ring(np.asarray(map[c, o:o+n*pixstride:pixstride], np.float64), float(phi0[r]), mmax)
+			leg[c, r] = map2leg_ring(np.asarray(map[c, o+pixstride*np.arange(n)], np.float64), float(phi0[r]), mmax)
 	return leg
 
 

@@ -582,7 +582,7 @@ void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, doubl
 	PXS_HIP(hipGetLastError());
 }
 
-void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax) {
+void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax, long hcomp) {
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
 	const long npair_all = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
 	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, 1);
@@ -592,7 +592,7 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 		const int nring = m.nring - (int)(2*q_lo);
 		{	StRingS1 s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
-			s.h = h + 2*q_lo*ldh; s.ldh = ldh; s.hcomp = m.nring; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
+			s.h = h + 2*q_lo*ldh; s.ldh = ldh; s.hcomp = hcomp > 0 ? hcomp : m.nring; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, tile_lines(a, 0, b, 8, 2*a), b, nphi_);
 			launch_stage(s, (long)nc*npair*s.ntile, st);

@@ -38,7 +38,8 @@ public:
 	// map -> leg[c][m][ring] * tab[m] * scale   (two real rings per complex transform; needs 2 mmax < nphi)
 	void map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale);
 	// h[c][ring][m] (row stride ldh) -> map
-	void h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax);
+	// (hcomp: rows of h per component when the map's rings are a row range of a larger h; 0 = the map's ring count)
+	void h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax, long hcomp = 0);
 	// leg on the map's rings -> quadrature-weighted leg on the CC grid (columns paired by parity)
 	void to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
 	           int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* wcc);

@@ -314,6 +314,9 @@ struct pxs_plan {
 	bool is_grid = false;
 	std::string geometry;
 	int nring = 0, nphi = 0;
+	// rows of a larger F1 grid (declination bands through pxs_plan_rings): the grid has nfull rings, the map's first ring is its
+	// ring row0.  Such plans share the CC-grid machinery of the grid plans for synthesis and its adjoint.  Grid plans: nfull = nring.
+	int nfull = 0, row0 = 0; bool band = false;
 	double phi0 = 0;
 	long ring_off0 = 0, ring_stride = 0, pix_stride = 1;   // user-map offset of (ring r, pixel x) = ring_off0 + r*ring_stride + x*pix_stride
 	int lmax = 0, mmax = 0; long lstride = 1;
@@ -396,7 +399,8 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 }
 
 void setup_resampling(pxs_plan* p) {
-	GridInfo gi = grid_info(p->geometry, p->nring);
+	if (p->nfull == 0) p->nfull = p->nring;
+	GridInfo gi = grid_info(p->geometry, p->nfull);
 	p->N = gi.N; p->mir_c = gi.c;
 	const int lmax = p->lmax;
 	p->Ncc = FftContext::good_size(std::max<long>(2L*lmax + 2, 4));
@@ -426,8 +430,10 @@ void setup_resampling(pxs_plan* p) {
 	{ std::vector<double2> pu(ps.size()); for (size_t k = 0; k < ps.size(); k++) pu[k] = make_double2(ps[k].x, -ps[k].y); p->ph_up = upload(pu); }
 	// synthesis: Legendre on the minimal CC grid + exact Fourier upsampling in theta pays once the map has clearly more rings
 	// (measured: at nring / ncc = 1.33 -- C2, C4 -- the detour pays for spin 2 and costs 11 ms per 64 scalar maps at C4)
-	{ const char* e = getenv("PXS_SYN_VIA_CC"); p->syn_via_cc = e ? atoi(e) != 0 : (p->nring > p->ncc + p->ncc/4);
-	  p->syn_via_cc0 = e ? atoi(e) != 0 : (p->nring > p->ncc + p->ncc/2); }
+	// (a band: what counts is the ring-pair slots of its own rings, unpaired rings take a whole slot)
+	{ const char* e = getenv("PXS_SYN_VIA_CC"); const long rings = p->band ? 2L*p->rs_map.npairs : p->nring;
+	  p->syn_via_cc = e ? atoi(e) != 0 : (rings > p->ncc + p->ncc/4);
+	  p->syn_via_cc0 = e ? atoi(e) != 0 : (rings > p->ncc + p->ncc/2); }
 	// sigma_i = sum_{|q|<=Ks} s_q e^{i q theta_i} on the M grid, via one device FFT
 	const long Ks = lmax + p->N/2;
 	PXS_REQUIRE(2*Ks < p->M, "internal: fine grid too small");
@@ -591,14 +597,17 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* 
 		return;
 	}
 	const long ldh = p->ld_h();
-	p->hbuf.ensure(sizeof(double2)*(size_t)nc*nr*ldh);
+	p->hbuf.ensure(sizeof(double2)*(size_t)nc*(have_h && p->band ? p->nfull : nr)*ldh);
 	if (!have_h) {      // (the CC synthesis path has written hbuf already, see resample_from_cc / FftChain::from_cc)
 		dim3 grid((nm+31)/32, (nr+31)/32, nc);
 		hipLaunchKernelGGL(transpose_mul_outcol, grid, dim3(256), sizeof(double2)*32*33, st, leg, (double2*)p->hbuf.p, nr, nm,
 			(long)nm*ldleg, (long)nr*ldh, (const double2*)p->phase.p, 1, 1.0, ldleg, ldh);
 	}
 	if (p->chain_rings) {
-		p->chain->h2map(st, p->hbuf.as<double2>(), ldh, p->map_desc(map, map_dtype, map_cstride, map_bstride, ncb), nc, p->mmax);
+		// (have_h on a band plan: h holds all nfull rings of the grid, the map's rings start at row0)
+		const bool full_h = have_h && p->band;
+		p->chain->h2map(st, p->hbuf.as<double2>() + (full_h ? (size_t)p->row0*ldh : 0), ldh, p->map_desc(map, map_dtype, map_cstride, map_bstride, ncb), nc, p->mmax,
+			full_h ? p->nfull : 0);
 		p->prof.end(st, PXS_STAGE_RING_FFT);
 		return;
 	}
@@ -859,6 +868,23 @@ int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64
 	std::vector<LDb> th(nring);
 	for (int r = 0; r < nring; r++) th[r] = theta[r];
 	p->rs_map.build(th); p->rs_map.upload_all();
+	// Rows of a Fejer-1 grid (a declination band of a CAR map, curvedsky.py:843-873): theta_r = (row0 + r + 1/2) pi / n.  Synthesis
+	// and its adjoint can then run their Legendre stage on the ~lmax+2 CC rings of that grid instead of the band's own ring-pair
+	// slots (an unpaired ring costs a whole slot); PXS_BAND_VIA_CC=0 turns it off.
+	{	static const bool on = [] { const char* e = getenv("PXS_BAND_VIA_CC"); return e ? atoi(e) != 0 : true; }();
+		if (on && !p->general && p->chain_rings && nring >= 2) {
+			const LDb d = th[1] - th[0];
+			const long n = d > 0 ? (long)llroundl(PIl/d) : 0;
+			const long k0 = n > 0 ? (long)llroundl(th[0]*n/PIl - 0.5L) : -1;
+			bool ok = n > nring && k0 >= 0 && k0 + nring <= n && lmax <= n - 1 && n < (1L << 30) && FftContext::supported(2*n);
+			for (int r = 0; ok && r < nring; r++) ok = fabsl(th[r] - ((LDb)(k0 + r) + 0.5L)*PIl/n) < 1e-11L;
+			if (ok) {
+				p->band = true; p->geometry = "F1"; p->nfull = (int)n; p->row0 = (int)k0;
+				setup_resampling(p.get());
+				if (!p->chain_theta()) { p->band = false; p->nfull = 0; p->row0 = 0; p->ncc = 0; }     // (no fused theta chain for this size: stay on the band's own rings)
+			}
+		}
+	}
 	*plan = p.release();
 	PXS_CATCH
 }
@@ -906,7 +932,7 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 	(void)nca;
 	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
 	if (!adjoint) {
-		if (p->is_grid && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0) {
+		if ((p->is_grid || (p->band && th)) && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0) {
 			const long ldc = p->ld_cc();
 			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
 			for (int b = 0; b < nb; b++)
@@ -914,9 +940,10 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 					p->leg2.as<double2>() + (size_t)b*ncm*nm*ldc, mode == PXS_MODE_DERIV1, &p->prof, ldc);
 			if (th) {	// fused chain: CC grid -> ring spectra of the map's rings, written ring-major for the ring FFT
 				const long ldh = p->ld_h();
-				p->hbuf.ensure(sizeof(double2)*(size_t)nct*nr*ldh);
+				const int nrh = p->band ? p->nfull : nr;          // (a band: h for every ring of the grid, the ring FFTs take its rows)
+				p->hbuf.ensure(sizeof(double2)*(size_t)nct*nrh*ldh);
 				p->prof.begin(st, PXS_STAGE_RESAMPLE);
-				p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
+				p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nrh, p->mir_c, nct, nm, spin, p->lmax,
 					p->ph_up.as<double2>(), p->phase.as<double2>(), 1.0/(double)p->Ncc);
 				p->prof.end(st, PXS_STAGE_RESAMPLE);
 				leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, ncb);
@@ -935,14 +962,21 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, nct, false, map_bstride, ncb);
 		}
 	} else {
-		map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
 		// the transpose of the synthesis through the CC grid, where that is the cheaper synthesis: F1 grids (no self-mirrored rings)
+		// and bands of them (rows outside the band are zero)
 		static const bool adj_cc = [] { const char* e = getenv("PXS_ADJ_VIA_CC"); return e ? atoi(e) != 0 : true; }();
-		if (adj_cc && p->is_grid && th && p->geometry == "F1" && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0) {
-			const long ldc = p->ld_cc();
+		const bool via = adj_cc && (p->is_grid || p->band) && th && p->geometry == "F1" && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
+		if (via && p->band) {
+			const long ldf = FftChain::pad8(p->nfull);
+			p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldf);
+			PXS_HIP(hipMemsetAsync(p->leg.p, 0, sizeof(double2)*(size_t)nct*nm*ldf, st));
+			map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>() + p->row0, 1.0, ldf, map_bstride, ncb);
+		} else map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
+		if (via) {
+			const long ldc = p->ld_cc(), ldin = p->band ? FftChain::pad8(p->nfull) : ldm;
 			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
 			p->prof.begin(st, PXS_STAGE_RESAMPLE);
-			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
+			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldin, p->band ? p->nfull : nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
 				p->ph_shift.as<double2>(), p->wadj.as<double2>());
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
 			for (int b = 0; b < nb; b++)

@@ -185,6 +185,33 @@ def check_general_rings(nside=4, lmax=14, big=False):
 			o32 = sht.synthesis(alm=alm.astype(np.complex64), spin=spin, mode=mode, **kw)
 			assert o32.dtype == np.float32 and rel(o32[:, used], ref[:, used]) < 1e-5
 
+def check_band_rings(n=96, r0=9, nr=70, nph=200, lmax=24):
+	"""rows r0 .. r0+nr of an n-ring Fejer-1 grid as explicit rings (a declination band on the cyl path, curvedsky.py:843-873, 928-962):
+	pxs_plan_rings recognises them and runs synthesis and its adjoint through the CC grid of the full grid; stored flipped in
+	both directions (descending ringstart, pixstride -1) as pixell_amd.curvedsky passes band maps"""
+	th = (r0+np.arange(nr)+0.5)*np.pi/n
+	ms = so._tri_mstart(lmax, lmax); rng = np.random.default_rng(8)
+	rs_plain = np.arange(nr, dtype=np.uint64)*nph
+	rs_flip = (np.arange(nr)[::-1]*nph+nph-1).astype(np.uint64)
+	for spin, mode in [(0, "STANDARD"), (2, "STANDARD"), (1, "DERIV1")]:
+		nca = 1 if (spin == 0 or mode == "DERIV1") else 2
+		alm = so.rand_alm_simple(lmax, nca, 6, spin=(spin if mode != "DERIV1" else 0,))
+		for rs, pstr in ((rs_plain, 1), (rs_flip, -1)):
+			kw = dict(theta=th, nphi=np.full(nr, nph, np.uint64), phi0=np.full(nr, -0.4), ringstart=rs, lmax=lmax, mstart=ms, pixstride=pstr)
+			ref = so.synthesis(alm=alm, spin=spin, mode=mode, **kw); out = sht.synthesis(alm=alm, spin=spin, mode=mode, **kw)
+			info = sht.synthesis.last_plan.info()
+			assert info["nring_syn"] < nr, "the band plan did not take the CC grid"
+			assert rel(out, ref) < TOL
+			pix = rng.standard_normal(ref.shape)
+			ra = so.adjoint_synthesis(map=pix, spin=spin, mode=mode, **kw); oa = sht.adjoint_synthesis(map=pix, spin=spin, mode=mode, **kw)
+			ra[:, :lmax+1] = ra[:, :lmax+1].real
+			assert relrms(oa, ra) < TOL
+
+@pytest.mark.hostsim
+def test_band_rings_hostsim(): check_band_rings()
+@pytest.mark.gpu
+def test_band_rings_gpu(): check_band_rings(); check_band_rings(n=1200, r0=150, nr=700, nph=2400, lmax=400)
+
 def check_prime_rings():
 	"""equal rings whose length has a prime factor > 2048 (no mixed-radix factorisation): general path + Bluestein"""
 	th = np.array([0.4, 1.3, np.pi-1.3, 2.5]); nph = 2*2053; lmax = 12
