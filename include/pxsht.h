@@ -42,7 +42,8 @@ typedef struct pxs_plan pxs_plan;
  * theta[nring] colatitudes, nphi[nring] pixels per ring (>= 1), phi0[nring] azimuth of pixel 0,
  * ringstart[nring] index of pixel 0 of each ring in the flat map, pixstride: stride between pixels of a ring.
  * Rings of equal length, phase and spacing (CAR maps) take the fused ring FFTs; any other ring set (healpix, profile
- * rings, ring subsets, nphi < mmax) the general path: one batched FFT per ring length. */
+ * rings, ring subsets, nphi < mmax) the general path: one batched FFT per ring length.  Equal rings that are consecutive
+ * rows of a Fejer-1 grid (a declination band) run their Legendre stage on the Clenshaw-Curtis grid of that grid. */
 int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64_t* nphi,
                    const double* phi0, const uint64_t* ringstart, int64_t pixstride,
                    int lmax, int mmax, const uint64_t* mstart, int64_t lstride, int device);
