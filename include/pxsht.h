@@ -100,6 +100,11 @@ int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out);
 #define PXS_NSTAGE 4
 int pxs_profile(pxs_plan* plan, int enable);
 int pxs_profile_read(pxs_plan* plan, double* ms, int* counts, int reset);
+/* FP64 flops the Legendre kernels EXECUTED since profiling was enabled (or since the last reset): flops[0] synthesis, flops[1]
+ * analysis.  Counted by the kernels themselves (steps run x ring pairs per lane x FMAs per step x 64 lanes x 2), so bench.py can
+ * quote the hardware FMA utilisation next to the algorithmic flop count of SURVEY 8(d) (which credits rings and degrees the
+ * kernels skip as polar-dead).  No reference counterpart. */
+int pxs_profile_flops(pxs_plan* plan, double* flops, int reset);
 
 /* N-d FFT over `naxes` axes of a strided array: the engine behind fft.engines["hip"].FFTW(a,b,axes,
  * direction) (pixell/fft.py:8-64,133-209) and enmap.fft/ifft (enmap.py:1307-1337).

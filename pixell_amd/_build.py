@@ -14,10 +14,23 @@ def needs_build(lib=LIB):
 	deps = sources()+glob.glob(os.path.join(CSRC, "*.hpp"))+[os.path.join(HERE, "..", "include", "pxsht.h")]
 	return any(os.path.getmtime(d) > t for d in deps)
 
+def hipcc_path():
+	return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+def compile_one(src, obj, verbose=False):
+	"""one translation unit -> gfx950 object (the build check of tests/test_capi.py compiles one with this, always for real)"""
+	cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]+os.environ.get("PXS_EXTRA_HIPCC_FLAGS", "").split()+["-c", src, "-o", obj]
+	if verbose: print(" ".join(cmd))
+	subprocess.check_call(cmd)
+	return obj
+
 def build(force=False, verbose=False):
-	"""hipcc cross-compiles for gfx950 without a GPU present."""
+	"""hipcc cross-compiles for gfx950 without a GPU present.
+	force (or PXS_FORCE_BUILD=1, or no object directory yet -- a fresh checkout): every translation unit is recompiled and the
+	library relinked, whatever the timestamps say; otherwise only what is older than its sources."""
+	force = force or os.environ.get("PXS_FORCE_BUILD", "0") == "1" or not os.path.isdir(os.path.join(HERE, "build"))
 	if not force and not needs_build(): return LIB
-	hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+	hipcc = hipcc_path()
 	objs = []
 	bdir = os.path.join(HERE, "build"); os.makedirs(bdir, exist_ok=True)
 	procs = []

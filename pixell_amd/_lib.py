@@ -1,8 +1,9 @@
 """ctypes loader of libpxsht.so (the HIP kernels behind include/pxsht.h).
 
 The product path has NO CPU fallback: if the library is missing or cannot be loaded this
-module raises.  The only alternative library it will load is the test-only host simulator
-(tests/hostsim), and only when a test sets PIXELL_AMD_HOSTSIM=1 explicitly."""
+module raises.  There is no switch in here that selects anything but pixell_amd/libpxsht.so: the
+CPU test-suite points `lib_path` at its simulator build itself (tests/conftest.py), and such a
+build says what it is in pxs_version() (`is_hostsim`)."""
 import ctypes, os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,7 +28,7 @@ def _declare(lib):
 	lib.pxs_gridweights.argtypes = [c.c_char_p, i32, vp]
 	lib.pxs_grid_maxlmax.argtypes = [c.c_char_p, i32]
 	lib.pxs_plan_info.argtypes = [vp, c.POINTER(i32), c.POINTER(i32), c.POINTER(i64)]
-	lib.pxs_profile.argtypes = [vp, i32]; lib.pxs_profile_read.argtypes = [vp, vp, vp, i32]
+	lib.pxs_profile.argtypes = [vp, i32]; lib.pxs_profile_read.argtypes = [vp, vp, vp, i32]; lib.pxs_profile_flops.argtypes = [vp, vp, i32]
 	lib.pxs_debug_theta_plan.argtypes = [i64, i32, vp]
 	lib.pxa_alm2cl.argtypes = [i32, i32, vp, i64, vp, vp, i32, vp, i32, i32, vp]
 	lib.pxa_lmatmul.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, vp]
@@ -40,13 +41,13 @@ def _declare(lib):
 	lib.pxf_fft_supported.argtypes = [i64]
 	lib.pxf_fft_good_size.argtypes = [i64]; lib.pxf_fft_good_size.restype = i64
 	for name in ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_synthesis", "pxs_analysis", "pxs_gridweights",
-			"pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported", "pxs_profile", "pxs_profile_read", "pxs_debug_theta_plan", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]:
+			"pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]:
 		getattr(lib, name).restype = i32
 	return lib
 
 EXPORTS = ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_plan_destroy", "pxs_synthesis", "pxs_analysis",
 	"pxs_gridweights", "pxs_grid_maxlmax", "pxs_plan_info", "pxf_fft_nd", "pxf_fft_supported",
-	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxs_debug_theta_plan", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]
+	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]
 
 def lib_path():
 	# PIXELL_AMD_LIB: another build of the same library (kernel A/B experiments, tools/chain_exp*.sh)
@@ -56,20 +57,17 @@ def load():
 	"""Return the loaded library, loading it on first use.  Raises if it is absent."""
 	global _lib, _is_hostsim
 	if _lib is not None: return _lib
-	if os.environ.get("PIXELL_AMD_HOSTSIM") == "1":
-		path = os.path.join(HERE, "..", "tests", "hostsim", "libpxsht_hostsim.so")
-		_is_hostsim = True
-	else:
-		path = lib_path()
+	path = lib_path()
 	if not os.path.exists(path):
 		raise ImportError("pixell_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
 			"(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
-	if not _is_hostsim:
-		# torch ships its own libamdhip64: let it be the HIP runtime of the process.  Loading libpxsht.so (which pulls in
-		# /opt/rocm's runtime) before torch left two runtimes in one process and hipSetDevice then reported no device.
-		try: import torch  # noqa: F401
-		except ImportError: pass
-	_lib = _declare(ctypes.CDLL(path))
+	# torch ships its own libamdhip64: let it be the HIP runtime of the process.  Loading libpxsht.so (which pulls in
+	# /opt/rocm's runtime) before torch left two runtimes in one process and hipSetDevice then reported no device.
+	try: import torch  # noqa: F401
+	except ImportError: pass
+	lib = _declare(ctypes.CDLL(path))
+	_is_hostsim = b"HOSTSIM" in lib.pxs_version()      # a g++ build of the kernel sources (tests/hostsim): host pointers, no streams
+	_lib = lib
 	return _lib
 
 def is_hostsim():

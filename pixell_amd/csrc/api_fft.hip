@@ -64,6 +64,13 @@ static const BluePlan& blue_plan(FftContext& fc, int device, hipStream_t st, lon
 static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
                      FftLoad ld, FftStore stf);
 
+static std::mutex g_blue_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> g_blue_scratch;
+// a stream is about to be destroyed: free the scratch keyed by it (a recycled handle must not inherit a stale buffer)
+void fft_release_stream(int device, hipStream_t st) {
+	{ std::lock_guard<std::mutex> g(g_blue_mu); g_blue_scratch.erase(std::make_pair(device, st)); }
+	fft_context(device).release_stream(st);
+}
+
 static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, bool forward, std::vector<AxisDim> dims, long is_e, long os_e,
                            FftLoad ld, FftStore stf) {
 	const bool c2r = ld.mode == LD_HERM && !ld.herm_fold;      // Hermitian half spectrum in, real line out
@@ -74,10 +81,10 @@ static void bluestein_axis(FftContext& fc, int device, hipStream_t st, long n, b
 	std::vector<AxisDim> d1 = dims, d2 = dims;
 	long lines = 1;
 	for (size_t k = dims.size(); k-- > 0;) { d1[k].os = lines*M; d2[k].is = lines*M; lines *= dims[k].n; }
-	// scratch per stream, grown on demand and kept (growing frees the old block: hipFree waits for the device)
-	static std::mutex smu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> scratches;
+	// scratch per stream, grown on demand and kept (growing frees the old block: hipFree waits for the device); owners of private
+	// streams give it back with fft_release_stream before they destroy the stream
 	DevBuf* sp;
-	{ std::lock_guard<std::mutex> g(smu); auto& u = scratches[std::make_pair(device, st)]; if (!u) u.reset(new DevBuf()); sp = u.get(); }
+	{ std::lock_guard<std::mutex> g(g_blue_mu); auto& u = g_blue_scratch[std::make_pair(device, st)]; if (!u) u.reset(new DevBuf()); sp = u.get(); }
 	DevBuf& scratch = *sp; scratch.ensure(sizeof(double2)*(size_t)lines*M);
 	{	// y = FFT_M(x w, zero padded)
 		FftLoad l1 = ld; l1.mul = bp.w.as<double2>();

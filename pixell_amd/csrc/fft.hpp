@@ -65,6 +65,7 @@ public:
 	struct SubView { int n, nfac, ns, generic; const void* pass; const int* perm; const double2* tw; };
 	SubView view(long n, int maxr = 1000);      // maxr: largest composite register radix the calling kernel has compiled in
 	const double2* twiddle_table(long n) { return bigtw(n); }
+	void release_stream(hipStream_t st) { std::lock_guard<std::mutex> g(mu_); temps_.erase(st); }   // four-step scratch of a stream that is going away
 	size_t temp_budget = size_t(4) << 30;   // bytes of four-step scratch per stream (set from the free memory in the constructor)
 private:
 	int device_;

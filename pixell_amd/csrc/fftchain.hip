@@ -137,15 +137,16 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 // ---------------------------------------------------------------------------------------------------------------
 // value of circle sample j of the packed pair of columns (2p, 2p+1): even + odd extension (cf. LD_MIRROR_PAIR in fft.hip)
 struct PairSrc {
-	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol;
-	__device__ __forceinline__ double2 get(int p, int j) const {
+	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol; long cstride;      // cstride: elements between the components of a launch
+	__device__ __forceinline__ double2 get(int comp, int p, int j) const {
 		int src = j; bool mir = false;
 		if (j >= nr) { src = N - j - mir_c; if (src < 0) src += N; mir = true; }
 		const int tj = 2*j + mir_c;
 		const bool selfm = tj == 0 || tj == N || tj == 2*N;       // the sample is its own mirror image
 		const int ca = 2*p;
-		double2 va = leg[(long)ca*ld + src];
-		double2 vb = (ca + 1 < ncol) ? leg[(long)(ca + 1)*ld + src] : make_double2(0, 0);
+		const double2* lc = leg + (long)comp*cstride;
+		double2 va = lc[(long)ca*ld + src];
+		double2 vb = (ca + 1 < ncol) ? lc[(long)(ca + 1)*ld + src] : make_double2(0, 0);
 		double2& vo = a_odd ? va : vb;
 		if (selfm) vo = make_double2(0, 0);
 		else if (mir) { vo.x = -vo.x; vo.y = -vo.y; }
@@ -157,12 +158,13 @@ struct PairSrc {
 struct StFirst : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
-	PairSrc src; int b; double2* Y; long ldY;
+	PairSrc src; int b; double2* Y; long ldY; int npair; FastDiv dnp;       // outer = comp*npair + pair
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
-		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0); return true; }
+		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
+		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
-		return src.get(c.outer, b*e + c.t0 + li); }
+		return src.get(c.comp, c.q0, b*e + c.t0 + li); }
 	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
 		if (li >= c.nl) return;
@@ -231,15 +233,18 @@ template<int MODE> struct StSplit : StageBase {
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
 	double2* out; long ld; const double2* w; const double2* tab; double scale; int TH; FastDiv da;
+	long ocstride; int groups; FastDiv dnp, dgr;      // components of a launch: output stride; MODE 0: outer = comp*npair + pair, MODE 1: outer = comp*groups + group
 	__device__ __forceinline__ int mirror_line(int k) const { int m = a - k - mir_c; if (m >= a) m -= a; if (m < 0) m += a; return m; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*(MODE == 0 ? TH : 1); c.nl = T;
+		if (MODE == 0) { c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; }
+		else { c.comp = fdiv(c.outer, dgr); c.q0 = (c.outer - c.comp*groups)*(T/2); }
 		if (MODE == 1) { if (mirror_line(c.t0) < c.t0) return false; }      // the tile of the mirror line does this one
 		return true; }
-	// line and pair of LDS slot li (line < 0: unused slot)
+	// line and pair (within its component) of LDS slot li (line < 0: unused slot)
 	__device__ __forceinline__ void slot(const TileC& c, int li, int& line, int& pair) const {
 		if (MODE == 0) {
-			pair = c.outer;
+			pair = c.q0;
 			const int prim = c.t0 + (li < TH ? li : li - TH);
 			line = -1;
 			if (prim < a) {
@@ -248,7 +253,7 @@ template<int MODE> struct StSplit : StageBase {
 				else if (prim < m) line = m;
 			}
 		} else {
-			pair = c.outer*(T/2) + (li >> 1);
+			pair = c.q0 + (li >> 1);
 			const int m = mirror_line(c.t0);
 			line = (li & 1) ? (m != c.t0 ? m : -1) : c.t0;
 			if (pair >= npair) line = -1;
@@ -257,7 +262,7 @@ template<int MODE> struct StSplit : StageBase {
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		int line, pair; slot(c, li, line, pair);
 		if (line < 0) return make_double2(0, 0);
-		return U[((long)pair*a + line)*ldU + e]; }
+		return U[(((long)c.comp*npair + pair)*a + line)*ldU + e]; }
 	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
 		int line, pair; slot(c, li, line, pair);
@@ -277,13 +282,14 @@ template<int MODE> struct StSplit : StageBase {
 		}
 		const int ca = 2*pair;
 		double2 va = a_odd ? od : ev, vb = a_odd ? ev : od;
+		double2* oc = out + (long)c.comp*ocstride;
 		if (MODE == 0) {
 			const double f = scale*(w ? w[t].x : 1.0);
-			out[(long)ca*ld + t] = cscale(va, f);
-			if (ca + 1 < ncol) out[(long)(ca + 1)*ld + t] = cscale(vb, f);
+			oc[(long)ca*ld + t] = cscale(va, f);
+			if (ca + 1 < ncol) oc[(long)(ca + 1)*ld + t] = cscale(vb, f);
 		} else {
-			out[(long)t*ld + ca] = cscale(cmul(va, cconj(tab[ca])), scale);
-			if (ca + 1 < ncol) out[(long)t*ld + ca + 1] = cscale(cmul(vb, cconj(tab[ca + 1])), scale);
+			oc[(long)t*ld + ca] = cscale(cmul(va, cconj(tab[ca])), scale);
+			if (ca + 1 < ncol) oc[(long)t*ld + ca + 1] = cscale(cmul(vb, cconj(tab[ca + 1])), scale);
 		}
 	}
 };
@@ -608,6 +614,28 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 	PXS_HIP(hipGetLastError());
 }
 
+// components per pass of a theta chain: all of them unless the two ping-pong buffers would exceed PXS_CHAIN_SCRATCH_GB (12) each
+static int theta_comp_chunk(int nc, size_t need1_per_comp, size_t need2_per_comp) {
+	static const size_t budget = [] { const char* e = getenv("PXS_CHAIN_SCRATCH_GB"); return (size_t)(e ? atol(e) : 12) << 30; }();
+	const size_t per = sizeof(double2)*std::max(need1_per_comp, need2_per_comp);
+	return (int)std::max<size_t>(1, std::min<size_t>((size_t)nc, budget/std::max<size_t>(per, 1)));
+}
+void FftChain::theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2) {
+	const size_t npair = (size_t)(nm + 1)/2;
+	size_t n1, n2;
+	if (kind == 0)      { n1 = npair*std::max(tp.g*pad8(tp.bN), tp.g*pad8(tp.g2)); n2 = npair*std::max(tp.g2*pad8(tp.g), tp.ac*pad8(tp.g)); }   // to_cc
+	else if (kind == 1) { n1 = npair*tp.g*pad8(tp.bN); n2 = npair*tp.ac*pad8(tp.g); }                                                    // from_cc_adjoint
+	else                { n1 = npair*tp.gs*pad8(tp.bs); n2 = npair*tp.aNs*pad8(tp.gs); }                                                  // from_cc
+	const int cc = theta_comp_chunk(nc, n1, n2);
+	b1 = sizeof(double2)*n1*cc; b2 = sizeof(double2)*n2*cc;
+}
+void FftChain::ring_scratch(long nring, int nc, bool analysis, size_t& b1) const {
+	const long npair = (nring + 1)/2, a = analysis ? ra_.a : rs_.a, b = analysis ? ra_.b : rs_.b;
+	b1 = sizeof(double2)*(size_t)nc*npair*a*pad8(b);       // (ring_chunk only shrinks it)
+}
+
+// All components of a call go through each stage in ONE launch (outer index = component * npair + pair; batched maps are
+// components here): 64 maps of 5400 rings are 5 launches of ~150 000 workgroups instead of 320 of ~10 000 with their tails.
 void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
                      int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* wcc)
 {
@@ -615,34 +643,36 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 	const long g = tp.g, bN = tp.bN, g2 = tp.g2, ac = tp.ac;
 	const long ldY1 = pad8(bN), ldZ2 = pad8(g), ldV3 = pad8(g2), ldU4 = pad8(g);
 	const size_t need1 = (size_t)npair*std::max(g*ldY1, g*ldV3), need2 = (size_t)npair*std::max(g2*ldZ2, ac*ldU4);
-	s1_.ensure(sizeof(double2)*need1); s2_.ensure(sizeof(double2)*need2);
-	for (int c = 0; c < nc; c++) {
+	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
+	for (int c0 = 0; c0 < nc; c0 += cchunk) {
+		const long ncl = std::min(cchunk, nc - c0);
 		{	StFirst s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
-			s.src.leg = leg + (size_t)c*nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
-			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1;
+			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, tile_lines(g, 0, bN, 8), bN, tp.N);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, g2);
 			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.M; s.kmax = -1; s.nyq = 1;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, tile_lines(bN, g2, g, 8), g, tp.M);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSigma s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, g);
 			s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.V = s1_.as<double2>(); s.ldV = ldV3; s.g = (int)g; s.g2 = (int)g2; s.sigma = sigma;
 			set_tiles(s, tile_lines(g, g, g2, 8), g2, tp.M);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g2); s.fb = mk(fc_, ac);
 			s.Y = s1_.as<double2>(); s.ldY = ldV3; s.Z = s2_.as<double2>(); s.ldZ = ldU4; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
 			s.ph = nullptr; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, tile_lines(g2, ac, g, 8), g, tp.Ncc);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
@@ -651,8 +681,9 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			set_tiles(s, T, (long)((ac/2 + 1 + TH - 1)/TH)*T, 0);
 			s.TH = TH;
 			s.U = s2_.as<double2>(); s.ldU = ldU4; s.a = (int)ac; s.g = (int)g; s.X = (int)tp.Ncc; s.mir_c = 0; s.nr_out = ncc; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
-			s.out = leg_cc + (size_t)c*nm*ldcc; s.ld = ldcc; s.w = wcc; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
-			launch_stage(s, npair*s.ntile, st);
+			s.out = leg_cc + (size_t)c0*nm*ldcc; s.ocstride = (long)nm*ldcc; s.dnp = make_fastdiv((uint32_t)npair); s.groups = 1; s.dgr = make_fastdiv(1);
+			s.ld = ldcc; s.w = wcc; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -669,21 +700,24 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 	const long npair = (nm + 1)/2;
 	const long g = tp.g, bN = tp.bN, ac = tp.ac;
 	const long ldY1 = pad8(bN), ldU = pad8(g);
-	s1_.ensure(sizeof(double2)*(size_t)npair*g*ldY1); s2_.ensure(sizeof(double2)*(size_t)npair*ac*ldU);
-	for (int c = 0; c < nc; c++) {
+	const size_t need1 = (size_t)npair*g*ldY1, need2 = (size_t)npair*ac*ldU;
+	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
+	for (int c0 = 0; c0 < nc; c0 += cchunk) {
+		const long ncl = std::min(cchunk, nc - c0);
 		{	StFirst s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
-			s.src.leg = leg + (size_t)c*nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
-			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1;
+			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, tile_lines(g, 0, bN, 8), bN, tp.N);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, ac);
 			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldU; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, tile_lines(bN, ac, g, 8), g, tp.Ncc);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
@@ -692,8 +726,9 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 			set_tiles(s, T, (long)((ac/2 + 1 + TH - 1)/TH)*T, 0);
 			s.TH = TH;
 			s.U = s2_.as<double2>(); s.ldU = ldU; s.a = (int)ac; s.g = (int)g; s.X = (int)tp.Ncc; s.mir_c = 0; s.nr_out = ncc; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
-			s.out = leg_cc + (size_t)c*nm*ldcc; s.ld = ldcc; s.w = w; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
-			launch_stage(s, npair*s.ntile, st);
+			s.out = leg_cc + (size_t)c0*nm*ldcc; s.ocstride = (long)nm*ldcc; s.dnp = make_fastdiv((uint32_t)npair); s.groups = 1; s.dgr = make_fastdiv(1);
+			s.ld = ldcc; s.w = w; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -705,21 +740,24 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 	const long npair = (nm + 1)/2;
 	const long gs = tp.gs, bs = tp.bs, aN = tp.aNs;
 	const long ldY = pad8(bs), ldZ = pad8(gs);
-	s1_.ensure(sizeof(double2)*(size_t)npair*gs*ldY); s2_.ensure(sizeof(double2)*(size_t)npair*aN*ldZ);
-	for (int c = 0; c < nc; c++) {
+	const size_t need1 = (size_t)npair*gs*ldY, need2 = (size_t)npair*aN*ldZ;
+	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
+	for (int c0 = 0; c0 < nc; c0 += cchunk) {
+		const long ncl = std::min(cchunk, nc - c0);
 		{	StFirst s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
-			s.src.leg = leg_cc + (size_t)c*nm*ldcc; s.src.ld = ldcc; s.src.nr = ncc; s.src.N = (int)tp.Ncc; s.src.mir_c = 0; s.src.a_odd = spin & 1; s.src.ncol = nm;
-			s.b = (int)bs; s.Y = s1_.as<double2>(); s.ldY = ldY;
+			s.src.leg = leg_cc + (size_t)c0*nm*ldcc; s.src.cstride = (long)nm*ldcc; s.src.ld = ldcc; s.src.nr = ncc; s.src.N = (int)tp.Ncc; s.src.mir_c = 0; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.b = (int)bs; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, tile_lines(gs, 0, bs, 8), bs, tp.Ncc);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bs); s.fb = mk(fc_, aN);
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)gs; s.X1 = (int)tp.Ncc; s.X2 = (int)tp.N; s.kmax = lmax; s.nyq = 0;
 			s.ph = ph_up; s.dg = make_fastdiv((uint32_t)gs);
 			set_tiles(s, tile_lines(bs, aN, gs, 8), gs, tp.N);
-			launch_stage(s, npair*s.ntile, st);
+			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<1> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
@@ -727,9 +765,10 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 			set_tiles(s, T, aN*T, 0);         // one tile per line: ntile = aN
 			s.TH = 0;
 			s.U = s2_.as<double2>(); s.ldU = ldZ; s.a = (int)aN; s.g = (int)gs; s.X = (int)tp.N; s.mir_c = mir_c; s.nr_out = nr; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
-			s.out = h + (size_t)c*nr*ldh; s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)aN);
 			const long groups = (npair + T/2 - 1)/(T/2);
-			launch_stage(s, groups*aN, st);
+			s.out = h + (size_t)c0*nr*ldh; s.ocstride = (long)nr*ldh; s.dnp = make_fastdiv((uint32_t)npair); s.groups = (int)groups; s.dgr = make_fastdiv((uint32_t)groups);
+			s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)aN);
+			launch_stage(s, ncl*groups*aN, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());

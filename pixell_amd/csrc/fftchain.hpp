@@ -50,6 +50,10 @@ public:
 	void from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
 	                     int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w);
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
+	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc)
+	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);
+	void ring_scratch(long nring, int nc, bool analysis, size_t& b1) const;
+	void reserve(size_t b1, size_t b2) { s1_.ensure(b1); s2_.ensure(b2); }
 private:
 	const double2* small_tw(long X, int n, int T);
 	template<class S> void set_tiles(S& s, int T, long nlines, long X);

@@ -17,9 +17,10 @@
 //    (mantissa, scale) with value = mantissa * 2^(800*scale), is advanced without accumulating
 //    until some lane of the wave reaches scale 0, then advanced with gated accumulation until all
 //    lanes have, then runs the branch-free fast loop;
-//  * analysis needs sum over rings (lanes) for every l: partial sums of 4 k-steps are transposed
-//    through a 16x66 LDS tile (conflict free) and reduced by 16 lanes each, one 128-byte store of
-//    partial moments per wave per 4 steps; a second tiny kernel sums the waves.
+//  * analysis needs the sum over rings (lanes) for every l: the 4 sums of a step are reduce-scattered over the lanes with
+//    v_permlane32_swap / v_permlane16_swap, one ds_write_b64 per step parks them in a tile of 16 steps; at a flush lane j owns
+//    output j, adds its 16 partial sums and the wave issues one contiguous 512-byte global_atomic_add_f64 into the moments
+//    (PXS_DETERMINISTIC=1: per-wave partial moments summed in wave order by reduce_partials instead).
 #include "legendre.hpp"
 #include <cmath>
 #include <algorithm>
@@ -73,7 +74,17 @@ struct LegK {
 	// recurrence seeds: the state of every chain at the end of phase A, per (m, wave): [nd][K][64] doubles, [ni][K][64] + 64 ints
 	// (the first of the last 64: the step reached).  mode 0: off, 1: run phase A and record, 2: load instead of running it
 	int seed_mode; double* seed_d; int* seed_i;
+	// executed-work counters (profiling on: pxs_profile; null otherwise): count[0] synthesis, count[1] analysis, in FMA instructions
+	// per lane: every wave adds (steps it ran) x K x (FMAs per ring pair and step: 6 per two degrees for spin 0, 12 per degree for
+	// spin s; 2 / 4 in the recurrence-only phase A).  x 64 lanes x 2 = the FP64 flops the hardware executed in the recurrences and
+	// accumulations (rings dropped as polar-dead and (wave, m) pairs skipped entirely are not in it, masked-off lanes are).
+	double* count;
 };
+#ifdef PXS_HOST_SIM
+#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) atomicAdd(a.count + (dir), (double)(expr))
+#else
+#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) unsafeAtomicAdd(a.count + (dir), (double)(expr))
+#endif
 
 // Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
 // scalar cache; workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  With the plain
@@ -373,6 +384,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 		// phase A: nobody at scale 0 yet -> recurrence only, 4 steps per check (S0_PHASE_A)
 		S0_SEEDED_PHASE_A
 		k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+		PXS_COUNT(0, (long)(nk - k)*K*6 + (a.seed_mode != 2 ? (long)k*K*2 : 0L));
 		// phase B: some lanes are still below scale 0.  The steps are the plain fast steps (no per-lane gating); every
 		// 4 steps the lanes below scale 0 are rescaled.  Such a lane accumulates scaled-up garbage meanwhile; its sums are
 		// reset when it reaches scale 0 (its true terms before that are < 2^-340 of the final value).
@@ -584,6 +596,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	int k = 0;
 	S0_SEEDED_PHASE_A
 	k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	PXS_COUNT(1, (long)(nk - k)*K*6 + (a.seed_mode != 2 ? (long)k*K*2 : 0L));
 	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = k + 1;      // rows before k are not written (reduce_partials skips them)
 	// ring data of the lanes that start at scale 0 or reached it during phase A (rings without signal have lam = 0)
 #pragma unroll
@@ -749,6 +762,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 		int j = 0;
 		SPIN_SEEDED_PHASE_A
 		j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+		PXS_COUNT(0, (long)(nl - j)*K*12 + (a.seed_mode != 2 ? (long)j*K*4 : 0L));
 		sg0 = ((l0 + j + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m) of the first accumulated step; pairs of steps keep the parity
 		// phase B: plain fast steps; every 4 steps the chains below scale 0 are rescaled.  A lane's sums hold scaled-up
 		// garbage until both of its chains are at scale 0, when they are reset (true terms before that: < 2^-340 of the result)
@@ -880,6 +894,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	int j = 0;
 	SPIN_SEEDED_PHASE_A
 	j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	PXS_COUNT(1, (long)(nl - j)*K*12 + (a.seed_mode != 2 ? (long)j*K*4 : 0L));
 	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = j + 1;      // rows before j are not written (reduce_partials skips them)
 	// ring data of the lanes whose chains start at scale 0 or both reached it during phase A
 #pragma unroll
@@ -1064,6 +1079,7 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	a.leg = leg; a.ld = ld > 0 ? ld : rs.nring;
 	a.ofs = std::max(100.0, 0.01*tb.lmax);
 	a.nmc = a.nm; a.xcd = xcd_map();
+	a.count = wk.count_on ? wk.count.as<double>() : nullptr;
 	return a;
 }
 

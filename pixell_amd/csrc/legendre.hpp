@@ -48,6 +48,7 @@ struct LegWork {     // scratch owned by the SHT plan
 	               ~Seeds() { if (written) (void)hipEventDestroy(written); } };
 	std::map<std::tuple<const void*, int, int, int>, Seeds> seeds;
 	size_t seed_budget = size_t(16) << 30, seed_bytes = 0;     // PXS_SEED_GB; 0 turns the seeds off
+	DevBuf count; bool count_on = false;                       // executed-work counters of the Legendre kernels (LegK::count), while profiling
 };
 
 

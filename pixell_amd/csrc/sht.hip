@@ -25,6 +25,7 @@ namespace pxs {
 
 FftContext& fft_context(int device);
 void fft_dense_lines(int device, hipStream_t st, long n, bool forward, long nlines, const double2* in, double2* out);   // api_fft.hip
+void fft_release_stream(int device, hipStream_t st);                                                                  // api_fft.hip
 const char* get_last_error();
 
 typedef long double LDb;
@@ -334,7 +335,7 @@ struct pxs_plan {
 	DevBuf g_blk_ring, g_blk_k0, g_nphi, g_zoff, g_rstart, g_phi0, gz; long g_nblk = 0;
 	std::vector<hipStream_t> gstreams; std::vector<hipEvent_t> gjoin; hipEvent_t gfork = nullptr;
 	~pxs_plan() {
-		for (auto s_ : gstreams) (void)hipStreamDestroy(s_);
+		for (auto s_ : gstreams) { pxs::fft_release_stream(device, s_); (void)hipStreamDestroy(s_); }
 		for (auto e : gjoin) (void)hipEventDestroy(e);
 		if (gfork) (void)hipEventDestroy(gfork);
 	}
@@ -907,7 +908,27 @@ int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out) {
 	return 0;
 }
 
-int pxs_profile(pxs_plan* p, int enable) { if (!p) return PXS_ERR_ARG; p->prof.enabled = enable != 0; return 0; }
+int pxs_profile(pxs_plan* p, int enable) {
+	PXS_TRY
+	PXS_REQUIRE(p, "pxs_profile: null plan");
+	p->prof.enabled = enable != 0;
+	if (enable && !p->wk.count.p) { PXS_HIP(hipSetDevice(p->device)); p->wk.count.alloc(2*sizeof(double)); PXS_HIP(hipMemset(p->wk.count.p, 0, 2*sizeof(double))); }
+	p->wk.count_on = enable != 0;
+	PXS_CATCH
+}
+
+int pxs_profile_flops(pxs_plan* p, double* flops, int reset) {
+	PXS_TRY
+	PXS_REQUIRE(p && flops, "pxs_profile_flops: null argument");
+	flops[0] = flops[1] = 0;
+	if (!p->wk.count.p) return 0;
+	PXS_HIP(hipSetDevice(p->device));
+	PXS_HIP(hipDeviceSynchronize());
+	double c[2]; PXS_HIP(hipMemcpy(c, p->wk.count.p, sizeof(c), hipMemcpyDeviceToHost));
+	flops[0] = c[0]*128.0; flops[1] = c[1]*128.0;          // FMA instructions per lane x 64 lanes x 2 flops
+	if (reset) PXS_HIP(hipMemset(p->wk.count.p, 0, sizeof(c)));
+	PXS_CATCH
+}
 
 int pxs_profile_read(pxs_plan* p, double* ms, int* counts, int reset) {
 	PXS_TRY
@@ -990,6 +1011,40 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 	}
 }
 
+// Scratch of a call is sized HERE, before its first launch (the fused-chain paths every BASELINE configuration takes; a plan's
+// buffers only grow, so this allocates on the first call of a kind and when a later call brings a larger batch).  The `ensure`
+// calls further down are then no-ops; they remain as the allocation points of the rarely taken paths (general ring sets,
+// unfused FFTs, the deterministic analysis), where a growing buffer is freed between launches through hipFree's device sync.
+static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool adjoint, int nb) {
+	if (p->general || !p->chain_rings) return;
+	const int ncm = synthesis ? ncomp_of(spin, mode, false) : (spin == 0 ? 1 : 2), nct = nb*ncm;
+	const size_t nm = (size_t)p->mmax + 1, nr = (size_t)p->nring, c16 = sizeof(double2);
+	const bool th = p->chain_theta();
+	const size_t ldm = (size_t)FftChain::pad8(p->nring), ldc = (size_t)p->ld_cc(), ldh = (size_t)p->ld_h();
+	const bool via_cc = (p->is_grid || (p->band && th)) && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
+	LegTables& tb = p->table(spin);
+	size_t c1 = 0, c2 = 0, r1 = 0;
+	auto theta = [&](int kind) { if (th) FftChain::theta_scratch(p->tp, (int)nm, nct, kind, c1, c2); };
+	if (synthesis && !adjoint) {                        // alm -> map
+		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
+		p->leg.ensure(c16*nct*nm*ldm);
+		if (via_cc) { p->leg2.ensure(c16*nct*nm*ldc); if (th) { p->hbuf.ensure(c16*nct*(p->band ? (size_t)p->nfull : nr)*ldh); theta(2); } }
+		else p->hbuf.ensure(c16*nct*nr*ldh);
+		p->chain->ring_scratch(p->nring, nct, false, r1);
+	} else if (synthesis) {                             // map -> alm, transpose of the synthesis
+		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
+		const bool via = (p->is_grid || p->band) && th && p->geometry == "F1" && via_cc;
+		p->leg.ensure(c16*nct*nm*(via && p->band ? (size_t)FftChain::pad8(p->nfull) : ldm));
+		if (via) { p->leg2.ensure(c16*nct*nm*ldc); theta(1); }
+		p->chain->ring_scratch(p->nring, nct, true, r1);
+	} else if (!adjoint && !p->wring.p && th) {         // analysis_2d
+		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
+		p->leg.ensure(c16*nct*nm*ldm); p->leg2.ensure(c16*nct*nm*ldc); theta(0);
+		p->chain->ring_scratch(p->nring, nct, true, r1);
+	} else return;
+	p->chain->reserve(std::max(c1, r1), c2);
+}
+
 // maps per pass of a batched call: bounded by the scratch the plan may hold (leg + leg_cc + h per map, and the chain scratch)
 static int batch_chunk(const pxs_plan* p, int nbatch, int ncm) {
 	if (nbatch <= 1 || !p->chain_rings) return 1;           // the unfused paths take one map at a time
@@ -1011,7 +1066,11 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint, int nbatch,
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
-	const int chunk = batch_chunk(p, nbatch, ncomp_of(spin, mode, false));
+	// (a grid whose ring FFTs are chained but whose theta resampling is not -- 2 ntheta with a prime factor >= 7 -- takes the
+	// CC detour through the unfused resampling, one map at a time)
+	const bool cc_unfused = !adjoint && (p->is_grid || p->band) && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0 && !p->chain_theta();
+	const int chunk = cc_unfused ? 1 : batch_chunk(p, nbatch, ncomp_of(spin, mode, false));
+	reserve_call(p, spin, mode, true, adjoint != 0, std::min(chunk, nbatch));
 	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
 		const int nb = std::min(chunk, nbatch - b0);
 		synthesis_core(p, spin, mode, adjoint, nb, (char*)alm + aesz*(size_t)b0*alm_bstride, alm_dtype, alm_cstride, alm_bstride,
@@ -1088,6 +1147,7 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint, int nbatch,
 	hipStream_t st = (hipStream_t)stream;
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
 	const int chunk = p->wring.p ? batch_chunk(p, nbatch, spin == 0 ? 1 : 2) : (adjoint || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
+	reserve_call(p, spin, PXS_MODE_STANDARD, false, adjoint != 0, std::min(chunk, nbatch));
 	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
 		const int nb = std::min(chunk, nbatch - b0);
 		analysis_core(p, spin, adjoint, nb, (char*)map + mesz*(size_t)b0*map_bstride, map_dtype, map_cstride, map_bstride,

@@ -89,7 +89,11 @@ def analyse_geometry(shape, wcs, tol=1e-6): return _geo.analyse(shape, wcs, tol=
 def get_method(shape, wcs, minfo=None, pix_tol=1e-6):
 	return _geo.method_of((minfo if minfo is not None else _geo.analyse(shape, wcs, tol=pix_tol)).case)
 def get_ring_info(shape, wcs, dtype=np.float64): return _geo.ring_tables(shape, wcs, dtype=dtype)
-def quad_weights(shape, wcs, pix_tol=1e-6): return _geo.ring_weights(shape, wcs, sht.get_gridweights, tol=pix_tol)
+def quad_weights(shape, wcs, pix_tol=1e-6, row_order="reference"):
+	"""curvedsky.quad_weights (curvedsky.py:492-505), result for result: the grid's ring weights / nx, SOUTH-first whatever the
+	map's row order (the reference reverses the north-first weights for every map).  row_order="map" returns them in the order of
+	the map's rows instead -- the two differ only for maps stored north to south."""
+	return _geo.ring_weights(shape, wcs, sht.get_gridweights, tol=pix_tol, row_order=row_order)
 
 # ---------------------------------------------------------------------------------------
 # array plumbing
@@ -343,7 +347,7 @@ def jacobi_inverse(forward, approx_backward, y, niter=0):
 		x = x+approx_backward(y-forward(x))
 	return x
 
-def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], weights=None, deriv=False, copy=False, verbose=False, adjoint=False, nthread=None, pix_tol=1e-6, niter=0):
+def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], weights=None, deriv=False, copy=False, verbose=False, adjoint=False, nthread=None, pix_tol=1e-6, niter=0, weights_order="reference"):
 	"""curvedsky.map2alm_cyl + map2alm_raw_cyl (curvedsky.py:843-873, 1050-1086): quadrature
 	weights (exact grid weights where available) + Jacobi refinement around the HIP transforms."""
 	if adjoint:
@@ -354,21 +358,33 @@ def map2alm_cyl(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], w
 	# (with deriv the alm has no component axis; the reference allocates [2,nelem] here and then fails its shape check)
 	alm, ainfo = prepare_alm(alm=alm, ainfo=ainfo, lmax=lmax, pre=map.shape[:-3] if deriv else map.shape[:-2], dtype=_np_dtype(mdata), convert=adjoint, like=mdata)
 	if minfo is None: minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
+	# Row weights.  The reference applies `weights` to the rows of its flipped buffer (north first: map2buffer, curvedsky.py:866-868),
+	# here the rings are the map's rows as stored.  weights_order="reference" (default) reproduces the reference result for result:
+	#   caller-supplied weights are taken north-first; default weights of a named grid are the grid's (physically right in both);
+	#   default weights off the grid are the pixel areas, which the reference reverses for every map (`if minfo.flip:` on a list,
+	#   curvedsky.py:860) -- right for maps stored south to north, mirrored for maps stored north to south.
+	# weights_order="map": weight i belongs to map row i, pixel areas unmirrored.
+	if weights_order not in ("reference", "map"): raise ValueError("weights_order must be 'reference' or 'map'")
+	ref_order = weights_order == "reference"
 	if weights is None:
 		if minfo.ducc_geo is not None and minfo.ducc_geo.name in _geo.WEIGHTED_GRIDS:
-			weights = quad_weights(map.shape, map.wcs, pix_tol=pix_tol)
+			weights = quad_weights(map.shape, map.wcs, pix_tol=pix_tol, row_order="map")
 		else:
 			# pixel area of each row (enmap.pixsizemap separable; curvedsky.py:858-860)
 			ny, nx = map.shape[-2:]
 			dec = enmap.pix2sky(map.shape, map.wcs, [np.concatenate([np.arange(ny)-0.5, [ny-0.5]]), np.zeros(ny+1)])[0]
 			dec = np.clip(dec, -np.pi/2, np.pi/2)
 			weights = np.abs(np.sin(dec[1:])-np.sin(dec[:-1]))*abs(map.wcs.wcs.cdelt[0])*degree
-	weights = np.asarray(weights, dtype=_np_dtype(mdata))
+			if ref_order and not minfo.flip[0]: weights = weights[::-1]
+	else:
+		weights = np.asarray(weights.cpu() if _is_tensor(weights) else weights)
+		if ref_order and minfo.flip[0]: weights = weights[::-1]
+	weights = np.ascontiguousarray(weights, dtype=_np_dtype(mdata))
 	pads = _native_pads(minfo, use_y=False)
 	if pads != ((0, 0), (0, 0)):
 		# partial-width map: zero-extend the rings to the full circle (curvedsky.py:866-871); weights are per row
 		pmap = _padded_like(map, pads, fill=not adjoint)
-		res = map2alm_cyl(pmap, alm=alm, ainfo=ainfo, lmax=lmax, spin=spin, weights=weights, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol, niter=niter)
+		res = map2alm_cyl(pmap, alm=alm, ainfo=ainfo, lmax=lmax, spin=spin, weights=weights, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol, niter=niter, weights_order="map")
 		if not adjoint: return res
 		_crop_into(map, pmap, pads)
 		return map
@@ -468,7 +484,7 @@ def alm2map_raw_cyl(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, 
 	return alm2map_cyl(alm, map, ainfo=ainfo, minfo=_require_case(map, minfo, ("2d", "cyl"), "alm2map_raw_cyl"), spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread)
 def map2alm_raw_cyl(map, alm=None, ainfo=None, lmax=None, spin=[0, 2], weights=None, deriv=False, copy=False, verbose=False, adjoint=False, niter=0, nthread=None):
 	"""weighted adjoint_synthesis + Jacobi refinement on the rows of a map whose rings close the circle (curvedsky.py:1050-1086)"""
-	return map2alm_cyl(map, alm=alm, ainfo=ainfo, minfo=_require_case(map, None, ("2d", "cyl"), "map2alm_raw_cyl"), lmax=lmax, spin=spin, weights=weights, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread, niter=niter)
+	return map2alm_cyl(map, alm=alm, ainfo=ainfo, minfo=_require_case(map, None, ("2d", "cyl"), "map2alm_raw_cyl"), lmax=lmax, spin=spin, weights=weights, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread, niter=niter, weights_order="map")      # (raw: weight i multiplies row i of the array handed in, curvedsky.py:1064-1065)
 
 def alm_complex2real(alm, ainfo=None):
 	"""complex alm (m >= 0 storage) -> real vector of the same information with unit Jacobian: the m = 0 block keeps its real
@@ -697,10 +713,23 @@ def transpose_alm(ainfo, alm, out=None):
 	return out
 alm_info.transpose_alm = lambda self, alm, out=None: transpose_alm(self, alm, out=out)
 
-def rand_alm_white(ainfo, pre=None, alm=None, seed=None, dtype=np.complex128, m_major=True):
+def rand_alm_white(ainfo, pre=None, alm=None, seed=None, dtype=np.complex128, m_major=True, rng="numpy"):
 	"""unit-variance complex Gaussian numbers for every alm slot.  To give the same alm as pixell for a seed (curvedsky.py:602-628)
 	the numbers come from numpy's legacy global RNG, are drawn in l-major order ((l,m) = (0,0), (1,0), (1,1), ...) and are
-	then moved to the m-major layout unless m_major is False."""
+	then moved to the m-major layout unless m_major is False.
+	rng="device" (ours, for throughput: Monte-Carlo loops spend 1.4 s per lmax-10^4 realisation in the host generator): the numbers
+	are drawn on the GPU (torch's Philox generator seeded with `seed`) straight into the m-major layout and stay there (a CUDA
+	tensor is returned) -- same distribution, NOT the reference's numbers for a seed."""
+	if rng == "device":
+		torch = _torch()
+		if alm is not None: raise ValueError("rng='device' allocates its own (device) alm")
+		g = torch.Generator(device="cuda")
+		if seed is not None: g.manual_seed(int(seed))
+		else: g.seed()
+		shape = (tuple(pre) if pre is not None else ())+(ainfo.nelem, 2)
+		rt = torch.float32 if np.dtype(dtype) == np.dtype(np.complex64) else torch.float64
+		return torch.view_as_complex(torch.randn(shape, generator=g, dtype=rt, device="cuda"))
+	if rng != "numpy": raise ValueError("rng must be 'numpy' or 'device'")
 	if seed is not None: np.random.seed(seed)
 	if alm is None: alm = np.empty((tuple(pre) if pre is not None else ())+(ainfo.nelem,), dtype)
 	fill_gauss(alm)
@@ -712,17 +741,21 @@ def rand_alm_white(ainfo, pre=None, alm=None, seed=None, dtype=np.complex128, m_
 		return alm
 	return ainfo.transpose_alm(alm, alm)
 
-def rand_alm(ps, ainfo=None, lmax=None, seed=None, dtype=np.complex128, m_major=True, return_ainfo=False):
+def rand_alm(ps, ainfo=None, lmax=None, seed=None, dtype=np.complex128, m_major=True, return_ainfo=False, rng="numpy"):
 	"""Gaussian alm with (cross) spectrum ps [nl], [nspec,nl] or [ncomp,ncomp,nl] (curvedsky.rand_alm, curvedsky.py:61-79):
 	white numbers (rand_alm_white), coloured by the matrix square root of the spectrum on the GPU (alm_info.lmul); the factor
-	1/sqrt(2) shares the variance between real and imaginary parts, m = 0 is made real with the full variance."""
+	1/sqrt(2) shares the variance between real and imaginary parts, m = 0 is made real with the full variance.
+	rng="device": see rand_alm_white (device-resident result, device generator)."""
 	ps = np.asarray(ps)
 	wps, ainfo = prepare_ps(ps, ainfo=ainfo, lmax=lmax)
-	white = rand_alm_white(ainfo, pre=[wps.shape[0]], seed=seed, dtype=dtype, m_major=m_major)
+	white = rand_alm_white(ainfo, pre=[wps.shape[0]], seed=seed, dtype=dtype, m_major=m_major, rng=rng)
 	colour = (_multi_sqrt(wps)/np.sqrt(2.0)).astype(real_dtype(dtype), copy=False)
 	alm = ainfo.lmul(white, colour)
-	m0 = alm[:, :ainfo.lmax+1]                        # the m = 0 column comes first in the m-major layout
-	m0.imag = 0; m0.real *= np.sqrt(2.0)
+	if _is_tensor(alm):
+		alm[:, :ainfo.lmax+1] = (alm[:, :ainfo.lmax+1].real*np.sqrt(2.0)).to(alm.dtype)
+	else:
+		m0 = alm[:, :ainfo.lmax+1]                        # the m = 0 column comes first in the m-major layout
+		m0.imag = 0; m0.real *= np.sqrt(2.0)
 	alm = alm[0] if ps.ndim == 1 else alm
 	return (alm, ainfo) if return_ainfo else alm
 

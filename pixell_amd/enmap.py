@@ -51,6 +51,7 @@ class dmap:
 def _sliced(parent, res, sel):
 	"""wrap the result of parent[sel] with the geometry it now has (None axes / Ellipsis / leading-axis indexing allowed)"""
 	nd = parent.ndim
+	if isinstance(parent, ndmap) and not isinstance(res, np.ndarray): return res     # every axis indexed: a numpy scalar stays one
 	sel = sel if isinstance(sel, tuple) else (sel,)
 	if any(isinstance(x, (list, np.ndarray)) or hasattr(x, "data_ptr") for x in sel):
 		return np.asarray(res) if isinstance(parent, ndmap) else res          # fancy indexing: no geometry

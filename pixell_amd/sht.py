@@ -82,6 +82,11 @@ class Plan:
 		_lib.check(_lib.load().pxs_profile_read(self.handle, ms, cnt, int(bool(reset))))
 		names = ["leg_syn", "leg_ana", "ring_fft", "resample"]
 		return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
+	def profile_flops(self, reset=True):
+		"""FP64 flops the Legendre kernels executed while profiling was on: (synthesis, analysis) (pxs_profile_flops)"""
+		f = (ctypes.c_double*2)()
+		_lib.check(_lib.load().pxs_profile_flops(self.handle, f, int(bool(reset))))
+		return f[0], f[1]
 	def info(self):
 		a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
 		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))

@@ -60,17 +60,19 @@ def flipped(shape, wcs, flip):
 	return tuple(shape), w
 
 def slice_geometry(shape, wcs, sel):
-	"""geometry of map[..., sel_y, sel_x] for two slice objects (any start / stop / step, negative steps included): the
-	first selected pixel becomes pixel 0 and the increments are multiplied by the step (what enmap.slice_geometry does,
-	enmap.py:264-285)"""
+	"""geometry of map[..., sel_y, sel_x] for two slice objects (any start / stop / step, negative steps included), with the
+	convention of enmap.slice_geometry (enmap.py:264-285): the new pixels tile the area the selected pixels covered, i.e. the
+	EDGE of the first selected pixel (its lower edge for a positive step, its upper edge for a negative one) stays where it was
+	and the pixel size is multiplied by the step.  For |step| = 1 that also keeps the pixel centres; for larger steps the centre
+	of new pixel p lies (|step| - 1)/2 old pixels beyond old pixel start + p*step."""
 	w = wcs.deepcopy()
 	oshape = list(shape)
 	for axis, sl in zip((-2, -1), sel):                   # y is the second WCS axis, x the first
 		n = shape[axis]; start, stop, step = sl.indices(n)
 		count = len(range(start, stop, step))
 		k = 1 if axis == -2 else 0
-		# 0-based pixel p of the new map is pixel start + p*step of the old one
-		w.wcs.crpix[k] = (w.wcs.crpix[k]-1-start)/step+1
+		edge = start-0.5 if step > 0 else start+0.5          # 0-based position of the outer edge of the first selected pixel
+		w.wcs.crpix[k] = (w.wcs.crpix[k]-1-edge)/step+0.5    # (1-based crpix: pixel centre c sits at crpix c+1)
 		w.wcs.cdelt[k] = w.wcs.cdelt[k]*step
 		oshape[axis] = count
 	return tuple(oshape), w

@@ -13,10 +13,15 @@ def _have_gpu():
 		return False
 
 HAVE_GPU = _have_gpu()
-if not HAVE_GPU:
-	# GPU-less container: the kernels' index logic is exercised through the TEST-ONLY host
-	# simulator (same .hip sources compiled with g++, see pixell_amd/csrc/hostsim.hpp).
-	os.environ["PIXELL_AMD_HOSTSIM"] = "1"
+HOSTSIM_LIB = os.path.join(ROOT, "tests", "hostsim", "libpxsht_hostsim.so")
+
+def use_hostsim():
+	"""GPU-less container: the kernels' index logic is exercised through the TEST-ONLY host simulator (same .hip sources compiled
+	with g++, see pixell_amd/csrc/hostsim.hpp).  The switch lives here, not in the product loader: the test process points the
+	loader's `lib_path` at the simulator build before anything loads the library."""
+	from pixell_amd import _lib
+	assert _lib._lib is None, "the library was loaded before the test configuration could select the simulator"
+	_lib.lib_path = lambda: HOSTSIM_LIB
 
 def pytest_configure(config):
 	config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -25,6 +30,7 @@ def pytest_configure(config):
 		sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
 		import build_hostsim
 		build_hostsim.build()
+		use_hostsim()
 
 def pytest_collection_modifyitems(config, items):
 	skip_gpu = pytest.mark.skip(reason="no GPU in this environment")

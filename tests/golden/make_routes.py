@@ -1,6 +1,6 @@
 """Exercise the two integration routes of INTEGRATION.md against the REFERENCE in this container and record fixtures.
 
-Run:  PIXELL_AMD_HOSTSIM=1 python tests/golden/make_routes.py     (needs /root/reference; never run on the GPU box)
+Run:  python tests/golden/make_routes.py     (needs /root/reference; never run on the GPU box)
 
 Route B2 -- stock pixell.curvedsky over pixell_amd.sht:  the reference's own curvedsky module is imported (stub astropy
   WCS, see _ref_harness.py) TWICE: once with the long-double oracle and once with pixell_amd.sht (kernels running in the
@@ -22,9 +22,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 sys.path.insert(0, HERE)
-os.environ.setdefault("PIXELL_AMD_HOSTSIM", "1")
 sys.path.insert(0, os.path.join(HERE, "..", "hostsim"))
 import build_hostsim; build_hostsim.build()
+sys.path.insert(0, os.path.join(HERE, ".."))
+import conftest; conftest.use_hostsim()      # the build container has no GPU: the kernels run in the test-only simulator
 from oracle import sht_oracle as so
 from pixell_amd import sht as psht, fft as pfft_amd
 import _ref_harness as H

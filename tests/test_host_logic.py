@@ -86,10 +86,16 @@ def test_slicing_moves_the_geometry():
 	for sel in [(Ellipsis, slice(2, 9), slice(4, 20)), (slice(None), slice(None, None, -1), slice(None)), (1, slice(3, None, 2), slice(None, None, -3)), (Ellipsis, slice(5, 7))]:
 		sub = m[sel]
 		assert isinstance(sub, enmap.ndmap) and np.array_equal(np.asarray(sub), np.asarray(m)[sel])
-		# the sky position of every pixel of the slice is that of the pixel it came from
+		# enmap.slice_geometry's convention (enmap.py:264-285, fixtures in test_round3_fixtures.py): the new pixels tile the area of
+		# the selected ones -- new pixel p spans old pixel start + p*step and the |step| - 1 old pixels after it in walking
+		# direction, so its centre lies (|step| - 1)/2 old pixels beyond the centre of old pixel start + p*step
 		yy, xx = np.mgrid[:12, :24]
 		src_y = np.broadcast_to(yy, m.shape)[sel]; src_x = np.broadcast_to(xx, m.shape)[sel]
-		src_y = src_y.reshape((-1,)+src_y.shape[-2:])[0]; src_x = src_x.reshape((-1,)+src_x.shape[-2:])[0]
+		src_y = src_y.reshape((-1,)+src_y.shape[-2:])[0].astype(float); src_x = src_x.reshape((-1,)+src_x.shape[-2:])[0].astype(float)
+		full = [s for s in sel if isinstance(s, slice)][-2:] if sel[0] is not Ellipsis else list(sel[1:])
+		full = [slice(None)]*(2-len(full))+full if sel[0] is not Ellipsis else full+[slice(None)]*(2-len(full))
+		sy, sx = [(s.step or 1) for s in full]
+		src_y += np.sign(sy)*(abs(sy)-1)/2; src_x += np.sign(sx)*(abs(sx)-1)/2
 		py, px = np.mgrid[:sub.shape[-2], :sub.shape[-1]]
 		assert np.allclose(enmap.pix2sky(sub.shape, sub.wcs, [py, px]), enmap.pix2sky(m.shape, m.wcs, [src_y, src_x]), atol=1e-13)
 	assert not isinstance(m[0, 3], enmap.ndmap)               # a pixel axis indexed away: plain array
