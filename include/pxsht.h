@@ -90,6 +90,10 @@ int pxs_plan_info(const pxs_plan* plan, int* nring_legendre_syn, int* nring_lege
  * out[10] = {ok, g, bN, g2, M, ac, Ncc, gs, bs, aNs} with N = g*bN, M = g*g2 (fine circle of the |sin| product), Ncc = ac*g
  * (Clenshaw-Curtis circle: Ncc/2+1 rings in the Legendre stage), synthesis: Ncc = gs*bs, N = aNs*gs.  See csrc/fftchain.hip. */
 int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out);
+/* Average milliseconds of one group of fused-chain stages of a plan, run `reps` times on scratch data (diagnostics and kernel
+ * experiments, tools/chain_lab.py).  kind 0: ring FFTs map -> leg (MA1, MA2), 1: ring FFTs h -> map (MS1, MS2), 2: theta
+ * resampling of the analysis (RA1-5), 3: of the synthesis (RS1-3), 4: transposed theta upsampling.  nc components in one call. */
+int pxs_debug_chain(pxs_plan* plan, int kind, int nc, int spin, int reps, double* ms);
 
 /* Optional device-side stage timers (hipEvents recorded on the launch stream around each stage):
  * used by bench.py to time the dominant kernel live.  ms[PXS_NSTAGE], counts[PXS_NSTAGE]. */

@@ -26,21 +26,46 @@
 
 namespace pxs {
 
+#ifndef PXS_CH_PTS
+#define PXS_CH_PTS 2560    /* complex points per tile */
+#endif
 #ifdef PXS_HOST_SIM
-static constexpr int CH_NT = 1, CH_MAXE = 2560;
+static constexpr int CH_NT = 1, CH_MAXE = PXS_CH_PTS;
 #else
 #ifndef PXS_CH_NT
 #define PXS_CH_NT 512      /* threads per workgroup: measured at config 3 (ring FFT + theta resampling, one stream) 256: 129 ms, 512: 115 ms */
 #endif
-static constexpr int CH_NT = PXS_CH_NT, CH_MAXE = (2560 + PXS_CH_NT - 1)/PXS_CH_NT;
+static constexpr int CH_NT = PXS_CH_NT, CH_MAXE = (PXS_CH_PTS + PXS_CH_NT - 1)/PXS_CH_NT;
 #endif
-static constexpr int CH_TILE_PTS = 2560;
+static constexpr int CH_TILE_PTS = PXS_CH_PTS;
 static constexpr int CH_NMAX = 512;           // longest LDS sub-transform of a chain stage      // points per tile = CH_NT * CH_MAXE on the device
 
 struct TileC { int outer, t0, nl, comp, q0; };
 
+// Tile-blocked intermediates (an option, see blocked_on()).  A stage whose lines are the fast index of its output ("line-fast"
+// store) writes runs of T*16 bytes (T = 8-16 lines: 128-256 bytes) at a row stride, and the next stage reads whole rows.  With the
+// blocked layout a writer's tile -- lines [t0, t0 + w) x all n outputs -- is ONE contiguous chunk [e][line in tile] of n*w points
+// at offset t0*n of its outer slab, and a reader, whose tile is Tr consecutive rows e, finds Tr*w points of every chunk contiguous
+// (1-2 KB).  BlkIn describes the chunks to the reader: width Tw of the full ones, their number, the width of the last one.
+struct BlkIn {
+	int Tw, nBf, wL; FastDiv dTTw, dTw, dwL;      // Tw = 0: plain rows of stride ld
+	// offset of (row `line` of nrows, element e of na) within the outer slab
+	__device__ __forceinline__ long off(int line, int e, int nrows) const {
+		const uint32_t B = fdiv((uint32_t)e, dTw);
+		const int w = (int)B < nBf ? Tw : wL;
+		return (long)B*Tw*nrows + (long)line*w + (e - (int)B*Tw);
+	}
+	// load order of a reader tile of T rows: chunk, row, element in chunk -- consecutive lanes read consecutive memory
+	__device__ __forceinline__ void split(int idx, int T, uint32_t& li, uint32_t& e) const {
+		uint32_t B = fdiv((uint32_t)idx, dTTw);
+		if ((int)B < nBf) { const uint32_t rem = idx - B*T*Tw; li = fdiv(rem, dTw); e = B*Tw + (rem - li*Tw); }
+		else { const uint32_t rem = idx - (uint32_t)nBf*T*Tw; li = fdiv(rem, dwL); e = (uint32_t)nBf*Tw + (rem - li*wL); }
+	}
+};
+
 struct StageBase {
 	LdsFft fa, fb;
+	BlkIn bin; int bout;       // input in the blocked layout (bin.Tw > 0); write the output blocked
 	int T; int ntile;
 	FastDiv dT, dna, dnb, dnt;
 	// four-step twiddle of the stage's output, W_X^{(t0 + li) e} = W_X^{t0 e} * W_X^{li e}: the first factor is gathered once per tile
@@ -86,7 +111,9 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 			const int idx = threadIdx.x + u*NT; pos[u] = -1;
 			if (idx < total) {
 				uint32_t li, e;
-				if (S::LOAD_LINE_FAST) { e = fdiv(idx, s.dT); li = idx - e*T; } else { li = fdiv(idx, s.dna); e = idx - li*na; }
+				if (S::LOAD_LINE_FAST) { e = fdiv(idx, s.dT); li = idx - e*T; }
+				else if (s.bin.Tw > 0) s.bin.split(idx, T, li, e);
+				else { li = fdiv(idx, s.dna); e = idx - li*na; }
 				v[u] = s.load(c, (int)li, (int)e);
 				if (S::INV_A) v[u].y = -v[u].y;
 				pos[u] = (int)li*s.fa.ns + s.fa.perm[e];
@@ -138,6 +165,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 // value of circle sample j of the packed pair of columns (2p, 2p+1): even + odd extension (cf. LD_MIRROR_PAIR in fft.hip)
 struct PairSrc {
 	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol; long cstride;      // cstride: elements between the components of a launch
+	const double2* w;        // optional per-ring weight (.x), applied to a ring sample and to its mirror image
 	__device__ __forceinline__ double2 get(int comp, int p, int j) const {
 		int src = j; bool mir = false;
 		if (j >= nr) { src = N - j - mir_c; if (src < 0) src += N; mir = true; }
@@ -150,7 +178,8 @@ struct PairSrc {
 		double2& vo = a_odd ? va : vb;
 		if (selfm) vo = make_double2(0, 0);
 		else if (mir) { vo.x = -vo.x; vo.y = -vo.y; }
-		return cadd(va, vb);
+		const double2 sum = cadd(va, vb);
+		return w ? cscale(sum, w[src].x) : sum;
 	}
 };
 
@@ -168,7 +197,8 @@ struct StFirst : StageBase {
 	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
 		if (li >= c.nl) return;
-		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(buf[li*ns + e], w); }
+		const long o = bout ? ((long)c.outer*b + c.t0)*fa.n + (long)e*c.nl + li : ((long)c.outer*fa.n + e)*ldY + c.t0 + li;
+		Y[o] = cmul(buf[li*ns + e], w); }
 };
 
 // pass 2 of transform X1 (forward, b1 points) + spectrum resize + pass 1 of transform X2 (backward, a2 points); shared modulus g.
@@ -180,11 +210,12 @@ struct StResize : StageBase {
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; double2* Z; long ldZ;
 	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
+	int adj;      // transposed padding rule (X1 > X2): conjugate phase, and the Nyquist slot of X2 collects 1/2 of both +-X2/2 bins of X1
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g - c.t0); return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
-		return Y[((long)c.outer*g + c.t0 + li)*ldY + e]; }
+		return bin.Tw > 0 ? Y[(long)c.outer*g*fa.n + bin.off(c.t0 + li, e, g)] : Y[((long)c.outer*g + c.t0 + li)*ldY + e]; }
 	__device__ __forceinline__ double2 mid(const TileC& c, int li, int e, const double2* A) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		const int k1 = c.t0 + li;
@@ -195,12 +226,23 @@ struct StResize : StageBase {
 		const int k = kap >= 0 ? kap : kap + X1;
 		const uint32_t k2 = fdiv((uint32_t)(k - k1), dg);
 		double2 v = A[k2];
+		if (adj) {
+			double2 t = ph ? ph[ak] : make_double2(1, 0);
+			if (2*ak == X2 && X1 != X2) {      // both bins are in this line: X1, X2 and hence +-X2/2 are congruent mod g
+				const double2 vm = A[fdiv((uint32_t)(X1 - ak - k1), dg)];
+				const double2 r = cadd(cmul(v, cconj(t)), cmul(vm, t));
+				return cscale(r, 0.5);
+			}
+			if (kap >= 0) t.y = -t.y;
+			return cmul(v, t);
+		}
 		if (nyq && 2*ak == X1) v = cscale(v, 0.5);
 		if (ph) { double2 t = ph[ak]; if (kap < 0) t.y = -t.y; v = cmul(v, t); }
 		return v; }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
 		if (li >= c.nl) return;
-		Z[((long)c.outer*fb.n + e)*ldZ + c.t0 + li] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
+		const long o = bout ? ((long)c.outer*g + c.t0)*fb.n + (long)e*c.nl + li : ((long)c.outer*fb.n + e)*ldZ + c.t0 + li;
+		Z[o] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
 };
 
 // pass 2 of IFFT_M (g points), pointwise product with the |sin| series samples, pass 1 of FFT_M (g points)
@@ -213,13 +255,14 @@ struct StSigma : StageBase {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g2 - c.t0); return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
-		return Z[((long)c.outer*g2 + c.t0 + li)*ldZ + e]; }
+		return bin.Tw > 0 ? Z[(long)c.outer*g2*fa.n + bin.off(c.t0 + li, e, g2)] : Z[((long)c.outer*g2 + c.t0 + li)*ldZ + e]; }
 	__device__ __forceinline__ double2 mid(const TileC& c, int li, int e, const double2* A) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		return cmul(cconj(A[e]), sigma[(c.t0 + li) + g2*e]); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
 		if (li >= c.nl) return;
-		V[((long)c.outer*g + e)*ldV + c.t0 + li] = cmul(buf[li*ns + e], w); }
+		const long o = bout ? ((long)c.outer*g2 + c.t0)*fb.n + (long)e*c.nl + li : ((long)c.outer*g + e)*ldV + c.t0 + li;
+		V[o] = cmul(buf[li*ns + e], w); }
 };
 
 // last pass of a backward chain (IFFT over r < g for the lines k1 < a, circle index t = k1 + a*k2) + separation of the packed pair
@@ -234,6 +277,7 @@ template<int MODE> struct StSplit : StageBase {
 	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
 	double2* out; long ld; const double2* w; const double2* tab; double scale; int TH; FastDiv da;
 	long ocstride; int groups; FastDiv dnp, dgr;      // components of a launch: output stride; MODE 0: outer = comp*npair + pair, MODE 1: outer = comp*groups + group
+	int self_half;     // self-mirrored output rings get weight 1/2 (adjoint of a mirror extension, which reads them once)
 	__device__ __forceinline__ int mirror_line(int k) const { int m = a - k - mir_c; if (m >= a) m -= a; if (m < 0) m += a; return m; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*(MODE == 0 ? TH : 1); c.nl = T;
@@ -262,6 +306,7 @@ template<int MODE> struct StSplit : StageBase {
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		int line, pair; slot(c, li, line, pair);
 		if (line < 0) return make_double2(0, 0);
+		if (MODE == 0 && bin.Tw > 0) return U[((long)c.comp*npair + pair)*a*fa.n + bin.off(line, e, a)];
 		return U[(((long)c.comp*npair + pair)*a + line)*ldU + e]; }
 	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
@@ -272,7 +317,7 @@ template<int MODE> struct StSplit : StageBase {
 		int tm = X - t - mir_c; if (tm >= X) tm -= X; if (tm < 0) tm += X;
 		const double2 z = cconj(buf[li*ns + e]);
 		double2 ev, od;
-		if (tm == t) { ev = z; od = make_double2(0, 0); }
+		if (tm == t) { ev = self_half ? cscale(z, 0.5) : z; od = make_double2(0, 0); }
 		else {
 			const int ml = mirror_line(line);
 			const int lp = (ml == line) ? li : (MODE == 0 ? (li < TH ? li + TH : li - TH) : (li ^ 1));
@@ -391,7 +436,8 @@ struct StRingS1 : StageBase {
 	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
 		if (li >= c.nl) return;
-		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
+		const long o = bout ? ((long)c.outer*b + c.t0)*fa.n + (long)e*c.nl + li : ((long)c.outer*fa.n + e)*ldY + c.t0 + li;
+		Y[o] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
 };
 
 // MS2: backward b-point transform over j2 for the lines k1; pixel x = k1 + a*k2: real part -> ring 2q, imaginary part -> ring 2q+1
@@ -404,7 +450,7 @@ struct StRingS2 : StageBase {
 		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
-		return Y[((long)c.outer*a + c.t0 + li)*ldY + e]; }
+		return bin.Tw > 0 ? Y[(long)c.outer*a*fa.n + bin.off(c.t0 + li, e, a)] : Y[((long)c.outer*a + c.t0 + li)*ldY + e]; }
 	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
 	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
 		if (li >= c.nl) return;
@@ -472,6 +518,19 @@ template<class S> void FftChain::set_tiles(S& s, int T, long nlines, long X) {
 	s.dna = make_fastdiv((uint32_t)s.fa.n); s.dnb = make_fastdiv((uint32_t)std::max(1, s.fb.n));
 	s.btw = nullptr; s.tws = nullptr;
 	if (X > 0) { s.tws = small_tw(X, S::TWO ? s.fb.n : s.fa.n, T); s.btw = s.tws ? fc_->twiddle_table(X) : nullptr; }
+}
+// blocked intermediates: OFF by default.  Measured (tools/chain_lab.py, same box): C3 chain stages 106.9 ms with rows, 108.1 ms
+// blocked; C4 26.6 / 26.6 -- the 128-byte runs of the intermediates are not what holds the chain kernels at ~3 TB/s (a bare
+// load-tile / LDS / store-tile kernel on contiguous 40 KB tiles reaches 5.3 TB/s with 2, 3 or 4 workgroups per CU, and an LDS-DMA
+// double-buffered persistent variant of it only 4.6: tools/dma_skel.hip).  PXS_CH_BLOCKED=1 turns the layout on for experiments.
+static bool blocked_on() { static const bool on = [] { const char* e = getenv("PXS_CH_BLOCKED"); return e ? atoi(e) != 0 : false; }(); return on; }
+// reader side of a blocked intermediate: the writer made chunks of Tw lines out of na, the reader's tile has T rows
+static BlkIn mk_blk(int Tw, long na, int T) {
+	BlkIn b; memset(&b, 0, sizeof(b));
+	if (!blocked_on()) return b;
+	b.Tw = Tw; b.nBf = (int)(na/Tw); b.wL = (int)(na - (long)b.nBf*Tw);
+	b.dTTw = make_fastdiv((uint32_t)(T*Tw)); b.dTw = make_fastdiv((uint32_t)Tw); b.dwL = make_fastdiv((uint32_t)std::max(b.wL, 1));
+	return b;
 }
 template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st) {
 	if (nblk <= 0) return;
@@ -592,6 +651,7 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
 	const long npair_all = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
 	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, 1);
+	const int T1 = tile_lines(a, 0, b, 8, 2*a), T2 = tile_lines(b, 0, a, 16, b);
 	s1_.ensure(sizeof(double2)*(size_t)nc*qchunk*a*ldY);
 	for (long q_lo = 0; q_lo < npair_all; q_lo += qchunk) {
 		const long npair = std::min(qchunk, npair_all - q_lo);
@@ -600,14 +660,14 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 			s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
 			s.h = h + 2*q_lo*ldh; s.ldh = ldh; s.hcomp = hcomp > 0 ? hcomp : m.nring; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
-			set_tiles(s, tile_lines(a, 0, b, 8, 2*a), b, nphi_);
+			set_tiles(s, T1, b, nphi_); s.bout = blocked_on();
 			launch_stage(s, (long)nc*npair*s.ntile, st);
 		}
 		{	StRingS2 s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.npair = (int)npair; s.m = map_addr(m); s.m.off0 += 2*q_lo*m.ring_stride; s.m.nring = nring;
 			s.dnp = make_fastdiv((uint32_t)npair);
-			set_tiles(s, tile_lines(b, 0, a, 16, b), a, 0);
+			set_tiles(s, T2, a, 0); s.bin = mk_blk(T1, b, T2);
 			launch_stage(s, (long)nc*npair*s.ntile, st);
 		}
 	}
@@ -625,7 +685,8 @@ void FftChain::theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size
 	size_t n1, n2;
 	if (kind == 0)      { n1 = npair*std::max(tp.g*pad8(tp.bN), tp.g*pad8(tp.g2)); n2 = npair*std::max(tp.g2*pad8(tp.g), tp.ac*pad8(tp.g)); }   // to_cc
 	else if (kind == 1) { n1 = npair*tp.g*pad8(tp.bN); n2 = npair*tp.ac*pad8(tp.g); }                                                    // from_cc_adjoint
-	else                { n1 = npair*tp.gs*pad8(tp.bs); n2 = npair*tp.aNs*pad8(tp.gs); }                                                  // from_cc
+	else if (kind == 2) { n1 = npair*tp.gs*pad8(tp.bs); n2 = npair*tp.aNs*pad8(tp.gs); }                                                  // from_cc
+	else                { n1 = npair*std::max(tp.g*pad8(tp.ac), tp.g*pad8(tp.g2)); n2 = npair*std::max(tp.g2*pad8(tp.g), tp.bN*pad8(tp.g)); }   // to_cc_adjoint
 	const int cc = theta_comp_chunk(nc, n1, n2);
 	b1 = sizeof(double2)*n1*cc; b2 = sizeof(double2)*n2*cc;
 }
@@ -644,6 +705,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 	const long ldY1 = pad8(bN), ldZ2 = pad8(g), ldV3 = pad8(g2), ldU4 = pad8(g);
 	const size_t need1 = (size_t)npair*std::max(g*ldY1, g*ldV3), need2 = (size_t)npair*std::max(g2*ldZ2, ac*ldU4);
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	const int T1 = tile_lines(g, 0, bN, 8), T2 = tile_lines(bN, g2, g, 8), T3 = tile_lines(g, g, g2, 8), T4 = tile_lines(g2, ac, g, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
@@ -651,27 +713,27 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
 			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
 			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
-			set_tiles(s, tile_lines(g, 0, bN, 8), bN, tp.N);
+			set_tiles(s, T1, bN, tp.N); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, g2);
 			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.M; s.kmax = -1; s.nyq = 1;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
-			set_tiles(s, tile_lines(bN, g2, g, 8), g, tp.M);
+			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSigma s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, g);
 			s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.V = s1_.as<double2>(); s.ldV = ldV3; s.g = (int)g; s.g2 = (int)g2; s.sigma = sigma;
-			set_tiles(s, tile_lines(g, g, g2, 8), g2, tp.M);
+			set_tiles(s, T3, g2, tp.M); s.bin = mk_blk(T2, g, T3); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g2); s.fb = mk(fc_, ac);
 			s.Y = s1_.as<double2>(); s.ldY = ldV3; s.Z = s2_.as<double2>(); s.ldZ = ldU4; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
 			s.ph = nullptr; s.dg = make_fastdiv((uint32_t)g);
-			set_tiles(s, tile_lines(g2, ac, g, 8), g, tp.Ncc);
+			set_tiles(s, T4, g, tp.Ncc); s.bin = mk_blk(T3, g2, T4); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
@@ -683,6 +745,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			s.U = s2_.as<double2>(); s.ldU = ldU4; s.a = (int)ac; s.g = (int)g; s.X = (int)tp.Ncc; s.mir_c = 0; s.nr_out = ncc; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
 			s.out = leg_cc + (size_t)c0*nm*ldcc; s.ocstride = (long)nm*ldcc; s.dnp = make_fastdiv((uint32_t)npair); s.groups = 1; s.dgr = make_fastdiv(1);
 			s.ld = ldcc; s.w = wcc; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
+			s.bin = mk_blk(T4, g, T);
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 	}
@@ -702,6 +765,7 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 	const long ldY1 = pad8(bN), ldU = pad8(g);
 	const size_t need1 = (size_t)npair*g*ldY1, need2 = (size_t)npair*ac*ldU;
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	const int T1 = tile_lines(g, 0, bN, 8), T2 = tile_lines(bN, ac, g, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
@@ -709,14 +773,14 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
 			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
 			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
-			set_tiles(s, tile_lines(g, 0, bN, 8), bN, tp.N);
+			set_tiles(s, T1, bN, tp.N); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, ac);
 			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldU; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
-			set_tiles(s, tile_lines(bN, ac, g, 8), g, tp.Ncc);
+			set_tiles(s, T2, g, tp.Ncc); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
@@ -728,7 +792,70 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 			s.U = s2_.as<double2>(); s.ldU = ldU; s.a = (int)ac; s.g = (int)g; s.X = (int)tp.Ncc; s.mir_c = 0; s.nr_out = ncc; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
 			s.out = leg_cc + (size_t)c0*nm*ldcc; s.ocstride = (long)nm*ldcc; s.dnp = make_fastdiv((uint32_t)npair); s.groups = 1; s.dgr = make_fastdiv(1);
 			s.ld = ldcc; s.w = w; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
+			s.bin = mk_blk(T2, g, T);
 			launch_stage(s, ncl*npair*s.ntile, st);
+		}
+	}
+	PXS_HIP(hipGetLastError());
+}
+
+// exact adjoint of to_cc (adjoint_analysis_2d): leg on the CC grid -> ring spectra h[c][ring][m] on the map's rings.
+// With to_cc = W R F_Ncc^-1 T F_M Sigma F_M^-1 P F_N E' (E': parity mirror extension of the ring samples, P: phase, Nyquist split and
+// zero padding N -> M, T: truncation to |k| <= lmax, R: restriction to the CC rings, W: weights) the adjoint is
+// E'^T F_N^-1 P^H F_M Sigma F_M^-1 T^T F_Ncc R^T W.  R^T zero-extends, but E'^T keeps only the part of the result with the column's
+// parity (times 2), every operator in between commutes with the reflection, so the zero extension may be replaced by the parity
+// mirror extension of W x with weight 1/2 off the poles: the chain then has the shape of from_cc -- pairs of columns of opposite
+// parity packed into one sequence and separated by reflection symmetry at the end, written ring-major for the ring FFT.
+void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
+                             int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* whalf, const double2* tab, double scale)
+{
+	const long npair = (nm + 1)/2;
+	const long g = tp.g, bN = tp.bN, g2 = tp.g2, ac = tp.ac;
+	const long ldY = pad8(ac), ldZ = pad8(g), ldV = pad8(g2);
+	const size_t need1 = (size_t)npair*std::max(g*ldY, g*ldV), need2 = (size_t)npair*std::max(g2*ldZ, bN*ldZ);
+	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	const int T1 = tile_lines(g, 0, ac, 8), T2 = tile_lines(ac, g2, g, 8), T3 = tile_lines(g, g, g2, 8), T4 = tile_lines(g2, bN, g, 8);
+	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
+	for (int c0 = 0; c0 < nc; c0 += cchunk) {
+		const long ncl = std::min(cchunk, nc - c0);
+		{	StFirst s; memset(&s, 0, sizeof(s));      // weighted mirror-pair extension on the CC circle, pass 1 of FFT_Ncc
+			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
+			s.src.leg = leg_cc + (size_t)c0*nm*ldcc; s.src.cstride = (long)nm*ldcc; s.src.ld = ldcc; s.src.nr = ncc; s.src.N = (int)tp.Ncc; s.src.mir_c = 0; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.src.w = whalf;
+			s.b = (int)ac; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
+			set_tiles(s, T1, ac, tp.Ncc); s.bout = blocked_on();
+			launch_stage(s, ncl*npair*s.ntile, st);
+		}
+		{	StResize s; memset(&s, 0, sizeof(s));     // pass 2 of FFT_Ncc, |k| <= lmax embedded in the M spectrum, pass 1 of IFFT_M
+			s.fa = mk(fc_, ac); s.fb = mk(fc_, g2);
+			s.Y = s1_.as<double2>(); s.ldY = ldY; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)g; s.X1 = (int)tp.Ncc; s.X2 = (int)tp.M; s.kmax = lmax; s.nyq = 0;
+			s.ph = nullptr; s.dg = make_fastdiv((uint32_t)g);
+			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, ac, T2); s.bout = blocked_on();
+			launch_stage(s, ncl*npair*s.ntile, st);
+		}
+		{	StSigma s; memset(&s, 0, sizeof(s));      // pass 2 of IFFT_M, x |sin| series, pass 1 of FFT_M
+			s.fa = mk(fc_, g); s.fb = mk(fc_, g);
+			s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.V = s1_.as<double2>(); s.ldV = ldV; s.g = (int)g; s.g2 = (int)g2; s.sigma = sigma;
+			set_tiles(s, T3, g2, tp.M); s.bin = mk_blk(T2, g, T3); s.bout = blocked_on();
+			launch_stage(s, ncl*npair*s.ntile, st);
+		}
+		{	StResize s; memset(&s, 0, sizeof(s));     // pass 2 of FFT_M, transposed padding M -> N (conjugate phase, Nyquist bins combined), pass 1 of IFFT_N
+			s.fa = mk(fc_, g2); s.fb = mk(fc_, bN);
+			s.Y = s1_.as<double2>(); s.ldY = ldV; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.N; s.kmax = -1; s.nyq = 0; s.adj = 1;
+			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
+			set_tiles(s, T4, g, tp.N); s.bin = mk_blk(T3, g2, T4);      // (plain rows out: the transposing split takes one line of many pairs)
+			launch_stage(s, ncl*npair*s.ntile, st);
+		}
+		{	StSplit<1> s; memset(&s, 0, sizeof(s));   // pass 2 of IFFT_N, the two parities apart, rings of the map, ring-major
+			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
+			int T = tile_lines(g, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
+			set_tiles(s, T, bN*T, 0);         // one tile per line: ntile = bN
+			s.TH = 0;
+			s.U = s2_.as<double2>(); s.ldU = ldZ; s.a = (int)bN; s.g = (int)g; s.X = (int)tp.N; s.mir_c = mir_c; s.nr_out = nr; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
+			const long groups = (npair + T/2 - 1)/(T/2);
+			s.out = h + (size_t)c0*nr*ldh; s.ocstride = (long)nr*ldh; s.dnp = make_fastdiv((uint32_t)npair); s.groups = (int)groups; s.dgr = make_fastdiv((uint32_t)groups);
+			s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)bN); s.self_half = 1;
+			launch_stage(s, ncl*groups*bN, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -742,6 +869,7 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 	const long ldY = pad8(bs), ldZ = pad8(gs);
 	const size_t need1 = (size_t)npair*gs*ldY, need2 = (size_t)npair*aN*ldZ;
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
+	const int T1 = tile_lines(gs, 0, bs, 8), T2 = tile_lines(bs, aN, gs, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
@@ -749,14 +877,14 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
 			s.src.leg = leg_cc + (size_t)c0*nm*ldcc; s.src.cstride = (long)nm*ldcc; s.src.ld = ldcc; s.src.nr = ncc; s.src.N = (int)tp.Ncc; s.src.mir_c = 0; s.src.a_odd = spin & 1; s.src.ncol = nm;
 			s.b = (int)bs; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
-			set_tiles(s, tile_lines(gs, 0, bs, 8), bs, tp.Ncc);
+			set_tiles(s, T1, bs, tp.Ncc); s.bout = blocked_on();
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bs); s.fb = mk(fc_, aN);
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)gs; s.X1 = (int)tp.Ncc; s.X2 = (int)tp.N; s.kmax = lmax; s.nyq = 0;
 			s.ph = ph_up; s.dg = make_fastdiv((uint32_t)gs);
-			set_tiles(s, tile_lines(bs, aN, gs, 8), gs, tp.N);
+			set_tiles(s, T2, gs, tp.N); s.bin = mk_blk(T1, bs, T2);      // (plain rows out, see to_cc_adjoint)
 			launch_stage(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<1> s; memset(&s, 0, sizeof(s));

@@ -49,8 +49,11 @@ public:
 	// exact transpose of from_cc for grids without self-mirrored rings: leg on the map's rings -> leg on the CC grid (w: 1/N_cc, half at the poles)
 	void from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
 	                     int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w);
+	// exact adjoint of to_cc: leg on the CC grid -> h[c][ring][m] * conj(tab[m]) * scale on the map's rings (whalf: the to_cc weights, halved off the poles)
+	void to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
+	                   int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* whalf, const double2* tab, double scale);
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
-	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc)
+	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc, 3: to_cc_adjoint)
 	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);
 	void ring_scratch(long nring, int nc, bool analysis, size_t& b1) const;
 	void reserve(size_t b1, size_t b2) { s1_.ensure(b1); s2_.ensure(b2); }

@@ -42,19 +42,61 @@ __global__ __launch_bounds__(256) void ps2d_kernel(long n, const void* __restric
 	if (odtype == PX_F32) ((float*)out)[i] = (float)r; else ((double*)out)[i] = r;
 }
 
-// sums of map, |l| and counts per bin floor(|l| / bsize); bins >= nbin are dropped (enmap._bin_helper, enmap.py:2533-2556)
+// sums of map, |l| and counts per bin floor(|l| / bsize); bins >= nbin are dropped (enmap._bin_helper, enmap.py:2533-2556).
+// A workgroup bins a 64 x 64 pixel tile: its pixels fall into a narrow range of |l| rings (~100 bins for 4096 pixels), so the
+// sums are collected in an LDS histogram that starts at the tile's smallest bin and only the touched bins go to memory with one
+// atomic each -- one global atomic per pixel and array (700 M at 10800 x 21600) made this the longest stage of the C5 pipeline.
+#define LBIN_TILE 64
+#define LBIN_LDS 512
+#ifdef PXS_HOST_SIM
+#define PXS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#else
+#define PXS_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#endif
 __global__ __launch_bounds__(256) void lbin_kernel(int ny, int nx, const double* __restrict__ ly, const double* __restrict__ lx, double bsize, int nbin,
 		const void* __restrict__ map, int dtype, int with_l, double* __restrict__ osum, double* __restrict__ olsum, double* __restrict__ ohit)
 {
-	const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y;
-	if (x >= nx) return;
-	const double l = sqrt(ly[y]*ly[y] + lx[x]*lx[x]);
-	const long bin = (long)floor(l/bsize);
-	if (bin < 0 || bin >= nbin) return;
-	const long i = (long)y*nx + x;
-	const double v = dtype == PX_F32 ? (double)((const float*)map)[i] : ((const double*)map)[i];
-	atomicAdd(osum + bin, v);
-	if (with_l) { atomicAdd(olsum + bin, l); atomicAdd(ohit + bin, 1.0); }
+	PXS_SHARED(double, hist);          // [3][LBIN_LDS] sums, |l| sums, counts; then one int: the tile's smallest bin
+	int* bmin = reinterpret_cast<int*>(hist + 3*LBIN_LDS);
+	const int tid = threadIdx.x, tx = tid & (LBIN_TILE - 1), ty = tid >> 6;
+	const int x = blockIdx.x*LBIN_TILE + tx, y0 = blockIdx.y*LBIN_TILE;
+	for (int k = tid; k < 3*LBIN_LDS; k += 256) hist[k] = 0.0;
+	if (tid == 0) *bmin = 0x7fffffff;
+	__syncthreads();
+	const double lxx = x < nx ? lx[x] : 0.0;
+	int lo = 0x7fffffff;
+	for (int j = ty; j < LBIN_TILE; j += 4) {
+		const int y = y0 + j;
+		if (x < nx && y < ny) { const double l = sqrt(ly[y]*ly[y] + lxx*lxx); const long bin = (long)floor(l/bsize); if (bin < lo) lo = (int)bin; }
+	}
+	if (lo != 0x7fffffff) atomicMin(bmin, lo);
+	__syncthreads();
+	const int base = *bmin;
+	for (int j = ty; j < LBIN_TILE; j += 4) {
+		const int y = y0 + j;
+		if (x >= nx || y >= ny) continue;
+		const double l = sqrt(ly[y]*ly[y] + lxx*lxx);
+		const long bin = (long)floor(l/bsize);
+		if (bin < 0 || bin >= nbin) continue;
+		const long i = (long)y*nx + x;
+		const double v = dtype == PX_F32 ? (double)((const float*)map)[i] : ((const double*)map)[i];
+		const long k = bin - base;
+		if (k < LBIN_LDS) {
+			PXS_ATOMIC_ADD(hist + k, v);
+			if (with_l) { PXS_ATOMIC_ADD(hist + LBIN_LDS + k, l); PXS_ATOMIC_ADD(hist + 2*LBIN_LDS + k, 1.0); }
+		} else {	// (a tile wider than the LDS histogram: coarse pixels with very fine bins)
+			PXS_ATOMIC_ADD(osum + bin, v);
+			if (with_l) { PXS_ATOMIC_ADD(olsum + bin, l); PXS_ATOMIC_ADD(ohit + bin, 1.0); }
+		}
+	}
+	__syncthreads();
+	for (int k = tid; k < LBIN_LDS; k += 256) {
+		const long bin = (long)base + k;
+		if (bin >= nbin) break;
+		// (without the counts a zero sum cannot tell an untouched bin from a cancelling one: adding 0 is harmless)
+		if (with_l) { const double h = hist[2*LBIN_LDS + k]; if (h != 0.0) { PXS_ATOMIC_ADD(osum + bin, hist[k]); PXS_ATOMIC_ADD(olsum + bin, hist[LBIN_LDS + k]); PXS_ATOMIC_ADD(ohit + bin, h); } }
+		else if (hist[k] != 0.0) PXS_ATOMIC_ADD(osum + bin, hist[k]);
+	}
 }
 
 // data[i] *= vec[(i / inner) % n]: multiply along one axis of a contiguous complex array (fft.shift's phase ramps, fft.py:347-368)
@@ -109,7 +151,7 @@ int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsiz
 	PXS_REQUIRE(dtype == PX_F32 || dtype == PX_F64, "pxm_lbin: map must be float32 or float64");
 	PXS_REQUIRE((d_lsum == nullptr) == (d_hit == nullptr), "pxm_lbin: give both or none of lsum, hit");
 	PXS_HIP(hipSetDevice(device));
-	if (nbin > 0) hipLaunchKernelGGL(lbin_kernel, dim3((nx+255)/256, ny), dim3(256), 0, (hipStream_t)stream, ny, nx, d_ly, d_lx, bsize, nbin,
+	if (nbin > 0) hipLaunchKernelGGL(lbin_kernel, dim3((nx + LBIN_TILE - 1)/LBIN_TILE, (ny + LBIN_TILE - 1)/LBIN_TILE), dim3(256), sizeof(double)*3*LBIN_LDS + 16, (hipStream_t)stream, ny, nx, d_ly, d_lx, bsize, nbin,
 		map, dtype, d_lsum ? 1 : 0, d_sum, d_lsum, d_hit);
 	PXS_HIP(hipGetLastError());
 	PXS_CATCH

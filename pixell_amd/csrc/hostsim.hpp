@@ -125,6 +125,7 @@ static inline double atomicAdd(double* p, double v) {   // lanes are OS threads 
 	uint64_t* q = reinterpret_cast<uint64_t*>(p); uint64_t old = __atomic_load_n(q, __ATOMIC_RELAXED), nw; double o;
 	do { std::memcpy(&o, &old, 8); double n = o + v; std::memcpy(&nw, &n, 8); } while (!__atomic_compare_exchange_n(q, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 	return o; }
+static inline int atomicMin(int* p, int v) { int old = __atomic_load_n(p, __ATOMIC_RELAXED); while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return old; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a*b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a+b; return r; }
 static inline int __shfl(int v, int src) { return (int)pxsim::xchg((uint64_t)(uint32_t)v, src); }

@@ -80,10 +80,12 @@ struct LegK {
 	// accumulations (rings dropped as polar-dead and (wave, m) pairs skipped entirely are not in it, masked-off lanes are).
 	double* count;
 };
+// (PXS_NCOUNT slots, one picked by the block index: 200 000 waves adding to ONE address cost ~10 ms per C3 step and 24 ms per C4 step)
+#define PXS_NCOUNT 1024
 #ifdef PXS_HOST_SIM
-#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) atomicAdd(a.count + (dir), (double)(expr))
+#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) atomicAdd(a.count + 2*(blockIdx.x & (PXS_NCOUNT - 1)) + (dir), (double)(expr))
 #else
-#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) unsafeAtomicAdd(a.count + (dir), (double)(expr))
+#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) unsafeAtomicAdd(a.count + 2*(blockIdx.x & (PXS_NCOUNT - 1)) + (dir), (double)(expr))
 #endif
 
 // Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
@@ -475,7 +477,10 @@ __device__ __forceinline__ int leg_flush_col(int lane) { return lane; }
 // LDS bytes than transposing all partial sums; the LDS write port was the limiter); row r of step kk goes to
 // red[(4 kk + r)*18 .. +16], so that lane j = 4 kk + r reads its 16 partial sums as 8 aligned 16-byte words.
 // (Tried and rejected: v_mfma_f64_4x4x4 with B = 1 as a lane adder: correct, but 8 dependent f64 MFMAs per step made the
-// kernel matrix-pipe bound; transposing all four sums through LDS: 145.1 against 142.1 ms.)
+// kernel matrix-pipe bound.  Round 3, with the lane layout from tools/mfma_probe.hip -- A at lane 16k+4b+i, B at 16k+4b+j, D at
+// 16i+4b+j -- and B_r = [j == r]: four MFMAs accumulate the four sums of a step into ONE register, 4 issues + a ds_write instead
+// of 9 VALU ops + a ds_write, 160 / 168 VGPRs: leg_ana_spin<4> 105.9 -> 112.9 ms, leg_ana_s0<8> 26.9 -> 31.0 ms at config 3: the
+// f64 MFMA shares the FMA pipe's throughput on MI355X, it does not add to it. transposing all four sums through LDS: 145.1 against 142.1 ms.)
 #define LEG_RED_STRIDE 18
 #define LEG_RED_DOUBLES (4*LEG_FSTEPS*LEG_RED_STRIDE)
 __device__ __forceinline__ void leg_swap32(double& a, double& b) {

@@ -328,7 +328,7 @@ struct pxs_plan {
 	DevBuf leg, leg2, hbuf, phase;
 	// analysis resampling (grid plans)
 	long N = 0; int mir_c = 0; long M = 0, Ncc = 0; int ncc = 0;
-	DevBuf ph_shift, ph_up, sigma, wcc, wadj, b1, b2;
+	DevBuf ph_shift, ph_up, sigma, wcc, wadj, whalf, b1, b2;
 	// general ring sets (gen_* kernels): rings of equal length are one dense block of z
 	struct GenGroup { long n, count, zoff; };
 	bool general = false; std::vector<GenGroup> groups; long npixz = 0;
@@ -453,6 +453,9 @@ void setup_resampling(pxs_plan* p) {
 		w[j] = make_double2((double)((PIl/p->nphi)*(2*PIl/p->Ncc)*e/((LDb)p->N*(LDb)p->M)), 0.0);
 	}
 	p->wcc = upload(w);
+	{	// the same weights for the fused adjoint of the analysis (FftChain::to_cc_adjoint): halved off the two pole rings
+		std::vector<double2> wh(w); for (int j = 1; j + 1 < p->ncc; j++) wh[j].x *= 0.5;
+		p->whalf = upload(wh); }
 	{	// weights of the transposed theta upsampling (FftChain::from_cc_adjoint): 1/N_cc, half at the two pole rings
 		std::vector<double2> wa(p->ncc);
 		for (int j = 0; j < p->ncc; j++) wa[j] = make_double2(((j == 0 || j == p->ncc-1) ? 0.5 : 1.0)/(double)p->Ncc, 0.0);
@@ -908,11 +911,49 @@ int pxs_debug_theta_plan(int64_t N, int lmax, int64_t* out) {
 	return 0;
 }
 
+/* diagnostics (tools/chain_lab.py): average ms of one fused-chain stage group of the plan on scratch data.
+ * kind 0: map2leg (MA1, MA2), 1: h2map (MS1, MS2), 2: to_cc (RA1-5), 3: from_cc (RS1-3), 4: from_cc_adjoint */
+int pxs_debug_chain(pxs_plan* p, int kind, int nc, int spin, int reps, double* ms) {
+	PXS_TRY
+	PXS_REQUIRE(p && ms && nc >= 1 && reps >= 1 && kind >= 0 && kind <= 4, "pxs_debug_chain: bad arguments");
+	PXS_REQUIRE(p->chain_rings && (kind < 2 || p->chain_theta()), "pxs_debug_chain: the plan has no fused chain for this stage");
+	PXS_HIP(hipSetDevice(p->device));
+	const size_t nm = (size_t)p->mmax + 1, nr = (size_t)p->nring, c16 = sizeof(double2);
+	const long ldm = FftChain::pad8(p->nring), ldc = p->ld_cc(), ldh = p->ld_h();
+	DevBuf dmap;
+	if (kind < 2) { dmap.alloc(sizeof(double)*(size_t)nc*nr*p->nphi); PXS_HIP(hipMemset(dmap.p, 0, dmap.bytes)); }
+	p->leg.ensure(c16*nc*nm*ldm); p->leg2.ensure(c16*nc*nm*std::max<long>(ldc, 8)); p->hbuf.ensure(c16*nc*nr*ldh);
+	PXS_HIP(hipMemset(p->leg.p, 0, p->leg.bytes)); PXS_HIP(hipMemset(p->leg2.p, 0, p->leg2.bytes)); PXS_HIP(hipMemset(p->hbuf.p, 0, p->hbuf.bytes));
+	hipStream_t st = nullptr;
+	auto run = [&]() {
+		const FftChain::MapDesc md = p->map_desc(dmap.p, PX_F64, (long)nr*p->nphi);
+		switch (kind) {
+		case 0: p->chain->map2leg(st, md, nc, p->mmax, p->leg.as<double2>(), ldm, p->phase.as<double2>(), 1.0); break;
+		case 1: p->chain->h2map(st, p->hbuf.as<double2>(), ldh, md, nc, p->mmax); break;
+		case 2: p->chain->to_cc(st, p->tp, p->leg.as<double2>(), ldm, p->nring, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, (int)nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>()); break;
+		case 3: p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, p->nring, p->mir_c, nc, (int)nm, spin, p->lmax,
+				p->ph_up.as<double2>(), p->phase.as<double2>(), 1.0/(double)p->Ncc); break;
+		default: p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldm, p->nring, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, (int)nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), p->wadj.as<double2>()); break;
+		}
+	};
+	run(); PXS_HIP(hipStreamSynchronize(st));
+	hipEvent_t e0, e1; PXS_HIP(hipEventCreate(&e0)); PXS_HIP(hipEventCreate(&e1));
+	PXS_HIP(hipEventRecord(e0, st));
+	for (int i = 0; i < reps; i++) run();
+	PXS_HIP(hipEventRecord(e1, st)); PXS_HIP(hipEventSynchronize(e1));
+	float t = 0; PXS_HIP(hipEventElapsedTime(&t, e0, e1));
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*ms = (double)t/reps;
+	PXS_CATCH
+}
+
 int pxs_profile(pxs_plan* p, int enable) {
 	PXS_TRY
 	PXS_REQUIRE(p, "pxs_profile: null plan");
 	p->prof.enabled = enable != 0;
-	if (enable && !p->wk.count.p) { PXS_HIP(hipSetDevice(p->device)); p->wk.count.alloc(2*sizeof(double)); PXS_HIP(hipMemset(p->wk.count.p, 0, 2*sizeof(double))); }
+	if (enable && !p->wk.count.p) { PXS_HIP(hipSetDevice(p->device)); p->wk.count.alloc(2*1024*sizeof(double)); PXS_HIP(hipMemset(p->wk.count.p, 0, p->wk.count.bytes)); }
 	p->wk.count_on = enable != 0;
 	PXS_CATCH
 }
@@ -924,9 +965,9 @@ int pxs_profile_flops(pxs_plan* p, double* flops, int reset) {
 	if (!p->wk.count.p) return 0;
 	PXS_HIP(hipSetDevice(p->device));
 	PXS_HIP(hipDeviceSynchronize());
-	double c[2]; PXS_HIP(hipMemcpy(c, p->wk.count.p, sizeof(c), hipMemcpyDeviceToHost));
-	flops[0] = c[0]*128.0; flops[1] = c[1]*128.0;          // FMA instructions per lane x 64 lanes x 2 flops
-	if (reset) PXS_HIP(hipMemset(p->wk.count.p, 0, sizeof(c)));
+	std::vector<double> c(p->wk.count.bytes/sizeof(double)); PXS_HIP(hipMemcpy(c.data(), p->wk.count.p, p->wk.count.bytes, hipMemcpyDeviceToHost));
+	for (size_t i = 0; i + 1 < c.size(); i += 2) { flops[0] += c[i]*128.0; flops[1] += c[i+1]*128.0; }     // FMA instructions per lane x 64 lanes x 2 flops
+	if (reset) PXS_HIP(hipMemset(p->wk.count.p, 0, p->wk.count.bytes));
 	PXS_CATCH
 }
 
@@ -1041,6 +1082,10 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
 		p->leg.ensure(c16*nct*nm*ldm); p->leg2.ensure(c16*nct*nm*ldc); theta(0);
 		p->chain->ring_scratch(p->nring, nct, true, r1);
+	} else if (adjoint && !p->wring.p && th) {          // adjoint_analysis_2d (fused transposed chain)
+		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
+		p->leg2.ensure(c16*nct*nm*ldc); p->hbuf.ensure(c16*nct*nr*ldh); theta(3);
+		p->chain->ring_scratch(p->nring, nct, false, r1);
 	} else return;
 	p->chain->reserve(std::max(c1, r1), c2);
 }
@@ -1107,7 +1152,24 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		PXS_HIP(hipGetLastError());
 		return;
 	}
-	const bool th = p->chain_theta() && !adjoint;       // (the adjoint of the analysis runs the unfused chain, dense rows)
+	const bool adj_fused = [] { const char* e = getenv("PXS_ADJ_ANA_FUSED"); return e ? atoi(e) != 0 : true; }();      // (read per call: the tests switch it)
+	if (adjoint && adj_fused && p->chain_theta()) {
+		// adjoint_analysis_2d through the fused transposed chain: Legendre synthesis on the CC grid, FftChain::to_cc_adjoint straight
+		// into the ring-major spectra, ring FFTs -- all maps of the call in every launch
+		const long ldc = p->ld_cc(), ldh = p->ld_h();
+		const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+		p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc); p->hbuf.ensure(sizeof(double2)*(size_t)nct*nr*ldh);
+		for (int b = 0; b < nb; b++)
+			leg_synthesis(st, p->rs_cc, tb, p->wk, (char*)alm + aesz*(size_t)b*alm_bstride, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				p->leg2.as<double2>() + (size_t)b*nc*nm*ldc, 0, &p->prof, ldc);
+		p->prof.begin(st, PXS_STAGE_RESAMPLE);
+		p->chain->to_cc_adjoint(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
+			p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->whalf.as<double2>(), p->phase.as<double2>(), 2.0);
+		p->prof.end(st, PXS_STAGE_RESAMPLE);
+		leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, nb > 1 ? nc : 0);
+		return;
+	}
+	const bool th = p->chain_theta() && !adjoint;       // (PXS_ADJ_ANA_FUSED=0: the adjoint of the analysis through the unfused chain, dense rows)
 	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
 	const int ncb = nb > 1 ? nc : 0;
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
@@ -1146,7 +1208,8 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint, int nbatch,
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
-	const int chunk = p->wring.p ? batch_chunk(p, nbatch, spin == 0 ? 1 : 2) : (adjoint || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
+	const bool adj_fused = [] { const char* e = getenv("PXS_ADJ_ANA_FUSED"); return e ? atoi(e) != 0 : true; }();
+	const int chunk = p->wring.p ? batch_chunk(p, nbatch, spin == 0 ? 1 : 2) : ((adjoint && !adj_fused) || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
 	reserve_call(p, spin, PXS_MODE_STANDARD, false, adjoint != 0, std::min(chunk, nbatch));
 	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
 		const int nb = std::min(chunk, nbatch - b0);

@@ -96,6 +96,30 @@ def test_mmax_lt_lmax_hostsim():
 def test_grid_gpu(geometry, nt, nph, lmax, spin):
 	check_grid(geometry, nt, nph, lmax, spin, random_map=(nt <= 300))
 
+def check_adjoint_analysis_fused(geometry, nt, nph, lmax, monkeypatch, nb=1):
+	"""adjoint_analysis_2d through the fused transposed chain (FftChain::to_cc_adjoint, all maps of a call per launch) against the
+	stage-by-stage transpose it replaces (PXS_ADJ_ANA_FUSED=0: dense rows, generic FFT engine, one map at a time), which the
+	small grids pin to the oracle"""
+	ms = so._tri_mstart(lmax, lmax)
+	for spin in (0, 2):
+		nc = 1 if spin == 0 else 2
+		alm = np.stack([so.rand_alm_simple(lmax, nc, 50+i, spin=(spin,)) for i in range(nb)])
+		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.25)
+		monkeypatch.setenv("PXS_ADJ_ANA_FUSED", "1")
+		a = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=a, **kw)
+		monkeypatch.setenv("PXS_ADJ_ANA_FUSED", "0")
+		b = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=b, **kw)
+		monkeypatch.delenv("PXS_ADJ_ANA_FUSED")
+		assert rel(a, b) < TOL, (geometry, nt, spin)
+
+@pytest.mark.hostsim
+def test_adjoint_analysis_fused_hostsim(monkeypatch):
+	check_adjoint_analysis_fused("F1", 36, 72, 35, monkeypatch); check_adjoint_analysis_fused("CC", 41, 80, 30, monkeypatch, nb=2)
+@pytest.mark.gpu
+def test_adjoint_analysis_fused_gpu(monkeypatch):
+	for g, nt, nph, lmax, nb in [("F1", 36, 72, 35, 1), ("CC", 41, 80, 30, 2), ("F1", 130, 300, 128, 3), ("CC", 514, 1200, 512, 1), ("F1", 1350, 2700, 1000, 2), ("F1", 640, 1280, 639, 1)]:
+		check_adjoint_analysis_fused(g, nt, nph, lmax, monkeypatch, nb=nb)
+
 @pytest.mark.gpu
 def test_config1_gpu():
 	"""BASELINE config 1: 1x(1024x2048) F1 map, lmax=512, map2alm -> alm2map against the CPU oracle"""
@@ -398,7 +422,7 @@ def check_batched(nb=3, geometry="F1", nt=24, nph=48, lmax=20):
 		adj = np.zeros_like(alm); sht.adjoint_synthesis_2d(alm=adj, map=out, **kw)
 		one = np.zeros_like(alm[0]); sht.adjoint_synthesis_2d(alm=one, map=out[1], **kw)
 		assert np.array_equal(one, adj[1])
-		aa = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=aa, **kw)       # (runs map by map inside the library)
+		aa = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=aa, **kw)
 		one = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm[nb-1], map=one, **kw)
 		assert np.array_equal(one, aa[nb-1])
 
