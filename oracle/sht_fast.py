@@ -70,6 +70,27 @@ def pixels_on_rings(leg, phi):
 			out[c, r] = np.real(leg[:, c, r] @ ph)        # (F_0 enters with its real part only)
 	return out
 
+_TABLES = {}
+def _resample_tables(geometry, ntheta, lmax):
+	"""what theta_resample needs that does not depend on the data (cached: the ring table alone is a Python loop over the circle)"""
+	key = (geometry, int(ntheta), int(lmax))
+	if key in _TABLES: return _TABLES[key]
+	g = so.grid_info(geometry, ntheta); N, c = g["N"], g["c"]; th0 = float(g["theta0"])
+	ring = np.array([so._ring_of(jp, N, c, ntheta) for jp in range(N)])
+	mirrored = np.arange(N) >= ntheta
+	K2 = N//2
+	k = np.arange(-K2, K2+1)
+	Q = lmax+K2
+	s_half = so._abs_sin_series(Q)
+	s = np.concatenate([s_half[:0:-1], s_half])                     # q = -Q..Q
+	nconv = len(k)+len(s)-1
+	nf = _good_even(nconv)
+	Ncc = _good_even(2*lmax+2)
+	t = dict(N=N, th0=th0, ring=ring, mirrored=mirrored, K2=K2, k=k, kmod=k % N, phase=np.exp(-1j*k*th0), Q=Q, nconv=nconv, nf=nf,
+		sfft=np.fft.fft(s, nf), hsel=np.arange(-lmax, lmax+1)+K2+Q, Ncc=Ncc, kk=np.arange(-lmax, lmax+1) % Ncc)
+	_TABLES[key] = t
+	return t
+
 def theta_resample(L, par, geometry, ntheta, lmax, workers=None):
 	"""Exact |sin|-weighted integration of the theta-interpolant, as samples on a CC grid.
 
@@ -81,41 +102,31 @@ def theta_resample(L, par, geometry, ntheta, lmax, workers=None):
 	about theta0, as sht_oracle._interp_matrix has it) and f_par its part of parity `par`."""
 	L = np.atleast_2d(np.asarray(L, np.complex128)); ncol = L.shape[0]
 	par = np.asarray(par, int).reshape(ncol)
-	if workers:          # threaded pocketfft (bench.py's cpu_baseline); numpy's otherwise
+	if workers:          # pocketfft through scipy (bench.py's cpu_baseline: one call per host thread, workers=1); numpy's otherwise
 		import scipy.fft as sfft
 		fft = lambda a, n=None, axis=-1: sfft.fft(a, n=n, axis=axis, workers=workers)
 		ifft = lambda a, n=None, axis=-1: sfft.ifft(a, n=n, axis=axis, workers=workers)
 	else: fft, ifft = np.fft.fft, np.fft.ifft
-	g = so.grid_info(geometry, ntheta); N, c = g["N"], g["c"]; th0 = float(g["theta0"])
+	T = _resample_tables(geometry, ntheta, lmax)
+	N, th0, K2 = T["N"], T["th0"], T["K2"]
 	# parity extension to the N full-circle samples
-	ring = np.array([so._ring_of(jp, N, c, ntheta) for jp in range(N)])
-	mirrored = np.arange(N) >= ntheta
-	sign = np.where(mirrored[None, :] & (par[:, None] == 1), -1.0, 1.0)
-	f = L[:, ring]*sign                                             # [ncol, N]
+	sign = np.where(T["mirrored"][None, :] & (par[:, None] == 1), -1.0, 1.0)
+	f = L[:, T["ring"]]*sign                                        # [ncol, N]
 	# interpolant spectrum c_k, |k| <= N/2 (index k + K2)
 	F = fft(f, axis=1)/N
-	K2 = N//2
-	k = np.arange(-K2, K2+1)
-	cspec = F[:, k % N]*np.exp(-1j*k*th0)[None, :]
+	cspec = F[:, T["kmod"]]*T["phase"][None, :]
 	if N % 2 == 0:
 		X = F[:, K2]                                                  # (1/N) sum_j f_j (-1)^j
 		cspec[:, 0]  = 0.5*X*np.exp(+1j*K2*th0)                       # k = -N/2
 		cspec[:, -1] = 0.5*X*np.exp(-1j*K2*th0)                       # k = +N/2
-	# h = f |sin|: Fourier coefficients |k| <= lmax by convolution with the |sin| series
-	Q = lmax+K2
-	s_half = so._abs_sin_series(Q)
-	s = np.concatenate([s_half[:0:-1], s_half])                     # q = -Q..Q
-	# full convolution via zero-padded FFTs
-	nconv = cspec.shape[1]+len(s)-1
-	nf = _good_even(nconv)
-	H = ifft(fft(cspec, nf, axis=1)*np.fft.fft(s, nf)[None, :], axis=1)[:, :nconv]
+	# h = f |sin|: Fourier coefficients |k| <= lmax by convolution with the |sin| series (full convolution via zero-padded FFTs)
+	H = ifft(fft(cspec, T["nf"], axis=1)*T["sfft"][None, :], axis=1)
 	# index i of H <-> k = i - K2 - Q
-	h = H[:, (np.arange(-lmax, lmax+1)+K2+Q)]                       # [ncol, 2 lmax + 1]
+	h = H[:, T["hsel"]]                                             # [ncol, 2 lmax + 1]
 	# evaluate g(theta) = sum_{|k|<=lmax} h_k e^{ik theta} on the CC circle of Ncc > 2 lmax points
-	Ncc = _good_even(2*lmax+2)
+	Ncc = T["Ncc"]
 	spec = np.zeros((ncol, Ncc), np.complex128)
-	kk = np.arange(-lmax, lmax+1)
-	spec[:, kk % Ncc] = h
+	spec[:, T["kk"]] = h
 	gcirc = ifft(spec, axis=1)*Ncc                           # g(2 pi j / Ncc)
 	ncc = Ncc//2+1
 	psgn = np.where(par == 1, -1.0, 1.0)[:, None]

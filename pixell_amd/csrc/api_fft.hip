@@ -1,6 +1,7 @@
 // C-ABI entry points for the N-d FFT (include/pxsht.h: pxf_*), built on FftContext.
 #include "../../include/pxsht.h"
 #include "fft.hpp"
+#include "fftchain.hpp"
 #include <map>
 #include <mutex>
 #include <memory>
@@ -65,9 +66,12 @@ static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::
                      FftLoad ld, FftStore stf);
 
 static std::mutex g_blue_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> g_blue_scratch;
+// chain engine (and its scratch) of the 2-D real -> complex fast path, per stream like the other scratch
+static std::mutex g_f2_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<FftChain>> g_f2;
 // a stream is about to be destroyed: free the scratch keyed by it (a recycled handle must not inherit a stale buffer)
 void fft_release_stream(int device, hipStream_t st) {
 	{ std::lock_guard<std::mutex> g(g_blue_mu); g_blue_scratch.erase(std::make_pair(device, st)); }
+	{ std::lock_guard<std::mutex> g(g_f2_mu); g_f2.erase(std::make_pair(device, st)); }
 	fft_context(device).release_stream(st);
 }
 
@@ -282,6 +286,19 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 			fft_axis(fc, st, rp.N, rp.forward, other_dims(ax, rshape, is, ostride), is[ax], ostride[ax], ld, stf);
 		}
 	} else if (kind == 0) {
+		{	// real map -> complex spectrum over the last two axes of dense arrays (what enmap.fft of a map is): the chain stages of
+			// the SHT's ring FFTs do it with two rows per complex line and the Hermitian half carried through the column passes
+			const long minpix = [] { const char* e = getenv("PXS_FFT2_FAST_MINPIX"); return e ? atol(e) : (1L << 16); }();    // (-1: never; read per call: the tests switch it)
+			bool dense = ndim >= 2 && naxes == 2 && ((axes[0] == ndim-2 && axes[1] == ndim-1) || (axes[0] == ndim-1 && axes[1] == ndim-2)) && in != out
+				&& in_dtype <= PX_F64 && out_dtype == PX_C128 && minpix >= 0 && (long)shape[ndim-1]*shape[ndim-2] >= minpix;
+			long acc = 1, npre = 1;
+			for (int k = ndim-1; k >= 0 && dense; k--) { dense = istride[k] == acc && ostride[k] == acc; acc *= shape[k]; if (k < ndim-2) npre *= shape[k]; }
+			if (dense) {
+				FftChain* ch;
+				{ std::lock_guard<std::mutex> g(g_f2_mu); auto& u = g_f2[std::make_pair(device, st)]; if (!u) u.reset(new FftChain(&fc)); ch = u.get(); }
+				if (ch->fft2_real(st, in, in_dtype, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)) return 0;
+			}
+		}
 		for (int t = 0; t < naxes; t++) {
 			int ax = axes[naxes-1-t];
 			bool first = (t == 0), lastpass = (t == naxes-1);

@@ -166,7 +166,9 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 struct PairSrc {
 	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol; long cstride;      // cstride: elements between the components of a launch
 	const double2* w;        // optional per-ring weight (.x), applied to a ring sample and to its mirror image
+	int plain;               // no packing, no extension: column p itself (the column transforms of the 2-D FFT)
 	__device__ __forceinline__ double2 get(int comp, int p, int j) const {
+		if (plain) return leg[(long)comp*cstride + (long)p*ld + j];
 		int src = j; bool mir = false;
 		if (j >= nr) { src = N - j - mir_c; if (src < 0) src += N; mir = true; }
 		const int tj = 2*j + mir_c;
@@ -405,7 +407,7 @@ struct StRingA2 : StageBase {
 		double2 xa = make_double2(0.5*(zp.x + zm.x), 0.5*(zp.y - zm.y));
 		const double2 d = make_double2(zp.x - zm.x, zp.y + zm.y);
 		double2 xb = make_double2(0.5*d.y, -0.5*d.x);
-		const double2 t = tab[k];
+		const double2 t = tab ? tab[k] : make_double2(1, 0);
 		double2* o = leg + ((long)c.comp*nm + k)*ldleg + 2*q;
 		o[0] = cscale(cmul(xa, t), scale);
 		if (2*q + 1 < nring) o[1] = cscale(cmul(xb, t), scale);
@@ -460,6 +462,33 @@ struct StRingS2 : StageBase {
 		const long o = bi*m.bstride + (c.comp - bi*m.ncb)*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
 		wr_real(m.ptr, m.dtype, o, v.x);
 		if (2*c.q0 + 1 < m.nring) wr_real(m.ptr, m.dtype, o + m.rstride, -v.y);
+	}
+};
+
+// last pass of the 2-D real -> complex FFT (FftChain::fft2_real): b-point transform over j2 for line k1 of T consecutive columns kx
+// of the half spectrum F[kx][ky]; writes out[ky][kx] (ky = k1 + a k2; kx fastest: runs of T points) and, for 0 < kx < nx - kx, the
+// Hermitian image out[(ny - ky) % ny][nx - kx] = conj
+struct StColOut : StageBase {
+	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
+	static constexpr int MAXR = 9, MINW = 1;
+	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out; double2* out; double scale; FastDiv dgr;
+	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
+		c.outer = fdiv(bx, dnt); c.t0 = bx - c.outer*ntile; c.nl = T;
+		c.comp = fdiv(c.outer, dgr); c.q0 = (c.outer - c.comp*groups)*T; return true; }
+	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
+		const int kx = c.q0 + li;
+		if (kx >= nm) return make_double2(0, 0);
+		return Y[(((long)c.comp*nm + kx)*a + c.t0)*ldY + e]; }
+	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
+	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+		const int kx = c.q0 + li;
+		if (kx >= nm) return;
+		const int ky = c.t0 + a*e;
+		double2 v = cscale(buf[li*ns + e], scale);
+		double2* oc = out + (long)c.comp*ny*nx;
+		// (backward transform of real input = conjugate of the forward one)
+		oc[(long)ky*nx + kx] = conj_out ? cconj(v) : v;
+		if (kx > 0 && 2*kx < nx) oc[(long)(ky == 0 ? 0 : ny - ky)*nx + (nx - kx)] = conj_out ? v : cconj(v);
 	}
 };
 
@@ -900,6 +929,41 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 		}
 	}
 	PXS_HIP(hipGetLastError());
+}
+
+// 2-D FFT of real maps [npre][ny][nx] -> complex [npre][ny][nx] (enmap.fft of a map, pixell/enmap.py:1307-1323), through the
+// chain stages: MA1 / MA2 transform two real rows per complex line and leave the half spectrum transposed, F[kx <= nx/2][y]; the
+// column transforms then run along contiguous rows (StFirst in plain mode, StColOut), and the last pass writes out[ky][kx] and its
+// Hermitian image.  Traffic: 7 x (8 bytes per pixel) + the complex output = 4.5 N x 16 bytes against 7.5 N x 16 for the same
+// transform as a complex one over both axes.  false: no usable factorisation (the caller takes the generic engine).
+bool FftChain::fft2_real(hipStream_t st, const void* in, int in_dtype, double2* out, long npre, long ny, long nx, bool forward, double scale) {
+	Split sy;
+	if (nx < 4 || ny < 4 || !split_balanced(ny, sy) || (nphi_ != nx && !plan_rings(nx))) return false;
+	const long nm = nx/2 + 1, ldF = pad8(ny), a = std::min(sy.a, sy.b), b = ny/a, ldY = pad8(b);
+	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] fft2_real %ld x %ld x %ld: rows %s, columns %ld x %ld\n", npre, ny, nx, describe().c_str(), a, b);
+	PXS_REQUIRE(npre*nm < (1L << 31)/std::max<long>(a, b), "fft2_real: too many lines");
+	// F (half spectrum, transposed) lives in s2_, the four-step intermediates of both axes in s1_
+	s2_.ensure(sizeof(double2)*(size_t)npre*nm*ldF);
+	MapDesc m; m.ptr = in; m.dtype = in_dtype; m.cstride = ny*nx; m.ring_off0 = 0; m.ring_stride = nx; m.pix_stride = 1; m.nring = (int)ny; m.nphi = nx;
+	map2leg(st, m, (int)npre, (int)(nm - 1), s2_.as<double2>(), ldF, nullptr, 1.0);
+	s1_.ensure(sizeof(double2)*(size_t)npre*nm*a*ldY);
+	{	StFirst s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
+		s.src.leg = s2_.as<double2>(); s.src.cstride = nm*ldF; s.src.ld = ldF; s.src.nr = (int)ny; s.src.N = (int)ny; s.src.ncol = (int)nm; s.src.plain = 1;
+		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)nm; s.dnp = make_fastdiv((uint32_t)nm);
+		set_tiles(s, tile_lines(a, 0, b, 8), b, ny);
+		launch_stage(s, npre*nm*s.ntile, st);
+	}
+	{	StColOut s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
+		int T = tile_lines(b, 0, nm, 8);
+		set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
+		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.nm = (int)nm; s.ny = (int)ny; s.nx = (int)nx; s.conj_out = forward ? 0 : 1; s.out = out; s.scale = scale;
+		s.groups = (int)((nm + T - 1)/T); s.dgr = make_fastdiv((uint32_t)s.groups);
+		launch_stage(s, npre*s.groups*a, st);
+	}
+	PXS_HIP(hipGetLastError());
+	return true;
 }
 
 } // namespace pxs

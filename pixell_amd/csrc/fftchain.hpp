@@ -52,6 +52,8 @@ public:
 	// exact adjoint of to_cc: leg on the CC grid -> h[c][ring][m] * conj(tab[m]) * scale on the map's rings (whalf: the to_cc weights, halved off the poles)
 	void to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
 	                   int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* whalf, const double2* tab, double scale);
+	// 2-D FFT of real [npre][ny][nx] (float32 / float64) into complex128 [npre][ny][nx]; false if nx or ny has no usable factorisation
+	bool fft2_real(hipStream_t st, const void* in, int in_dtype, double2* out, long npre, long ny, long nx, bool forward, double scale);
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
 	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc, 3: to_cc_adjoint)
 	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);

@@ -93,6 +93,52 @@ def test_fft_2d_large_gpu():
 	assert rel(h, np.fft.rfftn(a, axes=(-2, -1))) < 1e-12
 	assert rel(pfft.irfft(h, n=5400, axes=[-2, -1], normalize=True), a) < 1e-12
 
+def check_fft2_real(shapes, monkeypatch, tol=1e-12):
+	"""real map -> complex spectrum over the last two axes through the chain stages (FftChain::fft2_real: two rows per complex line,
+	Hermitian half through the column passes) against numpy, forward and backward, float64 and float32 input, and against the
+	generic engine (PXS_FFT2_FAST_MINPIX=-1) that it replaces for dense arrays"""
+	rng = np.random.default_rng(12)
+	for shp in shapes:
+		a = rng.standard_normal(shp)
+		monkeypatch.setenv("PXS_FFT2_FAST_MINPIX", "0")
+		f = pfft.fft(a, axes=[-2, -1]); b = pfft.ifft(a, np.zeros(shp, complex), axes=[-2, -1])
+		f32 = pfft.fft(a.astype(np.float32), np.zeros(shp, np.complex128), axes=[-2, -1])
+		monkeypatch.setenv("PXS_FFT2_FAST_MINPIX", "-1")
+		g = pfft.fft(a, axes=[-2, -1])
+		monkeypatch.delenv("PXS_FFT2_FAST_MINPIX")
+		ref = np.fft.fftn(a, axes=(-2, -1))
+		assert rel(f, ref) < tol and rel(g, ref) < tol and rel(b, np.conj(ref)) < tol, shp
+		assert rel(f32, np.fft.fftn(a.astype(np.float32).astype(np.float64), axes=(-2, -1))) < tol, shp
+
+@pytest.mark.hostsim
+def test_fft2_real_hostsim(monkeypatch): check_fft2_real([(2, 24, 40), (32, 25), (3, 15, 27), (1, 20, 18), (2, 45, 64)], monkeypatch)
+@pytest.mark.gpu
+def test_fft2_real_gpu(monkeypatch): check_fft2_real([(2, 24, 40), (32, 25), (3, 15, 27), (3, 100, 100), (2, 1350, 2700), (1, 2700, 5400), (2, 1000, 1024), (1, 1215, 2025)], monkeypatch)
+
+@pytest.mark.gpu
+def test_enmap_fft_config3_shape_gpu():
+	"""enmap.fft at the C3 map shape (21600 x 43200) against the DFT sum itself on sampled bins: for 12 columns kx the sum over x
+	is a host matrix product map @ e^{-2 pi i kx x / nx}, for 12 rows ky the sum over y of that -- 144 bins of the 9.3e8, none of
+	them through an FFT.  (only <= 2700 x 5400 had been compared with an independent transform.)"""
+	import torch
+	from pixell_amd import enmap
+	ny, nx = 21600, 43200
+	shape, wcs = enmap.fullsky_geometry(shape=(ny, nx))
+	g = torch.Generator(device="cuda"); g.manual_seed(3)
+	m = torch.randn((1, ny, nx), generator=g, dtype=torch.float64, device="cuda")
+	f = enmap.fft(enmap.dmap(m, wcs), normalize=False).tensor
+	kxs = np.array([0, 1, 2, 17, 1000, 10799, 10800, 21599, 21600, 21601, 32400, 43199]); kys = np.array([0, 1, 3, 50, 5399, 5400, 10799, 10800, 10801, 16200, 21598, 21599])
+	x = np.arange(nx); y = np.arange(ny)
+	ang = 2*np.pi*((kxs[None, :]*x[:, None]) % nx)/nx
+	host = m[0].cpu().numpy()
+	R = host @ np.cos(ang) - 1j*(host @ np.sin(ang))                  # [ny, nkx]
+	angy = 2*np.pi*((kys[:, None]*y[None, :]) % ny)/ny
+	ref = (np.cos(angy)-1j*np.sin(angy)) @ R                           # [nky, nkx]
+	got = f[0][torch.as_tensor(kys, device="cuda")][:, torch.as_tensor(kxs, device="cuda")].cpu().numpy()
+	assert np.max(np.abs(got-ref))/np.sqrt(ny*nx) < 1e-11               # bins of white noise have rms sqrt(npix)
+	back = enmap.ifft(enmap.dmap(f, wcs), normalize=False).tensor
+	assert float((back.real/(ny*nx)-m).abs().max()) < 1e-11
+
 def check_bluestein():
 	"""lengths with a prime factor > 2048 (numpy, the reference's fallback engine, takes any n): chirp-z through two 5-smooth FFTs"""
 	from pixell_amd._lib import PxsError
