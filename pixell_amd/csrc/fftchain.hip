@@ -86,6 +86,10 @@ __device__ __forceinline__ void wr_real(void* p, int dtype, long off, double v) 
 // one.  The prefetch registers pushed the single-transform stages to 151-169 VGPRs and the two-transform stages to 256 (172 with
 // 512-thread workgroups), and config 3 got slower: ring FFT 58 -> 67 ms, theta resampling 71 -> 129 ms (102 ms with 512 threads).
 // One tile per workgroup, many workgroups per CU in different phases, stays.)
+// (Tried in round 3, tools/chain_lab.py, profiles/r03_chain_lab_fused_passes.jsonl: fusing the first radix pass of a transform with
+// the global loads (each thread fetches the R inputs of its butterflies) and the last pass with the store -- 7 instead of 10 LDS
+// write sweeps and barriers in a two-transform stage.  93 VGPRs (two instead of three workgroups per CU), or 80 with spills under
+// __launch_bounds__: C3 chain stages 110.6 ms unfused, 124.8-136.8 ms fused; C4 27.0 / 28.4-30.4.  Not kept.)
 // S::MINW = 8 asks the compiler for <= 64 VGPRs (8 waves per SIMD = four 512-thread workgroups per CU where the LDS allows):
 // the ring stages, whose passes use radices up to 8 (S::MAXR), gain 6-12 % from it; with radix 9 compiled in the same bound spills.
 #ifndef PXS_HOST_SIM
