@@ -79,6 +79,9 @@ struct LegK {
 	// spin s; 2 / 4 in the recurrence-only phase A).  x 64 lanes x 2 = the FP64 flops the hardware executed in the recurrences and
 	// accumulations (rings dropped as polar-dead and (wave, m) pairs skipped entirely are not in it, masked-off lanes are).
 	double* count;
+	// maps of a batched call in one launch: the waves of one m of ALL maps sit next to each other in an XCD's queue, so the maps
+	// share the coefficient rows in L2 and the scalar cache.  Strides in elements of leg (double2), almt and mom (double).
+	int nb; long leg_bs, almt_bs, mom_bs;
 };
 // (PXS_NCOUNT slots, one picked by the block index: 200 000 waves adding to ONE address cost ~10 ms per C3 step and 24 ms per C4 step)
 #define PXS_NCOUNT 1024
@@ -97,16 +100,18 @@ struct LegK {
 // (Workgroups of 2-4 independent waves of the same m -- to share the rows in the CU's scalar cache -- were measured twice:
 // with __launch_bounds__(256) and the lane taken as threadIdx.x & 63 every kernel got slower even at one wave per workgroup
 // (config 3: leg_syn 106 -> 113 ms, leg_ana 144 -> 151 ms), 4 waves per workgroup 128 / 165 ms.  One wave per workgroup stays.)
-__device__ __forceinline__ bool leg_block(const LegK& a, int& wv, int& m) {
-	if (!a.xcd) { wv = blockIdx.x; m = blockIdx.y + a.m0; return true; }
+__device__ __forceinline__ bool leg_block(const LegK& a, int& wv, int& m, int& bb) {
+	if (!a.xcd) { wv = blockIdx.x; m = blockIdx.y + a.m0; bb = blockIdx.z; return true; }
 	const unsigned b = blockIdx.x, x = b & 7u, j = b >> 3;
-	const unsigned ml = j / (unsigned)a.nwave;
-	wv = (int)(j - ml*a.nwave);
+	const unsigned per_m = (unsigned)a.nwave*(unsigned)a.nb;
+	const unsigned ml = j / per_m, r = j - ml*per_m;
+	bb = (int)(r / (unsigned)a.nwave);
+	wv = (int)(r - (unsigned)bb*a.nwave);
 	const unsigned mi = ml*8u + x;
 	m = (int)mi + a.m0;
 	return mi < (unsigned)a.nmc;
 }
-static inline dim3 leg_grid(const LegK& a) { return a.xcd ? dim3((unsigned)(8*((a.nmc+7)/8)*a.nwave)) : dim3(a.nwave, a.nmc); }
+static inline dim3 leg_grid(const LegK& a) { return a.xcd ? dim3((unsigned)(8*((a.nmc+7)/8)*a.nwave*a.nb)) : dim3(a.nwave, a.nmc, a.nb); }
 
 
 // ---------------------------------------------------------------------------------
@@ -155,7 +160,9 @@ struct AlmK {
 	long nrows, cstride, lstride;
 	const long* row; const double* alpha; const uint64_t* mstart;
 	void* alm; double* almt; const double* mom;
+	long alm_bs, almt_bs, mom_bs;      // batched calls: blockIdx.z = map; strides in alm elements / doubles
 };
+__device__ __forceinline__ void* alm_of_batch(const AlmK& a) { return (char*)a.alm + (size_t)(a.dtype == PX_C64 ? 8 : 16)*(size_t)blockIdx.z*(size_t)a.alm_bs; }
 
 // spin 0: almt[row(m)+k] = alpha_k * ( eps_{l+1} a_l + eps_{l+2} a_{l+2},  a_{l+1} ),  l = m+2k
 __global__ __launch_bounds__(256) void alm_pre_s0(AlmK a) {
@@ -165,12 +172,13 @@ __global__ __launch_bounds__(256) void alm_pre_s0(AlmK a) {
 	if (k >= nk) return;
 	const int l = m + 2*k;
 	const long base = (long)a.mstart[m];
-	double2 a0 = ld_alm(a.alm, a.dtype, base + (long)l*a.lstride);
-	double2 a1 = (l+1 <= a.lmax) ? ld_alm(a.alm, a.dtype, base + (long)(l+1)*a.lstride) : make_double2(0, 0);
-	double2 a2 = (l+2 <= a.lmax) ? ld_alm(a.alm, a.dtype, base + (long)(l+2)*a.lstride) : make_double2(0, 0);
+	const void* alm = alm_of_batch(a);
+	double2 a0 = ld_alm(alm, a.dtype, base + (long)l*a.lstride);
+	double2 a1 = (l+1 <= a.lmax) ? ld_alm(alm, a.dtype, base + (long)(l+1)*a.lstride) : make_double2(0, 0);
+	double2 a2 = (l+2 <= a.lmax) ? ld_alm(alm, a.dtype, base + (long)(l+2)*a.lstride) : make_double2(0, 0);
 	const double al = a.alpha[a.row[m] + k];
 	const double e1 = eps_lm(l+1, m), e2 = eps_lm(l+2, m);
-	double* o = a.almt + 4*(a.row[m] + k);
+	double* o = a.almt + (long)blockIdx.z*a.almt_bs + 4*(a.row[m] + k);
 	o[0] = al*(e1*a0.x + e2*a2.x); o[1] = al*(e1*a0.y + e2*a2.y);
 	o[2] = al*a1.x;                o[3] = al*a1.y;
 }
@@ -182,14 +190,15 @@ __global__ __launch_bounds__(256) void alm_post_s0(AlmK a) {
 	if (k >= nk) return;
 	const int l = m + 2*k;
 	const long r = a.row[m] + k;
-	const double* M = a.mom + 4*r;
+	const double* M = a.mom + (long)blockIdx.z*a.mom_bs + 4*r;
 	const double al = a.alpha[r];
 	const double e1 = eps_lm(l+1, m), e0 = eps_lm(l, m);
 	double2 v = make_double2(e1*al*M[0], e1*al*M[1]);
 	if (k > 0) { const double alp = a.alpha[r-1]; v.x += e0*alp*M[-4]; v.y += e0*alp*M[-3]; }
 	const long base = (long)a.mstart[m];
-	st_alm(a.alm, a.dtype, base + (long)l*a.lstride, v);
-	if (l+1 <= a.lmax) st_alm(a.alm, a.dtype, base + (long)(l+1)*a.lstride, make_double2(al*M[2], al*M[3]));
+	void* alm = alm_of_batch(a);
+	st_alm(alm, a.dtype, base + (long)l*a.lstride, v);
+	if (l+1 <= a.lmax) st_alm(alm, a.dtype, base + (long)(l+1)*a.lstride, make_double2(al*M[2], al*M[3]));
 }
 // spin s: rows l = l0..lmax; almt = beta_l * ( a+ = -(E+iB),  a- = -(-1)^s (E-iB) )
 __global__ __launch_bounds__(256) void alm_pre_spin(AlmK a) {
@@ -198,13 +207,14 @@ __global__ __launch_bounds__(256) void alm_pre_spin(AlmK a) {
 	const int l = l0 + blockIdx.x*blockDim.x + threadIdx.x;
 	if (l > a.lmax) return;
 	const long idx = (long)a.mstart[m] + (long)l*a.lstride;
-	double2 E = ld_alm(a.alm, a.dtype, idx), B;
+	const void* alm = alm_of_batch(a);
+	double2 E = ld_alm(alm, a.dtype, idx), B;
 	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); E.x *= f; E.y *= f; B = make_double2(0, 0); }
-	else B = ld_alm(a.alm, a.dtype, idx + a.cstride);
+	else B = ld_alm(alm, a.dtype, idx + a.cstride);
 	const long r = a.row[m] + (l - l0);
 	const double be = a.alpha[r];
 	const double sg = (a.spin & 1) ? -1.0 : 1.0;
-	double* o = a.almt + 4*r;
+	double* o = a.almt + (long)blockIdx.z*a.almt_bs + 4*r;
 	o[0] = -be*(E.x - B.y); o[1] = -be*(E.y + B.x);
 	o[2] = -sg*be*(E.x + B.y); o[3] = -sg*be*(E.y - B.x);
 }
@@ -218,14 +228,15 @@ __global__ __launch_bounds__(256) void alm_post_spin(AlmK a) {
 	double2 E = make_double2(0, 0), B = make_double2(0, 0);
 	if (l >= l0) {
 		const long r = a.row[m] + (l - l0);
-		const double* M = a.mom + 4*r;
+		const double* M = a.mom + (long)blockIdx.z*a.mom_bs + 4*r;
 		const double be = a.alpha[r];
 		const double sg = (a.spin & 1) ? -1.0 : 1.0;
 		E = make_double2(-0.5*be*(M[0] + sg*M[2]), -0.5*be*(M[1] + sg*M[3]));
 		B = make_double2(-0.5*be*(M[1] - sg*M[3]),  0.5*be*(M[0] - sg*M[2]));
 	}
-	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); st_alm(a.alm, a.dtype, idx, make_double2(f*E.x, f*E.y)); }
-	else { st_alm(a.alm, a.dtype, idx, E); st_alm(a.alm, a.dtype, idx + a.cstride, B); }
+	void* alm = alm_of_batch(a);
+	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); st_alm(alm, a.dtype, idx, make_double2(f*E.x, f*E.y)); }
+	else { st_alm(alm, a.dtype, idx, E); st_alm(alm, a.dtype, idx + a.cstride, B); }
 }
 
 // mom[row] = sum over the waves that wrote that row.  A wave writes rows from the end of its phase A on and nothing at all
@@ -357,12 +368,12 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 
 template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 {
-	const int lane = threadIdx.x; int wv, m;
-	if (!leg_block(a, wv, m)) return;
+	const int lane = threadIdx.x; int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
-	const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
+	const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt + (long)bb*a.almt_bs) + row0;
 	double x[K], csq[K], lam1[K], lam2[K], p1r[K], p1i[K], p2r[K], p2i[K];
 	int sc[K], rn[K], rs[K];
 	bool alive_any = false;
@@ -424,7 +435,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
 			}
 		}
 	}
-	double2* __restrict__ out = a.leg + (long)m*a.ld;
+	double2* __restrict__ out = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
 #pragma unroll
 	for (int s = 0; s < K; s++) {      // ring indices and cos(theta) are re-read here rather than kept in registers through the loops
 		const int p = (wv*K + s)*64 + lane;
@@ -561,13 +572,13 @@ __device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst,
 template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 {
 	PXS_SHARED(double, red);
-	const int lane = threadIdx.x; int wv, m;
-	if (!leg_block(a, wv, m)) return;
+	const int lane = threadIdx.x; int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
-	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
-	const double2* __restrict__ in = a.leg + (long)m*a.ld;
+	double* __restrict__ pout = a.part + (long)bb*a.mom_bs + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
+	const double2* __restrict__ in = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
 	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
 	int sc[K];
 	bool alive_any = false;
@@ -746,12 +757,12 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 // workgroups once pushed it to 132 = 3 waves and leg_syn from 120 to 151 ms at config 3 -- keep an eye on that cliff.)
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
-	const int lane = threadIdx.x; int wv, m;
-	if (!leg_block(a, wv, m)) return;
+	const int lane = threadIdx.x; int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
-	double2* __restrict__ outq = a.leg + (long)m*a.ld;
-	double2* __restrict__ outu = a.leg + ((long)a.nm + m)*a.ld;
+	double2* __restrict__ outq = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
+	double2* __restrict__ outu = a.leg + (long)bb*a.leg_bs + ((long)a.nm + m)*a.ld;
 	SpinState<K> S; int rn[K], rs[K];
 	// north: P = sum G+ a+, M = sum G- a-;  south (before the sign): qs = sum +-G- a+, ns = sum +-G+ a-
 	double pnr[K], pni[K], mnr[K], mni[K], qsr[K], qsi[K], nsr[K], nsi[K];
@@ -763,7 +774,7 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 	if (nl > 0 && __any(alive_any)) {
 		const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 		const double4_t* __restrict__ coef = a.coef + row0;
-		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt) + row0;
+		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt + (long)bb*a.almt_bs) + row0;
 		int j = 0;
 		SPIN_SEEDED_PHASE_A
 		j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
@@ -866,16 +877,16 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 {
 	PXS_SHARED(double, red);
-	const int lane = threadIdx.x; int wv, m;
-	if (!leg_block(a, wv, m)) return;
+	const int lane = threadIdx.x; int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	if (nl <= 0) return;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const double4_t* __restrict__ coef = a.coef + row0;
-	double* __restrict__ pout = a.part + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
-	const double2* __restrict__ inq = a.leg + (long)m*a.ld;
-	const double2* __restrict__ inu = a.leg + ((long)a.nm + m)*a.ld;
+	double* __restrict__ pout = a.part + (long)bb*a.mom_bs + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
+	const double2* __restrict__ inq = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
+	const double2* __restrict__ inu = a.leg + (long)bb*a.leg_bs + ((long)a.nm + m)*a.ld;
 	SpinState<K> S; int rn[K], rs[K];
 	const bool polar = leg_wave_polar(a, wv, K);
 	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
@@ -1073,7 +1084,10 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 }
 
 
-static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, double2* leg, long ld, int K) {
+// doubles per map of the pre-scaled alm / the moments of a batched call
+static long leg_almt_stride(const LegTables& tb) { return 4*(tb.nrows + 4); }
+static long leg_mom_stride(const LegTables& tb) { return 4*std::max<long>(tb.nrows, 1); }
+static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, double2* leg, long ld, int K, int nb = 1, long leg_bs = 0) {
 	LegK a; memset(&a, 0, sizeof(a));
 	a.lmax = tb.lmax; a.mmax = tb.mmax; a.spin = tb.spin; a.nm = tb.mmax+1; a.npairs = rs.npairs; a.nring = rs.nring;
 	a.nwave = (rs.npairs + 64*K - 1)/(64*K);
@@ -1085,6 +1099,8 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	a.ofs = std::max(100.0, 0.01*tb.lmax);
 	a.nmc = a.nm; a.xcd = xcd_map();
 	a.count = wk.count_on ? wk.count.as<double>() : nullptr;
+	a.nb = nb; a.leg_bs = leg_bs; a.almt_bs = leg_almt_stride(tb); a.mom_bs = leg_mom_stride(tb);
+	PXS_REQUIRE((long)8*((a.nm + 7)/8)*a.nwave*nb < (1L << 31), "internal: Legendre grid too large for one launch");
 	return a;
 }
 
@@ -1122,8 +1138,16 @@ static void seeds_wait(LegWork::Seeds* sb, hipStream_t st) {
 	if (sb && sb->ready && sb->written && st != sb->wstream) PXS_HIP(hipStreamWaitEvent(st, sb->written, 0));
 }
 
-static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dtype, long cstride, const uint64_t* d_mstart, long lstride, int deriv1) {
+// will the next launch of this kind record seeds (first use on a plan, budget permitting)?
+static bool seeds_pending(LegWork& wk, const RingSet& rs, const LegTables& tb, int dir, int K) {
+	LegK probe; memset(&probe, 0, sizeof(probe)); probe.nm = tb.mmax + 1; probe.nwave = (rs.npairs + 64*K - 1)/(64*K);
+	LegWork::Seeds* sb = seeds_for(wk, rs, tb, dir, K, probe);
+	return sb != nullptr && !sb->ready;
+}
+
+static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dtype, long cstride, const uint64_t* d_mstart, long lstride, int deriv1, long alm_bs) {
 	AlmK k; memset(&k, 0, sizeof(k));
+	k.alm_bs = alm_bs; k.almt_bs = leg_almt_stride(tb); k.mom_bs = leg_mom_stride(tb);
 	k.lmax = tb.lmax; k.mmax = tb.mmax; k.spin = tb.spin; k.deriv1 = deriv1; k.dtype = dtype;
 	k.nrows = tb.nrows; k.cstride = cstride; k.lstride = lstride; k.row = tb.d_row.as<long>(); k.alpha = tb.d_alpha.as<double>();
 	k.mstart = d_mstart; k.alm = const_cast<void*>(alm); k.almt = wk.almt.as<double>(); k.mom = wk.mom.as<double>();
@@ -1132,49 +1156,66 @@ static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dty
 
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                   double2* leg, int deriv1, LegProfile* prof, long ld)
+                   double2* leg, int deriv1, LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
-	wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
-	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
+	PXS_REQUIRE(nb >= 1, "leg_synthesis: nb must be >= 1");
+	wk.almt.ensure(sizeof(double)*(size_t)leg_almt_stride(tb)*nb);
+	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
 	const int nm = tb.mmax+1;
-	if (tb.spin == 0) {
-		const int nkmax = tb.lmax/2 + 1;
-		hipLaunchKernelGGL(alm_pre_s0, dim3((nkmax+255)/256, nm), dim3(256), 0, st, ak);
-		const int K = k_syn0();
-		LegK a = make_legk(rs, tb, wk, leg, ld, K);
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+	const int K = tb.spin == 0 ? k_syn0() : k_syns();
+	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, dim3((tb.lmax/2 + 1 + 255)/256, nm, nb), dim3(256), 0, st, ak);
+	else              hipLaunchKernelGGL(alm_pre_spin, dim3((tb.lmax + 1 + 255)/256, nm, nb), dim3(256), 0, st, ak);
+	// maps [b0, b0 + n) in one launch
+	auto launch = [&](int b0, int n) {
+		LegK a = make_legk(rs, tb, wk, leg + (size_t)b0*leg_bstride, ld, K, n, leg_bstride);
+		a.almt += (size_t)b0*a.almt_bs;
 		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
 		if (prof) prof->begin(st, 0);
-		if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
-		else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
+		if (tb.spin == 0) {
+			if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
+			else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
+		} else {
+			if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
+			else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
+			else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
+		}
 		if (prof) prof->end(st, 0);
 		seeds_written(sb, st);
-	} else {
-		const int nlmax = tb.lmax + 1;
-		hipLaunchKernelGGL(alm_pre_spin, dim3((nlmax+255)/256, nm), dim3(256), 0, st, ak);
-		const int K = k_syns();
-		LegK a = make_legk(rs, tb, wk, leg, ld, K);
-		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
-		if (prof) prof->begin(st, 0);
-		if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
-		else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
-		else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
-		if (prof) prof->end(st, 0);
-		seeds_written(sb, st);
-	}
+	};
+	(void)aesz;
+	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
+	int b0 = 0;
+	if (nb > 1 && seeds_pending(wk, rs, tb, 0, K)) { launch(0, 1); b0 = 1; }
+	launch(b0, nb - b0);
 	PXS_HIP(hipGetLastError());
 }
 
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                  int deriv1, LegProfile* prof, long ld)
+                  int deriv1, LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
+	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
 	const int K = tb.spin == 0 ? k_ana0() : k_anas();
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
-	const long n4 = 4*std::max<long>(tb.nrows, 1);
-	wk.mom.ensure(sizeof(double)*n4);
+	const long n4 = leg_mom_stride(tb);
+	{	// the ordered (bitwise repeatable) scheme and the launch that records the seeds take one map at a time
+		const char* det0 = getenv("PXS_DETERMINISTIC");
+		const bool one_by_one = (det0 && atoi(det0) != 0) || seeds_pending(wk, rs, tb, 1, K);
+		if (nb > 1 && one_by_one) {
+			const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+			const int first = (det0 && atoi(det0) != 0) ? nb : 1;
+			for (int b = 0; b < first; b++)
+				leg_analysis(st, rs, tb, wk, leg + (size_t)b*leg_bstride, (char*)alm + aesz*(size_t)b*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, prof, ld, 1, 0, 0);
+			if (first < nb)
+				leg_analysis(st, rs, tb, wk, leg + (size_t)first*leg_bstride, (char*)alm + aesz*(size_t)first*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, prof, ld, nb - first, alm_bstride, leg_bstride);
+			return;
+		}
+	}
+	wk.mom.ensure(sizeof(double)*(size_t)n4*nb);
 	// Default: the waves of one m add their sums straight into mom with global_atomic_add_f64 -- the blocks of one m run back
 	// to back on one XCD (leg_block), so the row they share sits in that XCD's L2 while they do.  The order of those additions
 	// is not fixed: results repeat to rounding, not bit for bit.  PXS_DETERMINISTIC=1 selects the former scheme instead
@@ -1184,7 +1225,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	std::vector<int> cuts; cuts.push_back(0);
 	if (atomic) {
 		cuts.push_back(nm);
-		PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*n4, st));
+		PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nb, st));
 	} else {
 		// chunk m so that the per-wave partial moments stay below part_budget bytes
 		const size_t budget = wk.part_budget;
@@ -1208,7 +1249,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		const int m0 = cuts[c], m1 = cuts[c+1];
 		const long rows = tb.row[m1]-tb.row[m0];
 		if (rows <= 0) continue;
-		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K);
+		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg), ld, K, nb, leg_bstride);
 		a.m0 = m0; a.rowbase = tb.row[m0]; a.rows_chunk = rows; a.nmc = m1-m0; a.atomic = atomic ? 1 : 0;
 		seeds = seeds_for(wk, rs, tb, 1, K, a); seeds_wait(seeds, st);
 		if (atomic) { a.part = (double*)wk.mom.p; a.rowbase = 0; a.rows_chunk = 0; a.first = nullptr; }
@@ -1236,9 +1277,9 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 			(double*)wk.mom.p, tb.d_row.as<long>(), (const int*)wk.first.p, m0, m1-m0, tb.row[m0], rows, a.nwave);
 	}
 	seeds_written(seeds, st);
-	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1);
-	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm), dim3(256), 0, st, ak);
-	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm), dim3(256), 0, st, ak);
+	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
+	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm, nb), dim3(256), 0, st, ak);
+	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm, nb), dim3(256), 0, st, ak);
 	PXS_HIP(hipGetLastError());
 }
 

@@ -53,12 +53,13 @@ struct LegWork {     // scratch owned by the SHT plan
 
 
 // alm[(c) * alm_cstride + mstart[m] + l*lstride] -> leg[(c*nm + m)*ld + ring]  (c = 0 or 0,1; ld = 0: nring)
+// nb maps in one launch: map b reads alm + b*alm_bstride (alm elements) and writes leg + b*leg_bstride (double2 elements)
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                   double2* leg, int deriv1, LegProfile* prof = nullptr, long ld = 0);
+                   double2* leg, int deriv1, LegProfile* prof = nullptr, long ld = 0, int nb = 1, long alm_bstride = 0, long leg_bstride = 0);
 // transpose of leg_synthesis (no weights)
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
-                  int deriv1, LegProfile* prof = nullptr, long ld = 0);
+                  int deriv1, LegProfile* prof = nullptr, long ld = 0, int nb = 1, long alm_bstride = 0, long leg_bstride = 0);
 
 } // namespace pxs

@@ -997,9 +997,8 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 		if ((p->is_grid || (p->band && th)) && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0) {
 			const long ldc = p->ld_cc();
 			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
-			for (int b = 0; b < nb; b++)
-				leg_synthesis(st, p->rs_cc, tb, p->wk, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
-					p->leg2.as<double2>() + (size_t)b*ncm*nm*ldc, mode == PXS_MODE_DERIV1, &p->prof, ldc);
+			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				p->leg2.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldc, nb, alm_bstride, (long)ncm*nm*ldc);
 			if (th) {	// fused chain: CC grid -> ring spectra of the map's rings, written ring-major for the ring FFT
 				const long ldh = p->ld_h();
 				const int nrh = p->band ? p->nfull : nr;          // (a band: h for every ring of the grid, the ring FFTs take its rows)
@@ -1018,9 +1017,8 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 				leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, ncm, via_h);
 			}
 		} else {
-			for (int b = 0; b < nb; b++)
-				leg_synthesis(st, p->rs_map, tb, p->wk, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
-					p->leg.as<double2>() + (size_t)b*ncm*nm*ldm, mode == PXS_MODE_DERIV1, &p->prof, ldm);
+			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				p->leg.as<double2>(), mode == PXS_MODE_DERIV1, &p->prof, ldm, nb, alm_bstride, (long)ncm*nm*ldm);
 			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, nct, false, map_bstride, ncb);
 		}
 	} else {
@@ -1041,14 +1039,12 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldin, p->band ? p->nfull : nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
 				p->ph_shift.as<double2>(), p->wadj.as<double2>());
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
-			for (int b = 0; b < nb; b++)
-				leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>() + (size_t)b*ncm*nm*ldc, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
-					mode == PXS_MODE_DERIV1, &p->prof, ldc);
+			leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				mode == PXS_MODE_DERIV1, &p->prof, ldc, nb, alm_bstride, (long)ncm*nm*ldc);
 			return;
 		}
-		for (int b = 0; b < nb; b++)
-			leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>() + (size_t)b*ncm*nm*ldm, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
-				mode == PXS_MODE_DERIV1, &p->prof, ldm);
+		leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+			mode == PXS_MODE_DERIV1, &p->prof, ldm, nb, alm_bstride, (long)ncm*nm*ldm);
 	}
 }
 
@@ -1067,23 +1063,23 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 	size_t c1 = 0, c2 = 0, r1 = 0;
 	auto theta = [&](int kind) { if (th) FftChain::theta_scratch(p->tp, (int)nm, nct, kind, c1, c2); };
 	if (synthesis && !adjoint) {                        // alm -> map
-		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
+		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4)*nb);
 		p->leg.ensure(c16*nct*nm*ldm);
 		if (via_cc) { p->leg2.ensure(c16*nct*nm*ldc); if (th) { p->hbuf.ensure(c16*nct*(p->band ? (size_t)p->nfull : nr)*ldh); theta(2); } }
 		else p->hbuf.ensure(c16*nct*nr*ldh);
 		p->chain->ring_scratch(p->nring, nct, false, r1);
 	} else if (synthesis) {                             // map -> alm, transpose of the synthesis
-		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
+		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1)*nb);
 		const bool via = (p->is_grid || p->band) && th && p->geometry == "F1" && via_cc;
 		p->leg.ensure(c16*nct*nm*(via && p->band ? (size_t)FftChain::pad8(p->nfull) : ldm));
 		if (via) { p->leg2.ensure(c16*nct*nm*ldc); theta(1); }
 		p->chain->ring_scratch(p->nring, nct, true, r1);
 	} else if (!adjoint && !p->wring.p && th) {         // analysis_2d
-		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1));
+		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1)*nb);
 		p->leg.ensure(c16*nct*nm*ldm); p->leg2.ensure(c16*nct*nm*ldc); theta(0);
 		p->chain->ring_scratch(p->nring, nct, true, r1);
 	} else if (adjoint && !p->wring.p && th) {          // adjoint_analysis_2d (fused transposed chain)
-		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4));
+		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4)*nb);
 		p->leg2.ensure(c16*nct*nm*ldc); p->hbuf.ensure(c16*nct*nr*ldh); theta(3);
 		p->chain->ring_scratch(p->nring, nct, false, r1);
 	} else return;
@@ -1139,13 +1135,11 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		if (!adjoint) {
 			map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldw, map_bstride, ncbw);
 			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, p->wring.as<double2>());
-			for (int b = 0; b < nb; b++)
-				leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>() + (size_t)b*nc*nm*ldw, (char*)alm + aeszw*(size_t)b*alm_bstride, alm_dtype, alm_cstride,
-					p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldw);
+			leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride,
+				p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldw, nb, alm_bstride, (long)nc*nm*ldw);
 		} else {
-			for (int b = 0; b < nb; b++)
-				leg_synthesis(st, p->rs_map, tb, p->wk, (char*)alm + aeszw*(size_t)b*alm_bstride, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
-					p->leg.as<double2>() + (size_t)b*nc*nm*ldw, 0, &p->prof, ldw);
+			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				p->leg.as<double2>(), 0, &p->prof, ldw, nb, alm_bstride, (long)nc*nm*ldw);
 			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, p->wring.as<double2>());
 			leg2map(p, st, p->leg.as<double2>(), ldw, map, map_dtype, map_cstride, nct, false, map_bstride, ncbw);
 		}
@@ -1159,9 +1153,8 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		const long ldc = p->ld_cc(), ldh = p->ld_h();
 		const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
 		p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc); p->hbuf.ensure(sizeof(double2)*(size_t)nct*nr*ldh);
-		for (int b = 0; b < nb; b++)
-			leg_synthesis(st, p->rs_cc, tb, p->wk, (char*)alm + aesz*(size_t)b*alm_bstride, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
-				p->leg2.as<double2>() + (size_t)b*nc*nm*ldc, 0, &p->prof, ldc);
+		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+			p->leg2.as<double2>(), 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
 		p->prof.begin(st, PXS_STAGE_RESAMPLE);
 		p->chain->to_cc_adjoint(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
 			p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->whalf.as<double2>(), p->phase.as<double2>(), 2.0);
@@ -1184,8 +1177,7 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>());
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
 		} else { PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path"); resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin); }
-		for (int b = 0; b < nb; b++)
-			leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>() + (size_t)b*nc*nm*ldc, alm_of(b), alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc);
+		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
 	} else {
 		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
 		PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path");
