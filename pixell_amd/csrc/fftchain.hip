@@ -601,6 +601,19 @@ bool FftChain::plan_rings(long nphi) {
 	// synthesis: pass 2 tiles are 16 lines x b points -> the smaller factor last
 	ra_.a = std::min(s.a, s.b); ra_.b = nphi/ra_.a;
 	rs_.b = std::min(s.a, s.b); rs_.a = nphi/rs_.b;
+	// The map side of the ring stages moves 8-byte reals in runs of T lines.  Synthesis (MS2 WRITES the map: a partial 128-byte
+	// line is a read-modify-write): the first factor a a multiple of 16 and T a multiple of 16 (b <= 160) make every run whole,
+	// aligned lines; the largest such a <= 320 (8 lines of a points still fill a tile in MS1).  Analysis (MA1 reads the map): b the
+	// largest multiple of 16 up to 256.  Measured with tools/chain_lab.py (ms, h2map / map2leg of one component): C3 43200 =
+	// 240 x 180 -> 320 x 135: 8.13 -> 7.04 (288 x 150: 7.48, 400 x 108: 7.33); C4 10800 = 120 x 90 -> 240 x 45: 3.88 -> 3.45 per 8
+	// maps (80 x 135: 3.52, 144 x 75: 3.56); analysis 90 x 120 -> 45 x 240: 3.78 -> 3.45 (C3 stays 180 x 240; 150 x 288: 7.77 vs 7.54).
+	for (long a = 320; a >= 16; a -= 16) if (nphi % a == 0 && nphi/a <= 160 && nphi/a >= 2 && sub_ok(a) && sub_ok(nphi/a)) { rs_.a = a; rs_.b = nphi/a; break; }
+	for (long b = 256; b >= 16; b -= 16) if (nphi % b == 0 && nphi/b >= 2 && nphi/b <= 320 && sub_ok(b) && sub_ok(nphi/b)) { ra_.b = b; ra_.a = nphi/b; break; }
+	{	// experiments: force the first factor of the analysis / synthesis split
+		const char* ea = getenv("PXS_RING_A_ANA"); const char* es = getenv("PXS_RING_A_SYN");
+		if (ea && atol(ea) > 1 && nphi % atol(ea) == 0 && sub_ok(atol(ea)) && sub_ok(nphi/atol(ea))) { ra_.a = atol(ea); ra_.b = nphi/ra_.a; }
+		if (es && atol(es) > 1 && nphi % atol(es) == 0 && sub_ok(atol(es)) && sub_ok(nphi/atol(es))) { rs_.a = atol(es); rs_.b = nphi/rs_.a; }
+	}
 	return true;
 }
 
