@@ -41,6 +41,13 @@ HBM_PEAK_GBS = 8000.0
 def log(*a):
 	print(*a, file=sys.stderr, flush=True)
 
+def emit(res):
+	"""the ONE line on stdout: whatever native libraries left in libc's stdout buffer goes out first"""
+	try:
+		import ctypes; ctypes.CDLL(None).fflush(None)
+	except Exception: pass
+	print(json.dumps(res), flush=True)
+
 def nalm(lmax): return (lmax+1)*(lmax+2)//2
 
 def alg_flops_direction(cfg, R, nmaps=1):
@@ -291,7 +298,7 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 			peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9/HBM_PEAK_GBS, 4) if stage_ms["enmap_fft"] > 0 else 0.0),
 		checks=dict(roundtrip_rms_error=rt_err, alm2cl_invariance=cl_err, binned_ps2d_over_cl_median=flat_ratio), ducc0=probe_ducc0())
 	if world > 1: res["rccl_ranks_seen"] = world
-	if rank == 0: print(json.dumps(res), flush=True)
+	if rank == 0: emit(res)
 
 def main():
 	ap = argparse.ArgumentParser()
@@ -329,13 +336,25 @@ def main():
 	if backend != "nccl": local = local % torch.cuda.device_count()
 	torch.cuda.set_device(local)             # before the process group: RCCL binds the communicator to the current device
 	device = torch.device("cuda", local)
-	if world > 1:
+	# PXS_BENCH_FORCE_PG=1: a process group (and the alm gather) even with one rank -- exercises the RCCL calls of the N > 1 path on a one-GPU box
+	force_pg = world == 1 and os.environ.get("PXS_BENCH_FORCE_PG") == "1"
+	if force_pg:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+		os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+	if world > 1 or force_pg:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		# RCCL logs to stdout (this image sets NCCL_DEBUG=VERSION: a banner, from libc's buffer, i.e. at process exit, AFTER the JSON
+		# line): send its log to stderr and keep stdout to the one line the driver parses
+		os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
 		dist.init_process_group(backend)
+		dist.barrier()                               # creates the communicator now; anything it printed leaves libc's buffer before the timed part
+		try:
+			import ctypes; ctypes.CDLL(None).fflush(None)
+		except Exception: pass
 	if args.config == "c5":
 		try: run_c5(args, torch, dist, rank, world, local, device, backend)
 		finally:
-			if world > 1: dist.destroy_process_group()
+			if world > 1 or force_pg: dist.destroy_process_group()
 		return
 	from pixell_amd import curvedsky, enmap, sht, dist as pdist
 	cfg = CONFIGS[args.config]
@@ -370,7 +389,7 @@ def main():
 	plan = sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1)
 	info = plan.info()
 	gather = None; side = None; ranks_seen = None
-	if world > 1 and not args.no_gather:
+	if (world > 1 or force_pg) and not args.no_gather:
 		rows = [ncomp*(pdist.shard_range(ntot, r, world)[1]-pdist.shard_range(ntot, r, world)[0]) for r in range(world)] if batched else [ncomp]*world
 		gather = pdist.AlmGather(alm_out, rows, device, backend)
 		side = torch.cuda.Stream(device=device)
@@ -388,17 +407,17 @@ def main():
 
 	for _ in range(args.warmup): step()
 	torch.cuda.synchronize()
-	if world > 1: dist.barrier()
+	if world > 1 or force_pg: dist.barrier()
 	plan.profile(True)
 	torch.cuda.synchronize()
 	t0 = time.perf_counter()
 	for _ in range(args.steps): step()
 	torch.cuda.synchronize()
-	if world > 1: dist.barrier()
+	if world > 1 or force_pg: dist.barrier()
 	torch.cuda.synchronize()
 	dt = time.perf_counter()-t0
 	prof = plan.profile_read(reset=True); fl_syn, fl_ana = plan.profile_flops(reset=True); plan.profile(False)
-	if world > 1:
+	if world > 1 or force_pg:
 		t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 	ms_step = dt/args.steps*1e3
@@ -464,8 +483,8 @@ def main():
 				res["cpu_baseline"] = cpu_baseline(dict(cfg, ncomp=ncomp))
 			except Exception as e:   # the baseline must never take the GPU number down with it
 				log("cpu_baseline failed: %r" % (e,)); res["cpu_baseline"] = None
-		print(json.dumps(res), flush=True)
-	if world > 1: dist.destroy_process_group()
+		emit(res)
+	if world > 1 or force_pg: dist.destroy_process_group()
 
 if __name__ == "__main__":
 	main()

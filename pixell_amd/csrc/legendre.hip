@@ -1163,7 +1163,6 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	wk.almt.ensure(sizeof(double)*(size_t)leg_almt_stride(tb)*nb);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
 	const int nm = tb.mmax+1;
-	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
 	const int K = tb.spin == 0 ? k_syn0() : k_syns();
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, dim3((tb.lmax/2 + 1 + 255)/256, nm, nb), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_pre_spin, dim3((tb.lmax + 1 + 255)/256, nm, nb), dim3(256), 0, st, ak);
@@ -1184,7 +1183,6 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		if (prof) prof->end(st, 0);
 		seeds_written(sb, st);
 	};
-	(void)aesz;
 	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
 	int b0 = 0;
 	if (nb > 1 && seeds_pending(wk, rs, tb, 0, K)) { launch(0, 1); b0 = 1; }

@@ -989,8 +989,6 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 	const bool th = p->chain_theta();
 	const long ldm = p->chain_rings ? FftChain::pad8(nr) : nr;
 	const int ncb = nb > 1 ? ncm : 0;
-	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
-	auto alm_of = [&](int b) { return (void*)((char*)alm + aesz*(size_t)b*alm_bstride); };
 	(void)nca;
 	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
 	if (!adjoint) {
@@ -1129,7 +1127,6 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 	if (p->wring.p) {	// DH / F2: analysis = adjoint synthesis of the weighted map (its adjoint: synthesis, then the weights)
 		const long ldw = p->chain_rings ? FftChain::pad8(nr) : nr;
 		const int ncbw = nb > 1 ? nc : 0;
-		const size_t aeszw = alm_dtype == PX_C64 ? 8 : 16;
 		p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldw);
 		const long tot = (long)nct*nm*nr;
 		if (!adjoint) {
@@ -1151,7 +1148,6 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		// adjoint_analysis_2d through the fused transposed chain: Legendre synthesis on the CC grid, FftChain::to_cc_adjoint straight
 		// into the ring-major spectra, ring FFTs -- all maps of the call in every launch
 		const long ldc = p->ld_cc(), ldh = p->ld_h();
-		const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
 		p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc); p->hbuf.ensure(sizeof(double2)*(size_t)nct*nr*ldh);
 		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
 			p->leg2.as<double2>(), 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
@@ -1165,8 +1161,6 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 	const bool th = p->chain_theta() && !adjoint;       // (PXS_ADJ_ANA_FUSED=0: the adjoint of the analysis through the unfused chain, dense rows)
 	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
 	const int ncb = nb > 1 ? nc : 0;
-	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
-	auto alm_of = [&](int b) { return (void*)((char*)alm + aesz*(size_t)b*alm_bstride); };
 	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
 	p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
 	if (!adjoint) {
