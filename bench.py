@@ -162,7 +162,7 @@ def fft_block(dmap_comp, enmap, torch, reps=3):
 	return dict(shape=[ny, nx], real_to_complex_ms=round(t_r2c*1e3, 3), real_to_complex_GBps=round(b_r2c/t_r2c/1e9, 1),
 		complex_to_complex_ms=round(t_c2c*1e3, 3), complex_to_complex_GBps=round(b_c2c/t_c2c/1e9, 1),
 		frac_of_8TBps=round(b_r2c/t_r2c/1e9/HBM_PEAK_GBS, 4), frac_of_8TBps_complex_to_complex=round(b_c2c/t_c2c/1e9/HBM_PEAK_GBS, 4), roundtrip_max_error=err,
-		note="frac_of_8TBps is enmap.fft of a real map (what the path transforms): real rows go two per complex line through the chain stages and only the Hermitian half runs through the column passes, 4.5 N x 16 bytes of traffic for (8 + 16) N algorithmic bytes; complex input (enmap.ifft) takes the generic engine: both axes exceed the LDS (160 KiB = 10240 complex128 points), so each axis is a two-pass four-step transform, 4 reads + 4 writes of the array against the 1 + 1 the algorithmic count credits",
+		note="frac_of_8TBps is enmap.fft of a real map (what the path transforms): real rows go two per complex line through the chain stages and only the Hermitian half runs through the column passes, 4.5 N x 16 bytes of traffic for (8 + 16) N algorithmic bytes; complex input (enmap.ifft) goes through the same stage kinds (rows into a transposed intermediate, columns back): both axes exceed the LDS (160 KiB = 10240 complex128 points), so each axis is a two-pass four-step transform, 4 reads + 4 writes of the array against the 1 + 1 the algorithmic count credits",
 		cpu_baseline=dict(kind="reference", engine="numpy.fft.fftn (pixell.fft numpy engine)", cores=1, sample="%dx%d float64 block" % (sy, sx),
 			seconds=round(t_np, 4), GBps=round(sy*sx*24/t_np/1e9, 3)))
 

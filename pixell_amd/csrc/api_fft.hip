@@ -286,17 +286,19 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 			fft_axis(fc, st, rp.N, rp.forward, other_dims(ax, rshape, is, ostride), is[ax], ostride[ax], ld, stf);
 		}
 	} else if (kind == 0) {
-		{	// real map -> complex spectrum over the last two axes of dense arrays (what enmap.fft of a map is): the chain stages of
-			// the SHT's ring FFTs do it with two rows per complex line and the Hermitian half carried through the column passes
+		{	// 2-D transforms over the last two axes of dense arrays (enmap.fft / ifft) through the chain stages.  Real maps: two rows per
+			// complex line, the Hermitian half carried through the column passes; complex input: rows into a transposed intermediate, columns back
 			const long minpix = [] { const char* e = getenv("PXS_FFT2_FAST_MINPIX"); return e ? atol(e) : (1L << 16); }();    // (-1: never; read per call: the tests switch it)
-			bool dense = ndim >= 2 && naxes == 2 && ((axes[0] == ndim-2 && axes[1] == ndim-1) || (axes[0] == ndim-1 && axes[1] == ndim-2)) && in != out
-				&& in_dtype <= PX_F64 && out_dtype == PX_C128 && minpix >= 0 && (long)shape[ndim-1]*shape[ndim-2] >= minpix;
+			const bool real_in = in_dtype <= PX_F64;
+			bool dense = ndim >= 2 && naxes == 2 && ((axes[0] == ndim-2 && axes[1] == ndim-1) || (axes[0] == ndim-1 && axes[1] == ndim-2)) && (in != out || !real_in)
+				&& (real_in || in_dtype == PX_C128) && out_dtype == PX_C128 && minpix >= 0 && (long)shape[ndim-1]*shape[ndim-2] >= minpix;
 			long acc = 1, npre = 1;
 			for (int k = ndim-1; k >= 0 && dense; k--) { dense = istride[k] == acc && ostride[k] == acc; acc *= shape[k]; if (k < ndim-2) npre *= shape[k]; }
 			if (dense) {
 				FftChain* ch;
 				{ std::lock_guard<std::mutex> g(g_f2_mu); auto& u = g_f2[std::make_pair(device, st)]; if (!u) u.reset(new FftChain(&fc)); ch = u.get(); }
-				if (ch->fft2_real(st, in, in_dtype, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)) return 0;
+				if (real_in ? ch->fft2_real(st, in, in_dtype, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)
+				            : ch->fft2_c2c(st, (const double2*)in, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)) return 0;
 			}
 		}
 		for (int t = 0; t < naxes; t++) {

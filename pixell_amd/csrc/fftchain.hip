@@ -170,9 +170,9 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 struct PairSrc {
 	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol; long cstride;      // cstride: elements between the components of a launch
 	const double2* w;        // optional per-ring weight (.x), applied to a ring sample and to its mirror image
-	int plain;               // no packing, no extension: column p itself (the column transforms of the 2-D FFT)
+	int plain, conj;         // plain: no packing, no extension: column p itself (the 2-D FFTs); conj: conjugated (backward transform as conj FFT conj)
 	__device__ __forceinline__ double2 get(int comp, int p, int j) const {
-		if (plain) return leg[(long)comp*cstride + (long)p*ld + j];
+		if (plain) { const double2 v = leg[(long)comp*cstride + (long)p*ld + j]; return conj ? cconj(v) : v; }
 		int src = j; bool mir = false;
 		if (j >= nr) { src = N - j - mir_c; if (src < 0) src += N; mir = true; }
 		const int tj = 2*j + mir_c;
@@ -469,13 +469,14 @@ struct StRingS2 : StageBase {
 	}
 };
 
-// last pass of the 2-D real -> complex FFT (FftChain::fft2_real): b-point transform over j2 for line k1 of T consecutive columns kx
-// of the half spectrum F[kx][ky]; writes out[ky][kx] (ky = k1 + a k2; kx fastest: runs of T points) and, for 0 < kx < nx - kx, the
-// Hermitian image out[(ny - ky) % ny][nx - kx] = conj
+// last pass of a transform of the 2-D FFTs (FftChain::fft2_real / fft2_c2c), with the transpose: b-point transform over j2 for line k1
+// of T consecutive outer lines kx (columns of the spectrum, or rows of the input); writes out[ky = k1 + a k2][kx] (kx fastest: runs of T
+// points; row stride ldo) and, with herm (real input: kx runs over the half spectrum), for 0 < kx < nx - kx the Hermitian image
+// out[(ny - ky) % ny][nx - kx] = conj
 struct StColOut : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
-	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out; double2* out; double scale; FastDiv dgr;
+	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out, herm; double2* out; long ldo, ocomp; double scale; FastDiv dgr;
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = bx - c.outer*ntile; c.nl = T;
 		c.comp = fdiv(c.outer, dgr); c.q0 = (c.outer - c.comp*groups)*T; return true; }
@@ -489,10 +490,10 @@ struct StColOut : StageBase {
 		if (kx >= nm) return;
 		const int ky = c.t0 + a*e;
 		double2 v = cscale(buf[li*ns + e], scale);
-		double2* oc = out + (long)c.comp*ny*nx;
-		// (backward transform of real input = conjugate of the forward one)
-		oc[(long)ky*nx + kx] = conj_out ? cconj(v) : v;
-		if (kx > 0 && 2*kx < nx) oc[(long)(ky == 0 ? 0 : ny - ky)*nx + (nx - kx)] = conj_out ? v : cconj(v);
+		double2* oc = out + (long)c.comp*ocomp;
+		// (backward transform = conjugate of the forward one of the conjugated input)
+		oc[(long)ky*ldo + kx] = conj_out ? cconj(v) : v;
+		if (herm && kx > 0 && 2*kx < nx) oc[(long)(ky == 0 ? 0 : ny - ky)*ldo + (nx - kx)] = conj_out ? v : cconj(v);
 	}
 };
 
@@ -976,9 +977,46 @@ bool FftChain::fft2_real(hipStream_t st, const void* in, int in_dtype, double2* 
 		int T = tile_lines(b, 0, nm, 8);
 		set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
 		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.nm = (int)nm; s.ny = (int)ny; s.nx = (int)nx; s.conj_out = forward ? 0 : 1; s.out = out; s.scale = scale;
+		s.herm = 1; s.ldo = nx; s.ocomp = ny*nx;
 		s.groups = (int)((nm + T - 1)/T); s.dgr = make_fastdiv((uint32_t)s.groups);
 		launch_stage(s, npre*s.groups*a, st);
 	}
+	PXS_HIP(hipGetLastError());
+	return true;
+}
+
+// 2-D complex FFT [npre][ny][nx] -> [npre][ny][nx] (enmap.ifft, enmap.fft of complex maps) with the same stage kinds: rows (StFirst
+// plain over the lines of a row, StColOut into the transposed F[kx][y]), then columns along contiguous rows of F (StFirst plain,
+// StColOut into out[ky][kx]).  Backward: conj on the way in and out.  false: no usable factorisation.
+bool FftChain::fft2_c2c(hipStream_t st, const double2* in, double2* out, long npre, long ny, long nx, bool forward, double scale) {
+	Split sx, sy;
+	if (nx < 4 || ny < 4 || !split_balanced(nx, sx) || !split_balanced(ny, sy)) return false;
+	const long ax = std::min(sx.a, sx.b), bx = nx/ax, ay = std::min(sy.a, sy.b), by = ny/ay, ldF = pad8(ny);
+	if (npre*std::max(nx, ny) >= (1L << 31)/512) return false;
+	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] fft2_c2c %ld x %ld x %ld: rows %ld x %ld, columns %ld x %ld\n", npre, ny, nx, ax, bx, ay, by);
+	s1_.ensure(sizeof(double2)*(size_t)npre*std::max(ny*ax*pad8(bx), nx*ay*pad8(by)));
+	s2_.ensure(sizeof(double2)*(size_t)npre*nx*ldF);
+	auto first = [&](const double2* src, long nlines, long ld, long n, long a, long b, int conj) {
+		StFirst s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
+		s.src.leg = src; s.src.cstride = nlines*ld; s.src.ld = ld; s.src.nr = (int)n; s.src.N = (int)n; s.src.ncol = (int)nlines; s.src.plain = 1; s.src.conj = conj;
+		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.npair = (int)nlines; s.dnp = make_fastdiv((uint32_t)nlines);
+		set_tiles(s, tile_lines(a, 0, b, 8), b, n);
+		launch_stage(s, npre*nlines*s.ntile, st);
+	};
+	auto second = [&](double2* dst, long nlines, long ldo, long ocomp, long a, long b, int conj, double sc) {
+		StColOut s; memset(&s, 0, sizeof(s));
+		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
+		int T = tile_lines(b, 0, nlines, 8);
+		set_tiles(s, T, a*T, 0);
+		s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.a = (int)a; s.nm = (int)nlines; s.ny = 0; s.nx = 0; s.conj_out = conj; s.herm = 0; s.out = dst; s.ldo = ldo; s.ocomp = ocomp; s.scale = sc;
+		s.groups = (int)((nlines + T - 1)/T); s.dgr = make_fastdiv((uint32_t)s.groups);
+		launch_stage(s, npre*s.groups*a, st);
+	};
+	first(in, ny, nx, nx, ax, bx, forward ? 0 : 1);                           // rows y: lines of nx points
+	second(s2_.as<double2>(), ny, ldF, nx*ldF, ax, bx, 0, 1.0);               // -> F[kx][y]
+	first(s2_.as<double2>(), nx, ldF, ny, ay, by, 0);                         // columns kx: contiguous lines of ny points
+	second(out, nx, nx, ny*nx, ay, by, forward ? 0 : 1, scale);               // -> out[ky][kx]
 	PXS_HIP(hipGetLastError());
 	return true;
 }

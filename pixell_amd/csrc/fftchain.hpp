@@ -54,6 +54,8 @@ public:
 	                   int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* whalf, const double2* tab, double scale);
 	// 2-D FFT of real [npre][ny][nx] (float32 / float64) into complex128 [npre][ny][nx]; false if nx or ny has no usable factorisation
 	bool fft2_real(hipStream_t st, const void* in, int in_dtype, double2* out, long npre, long ny, long nx, bool forward, double scale);
+	// 2-D FFT of complex128 [npre][ny][nx] (in == out allowed); false if nx or ny has no usable factorisation
+	bool fft2_c2c(hipStream_t st, const double2* in, double2* out, long npre, long ny, long nx, bool forward, double scale);
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
 	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc, 3: to_cc_adjoint)
 	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);

@@ -109,6 +109,15 @@ def check_fft2_real(shapes, monkeypatch, tol=1e-12):
 		ref = np.fft.fftn(a, axes=(-2, -1))
 		assert rel(f, ref) < tol and rel(g, ref) < tol and rel(b, np.conj(ref)) < tol, shp
 		assert rel(f32, np.fft.fftn(a.astype(np.float32).astype(np.float64), axes=(-2, -1))) < tol, shp
+		# complex input (enmap.ifft, fft of complex maps: FftChain::fft2_c2c), forward, backward, in place
+		z = a+1j*rng.standard_normal(shp); refz = np.fft.fftn(z, axes=(-2, -1))
+		monkeypatch.setenv("PXS_FFT2_FAST_MINPIX", "0")
+		fz = pfft.fft(z, axes=[-2, -1]); bz = pfft.ifft(z, axes=[-2, -1], normalize=True)
+		iz = z.copy(); pfft.fft(iz, iz, axes=[-2, -1])
+		monkeypatch.setenv("PXS_FFT2_FAST_MINPIX", "-1")
+		gz = pfft.fft(z, axes=[-2, -1])
+		monkeypatch.delenv("PXS_FFT2_FAST_MINPIX")
+		assert rel(fz, refz) < tol and rel(gz, refz) < tol and rel(iz, refz) < tol and rel(bz, np.fft.ifftn(z, axes=(-2, -1))) < tol, shp
 
 @pytest.mark.hostsim
 def test_fft2_real_hostsim(monkeypatch): check_fft2_real([(2, 24, 40), (32, 25), (3, 15, 27), (1, 20, 18), (2, 45, 64)], monkeypatch)
