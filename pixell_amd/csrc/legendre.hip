@@ -366,7 +366,9 @@ __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
 		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
 	} }
 
-template<int K> __global__ __launch_bounds__(64) void leg_syn_s0(const LegK a)
+// K = 4 is asked to fit 7 waves per SIMD (72 instead of 74 VGPRs, no spills): the synthesis kernels are short of waves, not of
+// registers per wave (pinned to 2 / 3 / 4 waves per SIMD leg_syn_spin<3> takes 1.51 / 1.29 / 1.0 of its time): C4 leg_syn 126.3 -> 121.9 ms
+template<int K> __global__ __launch_bounds__(64, (K == 4 ? 7 : 1)) void leg_syn_s0(const LegK a)
 {
 	const int lane = threadIdx.x; int wv, m, bb;
 	if (!leg_block(a, wv, m, bb)) return;
@@ -755,6 +757,7 @@ template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv,
 
 // (leg_syn_spin<3> must stay below 128 VGPRs = 4 waves per SIMD; computing the lane as threadIdx.x & 63 for multi-wave
 // workgroups once pushed it to 132 = 3 waves and leg_syn from 120 to 151 ms at config 3 -- keep an eye on that cliff.)
+// (leg_syn_spin<3> held to 96 VGPRs = 5 waves per SIMD by __launch_bounds__: 20 bytes of spills, 102.0 -> 100.1 ms at C3: inside the noise, not kept)
 template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 {
 	const int lane = threadIdx.x; int wv, m, bb;
