@@ -20,8 +20,9 @@
 // on MI355X with tools/stride_bw.hip).  All global loads of a tile are issued before the first LDS write.
 // Replaces ducc0's ring FFTs / resample_theta inside synthesis_2d / analysis_2d (pixell/curvedsky.py:907-924, 1032-1046).
 #include "fftchain.hpp"
-#include "fft_dev.hpp"
+#include "fft2_dev.hpp"
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 namespace pxs {
@@ -72,6 +73,10 @@ struct StageBase {
 	// from the full table btw (into LDS), the second comes from a small table tws[e][li] shared by all tiles (coalesced reads).
 	// (One gather per point from the full table made every wave instruction touch 64 cache lines.)
 	const double2* btw; const double2* tws;
+	// second-generation kernel (chain2_kernel): DIF transforms with large register radices, tiles walked by persistent workgroups
+	Fft2 a2, b2; int ntiles2;
+	FastDiv dtplA[3], dtplB[3];     // tasks per line of every pass
+	FastDiv dK0, dRL;               // four-step twiddle tables of the stored transform: K0 = n / R_last, R_last
 };
 
 __device__ __forceinline__ double2 cscale(double2 a, double f) { return make_double2(a.x*f, a.y*f); }
@@ -139,7 +144,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 			const int idx = threadIdx.x + u*NT; pos[u] = -1;
 			if (idx < total) {
 				const uint32_t e = fdiv(idx, s.dT), li = idx - e*T;
-				v[u] = s.mid(c, (int)li, (int)e, buf + li*s.fa.ns);
+				{ const double2* Al = buf + li*s.fa.ns; v[u] = s.mid(c, (int)li, (int)e, [&](int k) { return Al[k]; }); }
 				if (S::INV_B) v[u].y = -v[u].y;
 				pos[u] = (int)li*s.fb.ns + s.fb.perm[e];
 			}
@@ -158,8 +163,215 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 			if (S::STORE_LINE_FAST) { e = fdiv(idx, s.dT); li = idx - e*T; } else { li = fdiv(idx, dl); e = idx - li*nlast; }
 			double2 w = make_double2(1, 0);
 			if (have_tw) w = cmul(twx[e], s.tws[e*T + li]);
-			s.store(c, (int)li, (int)e, buf, nslast, w);
+			s.store(c, (int)li, (int)e, [&](int l2, int e2) { return buf[l2*nslast + e2]; }, w);
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// second-generation chain kernel (round 4)
+// ---------------------------------------------------------------------------------------------------------------
+// What limited chain_kernel (SQ counters of round 4, profiles/r04_chain_sq_v1.txt): the VALU ~50 % busy, the LDS ~50 % busy with
+// 44-52 % of its active cycles lost to bank conflicts, waves parked at barriers / waitcnt 65-73 % of their time -- per tile the
+// VALU time (2.6 us), the LDS time (2.6 us) and the memory latency ADD UP instead of overlapping: ten barriered sweeps, one
+// radix <= 9 butterfly per thread and sweep.  This kernel:
+//   * persistent workgroups walk over the tiles; a tile whose lines are contiguous rows (S::LOADK == 0) arrives by LDS-DMA
+//     (global_load_lds_dwordx4, 64 x 16 bytes per wave instruction, natural order -- the transforms are decimation in frequency)
+//     while the previous tile is still being worked on; raw s_barrier + lgkmcnt-only waits keep the DMA in flight, the one
+//     vmcnt(0) sits where the tile is needed.  Nothing between the DMA issue and that wait consumes a global load (the four-step
+//     twiddles of the store come from two small per-tile LDS tables fetched BEFORE the DMA is issued): a later load cannot return
+//     before an earlier one, so any such use would wait for the whole tile;
+//   * at most three passes per transform with register radices up to 25 (fft2_dev.hpp): 4 barriers per two-transform tile
+//     instead of 10, a third of the LDS store traffic;
+//   * the last pass hands its results to the store in registers (S::STOREK == 0), the first pass of an elementwise-loading stage
+//     (S::LOADK == 1) takes its inputs straight from global memory, the second transform of a two-transform stage pulls its
+//     inputs through S::mid from the first one's output;
+//   * layouts are padded (Fft2::rs, ns: chosen on the host by counting bank conflicts of every pass with the ds_read_b128 /
+//     ds_write_b128 lane groups of gfx950).
+// Four-step twiddle of output k = k0 + K0*i (i: register index of the last pass) of line L = t0 + li:
+//   W_X^{L k} = F1[li][k0] * F2[li][i],  F1 = W_X^{L k0},  F2 = W_X^{L K0 i}:  T*(K0 + R_last) table entries per tile.
+#ifdef PXS_HOST_SIM
+#define PXS_DMA16(gp, lbase, lane) ((lbase)[lane] = *(gp))
+#define PXS_WAIT_VM0()
+static constexpr int CH2_NT_A = 1, CH2_NT_B = 1;
+#else
+__device__ __forceinline__ void pxs_dma16(const double2* g, double2* l) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+#define PXS_DMA16(gp, lbase, lane) pxs_dma16((gp), (lbase))
+#define PXS_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+static constexpr int CH2_NT_A = 128, CH2_NT_B = 256;
+#endif
+static constexpr int CH2_TWN = 8;        // per-thread registers of the twiddle prefetch: T*(K0 + R_last) <= CH2_TWN * NT
+
+template<class F> __device__ __forceinline__ void f2_dispatch(int R, F&& f) {
+	switch (R) {
+		case 2: f(std::integral_constant<int, 2>{}); break;   case 3: f(std::integral_constant<int, 3>{}); break;
+		case 4: f(std::integral_constant<int, 4>{}); break;   case 5: f(std::integral_constant<int, 5>{}); break;
+		case 6: f(std::integral_constant<int, 6>{}); break;   case 8: f(std::integral_constant<int, 8>{}); break;
+		case 9: f(std::integral_constant<int, 9>{}); break;   case 10: f(std::integral_constant<int, 10>{}); break;
+		case 12: f(std::integral_constant<int, 12>{}); break; case 15: f(std::integral_constant<int, 15>{}); break;
+		case 16: f(std::integral_constant<int, 16>{}); break; case 18: f(std::integral_constant<int, 18>{}); break;
+		case 20: f(std::integral_constant<int, 20>{}); break;
+		default: break;
+	}
+}
+
+// one pass of transform f on T lines: in(task, i) -> input i of the butterfly, out(task, i, value) <- output i
+template<int NT, class In, class Out>
+__device__ __forceinline__ void f2_pass(const Fft2& f, int q, int T, FastDiv dT, FastDiv dtpl, bool line_fast, const double2* tw, In&& in, Out&& out) {
+	const int R = f2_radix(f, q), tpl = f.n / R, total = T*tpl;
+	const bool twd = q + 1 < f.np;
+	f2_dispatch(R, [&](auto Rc) {
+		constexpr int RR = decltype(Rc)::value;
+		for (int t = threadIdx.x; t < total; t += NT) {
+			F2Task k; int tl;
+			if (line_fast) { tl = (int)fdiv((uint32_t)t, dT); k.li = t - tl*T; } else { k.li = (int)fdiv((uint32_t)t, dtpl); tl = t - k.li*tpl; }
+			f2_decode(f, q, tl, k);
+			double2 v[RR];
+#pragma unroll
+			for (int i = 0; i < RR; i++) v[i] = in(k, i);
+			dft_reg<RR>(v);
+			if (twd && k.step != 0) {
+#pragma unroll
+				for (int i = 1; i < RR; i++) v[i] = cmul(v[i], tw[i*k.step]);
+			}
+#pragma unroll
+			for (int i = 0; i < RR; i++) out(k, i, v[i]);
+		}
+	});
+}
+
+template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(const S s)
+{
+	PXS_SHARED(double2, lds);
+	const Fft2& fa = s.a2; const Fft2& fb = s.b2;
+	const Fft2& fl = S::TWO ? fb : fa;               // the transform whose output is stored
+	const int na = fa.n, nb = S::TWO ? fb.n : 0;
+	const int T = s.T;
+	const FastDiv dT = s.dT;
+	const int szA = ((T*fa.ns + 63) & ~63);           // DMA granularity: whole wave instructions
+	const bool dbl = !S::TWO && S::LOADK == 0;        // two input buffers: the next tile arrives while this one is transformed in place
+	// DMA destinations first (LDS-DMA bases are 16-bit offsets)
+	double2* bufA = lds;
+	double2* bufB = bufA + (dbl ? 2 : 1)*szA;
+	double2* twa = bufB + (S::TWO ? T*fb.ns : 0); double2* twb = twa + na;
+	const int K0 = fl.n / f2_radix(fl, fl.np - 1), RL = f2_radix(fl, fl.np - 1);
+	const int nF = T*(K0 + RL);                       // F1[li][k0] | F2[li][i]
+	double2* ftw = twb + nb;                          // two of them (tile parity)
+	const bool have_tw = S::HAS_TW && s.btw != nullptr;
+	for (int k = threadIdx.x; k < na; k += NT) twa[k] = fa.tw[k];
+	if (S::TWO) for (int k = threadIdx.x; k < nb; k += NT) twb[k] = fb.tw[k];
+
+	TileC c, cn;
+	const int ntiles = s.ntiles2;
+	auto next_valid = [&](int t, TileC& cc) { while (t < ntiles && !s.decode(t, cc)) t += (int)gridDim.x; return t; };
+	auto fetch_rows = [&](const TileC& cc, double2* dst) {
+		// slot S of the buffer <- point (li, e) of the tile; padding slots and absent lines are skipped
+		for (int S0 = threadIdx.x; S0 < szA; S0 += NT) {
+			const uint32_t li = fdiv((uint32_t)S0, fa.dns), sl = S0 - li*fa.ns;
+			const uint32_t blk = fdiv(sl, fa.drs), r = sl - blk*fa.rs;
+			const double2* rp = ((int)li < T && (int)r < fa.M1 && (int)blk < fa.R0) ? s.row(cc, (int)li) : nullptr;
+			if (rp) PXS_DMA16(rp + blk*fa.M1 + r, dst + (S0 - (int)(threadIdx.x & 63)), (int)(threadIdx.x & 63));
+		}
+	};
+	// four-step twiddle tables of a tile, fetched into registers (they are written to LDS when the tile's turn comes)
+	double2 tw0 = make_double2(0, 0), tw1 = tw0, tw2 = tw0, tw3 = tw0, tw4 = tw0, tw5 = tw0, tw6 = tw0, tw7 = tw0;
+	auto tw_src = [&](const TileC& cc, int u) -> const double2* {
+		const int idx = threadIdx.x + u*NT;
+		if (idx >= nF) return nullptr;
+		const bool second = idx >= T*K0;
+		const int j = second ? idx - T*K0 : idx, per = second ? RL : K0;
+		const int li = (int)fdiv((uint32_t)j, second ? s.dRL : s.dK0), kk = j - li*per;
+		return s.btw + (long)(cc.t0 + li)*(second ? K0*kk : kk);
+	};
+#ifdef PXS_HOST_SIM      /* one OS thread per workgroup: the tables are filled straight from the big table when the tile's turn comes */
+#define PXS_TW_FETCH(cc) { }
+#define PXS_TW_PUT(F) { for (int u_ = 0; u_*NT < nF; u_++) { const double2* p_ = tw_src(c, u_); if (p_) (F)[threadIdx.x + u_*NT] = *p_; } }
+#else
+#define PXS_TW_FETCH1(cc, u, r) { if ((u)*NT < nF) { const double2* p_ = tw_src(cc, u); if (p_) r = *p_; } }
+#define PXS_TW_FETCH(cc) { PXS_TW_FETCH1(cc, 0, tw0) PXS_TW_FETCH1(cc, 1, tw1) PXS_TW_FETCH1(cc, 2, tw2) PXS_TW_FETCH1(cc, 3, tw3) \
+	PXS_TW_FETCH1(cc, 4, tw4) PXS_TW_FETCH1(cc, 5, tw5) PXS_TW_FETCH1(cc, 6, tw6) PXS_TW_FETCH1(cc, 7, tw7) }
+#define PXS_TW_PUT1(F, u, r) { const int idx_ = threadIdx.x + (u)*NT; if (idx_ < nF) (F)[idx_] = r; }
+#define PXS_TW_PUT(F) { PXS_TW_PUT1(F, 0, tw0) PXS_TW_PUT1(F, 1, tw1) PXS_TW_PUT1(F, 2, tw2) PXS_TW_PUT1(F, 3, tw3) \
+	PXS_TW_PUT1(F, 4, tw4) PXS_TW_PUT1(F, 5, tw5) PXS_TW_PUT1(F, 6, tw6) PXS_TW_PUT1(F, 7, tw7) }
+#endif
+	int tile = next_valid((int)blockIdx.x, c), par = 0;
+	if (tile < ntiles) { if (have_tw) PXS_TW_FETCH(c) if (S::LOADK == 0) fetch_rows(c, bufA); }
+	while (tile < ntiles) {
+		double2* A = bufA + (dbl ? par*szA : 0);
+		double2* F = ftw + par*nF;
+		if (have_tw) PXS_TW_PUT(F)
+		if (S::LOADK == 0) PXS_WAIT_VM0();
+		PXS_LDS_BARRIER();
+		const int tnext = next_valid(tile + (int)gridDim.x, cn);
+		if (dbl && tnext < ntiles) fetch_rows(cn, bufA + (par ^ 1)*szA);
+		if (!S::TWO && have_tw && tnext < ntiles) PXS_TW_FETCH(cn)      // (elementwise-loading stages: no DMA to keep clear of)
+		// output of the stored transform: value X[k] of line li, k = task.k0 + i*task.kstride
+		auto emit = [&](const F2Task& k, int i, double2 v) {
+			const int e = k.k0 + i*k.kstride;
+			double2 w = make_double2(1, 0);
+			if (have_tw) w = cmul(F[k.li*K0 + k.k0], F[T*K0 + k.li*RL + i]);
+			s.store(c, k.li, e, [&](int, int) { return v; }, w);
+		};
+		// ---- first transform (only the input / output combinations a stage can take are instantiated: each one is a set of
+		// register-radix butterflies)
+		for (int q = 0; q < fa.np; q++) {
+			const bool first = q == 0, last = q + 1 == fa.np;
+			constexpr bool CAN_REGS = !S::TWO && S::STOREK == 0;
+			const bool to_regs = CAN_REGS && last;
+			auto in_lds = [&](const F2Task& k, int i) { double2 v = A[k.li*fa.ns + k.base + i*k.istride]; if (S::INV_A && first) v.y = -v.y; return v; };
+			auto out_lds = [&](const F2Task& k, int i, double2 v) { A[k.li*fa.ns + k.base + i*k.istride] = v; };
+			bool done = false;
+			if constexpr (S::LOADK == 1) {
+				if (first) {
+					auto in_glb = [&](const F2Task& k, int i) { double2 v = s.load(c, k.li, k.base + i*(fa.np == 1 ? 1 : fa.M1)); if (S::INV_A) v.y = -v.y; return v; };
+					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT>(fa, q, T, dT, s.dtplA[q], true, twa, in_glb, emit); done = true; } }
+					if (!done) { f2_pass<NT>(fa, q, T, dT, s.dtplA[q], true, twa, in_glb, out_lds); done = true; }
+				}
+			}
+			if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT>(fa, q, T, dT, s.dtplA[q], true, twa, in_lds, emit); done = true; } }
+			if (!done) f2_pass<NT>(fa, q, T, dT, s.dtplA[q], false, twa, in_lds, out_lds);
+			if (!to_regs) PXS_LDS_BARRIER();
+		}
+		// ---- second transform: inputs pulled through S::mid from the first one's output
+		if constexpr (S::TWO) {
+			for (int q = 0; q < fb.np; q++) {
+				const bool first = q == 0, last = q + 1 == fb.np;
+				constexpr bool CAN_REGS = S::STOREK == 0;
+				const bool to_regs = CAN_REGS && last;
+				auto in_mid = [&](const F2Task& k, int i) {
+					const double2* Al = A + k.li*fa.ns;
+					double2 v = s.mid(c, k.li, k.base + i*(fb.np == 1 ? 1 : fb.M1), [&](int kk) { return Al[fa.slot_out(kk)]; });
+					if (S::INV_B) v.y = -v.y;
+					return v; };
+				auto in_lds = [&](const F2Task& k, int i) { return bufB[k.li*fb.ns + k.base + i*k.istride]; };
+				auto out_lds = [&](const F2Task& k, int i, double2 v) { bufB[k.li*fb.ns + k.base + i*k.istride] = v; };
+				bool done = false;
+				if (first) {
+					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT>(fb, q, T, dT, s.dtplB[q], true, twb, in_mid, emit); done = true; } }
+					if (!done) { f2_pass<NT>(fb, q, T, dT, s.dtplB[q], false, twb, in_mid, out_lds); done = true; }
+				}
+				if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT>(fb, q, T, dT, s.dtplB[q], true, twb, in_lds, emit); done = true; } }
+				if (!done) f2_pass<NT>(fb, q, T, dT, s.dtplB[q], false, twb, in_lds, out_lds);
+				if (!to_regs || first) PXS_LDS_BARRIER();
+				if (first && tnext < ntiles) {      // the input buffer is free: the next tile's twiddles, then its rows (nothing after this consumes a global load)
+					if (have_tw) PXS_TW_FETCH(cn)
+					if (S::LOADK == 0) fetch_rows(cn, bufA);
+				}
+			}
+		}
+		if (S::STOREK == 1) {      // stores that combine two lines read the finished transform from LDS
+			const double2* Bf = S::TWO ? bufB : A;
+			const int nl_ = fl.n, total = T*nl_;
+			const FastDiv dl = S::TWO ? s.dnb : s.dna;
+			for (int idx = threadIdx.x; idx < total; idx += NT) {
+				uint32_t li, e;
+				if (S::STORE_LINE_FAST) { e = fdiv((uint32_t)idx, dT); li = idx - e*T; } else { li = fdiv((uint32_t)idx, dl); e = idx - li*nl_; }
+				s.store(c, (int)li, (int)e, [&](int l2, int e2) { return Bf[l2*fl.ns + fl.slot_out(e2)]; }, make_double2(1, 0));
+			}
+		}
+		c = cn; tile = tnext; par ^= 1;
 	}
 }
 
@@ -194,17 +406,19 @@ struct StFirst : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	PairSrc src; int b; double2* Y; long ldY; int npair; FastDiv dnp;       // outer = comp*npair + pair
+	static constexpr bool V2 = true; static constexpr int LOADK = 1, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC&, int) const { return nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
 		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		return src.get(c.comp, c.q0, b*e + c.t0 + li); }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2 w) const {
 		if (li >= c.nl) return;
 		const long o = bout ? ((long)c.outer*b + c.t0)*fa.n + (long)e*c.nl + li : ((long)c.outer*fa.n + e)*ldY + c.t0 + li;
-		Y[o] = cmul(buf[li*ns + e], w); }
+		Y[o] = cmul(val(li, e), w); }
 };
 
 // pass 2 of transform X1 (forward, b1 points) + spectrum resize + pass 1 of transform X2 (backward, a2 points); shared modulus g.
@@ -217,12 +431,14 @@ struct StResize : StageBase {
 	const double2* Y; long ldY; double2* Z; long ldZ;
 	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
 	int adj;      // transposed padding rule (X1 > X2): conjugate phase, and the Nyquist slot of X2 collects 1/2 of both +-X2/2 bins of X1
+	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return li < c.nl ? Y + ((long)c.outer*g + c.t0 + li)*ldY : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g - c.t0); return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		return bin.Tw > 0 ? Y[(long)c.outer*g*fa.n + bin.off(c.t0 + li, e, g)] : Y[((long)c.outer*g + c.t0 + li)*ldY + e]; }
-	__device__ __forceinline__ double2 mid(const TileC& c, int li, int e, const double2* A) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC& c, int li, int e, AF&& A) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		const int k1 = c.t0 + li;
 		const int jp = g*e + k1;
@@ -231,11 +447,11 @@ struct StResize : StageBase {
 		if ((kmax >= 0 && ak > kmax) || 2*ak > X1) return make_double2(0, 0);
 		const int k = kap >= 0 ? kap : kap + X1;
 		const uint32_t k2 = fdiv((uint32_t)(k - k1), dg);
-		double2 v = A[k2];
+		double2 v = A((int)k2);
 		if (adj) {
 			double2 t = ph ? ph[ak] : make_double2(1, 0);
 			if (2*ak == X2 && X1 != X2) {      // both bins are in this line: X1, X2 and hence +-X2/2 are congruent mod g
-				const double2 vm = A[fdiv((uint32_t)(X1 - ak - k1), dg)];
+				const double2 vm = A((int)fdiv((uint32_t)(X1 - ak - k1), dg));
 				const double2 r = cadd(cmul(v, cconj(t)), cmul(vm, t));
 				return cscale(r, 0.5);
 			}
@@ -245,10 +461,10 @@ struct StResize : StageBase {
 		if (nyq && 2*ak == X1) v = cscale(v, 0.5);
 		if (ph) { double2 t = ph[ak]; if (kap < 0) t.y = -t.y; v = cmul(v, t); }
 		return v; }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2 w) const {
 		if (li >= c.nl) return;
 		const long o = bout ? ((long)c.outer*g + c.t0)*fb.n + (long)e*c.nl + li : ((long)c.outer*fb.n + e)*ldZ + c.t0 + li;
-		Z[o] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
+		Z[o] = cmul(cconj(val(li, e)), cconj(w)); }
 };
 
 // pass 2 of IFFT_M (g points), pointwise product with the |sin| series samples, pass 1 of FFT_M (g points)
@@ -257,18 +473,20 @@ struct StSigma : StageBase {
 	static constexpr bool TWO = true, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Z; long ldZ; double2* V; long ldV; int g, g2; const double2* sigma;
+	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return li < c.nl ? Z + ((long)c.outer*g2 + c.t0 + li)*ldZ : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g2 - c.t0); return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		return bin.Tw > 0 ? Z[(long)c.outer*g2*fa.n + bin.off(c.t0 + li, e, g2)] : Z[((long)c.outer*g2 + c.t0 + li)*ldZ + e]; }
-	__device__ __forceinline__ double2 mid(const TileC& c, int li, int e, const double2* A) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC& c, int li, int e, AF&& A) const {
 		if (li >= c.nl) return make_double2(0, 0);
-		return cmul(cconj(A[e]), sigma[(c.t0 + li) + g2*e]); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+		return cmul(cconj(A(e)), sigma[(c.t0 + li) + g2*e]); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2 w) const {
 		if (li >= c.nl) return;
 		const long o = bout ? ((long)c.outer*g2 + c.t0)*fb.n + (long)e*c.nl + li : ((long)c.outer*g + e)*ldV + c.t0 + li;
-		V[o] = cmul(buf[li*ns + e], w); }
+		V[o] = cmul(val(li, e), w); }
 };
 
 // last pass of a backward chain (IFFT over r < g for the lines k1 < a, circle index t = k1 + a*k2) + separation of the packed pair
@@ -284,6 +502,10 @@ template<int MODE> struct StSplit : StageBase {
 	double2* out; long ld; const double2* w; const double2* tab; double scale; int TH; FastDiv da;
 	long ocstride; int groups; FastDiv dnp, dgr;      // components of a launch: output stride; MODE 0: outer = comp*npair + pair, MODE 1: outer = comp*groups + group
 	int self_half;     // self-mirrored output rings get weight 1/2 (adjoint of a mirror extension, which reads them once)
+	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 1;
+	__device__ __forceinline__ const double2* row(const TileC& c, int li) const {
+		int line, pair; slot(c, li, line, pair);
+		return line >= 0 ? U + (((long)c.comp*npair + pair)*a + line)*ldU : nullptr; }
 	__device__ __forceinline__ int mirror_line(int k) const { int m = a - k - mir_c; if (m >= a) m -= a; if (m < 0) m += a; return m; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*(MODE == 0 ? TH : 1); c.nl = T;
@@ -314,21 +536,21 @@ template<int MODE> struct StSplit : StageBase {
 		if (line < 0) return make_double2(0, 0);
 		if (MODE == 0 && bin.Tw > 0) return U[((long)c.comp*npair + pair)*a*fa.n + bin.off(line, e, a)];
 		return U[(((long)c.comp*npair + pair)*a + line)*ldU + e]; }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2) const {
 		int line, pair; slot(c, li, line, pair);
 		if (line < 0) return;
 		const int t = line + a*e;
 		if (t >= nr_out) return;
 		int tm = X - t - mir_c; if (tm >= X) tm -= X; if (tm < 0) tm += X;
-		const double2 z = cconj(buf[li*ns + e]);
+		const double2 z = cconj(val(li, e));
 		double2 ev, od;
 		if (tm == t) { ev = self_half ? cscale(z, 0.5) : z; od = make_double2(0, 0); }
 		else {
 			const int ml = mirror_line(line);
 			const int lp = (ml == line) ? li : (MODE == 0 ? (li < TH ? li + TH : li - TH) : (li ^ 1));
 			const int e2 = (int)fdiv((uint32_t)(tm - ml), da);
-			const double2 y = cconj(buf[lp*ns + e2]);
+			const double2 y = cconj(val(lp, e2));
 			ev = make_double2(0.5*(z.x + y.x), 0.5*(z.y + y.y)); od = make_double2(0.5*(z.x - y.x), 0.5*(z.y - y.y));
 		}
 		const int ca = 2*pair;
@@ -355,6 +577,8 @@ struct StRingA1 : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	MapAddr m; int b, npair; double2* Y; long ldY; FastDiv dnp;
+	static constexpr bool V2 = true; static constexpr int LOADK = 1, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC&, int) const { return nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
 		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
@@ -366,10 +590,10 @@ struct StRingA1 : StageBase {
 		const double re = rd_real(m.ptr, m.dtype, o).x;
 		const double im = (2*c.q0 + 1 < m.nring) ? rd_real(m.ptr, m.dtype, o + m.rstride).x : 0.0;
 		return make_double2(re, im); }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2 w) const {
 		if (li >= c.nl) return;
-		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(buf[li*ns + e], w); }
+		Y[((long)c.outer*fa.n + e)*ldY + c.t0 + li] = cmul(val(li, e), w); }
 };
 
 // MA2: b-point FFT over j2 for the lines k1 and a - k1 of T/2 ring pairs; bin k = k1 + a*k2 <= mmax is unpacked with its
@@ -378,6 +602,10 @@ struct StRingA2 : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, X, npair, groups, nring, mmax; double2* leg; long ldleg; int nm; const double2* tab; double scale; FastDiv da, dgr;
+	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 1;
+	__device__ __forceinline__ const double2* row(const TileC& c, int li) const {
+		int line, q; slot(c, li, line, q);
+		return line >= 0 ? Y + (((long)c.comp*npair + q)*a + line)*ldY : nullptr; }
 	__device__ __forceinline__ int mirror_line(int k) const { return k == 0 ? 0 : a - k; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = bx - c.outer*ntile; c.nl = T;
@@ -393,19 +621,19 @@ struct StRingA2 : StageBase {
 		int line, q; slot(c, li, line, q);
 		if (line < 0) return make_double2(0, 0);
 		return Y[(((long)c.comp*npair + q)*a + line)*ldY + e]; }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2) const {
 		int line, q; slot(c, li, line, q);
 		if (line < 0) return;
 		const int k = line + a*e;
 		if (k > mmax) return;
-		const double2 zp = buf[li*ns + e];
+		const double2 zp = val(li, e);
 		double2 zm;
 		if (k == 0) zm = zp;
 		else {
 			const int kp = X - k, ml = mirror_line(line);
 			const int lp = (ml == line) ? li : (li ^ 1);
-			zm = buf[lp*ns + (int)fdiv((uint32_t)(kp - ml), da)];
+			zm = val(lp, (int)fdiv((uint32_t)(kp - ml), da));
 		}
 		// X_a = (Z[k] + conj Z[n-k])/2, X_b = -i (Z[k] - conj Z[n-k])/2
 		double2 xa = make_double2(0.5*(zp.x + zm.x), 0.5*(zp.y - zm.y));
@@ -423,6 +651,8 @@ struct StRingS1 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* h; long ldh, hcomp; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;      // hcomp: rows of h per component
+	static constexpr bool V2 = true; static constexpr int LOADK = 1, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC&, int) const { return nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
 		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
@@ -439,11 +669,11 @@ struct StRingS1 : StageBase {
 		if (m == 0) { ha.y = 0; hb.y = 0; }
 		if (cj) { ha.y = -ha.y; hb.y = -hb.y; }
 		return make_double2(ha.x - hb.y, ha.y + hb.x); }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2 w) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2 w) const {
 		if (li >= c.nl) return;
 		const long o = bout ? ((long)c.outer*b + c.t0)*fa.n + (long)e*c.nl + li : ((long)c.outer*fa.n + e)*ldY + c.t0 + li;
-		Y[o] = cmul(cconj(buf[li*ns + e]), cconj(w)); }
+		Y[o] = cmul(cconj(val(li, e)), cconj(w)); }
 };
 
 // MS2: backward b-point transform over j2 for the lines k1; pixel x = k1 + a*k2: real part -> ring 2q, imaginary part -> ring 2q+1
@@ -451,17 +681,19 @@ struct StRingS2 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, npair; MapAddr m; FastDiv dnp;
+	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return li < c.nl ? Y + ((long)c.outer*a + c.t0 + li)*ldY : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, a - c.t0);
 		c.comp = fdiv(c.outer, dnp); c.q0 = c.outer - c.comp*npair; return true; }
 	__device__ __forceinline__ double2 load(const TileC& c, int li, int e) const {
 		if (li >= c.nl) return make_double2(0, 0);
 		return bin.Tw > 0 ? Y[(long)c.outer*a*fa.n + bin.off(c.t0 + li, e, a)] : Y[((long)c.outer*a + c.t0 + li)*ldY + e]; }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2) const {
 		if (li >= c.nl) return;
 		const int x = c.t0 + li + a*e;
-		const double2 v = buf[li*ns + e];                     // conj of the backward transform: the imaginary part flips sign
+		const double2 v = val(li, e);                     // conj of the backward transform: the imaginary part flips sign
 		const int bi = (int)fdiv(c.comp, m.dncb);
 		const long o = bi*m.bstride + (c.comp - bi*m.ncb)*m.cstride + m.off0 + (2L*c.q0)*m.rstride + x*m.pstride;
 		wr_real(m.ptr, m.dtype, o, v.x);
@@ -477,6 +709,8 @@ struct StColOut : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out, herm; double2* out; long ldo, ocomp; double scale; FastDiv dgr;
+	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return c.q0 + li < nm ? Y + (((long)c.comp*nm + c.q0 + li)*a + c.t0)*ldY : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = bx - c.outer*ntile; c.nl = T;
 		c.comp = fdiv(c.outer, dgr); c.q0 = (c.outer - c.comp*groups)*T; return true; }
@@ -484,12 +718,12 @@ struct StColOut : StageBase {
 		const int kx = c.q0 + li;
 		if (kx >= nm) return make_double2(0, 0);
 		return Y[(((long)c.comp*nm + kx)*a + c.t0)*ldY + e]; }
-	__device__ __forceinline__ double2 mid(const TileC&, int, int, const double2*) const { return make_double2(0, 0); }
-	__device__ __forceinline__ void store(const TileC& c, int li, int e, const double2* buf, int ns, double2) const {
+	template<class AF> __device__ __forceinline__ double2 mid(const TileC&, int, int, AF&&) const { return make_double2(0, 0); }
+	template<class VF> __device__ __forceinline__ void store(const TileC& c, int li, int e, VF&& val, double2) const {
 		const int kx = c.q0 + li;
 		if (kx >= nm) return;
 		const int ky = c.t0 + a*e;
-		double2 v = cscale(buf[li*ns + e], scale);
+		double2 v = cscale(val(li, e), scale);
 		double2* oc = out + (long)c.comp*ocomp;
 		// (backward transform = conjugate of the forward one of the conjugated input)
 		oc[(long)ky*ldo + kx] = conj_out ? cconj(v) : v;
@@ -500,6 +734,8 @@ struct StColOut : StageBase {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
+// 0: first-generation kernel everywhere (PXS_CHAIN_V1=1: A/B measurements)
+static bool chain_v2_on() { static const bool on = [] { const char* e = getenv("PXS_CHAIN_V1"); return !(e && atoi(e) != 0); }(); return on; }
 static bool smooth235(long n) { if (n < 1) return false; for (int p : {2, 3, 5}) while (n % p == 0) n /= p; return n == 1; }
 bool FftChain::sub_ok(long n) { return n >= 2 && n <= CH_NMAX && smooth235(n); }
 
@@ -534,9 +770,16 @@ const double2* FftChain::small_tw(long X, int n, int T) {
 // tab_pts >= 0 (ring stages, which run at <= 64 VGPRs) and PXS_RING_TILE_KB = k > 0: shrink the tile until tile + tab_pts table
 // entries fit k KiB of LDS (k = 39.5: four workgroups per CU).  Off by default -- measured at C3 / C4 / C2: ring FFT stages
 // 47.4 / 60.6 / 2.85 ms with 39.5 KiB tiles against 46.4 / 60.8 / 2.83 ms with the full 2560-point tiles.
+static bool f2_factor(int n, int& np, int* R);
 static int tile_lines(long n_a, long n_b, long nlines, int mult, long tab_pts = -1) {
 	const long n = std::max(n_a, n_b);
 	long T = CH_TILE_PTS / n;
+	// second-generation kernel: padded buffers; a single-transform stage keeps TWO input tiles (the LDS-DMA destination must stay
+	// below 64 KiB = 4096 points), a two-transform stage an input and an output tile (two workgroups per CU: < 75 KiB each)
+	if (chain_v2_on()) {
+		auto padded = [](long m) { int np, R[3]; return m > 0 && f2_factor((int)m, np, R) ? m + (np > 1 ? R[0] : 0) + 16 : m; };      // mk2's search range
+		T = std::min(T, n_b > 0 ? 4400/(padded(n_a) + padded(n_b)) : 2040/padded(n));
+	}
 	if (T >= mult) T -= T % mult;
 	if (T < 1) T = 1;
 	const long cap = ((nlines + mult - 1)/mult)*mult;
@@ -566,6 +809,145 @@ static BlkIn mk_blk(int Tw, long na, int T) {
 	b.dTTw = make_fastdiv((uint32_t)(T*Tw)); b.dTw = make_fastdiv((uint32_t)Tw); b.dwL = make_fastdiv((uint32_t)std::max(b.wL, 1));
 	return b;
 }
+// ---- second-generation kernel: transform plans and launch -------------------------------------------------------------------
+
+static const int F2_RADICES[] = {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20};
+// n as a product of at most three register radices: fewest passes, then the smallest largest radix; ascending order (the first
+// pass works on the longest rows, which wastes the least padding)
+static bool f2_factor(int n, int& np, int* R) {
+	auto ok = [](int r) { for (int x : F2_RADICES) if (x == r) return true; return false; };
+	if (n == 1) { np = 1; R[0] = R[1] = R[2] = 1; return true; }
+	if (ok(n)) { np = 1; R[0] = n; R[1] = R[2] = 1; return true; }
+	int best = 1 << 30, b0 = 0, b1 = 0;
+	for (int r0 : F2_RADICES) if (n % r0 == 0 && ok(n/r0) && r0 <= n/r0) { const int m = n/r0; if (m < best) { best = m; b0 = r0; b1 = n/r0; } }
+	if (b0) { np = 2; R[0] = b0; R[1] = b1; R[2] = 1; return true; }
+	int c0 = 0, c1 = 0, c2 = 0; best = 1 << 30;
+	for (int r0 : F2_RADICES) if (n % r0 == 0) for (int r1 : F2_RADICES) if ((n/r0) % r1 == 0 && r0 <= r1) {
+		const int r2 = n/r0/r1;
+		if (!ok(r2) || r1 > r2) continue;
+		if (r2 < best) { best = r2; c0 = r0; c1 = r1; c2 = r2; }
+	}
+	if (!c0) return false;
+	np = 3; R[0] = c0; R[1] = c1; R[2] = c2; return true;
+}
+bool FftChain::sub_ok2(long n) { int np, R[3]; return n >= 2 && n <= CH_NMAX && smooth235(n) && f2_factor((int)n, np, R); }
+
+// extra LDS cycles of one wave instruction: lanes -> 16-byte slots (-1: lane inactive)
+static int f2_read_conflicts(const int* slot) {
+	static const int G[4][16] = { {0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27}, {4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31},
+	                              {32,33,34,35,44,45,46,47,52,53,54,55,56,57,58,59}, {36,37,38,39,40,41,42,43,48,49,50,51,60,61,62,63} };
+	int extra = 0;
+	for (int g = 0; g < 4; g++) {
+		int cnt[16] = {0}, seen[16][16], mx = 0;
+		for (int i = 0; i < 16; i++) {
+			const int sl = slot[G[g][i]]; if (sl < 0) continue;
+			const int b = sl & 15; bool dup = false;
+			for (int j = 0; j < cnt[b]; j++) if (seen[b][j] == sl) dup = true;       // identical addresses broadcast
+			if (!dup) seen[b][cnt[b]++] = sl;
+			mx = std::max(mx, cnt[b]);
+		}
+		extra += std::max(0, mx - 1);
+	}
+	return extra;
+}
+static int f2_write_conflicts(const int* slot) {      // ds_write_b128: 8 groups of 8 contiguous lanes, 32 banks = 8 slots
+	int extra = 0;
+	for (int g = 0; g < 8; g++) {
+		int cnt[8] = {0}, mx = 0;
+		for (int i = 0; i < 8; i++) { const int sl = slot[8*g + i]; if (sl >= 0) mx = std::max(mx, ++cnt[sl & 7]); }
+		extra += std::max(0, mx - 1);
+	}
+	return extra;
+}
+static void f2_host_decode(const Fft2& f, int q, int tl, int& base) {
+	if (q == 0) { base = f.np == 1 ? 0 : tl; return; }
+	if (f.np == 2) { base = tl*f.rs; return; }
+	if (q == 1) { const int k1 = tl / f.M2, r = tl % f.M2; base = k1*f.rs + r; return; }
+	{ const int k1 = tl / f.R1, k2 = tl % f.R1; base = k1*f.rs + k2*f.M2; }
+}
+static int f2_host_slot_out(const Fft2& f, int k) {
+	if (f.np == 1) return k;
+	const int q = k / f.R0, k1 = k % f.R0;
+	if (f.np == 2) return k1*f.rs + q;
+	return k1*f.rs + (q % f.R1)*f.M2 + q / f.R1;
+}
+// lf[q]: tasks of pass q dealt line-fastest; rd[q] / wr[q]: the pass reads / writes the LDS buffer; store_lds: a final read sweep in
+// store order (line fastest, frequency next)
+static double f2_layout_cost(const Fft2& f, int T, int NT, const bool* lf, const bool* rd, const bool* wr, bool store_lds) {
+	double cost = 0; int slot[64];
+	const int radix[3] = {f.R0, f.R1, f.R2};
+	for (int q = 0; q < f.np; q++) {
+		const int tpl = f.n/radix[q], total = T*tpl;
+		for (int t0 = 0; t0 < total && t0 < NT; t0 += 64) {
+			for (int l = 0; l < 64; l++) {
+				const int t = t0 + l;
+				if (t >= total) { slot[l] = -1; continue; }
+				int li, tl; if (lf[q]) { tl = t / T; li = t % T; } else { li = t / tpl; tl = t % tpl; }
+				int base; f2_host_decode(f, q, tl, base);
+				slot[l] = li*f.ns + base;
+			}
+			if (rd[q]) cost += f2_read_conflicts(slot)*radix[q];
+			if (wr[q]) cost += 0.5*f2_write_conflicts(slot)*radix[q];
+		}
+	}
+	if (store_lds) {
+		const int total = T*f.n;
+		for (int t0 = 0; t0 < total && t0 < NT; t0 += 64) {
+			for (int l = 0; l < 64; l++) { const int t = t0 + l; slot[l] = t < total ? (t % T)*f.ns + f2_host_slot_out(f, t / T) : -1; }
+			cost += f2_read_conflicts(slot);
+		}
+	}
+	return cost;
+}
+
+// plan of an n-point transform for tiles of T lines: radices and the padded layout with the fewest bank conflicts
+Fft2 FftChain::mk2(long n, int T, int NT, int kind) {
+	Fft2 f; memset(&f, 0, sizeof(f));
+	if (n <= 0) { f.n = 0; f.np = 0; f.R0 = f.R1 = f.R2 = 1; return f; }
+	{	std::lock_guard<std::mutex> g(mu_);
+		auto it = f2_.find(std::make_tuple(n, T, NT, kind));
+		if (it != f2_.end()) return it->second; }
+	int np, R[3];
+	PXS_REQUIRE(f2_factor((int)n, np, R), "internal: no register-radix factorisation");
+	f.n = (int)n; f.np = np; f.R0 = R[0]; f.R1 = R[1]; f.R2 = R[2];
+	f.M1 = f.n/f.R0; f.M2 = np == 3 ? f.M1/f.R1 : 1;
+	// kind: bit 0 = first pass reads global memory (elementwise loads, line-fastest), bit 1 = last pass goes to registers (line-fastest,
+	// no LDS write), bit 2 = a store sweep reads the result from LDS, bit 3 = the first pass pulls through S::mid (irregular reads of
+	// ANOTHER buffer: not modelled)
+	bool lf[3] = {false, false, false}, rd[3] = {true, true, true}, wr[3] = {true, true, true};
+	if (kind & 1) { lf[0] = true; rd[0] = false; }
+	if (kind & 8) rd[0] = false;
+	if (kind & 2) { lf[np-1] = true; wr[np-1] = false; }
+	double best = 1e300; int brs = f.M1, bns = f.n;
+	static const int nopad = [] { const char* e = getenv("PXS_CH2_NOPAD"); return e ? atoi(e) : 0; }();       // experiments
+	const int rs_hi = (np == 1 || nopad) ? f.M1 : f.M1 + 1;
+	for (int rs = f.M1; rs <= rs_hi; rs++) {
+		const int row = np == 1 ? f.n : f.R0*rs;
+		for (int ns = row; ns <= (nopad ? row : row + 16); ns++) {
+			f.rs = rs; f.ns = ns;
+			const double c = f2_layout_cost(f, T, NT, lf, rd, wr, (kind & 4) != 0) + 0.02*(ns - f.n);      // a little for the LDS footprint
+			if (c < best) { best = c; brs = rs; bns = ns; }
+		}
+	}
+	f.rs = brs; f.ns = bns;
+	f.dM1 = make_fastdiv((uint32_t)f.M1); f.dM2 = make_fastdiv((uint32_t)std::max(f.M2, 1)); f.dR0 = make_fastdiv((uint32_t)f.R0); f.dR1 = make_fastdiv((uint32_t)f.R1);
+	f.drs = make_fastdiv((uint32_t)f.rs); f.dns = make_fastdiv((uint32_t)f.ns);
+	f.tw = fc_->twiddle_table(n);
+	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] fft2 n=%ld T=%d kind=%d: %d x %d x %d, rs=%d (M1=%d) ns=%d, conflict cost %.1f\n", n, T, kind, f.R0, f.R1, f.R2, f.rs, f.M1, f.ns, best - 0.02*(f.ns - f.n));
+	std::lock_guard<std::mutex> g(mu_);
+	f2_[std::make_tuple(n, T, NT, kind)] = f;
+	return f;
+}
+
+static int device_cus() {
+#ifdef PXS_HOST_SIM
+	return 2;
+#else
+	static const int n = [] { int d = 0, v = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v > 0 ? v : 256; }();
+	return n;
+#endif
+}
+
 template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st) {
 	if (nblk <= 0) return;
 	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= CH_TILE_PTS, "internal: chain tile too large");
@@ -577,6 +959,47 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	(void)once;
 #endif
 	hipLaunchKernelGGL((chain_kernel<S, CH_NT, CH_MAXE>), dim3((unsigned)nblk), dim3(CH_NT), sh, st, s);
+}
+
+// second-generation launch: s carries the v1 description of the stage (tiles, T, fa.n / fb.n, btw); this adds the DIF plans
+template<class S> void FftChain::launch_stage2(S& s, long ntiles, hipStream_t st) {
+	if (ntiles <= 0) return;
+	PXS_REQUIRE(ntiles < (1L << 31), "internal: chain grid too large");
+	constexpr int NT = CH2_NT_B;
+	const int na = s.fa.n, nb = S::TWO ? s.fb.n : 0;
+	const int kindA = (S::LOADK == 1 ? 1 : 0) | ((!S::TWO && S::STOREK == 0) ? 2 : 0) | ((!S::TWO && S::STOREK == 1) ? 4 : 0);
+	const int kindB = 8 | (S::STOREK == 0 ? 2 : 4);
+	s.a2 = mk2(na, s.T, NT, kindA);
+	s.b2 = mk2(nb, s.T, NT, kindB);
+	const Fft2& fl = S::TWO ? s.b2 : s.a2;
+	const int radA[3] = {s.a2.R0, s.a2.R1, s.a2.R2}, radB[3] = {s.b2.R0, s.b2.R1, s.b2.R2};
+	for (int q = 0; q < 3; q++) { s.dtplA[q] = make_fastdiv((uint32_t)std::max(1, na/radA[q])); s.dtplB[q] = make_fastdiv((uint32_t)std::max(1, nb/std::max(1, radB[q]))); }
+	const int RL = fl.np == 1 ? fl.R0 : (fl.np == 2 ? fl.R1 : fl.R2), K0 = fl.n/RL;
+	s.dK0 = make_fastdiv((uint32_t)K0); s.dRL = make_fastdiv((uint32_t)RL);
+	s.ntiles2 = (int)ntiles;
+	const size_t szA = ((size_t)s.T*s.a2.ns + 63) & ~(size_t)63;
+	const bool dbl = !S::TWO && S::LOADK == 0;
+	const size_t nF = (size_t)s.T*(K0 + RL);
+#ifndef PXS_HOST_SIM
+	PXS_REQUIRE(!(S::HAS_TW && s.btw) || nF <= (size_t)CH2_TWN*NT, "internal: four-step twiddle tables too large");
+#endif
+	const size_t sh = sizeof(double2)*((dbl ? 2 : 1)*szA + (S::TWO ? (size_t)s.T*s.b2.ns : 0) + na + nb + (S::HAS_TW ? 2*nF : 0) + 2);
+	PXS_REQUIRE(sh <= 160*1024 - 256, "internal: chain tile too large for the LDS");
+	PXS_REQUIRE(((dbl ? 2 : 1)*szA)*sizeof(double2) <= 65536, "internal: LDS-DMA destination beyond 64 KiB");
+	static const int wg_cap = [] { const char* e = getenv("PXS_CH2_WGS"); return e ? atoi(e) : 0; }();
+	int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160*1024 - 256)/sh));
+	if (wg_cap > 0) wgs = std::min(wgs, wg_cap);
+	const long grid = std::min<long>(ntiles, (long)device_cus()*wgs);
+#ifndef PXS_HOST_SIM
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain2_kernel<S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
+	(void)once;
+#endif
+	hipLaunchKernelGGL((chain2_kernel<S, NT>), dim3((unsigned)grid), dim3(NT), sh, st, s);
+}
+// v2 when the stage's transforms have register-radix plans, else v1
+template<class S> void FftChain::launch_any(S& s, long nblk, hipStream_t st) {
+	if (chain_v2_on() && S::V2 && sub_ok2(s.fa.n) && (!S::TWO || sub_ok2(s.fb.n))) launch_stage2(s, nblk, st);
+	else launch_stage(s, nblk, st);
 }
 
 // balanced split n = a*b with both factors usable
@@ -679,7 +1102,7 @@ void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, doubl
 			s.m = map_addr(m); s.m.off0 += 2*q_lo*m.ring_stride; s.m.nring = nring;
 			s.b = (int)b; s.npair = (int)npair; s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, tile_lines(a, 0, b, 16, 2*a), b, nphi_);
-			launch_stage(s, (long)nc*npair*s.ntile, st);
+			launch_any(s, (long)nc*npair*s.ntile, st);
 		}
 		{	StRingA2 s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
@@ -688,7 +1111,7 @@ void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, doubl
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
 			s.groups = (int)((npair + T/2 - 1)/(T/2)); s.da = make_fastdiv((uint32_t)a); s.dgr = make_fastdiv((uint32_t)s.groups);
 			s.leg = leg + 2*q_lo; s.ldleg = ldleg; s.nm = mmax + 1; s.tab = tab; s.scale = scale;
-			launch_stage(s, (long)nc*s.groups*a, st);
+			launch_any(s, (long)nc*s.groups*a, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -708,14 +1131,14 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 			s.h = h + 2*q_lo*ldh; s.ldh = ldh; s.hcomp = hcomp > 0 ? hcomp : m.nring; s.b = (int)b; s.X = (int)nphi_; s.npair = (int)npair; s.nring = nring; s.mmax = mmax;
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T1, b, nphi_); s.bout = blocked_on();
-			launch_stage(s, (long)nc*npair*s.ntile, st);
+			launch_any(s, (long)nc*npair*s.ntile, st);
 		}
 		{	StRingS2 s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, b, 8); s.fb = mk(fc_, 0, 8);
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.npair = (int)npair; s.m = map_addr(m); s.m.off0 += 2*q_lo*m.ring_stride; s.m.nring = nring;
 			s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T2, a, 0); s.bin = mk_blk(T1, b, T2);
-			launch_stage(s, (long)nc*npair*s.ntile, st);
+			launch_any(s, (long)nc*npair*s.ntile, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -761,27 +1184,27 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
 			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T1, bN, tp.N); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, g2);
 			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.M; s.kmax = -1; s.nyq = 1;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StSigma s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, g);
 			s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.V = s1_.as<double2>(); s.ldV = ldV3; s.g = (int)g; s.g2 = (int)g2; s.sigma = sigma;
 			set_tiles(s, T3, g2, tp.M); s.bin = mk_blk(T2, g, T3); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g2); s.fb = mk(fc_, ac);
 			s.Y = s1_.as<double2>(); s.ldY = ldV3; s.Z = s2_.as<double2>(); s.ldZ = ldU4; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
 			s.ph = nullptr; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T4, g, tp.Ncc); s.bin = mk_blk(T3, g2, T4); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
@@ -793,7 +1216,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			s.out = leg_cc + (size_t)c0*nm*ldcc; s.ocstride = (long)nm*ldcc; s.dnp = make_fastdiv((uint32_t)npair); s.groups = 1; s.dgr = make_fastdiv(1);
 			s.ld = ldcc; s.w = wcc; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
 			s.bin = mk_blk(T4, g, T);
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -821,14 +1244,14 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
 			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T1, bN, tp.N); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, ac);
 			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldU; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.Ncc; s.kmax = lmax; s.nyq = 0;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T2, g, tp.Ncc); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
@@ -840,7 +1263,7 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 			s.out = leg_cc + (size_t)c0*nm*ldcc; s.ocstride = (long)nm*ldcc; s.dnp = make_fastdiv((uint32_t)npair); s.groups = 1; s.dgr = make_fastdiv(1);
 			s.ld = ldcc; s.w = w; s.tab = nullptr; s.scale = 1.0; s.da = make_fastdiv((uint32_t)ac);
 			s.bin = mk_blk(T2, g, T);
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -871,27 +1294,27 @@ void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2*
 			s.src.w = whalf;
 			s.b = (int)ac; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T1, ac, tp.Ncc); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));     // pass 2 of FFT_Ncc, |k| <= lmax embedded in the M spectrum, pass 1 of IFFT_M
 			s.fa = mk(fc_, ac); s.fb = mk(fc_, g2);
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)g; s.X1 = (int)tp.Ncc; s.X2 = (int)tp.M; s.kmax = lmax; s.nyq = 0;
 			s.ph = nullptr; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, ac, T2); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StSigma s; memset(&s, 0, sizeof(s));      // pass 2 of IFFT_M, x |sin| series, pass 1 of FFT_M
 			s.fa = mk(fc_, g); s.fb = mk(fc_, g);
 			s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.V = s1_.as<double2>(); s.ldV = ldV; s.g = (int)g; s.g2 = (int)g2; s.sigma = sigma;
 			set_tiles(s, T3, g2, tp.M); s.bin = mk_blk(T2, g, T3); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));     // pass 2 of FFT_M, transposed padding M -> N (conjugate phase, Nyquist bins combined), pass 1 of IFFT_N
 			s.fa = mk(fc_, g2); s.fb = mk(fc_, bN);
 			s.Y = s1_.as<double2>(); s.ldY = ldV; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.N; s.kmax = -1; s.nyq = 0; s.adj = 1;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T4, g, tp.N); s.bin = mk_blk(T3, g2, T4);      // (plain rows out: the transposing split takes one line of many pairs)
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<1> s; memset(&s, 0, sizeof(s));   // pass 2 of IFFT_N, the two parities apart, rings of the map, ring-major
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
@@ -902,7 +1325,7 @@ void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2*
 			const long groups = (npair + T/2 - 1)/(T/2);
 			s.out = h + (size_t)c0*nr*ldh; s.ocstride = (long)nr*ldh; s.dnp = make_fastdiv((uint32_t)npair); s.groups = (int)groups; s.dgr = make_fastdiv((uint32_t)groups);
 			s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)bN); s.self_half = 1;
-			launch_stage(s, ncl*groups*bN, st);
+			launch_any(s, ncl*groups*bN, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -925,14 +1348,14 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 			s.src.leg = leg_cc + (size_t)c0*nm*ldcc; s.src.cstride = (long)nm*ldcc; s.src.ld = ldcc; s.src.nr = ncc; s.src.N = (int)tp.Ncc; s.src.mir_c = 0; s.src.a_odd = spin & 1; s.src.ncol = nm;
 			s.b = (int)bs; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T1, bs, tp.Ncc); s.bout = blocked_on();
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bs); s.fb = mk(fc_, aN);
 			s.Y = s1_.as<double2>(); s.ldY = ldY; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)gs; s.X1 = (int)tp.Ncc; s.X2 = (int)tp.N; s.kmax = lmax; s.nyq = 0;
 			s.ph = ph_up; s.dg = make_fastdiv((uint32_t)gs);
 			set_tiles(s, T2, gs, tp.N); s.bin = mk_blk(T1, bs, T2);      // (plain rows out, see to_cc_adjoint)
-			launch_stage(s, ncl*npair*s.ntile, st);
+			launch_any(s, ncl*npair*s.ntile, st);
 		}
 		{	StSplit<1> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
@@ -943,7 +1366,7 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 			const long groups = (npair + T/2 - 1)/(T/2);
 			s.out = h + (size_t)c0*nr*ldh; s.ocstride = (long)nr*ldh; s.dnp = make_fastdiv((uint32_t)npair); s.groups = (int)groups; s.dgr = make_fastdiv((uint32_t)groups);
 			s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)aN);
-			launch_stage(s, ncl*groups*aN, st);
+			launch_any(s, ncl*groups*aN, st);
 		}
 	}
 	PXS_HIP(hipGetLastError());
@@ -970,7 +1393,7 @@ bool FftChain::fft2_real(hipStream_t st, const void* in, int in_dtype, double2* 
 		s.src.leg = s2_.as<double2>(); s.src.cstride = nm*ldF; s.src.ld = ldF; s.src.nr = (int)ny; s.src.N = (int)ny; s.src.ncol = (int)nm; s.src.plain = 1;
 		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)nm; s.dnp = make_fastdiv((uint32_t)nm);
 		set_tiles(s, tile_lines(a, 0, b, 8), b, ny);
-		launch_stage(s, npre*nm*s.ntile, st);
+		launch_any(s, npre*nm*s.ntile, st);
 	}
 	{	StColOut s; memset(&s, 0, sizeof(s));
 		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
@@ -979,7 +1402,7 @@ bool FftChain::fft2_real(hipStream_t st, const void* in, int in_dtype, double2* 
 		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.nm = (int)nm; s.ny = (int)ny; s.nx = (int)nx; s.conj_out = forward ? 0 : 1; s.out = out; s.scale = scale;
 		s.herm = 1; s.ldo = nx; s.ocomp = ny*nx;
 		s.groups = (int)((nm + T - 1)/T); s.dgr = make_fastdiv((uint32_t)s.groups);
-		launch_stage(s, npre*s.groups*a, st);
+		launch_any(s, npre*s.groups*a, st);
 	}
 	PXS_HIP(hipGetLastError());
 	return true;
@@ -1002,7 +1425,7 @@ bool FftChain::fft2_c2c(hipStream_t st, const double2* in, double2* out, long np
 		s.src.leg = src; s.src.cstride = nlines*ld; s.src.ld = ld; s.src.nr = (int)n; s.src.N = (int)n; s.src.ncol = (int)nlines; s.src.plain = 1; s.src.conj = conj;
 		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.npair = (int)nlines; s.dnp = make_fastdiv((uint32_t)nlines);
 		set_tiles(s, tile_lines(a, 0, b, 8), b, n);
-		launch_stage(s, npre*nlines*s.ntile, st);
+		launch_any(s, npre*nlines*s.ntile, st);
 	};
 	auto second = [&](double2* dst, long nlines, long ldo, long ocomp, long a, long b, int conj, double sc) {
 		StColOut s; memset(&s, 0, sizeof(s));
@@ -1011,7 +1434,7 @@ bool FftChain::fft2_c2c(hipStream_t st, const double2* in, double2* out, long np
 		set_tiles(s, T, a*T, 0);
 		s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.a = (int)a; s.nm = (int)nlines; s.ny = 0; s.nx = 0; s.conj_out = conj; s.herm = 0; s.out = dst; s.ldo = ldo; s.ocomp = ocomp; s.scale = sc;
 		s.groups = (int)((nlines + T - 1)/T); s.dgr = make_fastdiv((uint32_t)s.groups);
-		launch_stage(s, npre*s.groups*a, st);
+		launch_any(s, npre*s.groups*a, st);
 	};
 	first(in, ny, nx, nx, ax, bx, forward ? 0 : 1);                           // rows y: lines of nx points
 	second(s2_.as<double2>(), ny, ldF, nx*ldF, ax, bx, 0, 1.0);               // -> F[kx][y]

@@ -3,6 +3,7 @@
 // array is written once and read once.
 #pragma once
 #include "fft.hpp"
+#include "fft2_dev.hpp"
 #include <tuple>
 #include <map>
 #include <mutex>
@@ -25,6 +26,7 @@ public:
 	explicit FftChain(FftContext* fc) : fc_(fc) {}
 	// can the engine run its LDS passes on lines of this length (radices 2,3,4,5, length <= 512)?
 	static bool sub_ok(long n);
+	static bool sub_ok2(long n);      // ... and the second-generation kernel (at most three register radices <= 20)
 	static long pad8(long n) { return (n + 7) & ~7L; }
 	// ring FFT split of nphi for analysis (map -> leg) and synthesis (h -> map); false: no usable factorisation
 	bool plan_rings(long nphi);
@@ -64,6 +66,10 @@ public:
 private:
 	const double2* small_tw(long X, int n, int T);
 	template<class S> void set_tiles(S& s, int T, long nlines, long X);
+	Fft2 mk2(long n, int T, int NT, int kind);
+	template<class S> void launch_stage2(S& s, long ntiles, hipStream_t st);
+	template<class S> void launch_any(S& s, long nblk, hipStream_t st);
+	std::map<std::tuple<long, int, int, int>, Fft2> f2_;
 	std::mutex mu_;
 	std::map<std::tuple<long, int, int>, DevBuf> stw_;
 	FftContext* fc_;
