@@ -377,16 +377,26 @@ def main():
 	ncomp_all = ncomp*nmaps
 	alm_in = torch.cat([make_alm(cfg, 1000+lo+i, device) for i in range(nmaps)], 0) if batched else make_alm(cfg, 1000+rank, device)
 	dmap = enmap.dmap(torch.zeros((ncomp_all, ny, nx), dtype=torch.float64, device=device), wcs)
-	curvedsky.alm2map(alm_in, dmap, spin=cfg["spin"], ainfo=ainfo)      # synthetic band-limited input (also builds plans)
 	alm_out = torch.zeros_like(alm_in)
-	curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo)
 	torch.cuda.synchronize()
+	# ---- the cold call, piece by piece (a script that transforms once on a geometry pays all of it; the timed steps below pay none):
+	# plan object (ring tables, FFT-chain plans, theta-resampling tables), recurrence tables of every spin (host long double, threaded),
+	# the first transform of each direction (scratch allocation, recurrence seeds recorded), the second round trip (seeds loaded)
+	def timed(fn):
+		torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return (time.perf_counter()-t)*1e3, r
+	minfo = curvedsky.analyse_geometry(dmap.shape, wcs)
+	t_plan, plan = timed(lambda: sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1))
+	t_tab, _ = timed(lambda: [plan.set_option("build_tables", s) for s in sorted(set(cfg["spin"]))])
+	t_syn1, _ = timed(lambda: curvedsky.alm2map(alm_in, dmap, spin=cfg["spin"], ainfo=ainfo))      # synthetic band-limited input
+	t_ana1, _ = timed(lambda: curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo))
 	rt_err = float((alm_out-alm_in).abs().pow(2).mean().sqrt()/alm_in.abs().pow(2).mean().sqrt())
-	log("[rank %d] setup %.1fs; %d map(s); round-trip rms error %.2e" % (rank, time.time()-t0, nmaps, rt_err))
+	t_rt2, _ = timed(lambda: (curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo), curvedsky.alm2map(alm_out, dmap, spin=cfg["spin"], ainfo=ainfo)))
+	cold = dict(plan_build_ms=round(t_plan+t_tab, 1), plan_object_ms=round(t_plan, 1), recurrence_tables_ms=round(t_tab, 1),
+		first_alm2map_ms=round(t_syn1, 1), first_map2alm_ms=round(t_ana1, 1), first_roundtrip_ms=round(t_plan+t_tab+t_syn1+t_ana1, 1), second_roundtrip_ms=round(t_rt2, 1),
+		note="first_roundtrip_ms = plan_build_ms + the first transform of each direction on the fresh plan (scratch allocation, recurrence seeds recorded where the plan uses them); steady_ms is the timed step")
+	log("[rank %d] setup %.1fs; %d map(s); round-trip rms error %.2e; cold call: %s" % (rank, time.time()-t0, nmaps, rt_err, {k: v for k, v in cold.items() if k != "note"}))
 	# north_star: alm must come back to < 1e-8 relative rms.  A throughput number of a transform that does not is worthless.
 	if not (rt_err < 1e-8) and not os.environ.get("PXS_BENCH_NOCHECK"): raise SystemExit("bench.py: round-trip rms error %.3e exceeds 1e-8 -- refusing to time a wrong transform" % rt_err)
-	minfo = curvedsky.analyse_geometry(dmap.shape, wcs)
-	plan = sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1)
 	info = plan.info()
 	gather = None; side = None; ranks_seen = None
 	if (world > 1 or force_pg) and not args.no_gather:
@@ -423,6 +433,27 @@ def main():
 	ms_step = dt/args.steps*1e3
 	maps_total = ntot if batched else world
 	value = maps_total*args.steps/dt
+	cold["steady_ms"] = round(ms_step, 3)
+	# ---- the weights form of the analysis (pxs_plan_option "analysis" = 1; the reference's cyl route, curvedsky.py:852-861, 1068-1084) where
+	# the grid has >= 2 lmax + 2 rings: same alm for band-limited maps, three theta-resampling stages instead of five.  Reported beside
+	# the default (the interpolant, which is what ducc0's analysis_2d integrates); never `value`.
+	ana_w = None
+	if ny >= 2*lmax+2 and world == 1 and not batched:
+		try:
+			aw = torch.zeros_like(alm_out)
+			def wstep():
+				curvedsky.map2alm(dmap, alm=aw, spin=cfg["spin"], ainfo=ainfo, analysis="weights")
+				curvedsky.alm2map(aw, dmap, spin=cfg["spin"], ainfo=ainfo)
+			wstep(); torch.cuda.synchronize()
+			w_err = float((aw-alm_out).abs().pow(2).mean().sqrt()/alm_out.abs().pow(2).mean().sqrt())
+			plan.profile(True); torch.cuda.synchronize(); tw = time.perf_counter()
+			for _ in range(args.steps): wstep()
+			torch.cuda.synchronize(); dtw = time.perf_counter()-tw
+			pw = plan.profile_read(reset=True); plan.profile_flops(reset=True); plan.profile(False)
+			ana_w = dict(ms_per_step=round(dtw/args.steps*1e3, 3), value=round(args.steps/dtw, 4), unit="round-trips/s", stage_ms_per_step={k: round(v[0]/args.steps, 3) for k, v in pw.items()},
+				alm_rms_difference_from_default=w_err, note="map2alm(..., analysis='weights') + alm2map; an option, not the default: on maps that are not band-limited the two forms differ")
+			del aw
+		except Exception as e: log("weights-analysis leg failed: %r" % (e,))
 
 	# ---- roofline of the dominant kernel family (Legendre; FP64 FMA bound) ----
 	R_syn, R_ana = info["nring_syn"], info["nring_ana"]
@@ -464,6 +495,7 @@ def main():
 		stage_note="stages run back to back on one stream (hipEvent-bracketed inside the library)",
 		plan_state="data-independent tables built with the plan or by its first transform (untimed warm-up): recurrence coefficients, twiddles, CC quadrature, and the recurrence seeds of DESIGN.md section 4; every timed step runs the full transform on the resident map",
 		hbm_algorithmic_GBps=round(hbm_gbs, 1), hbm_frac_of_8TBps=round(hbm_gbs/HBM_PEAK_GBS, 5),
+		cold_start=cold, analysis_weights=ana_w,
 		roundtrip_rms_error=rt_err, ducc0=probe_ducc0())
 	if ranks_seen is not None: res["rccl_ranks_seen"] = ranks_seen; res["collective"] = gather.describe()
 	if rank == 0:

@@ -77,6 +77,15 @@ int pxs_analysis(pxs_plan* plan, int spin, int adjoint, int nbatch,
                  void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride,
                  void* alm, int alm_dtype, int64_t alm_cstride, int64_t alm_bstride, void* stream);
 
+/* Plan options.  "analysis": how pxs_analysis integrates over theta on grid2d plans --
+ *   0 (default) "interpolant": exact quadrature of the theta-interpolant, exact down to ntheta = lmax + 1 (curvedsky.py:1018-1048);
+ *   1 "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route (curvedsky.py:852-861, 1068-1084:
+ *     get_gridweights / nphi, then adjoint_synthesis), applied when ntheta >= 2 lmax + 2, where it is exact for band-limited maps
+ *     (smaller grids keep the interpolant).  The adjoint (adjoint = 1) follows the same choice: synthesis, then the weights.
+ * Takes effect for the calls issued after it returns.
+ * "build_tables" (value = spin): builds the recurrence tables of that spin now instead of inside the first transform that needs them. */
+int pxs_plan_option(pxs_plan* plan, const char* name, int64_t value);
+
 /* ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855): out[ntheta], sum = 4 pi. Host memory. */
 int pxs_gridweights(const char* geometry, int ntheta, double* out);
 

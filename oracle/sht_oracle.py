@@ -451,16 +451,18 @@ def _gl(nq):
 	return np.arccos(x)[::-1].copy(), w[::-1].copy()
 
 def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0,
-		nthreads=0, lstride=1):
+		nthreads=0, lstride=1, weights=False):
 	"""ducc0.sht.experimental.analysis_2d (curvedsky.py:1032-1046): exact integration of
-	the theta-interpolant, evaluated here on Gauss-Legendre nodes."""
+	the theta-interpolant, evaluated here on Gauss-Legendre nodes.
+	weights=True (ours, the product's analysis="weights"): ring quadrature weights + adjoint synthesis, the reference's cyl route
+	(curvedsky.py:852-861, 1068-1084); exact for band-limited maps on grids with nt >= 2 lmax + 2."""
 	map = np.asarray(map)
 	nc, nt, nph = map.shape
 	if mmax is None: mmax = lmax
 	if mstart is None: mstart = _tri_mstart(lmax, mmax)
 	if lmax > grid_maxlmax(geometry, nt):
 		raise ValueError("too few rings for analysis up to requested lmax")
-	if geometry in ("DH", "F2"):
+	if geometry in ("DH", "F2") or weights:
 		w = get_gridweights(geometry, nt)/nph
 		return adjoint_synthesis_2d(alm=alm, map=map*w[None, :, None], spin=spin, lmax=lmax,
 			geometry=geometry, mmax=mmax, mstart=mstart, phi0=phi0, lstride=lstride)
@@ -487,12 +489,12 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	return alm
 
 def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0,
-		nthreads=0, lstride=1):
-	"""Exact transpose of analysis_2d (curvedsky.py:1032)."""
+		nthreads=0, lstride=1, weights=False):
+	"""Exact transpose of analysis_2d (curvedsky.py:1032); weights=True: of its weights form (synthesis, then the ring weights)."""
 	nc, nt, nph = map.shape
 	if mmax is None: mmax = lmax
 	if mstart is None: mstart = _tri_mstart(lmax, mmax)
-	if geometry in ("DH", "F2"):
+	if geometry in ("DH", "F2") or weights:
 		w = get_gridweights(geometry, nt)/nph
 		synthesis_2d(alm=alm, map=map, spin=spin, lmax=lmax, geometry=geometry, mmax=mmax,
 			mstart=mstart, phi0=phi0, lstride=lstride)

@@ -70,7 +70,8 @@ template<int R> __device__ __forceinline__ void dft_reg(double2* v) {
 }
 
 // ---- transform descriptor -------------------------------------------------------------------------------------------
-static constexpr int F2_MAXR = 20;      // largest radix the chain kernels dispatch to (24 and 25 exist as codelets)
+static constexpr int F2_MAXR = 9;        // largest radix the chain kernels dispatch to (10 ... 25 exist as codelets; see chain2_kernel)
+static constexpr int F2_MAXR_FIRST = 6;  // ... in a pass that takes its inputs from global memory or through a stage's mid()
 struct Fft2 {
 	int n, np;            // points, passes (1..3)
 	int R0, R1, R2;       // radices in DIF order (unused ones = 1)

@@ -193,36 +193,42 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 #ifdef PXS_HOST_SIM
 #define PXS_DMA16(gp, lbase, lane) ((lbase)[lane] = *(gp))
 #define PXS_WAIT_VM0()
-static constexpr int CH2_NT_A = 1, CH2_NT_B = 1;
+static constexpr int CH2_NT = 1;
+#define PXS_CH2_BOUNDS
 #else
 __device__ __forceinline__ void pxs_dma16(const double2* g, double2* l) {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 #define PXS_DMA16(gp, lbase, lane) pxs_dma16((gp), (lbase))
 #define PXS_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-static constexpr int CH2_NT_A = 128, CH2_NT_B = 256;
+#ifndef PXS_CH2_NT
+#define PXS_CH2_NT 512
 #endif
-static constexpr int CH2_TWN = 8;        // per-thread registers of the twiddle prefetch: T*(K0 + R_last) <= CH2_TWN * NT
+static constexpr int CH2_NT = PXS_CH2_NT;
+// two workgroups per CU (each ~75 KiB of LDS): 2 NT / 64 waves on 4 SIMDs = NT / 128 waves per SIMD -> 128 VGPRs at 512 threads
+#define PXS_CH2_BOUNDS __launch_bounds__(NT, (NT >= 128 ? NT/128 : 1))
+#endif
 
-template<class F> __device__ __forceinline__ void f2_dispatch(int R, F&& f) {
+// (a kernel holds the butterflies of every radix a pass may take, and its register allocation is the maximum over them: the passes
+// that pull their inputs from global memory or through S::mid -- many address registers next to the data -- take radices up to
+// F2_MAXR_FIRST only, see f2_factor)
+template<int MAXR, class F> __device__ __forceinline__ void f2_dispatch(int R, F&& f) {
 	switch (R) {
 		case 2: f(std::integral_constant<int, 2>{}); break;   case 3: f(std::integral_constant<int, 3>{}); break;
 		case 4: f(std::integral_constant<int, 4>{}); break;   case 5: f(std::integral_constant<int, 5>{}); break;
-		case 6: f(std::integral_constant<int, 6>{}); break;   case 8: f(std::integral_constant<int, 8>{}); break;
-		case 9: f(std::integral_constant<int, 9>{}); break;   case 10: f(std::integral_constant<int, 10>{}); break;
-		case 12: f(std::integral_constant<int, 12>{}); break; case 15: f(std::integral_constant<int, 15>{}); break;
-		case 16: f(std::integral_constant<int, 16>{}); break; case 18: f(std::integral_constant<int, 18>{}); break;
-		case 20: f(std::integral_constant<int, 20>{}); break;
+		case 6: f(std::integral_constant<int, 6>{}); break;
+		case 8: if constexpr (MAXR >= 8) f(std::integral_constant<int, 8>{}); break;
+		case 9: if constexpr (MAXR >= 9) f(std::integral_constant<int, 9>{}); break;
 		default: break;
 	}
 }
 
 // one pass of transform f on T lines: in(task, i) -> input i of the butterfly, out(task, i, value) <- output i
-template<int NT, class In, class Out>
+template<int NT, int MAXR, class In, class Out>
 __device__ __forceinline__ void f2_pass(const Fft2& f, int q, int T, FastDiv dT, FastDiv dtpl, bool line_fast, const double2* tw, In&& in, Out&& out) {
 	const int R = f2_radix(f, q), tpl = f.n / R, total = T*tpl;
 	const bool twd = q + 1 < f.np;
-	f2_dispatch(R, [&](auto Rc) {
+	f2_dispatch<MAXR>(R, [&](auto Rc) {
 		constexpr int RR = decltype(Rc)::value;
 		for (int t = threadIdx.x; t < total; t += NT) {
 			F2Task k; int tl;
@@ -242,7 +248,7 @@ __device__ __forceinline__ void f2_pass(const Fft2& f, int q, int T, FastDiv dT,
 	});
 }
 
-template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(const S s)
+template<class S, int NT> __global__ PXS_CH2_BOUNDS void chain2_kernel(const S s)
 {
 	PXS_SHARED(double2, lds);
 	const Fft2& fa = s.a2; const Fft2& fb = s.b2;
@@ -252,14 +258,14 @@ template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(co
 	const FastDiv dT = s.dT;
 	const int szA = ((T*fa.ns + 63) & ~63);           // DMA granularity: whole wave instructions
 	const bool dbl = !S::TWO && S::LOADK == 0;        // two input buffers: the next tile arrives while this one is transformed in place
-	// DMA destinations first (LDS-DMA bases are 16-bit offsets)
-	double2* bufA = lds;
+	const int K0 = fl.n / f2_radix(fl, fl.np - 1), RL = f2_radix(fl, fl.np - 1);
+	const bool have_tw = S::HAS_TW && s.btw != nullptr;
+	const int nF = T*(K0 + RL), nFp = (nF + 63) & ~63;           // F1[li][k0] | F2[li][i]
+	// DMA destinations first (they must sit below 64 KiB): the two four-step twiddle tables (tile parity), then the row buffer(s)
+	double2* ftw = lds;
+	double2* bufA = ftw + (S::HAS_TW ? 2*nFp : 0);
 	double2* bufB = bufA + (dbl ? 2 : 1)*szA;
 	double2* twa = bufB + (S::TWO ? T*fb.ns : 0); double2* twb = twa + na;
-	const int K0 = fl.n / f2_radix(fl, fl.np - 1), RL = f2_radix(fl, fl.np - 1);
-	const int nF = T*(K0 + RL);                       // F1[li][k0] | F2[li][i]
-	double2* ftw = twb + nb;                          // two of them (tile parity)
-	const bool have_tw = S::HAS_TW && s.btw != nullptr;
 	for (int k = threadIdx.x; k < na; k += NT) twa[k] = fa.tw[k];
 	if (S::TWO) for (int k = threadIdx.x; k < nb; k += NT) twb[k] = fb.tw[k];
 
@@ -275,38 +281,32 @@ template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(co
 			if (rp) PXS_DMA16(rp + blk*fa.M1 + r, dst + (S0 - (int)(threadIdx.x & 63)), (int)(threadIdx.x & 63));
 		}
 	};
-	// four-step twiddle tables of a tile, fetched into registers (they are written to LDS when the tile's turn comes)
-	double2 tw0 = make_double2(0, 0), tw1 = tw0, tw2 = tw0, tw3 = tw0, tw4 = tw0, tw5 = tw0, tw6 = tw0, tw7 = tw0;
-	auto tw_src = [&](const TileC& cc, int u) -> const double2* {
-		const int idx = threadIdx.x + u*NT;
-		if (idx >= nF) return nullptr;
-		const bool second = idx >= T*K0;
-		const int j = second ? idx - T*K0 : idx, per = second ? RL : K0;
-		const int li = (int)fdiv((uint32_t)j, second ? s.dRL : s.dK0), kk = j - li*per;
-		return s.btw + (long)(cc.t0 + li)*(second ? K0*kk : kk);
+	// four-step twiddle tables of a tile: gathered from the full table straight into LDS (no registers; padding slots and absent
+	// lines fetch entry 0)
+	auto fetch_tw = [&](const TileC& cc, double2* Fd) {
+		for (int i0 = threadIdx.x; i0 < nFp; i0 += NT) {
+			const double2* src = s.btw;
+			if (i0 < nF) {
+				const bool second = i0 >= T*K0;
+				const int j = second ? i0 - T*K0 : i0, per = second ? RL : K0;
+				const int li = (int)fdiv((uint32_t)j, second ? s.dRL : s.dK0), kk = j - li*per;
+				if (li < cc.nl) src = s.btw + (long)(cc.t0 + li)*(second ? K0*kk : kk);
+			}
+			PXS_DMA16(src, Fd + (i0 - (int)(threadIdx.x & 63)), (int)(threadIdx.x & 63));
+		}
 	};
-#ifdef PXS_HOST_SIM      /* one OS thread per workgroup: the tables are filled straight from the big table when the tile's turn comes */
-#define PXS_TW_FETCH(cc) { }
-#define PXS_TW_PUT(F) { for (int u_ = 0; u_*NT < nF; u_++) { const double2* p_ = tw_src(c, u_); if (p_) (F)[threadIdx.x + u_*NT] = *p_; } }
-#else
-#define PXS_TW_FETCH1(cc, u, r) { if ((u)*NT < nF) { const double2* p_ = tw_src(cc, u); if (p_) r = *p_; } }
-#define PXS_TW_FETCH(cc) { PXS_TW_FETCH1(cc, 0, tw0) PXS_TW_FETCH1(cc, 1, tw1) PXS_TW_FETCH1(cc, 2, tw2) PXS_TW_FETCH1(cc, 3, tw3) \
-	PXS_TW_FETCH1(cc, 4, tw4) PXS_TW_FETCH1(cc, 5, tw5) PXS_TW_FETCH1(cc, 6, tw6) PXS_TW_FETCH1(cc, 7, tw7) }
-#define PXS_TW_PUT1(F, u, r) { const int idx_ = threadIdx.x + (u)*NT; if (idx_ < nF) (F)[idx_] = r; }
-#define PXS_TW_PUT(F) { PXS_TW_PUT1(F, 0, tw0) PXS_TW_PUT1(F, 1, tw1) PXS_TW_PUT1(F, 2, tw2) PXS_TW_PUT1(F, 3, tw3) \
-	PXS_TW_PUT1(F, 4, tw4) PXS_TW_PUT1(F, 5, tw5) PXS_TW_PUT1(F, 6, tw6) PXS_TW_PUT1(F, 7, tw7) }
-#endif
 	int tile = next_valid((int)blockIdx.x, c), par = 0;
-	if (tile < ntiles) { if (have_tw) PXS_TW_FETCH(c) if (S::LOADK == 0) fetch_rows(c, bufA); }
+	if (tile < ntiles) { if (have_tw) fetch_tw(c, ftw); if (S::LOADK == 0) fetch_rows(c, bufA); }
 	while (tile < ntiles) {
 		double2* A = bufA + (dbl ? par*szA : 0);
-		double2* F = ftw + par*nF;
-		if (have_tw) PXS_TW_PUT(F)
-		if (S::LOADK == 0) PXS_WAIT_VM0();
+		const double2* F = ftw + par*nFp;
+		PXS_WAIT_VM0();
 		PXS_LDS_BARRIER();
 		const int tnext = next_valid(tile + (int)gridDim.x, cn);
-		if (dbl && tnext < ntiles) fetch_rows(cn, bufA + (par ^ 1)*szA);
-		if (!S::TWO && have_tw && tnext < ntiles) PXS_TW_FETCH(cn)      // (elementwise-loading stages: no DMA to keep clear of)
+		if (!S::TWO && tnext < ntiles) {        // (single-transform stages: the other buffers are free from here on)
+			if (have_tw) fetch_tw(cn, ftw + (par ^ 1)*nFp);
+			if (dbl) fetch_rows(cn, bufA + (par ^ 1)*szA);
+		}
 		// output of the stored transform: value X[k] of line li, k = task.k0 + i*task.kstride
 		auto emit = [&](const F2Task& k, int i, double2 v) {
 			const int e = k.k0 + i*k.kstride;
@@ -318,6 +318,7 @@ template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(co
 		// register-radix butterflies)
 		for (int q = 0; q < fa.np; q++) {
 			const bool first = q == 0, last = q + 1 == fa.np;
+			const FastDiv dA = q == 0 ? s.dtplA[0] : (q == 1 ? s.dtplA[1] : s.dtplA[2]);      // (a run-time index into the by-value argument would put it in scratch)
 			constexpr bool CAN_REGS = !S::TWO && S::STOREK == 0;
 			const bool to_regs = CAN_REGS && last;
 			auto in_lds = [&](const F2Task& k, int i) { double2 v = A[k.li*fa.ns + k.base + i*k.istride]; if (S::INV_A && first) v.y = -v.y; return v; };
@@ -326,18 +327,19 @@ template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(co
 			if constexpr (S::LOADK == 1) {
 				if (first) {
 					auto in_glb = [&](const F2Task& k, int i) { double2 v = s.load(c, k.li, k.base + i*(fa.np == 1 ? 1 : fa.M1)); if (S::INV_A) v.y = -v.y; return v; };
-					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT>(fa, q, T, dT, s.dtplA[q], true, twa, in_glb, emit); done = true; } }
-					if (!done) { f2_pass<NT>(fa, q, T, dT, s.dtplA[q], true, twa, in_glb, out_lds); done = true; }
+					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT, F2_MAXR_FIRST>(fa, q, T, dT, dA, true, twa, in_glb, emit); done = true; } }
+					if (!done) { f2_pass<NT, F2_MAXR_FIRST>(fa, q, T, dT, dA, true, twa, in_glb, out_lds); done = true; }
 				}
 			}
-			if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT>(fa, q, T, dT, s.dtplA[q], true, twa, in_lds, emit); done = true; } }
-			if (!done) f2_pass<NT>(fa, q, T, dT, s.dtplA[q], false, twa, in_lds, out_lds);
+			if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT, F2_MAXR>(fa, q, T, dT, dA, true, twa, in_lds, emit); done = true; } }
+			if (!done) f2_pass<NT, F2_MAXR>(fa, q, T, dT, dA, false, twa, in_lds, out_lds);
 			if (!to_regs) PXS_LDS_BARRIER();
 		}
 		// ---- second transform: inputs pulled through S::mid from the first one's output
 		if constexpr (S::TWO) {
 			for (int q = 0; q < fb.np; q++) {
 				const bool first = q == 0, last = q + 1 == fb.np;
+				const FastDiv dB = q == 0 ? s.dtplB[0] : (q == 1 ? s.dtplB[1] : s.dtplB[2]);
 				constexpr bool CAN_REGS = S::STOREK == 0;
 				const bool to_regs = CAN_REGS && last;
 				auto in_mid = [&](const F2Task& k, int i) {
@@ -349,14 +351,14 @@ template<class S, int NT> __global__ __launch_bounds__(NT) void chain2_kernel(co
 				auto out_lds = [&](const F2Task& k, int i, double2 v) { bufB[k.li*fb.ns + k.base + i*k.istride] = v; };
 				bool done = false;
 				if (first) {
-					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT>(fb, q, T, dT, s.dtplB[q], true, twb, in_mid, emit); done = true; } }
-					if (!done) { f2_pass<NT>(fb, q, T, dT, s.dtplB[q], false, twb, in_mid, out_lds); done = true; }
+					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT, F2_MAXR_FIRST>(fb, q, T, dT, dB, true, twb, in_mid, emit); done = true; } }
+					if (!done) { f2_pass<NT, F2_MAXR_FIRST>(fb, q, T, dT, dB, false, twb, in_mid, out_lds); done = true; }
 				}
-				if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT>(fb, q, T, dT, s.dtplB[q], true, twb, in_lds, emit); done = true; } }
-				if (!done) f2_pass<NT>(fb, q, T, dT, s.dtplB[q], false, twb, in_lds, out_lds);
+				if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT, F2_MAXR>(fb, q, T, dT, dB, true, twb, in_lds, emit); done = true; } }
+				if (!done) f2_pass<NT, F2_MAXR>(fb, q, T, dT, dB, false, twb, in_lds, out_lds);
 				if (!to_regs || first) PXS_LDS_BARRIER();
-				if (first && tnext < ntiles) {      // the input buffer is free: the next tile's twiddles, then its rows (nothing after this consumes a global load)
-					if (have_tw) PXS_TW_FETCH(cn)
+				if (first && tnext < ntiles) {      // the input buffer is free (and nothing below consumes a global load): the next tile's twiddles and rows
+					if (have_tw) fetch_tw(cn, ftw + (par ^ 1)*nFp);
 					if (S::LOADK == 0) fetch_rows(cn, bufA);
 				}
 			}
@@ -403,6 +405,7 @@ struct PairSrc {
 
 // pass 1 of the first transform of a chain: circle index j = b*j1 + j2, line = j2, a-point FFT over j1, four-step twiddle
 struct StFirst : StageBase {
+	static constexpr int SID = 0;
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	PairSrc src; int b; double2* Y; long ldY; int npair; FastDiv dnp;       // outer = comp*npair + pair
@@ -426,6 +429,7 @@ struct StFirst : StageBase {
 // resize rule: signed frequency kappa of the X2 slot; zero beyond kmax (or beyond X1/2); Nyquist bin of X1 halved when nyq;
 // optional phase table ph[|kappa|], conjugated for kappa < 0.
 struct StResize : StageBase {
+	static constexpr int SID = 1;
 	static constexpr bool TWO = true, INV_A = false, INV_B = true, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; double2* Z; long ldZ;
@@ -470,6 +474,7 @@ struct StResize : StageBase {
 // pass 2 of IFFT_M (g points), pointwise product with the |sin| series samples, pass 1 of FFT_M (g points)
 // in: Z[outer][k1' < g2][r < g]; out: V[outer][k1'' < g][k1' < g2]
 struct StSigma : StageBase {
+	static constexpr int SID = 2;
 	static constexpr bool TWO = true, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Z; long ldZ; double2* V; long ldV; int g, g2; const double2* sigma;
@@ -496,6 +501,7 @@ struct StSigma : StageBase {
 // MODE 1: a tile holds T/2 pairs x (line, mirror line), slot = 2*pi + which;
 //         out = h[t*ld + col] * conj(tab[col]) * scale                      (synthesis: ring-major rows for the ring FFT)
 template<int MODE> struct StSplit : StageBase {
+	static constexpr int SID = 3 + MODE;
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
@@ -561,8 +567,9 @@ template<int MODE> struct StSplit : StageBase {
 			oc[(long)ca*ld + t] = cscale(va, f);
 			if (ca + 1 < ncol) oc[(long)(ca + 1)*ld + t] = cscale(vb, f);
 		} else {
-			oc[(long)t*ld + ca] = cscale(cmul(va, cconj(tab[ca])), scale);
-			if (ca + 1 < ncol) oc[(long)t*ld + ca + 1] = cscale(cmul(vb, cconj(tab[ca + 1])), scale);
+			const double f = scale*(w ? w[t].x : 1.0);
+			oc[(long)t*ld + ca] = cscale(cmul(va, cconj(tab[ca])), f);
+			if (ca + 1 < ncol) oc[(long)t*ld + ca + 1] = cscale(cmul(vb, cconj(tab[ca + 1])), f);
 		}
 	}
 };
@@ -574,6 +581,7 @@ struct MapAddr { void* ptr; int dtype; long cstride, bstride, off0, rstride, pst
 
 // MA1: two real rings as one complex line z = ring(2q) + i ring(2q+1); pixel x = b*j1 + j2, line = j2, a-point FFT over j1
 struct StRingA1 : StageBase {
+	static constexpr int SID = 5;
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	MapAddr m; int b, npair; double2* Y; long ldY; FastDiv dnp;
@@ -599,6 +607,7 @@ struct StRingA1 : StageBase {
 // MA2: b-point FFT over j2 for the lines k1 and a - k1 of T/2 ring pairs; bin k = k1 + a*k2 <= mmax is unpacked with its
 // partner bin nphi - k (in the mirror line) into the spectra of the two rings and written as leg[m][2q], leg[m][2q+1]
 struct StRingA2 : StageBase {
+	static constexpr int SID = 6;
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, X, npair, groups, nring, mmax; double2* leg; long ldleg; int nm; const double2* tab; double scale; FastDiv da, dgr;
@@ -648,6 +657,7 @@ struct StRingA2 : StageBase {
 
 // MS1: Hermitian pair load from h[comp][ring][m]: bin k = b*j1 + j2, line = j2, backward a-point transform over j1
 struct StRingS1 : StageBase {
+	static constexpr int SID = 7;
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* h; long ldh, hcomp; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;      // hcomp: rows of h per component
@@ -678,6 +688,7 @@ struct StRingS1 : StageBase {
 
 // MS2: backward b-point transform over j2 for the lines k1; pixel x = k1 + a*k2: real part -> ring 2q, imaginary part -> ring 2q+1
 struct StRingS2 : StageBase {
+	static constexpr int SID = 8;
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, npair; MapAddr m; FastDiv dnp;
@@ -706,6 +717,7 @@ struct StRingS2 : StageBase {
 // points; row stride ldo) and, with herm (real input: kx runs over the half spectrum), for 0 < kx < nx - kx the Hermitian image
 // out[(ny - ky) % ny][nx - kx] = conj
 struct StColOut : StageBase {
+	static constexpr int SID = 9;
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out, herm; double2* out; long ldo, ocomp; double scale; FastDiv dgr;
@@ -734,8 +746,15 @@ struct StColOut : StageBase {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-// 0: first-generation kernel everywhere (PXS_CHAIN_V1=1: A/B measurements)
-static bool chain_v2_on() { static const bool on = [] { const char* e = getenv("PXS_CHAIN_V1"); return !(e && atoi(e) != 0); }(); return on; }
+// Which stages take the second-generation kernel: bit SID of PXS_CHAIN_V2 (0: none, -1: all; StFirst 0, StResize 1, StSigma 2,
+// StSplit<0> 3, StSplit<1> 4, RingA1 5, RingA2 6, RingS1 7, RingS2 8, ColOut 9).  History: the first form of this kernel (radices up
+// to 20 dispatched at run time, 256 threads) cost 256 VGPRs -- one wave per SIMD -- and ran the C3 chain stages in 289 ms against 107 ms
+// for chain_kernel (profiles/r04_chain_lab_v2.jsonl).
+#ifndef PXS_CHAIN_V2_DEFAULT
+#define PXS_CHAIN_V2_DEFAULT 0
+#endif
+static long chain_v2_mask() { static const long m = [] { const char* e = getenv("PXS_CHAIN_V2"); return e ? strtol(e, nullptr, 0) : (long)PXS_CHAIN_V2_DEFAULT; }(); return m; }
+static bool chain_v2_on(int sid) { return sid >= 0 && ((chain_v2_mask() >> sid) & 1) != 0; }
 static bool smooth235(long n) { if (n < 1) return false; for (int p : {2, 3, 5}) while (n % p == 0) n /= p; return n == 1; }
 bool FftChain::sub_ok(long n) { return n >= 2 && n <= CH_NMAX && smooth235(n); }
 
@@ -770,16 +789,9 @@ const double2* FftChain::small_tw(long X, int n, int T) {
 // tab_pts >= 0 (ring stages, which run at <= 64 VGPRs) and PXS_RING_TILE_KB = k > 0: shrink the tile until tile + tab_pts table
 // entries fit k KiB of LDS (k = 39.5: four workgroups per CU).  Off by default -- measured at C3 / C4 / C2: ring FFT stages
 // 47.4 / 60.6 / 2.85 ms with 39.5 KiB tiles against 46.4 / 60.8 / 2.83 ms with the full 2560-point tiles.
-static bool f2_factor(int n, int& np, int* R);
 static int tile_lines(long n_a, long n_b, long nlines, int mult, long tab_pts = -1) {
 	const long n = std::max(n_a, n_b);
 	long T = CH_TILE_PTS / n;
-	// second-generation kernel: padded buffers; a single-transform stage keeps TWO input tiles (the LDS-DMA destination must stay
-	// below 64 KiB = 4096 points), a two-transform stage an input and an output tile (two workgroups per CU: < 75 KiB each)
-	if (chain_v2_on()) {
-		auto padded = [](long m) { int np, R[3]; return m > 0 && f2_factor((int)m, np, R) ? m + (np > 1 ? R[0] : 0) + 16 : m; };      // mk2's search range
-		T = std::min(T, n_b > 0 ? 4400/(padded(n_a) + padded(n_b)) : 2040/padded(n));
-	}
 	if (T >= mult) T -= T % mult;
 	if (T < 1) T = 1;
 	const long cap = ((nlines + mult - 1)/mult)*mult;
@@ -811,18 +823,19 @@ static BlkIn mk_blk(int Tw, long na, int T) {
 }
 // ---- second-generation kernel: transform plans and launch -------------------------------------------------------------------
 
-static const int F2_RADICES[] = {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20};
+static const int F2_RADICES[] = {2, 3, 4, 5, 6, 8, 9};
 // n as a product of at most three register radices: fewest passes, then the smallest largest radix; ascending order (the first
-// pass works on the longest rows, which wastes the least padding)
-static bool f2_factor(int n, int& np, int* R) {
+// pass works on the longest rows, which wastes the least padding).  maxfirst: cap on the first radix (passes that pull their inputs
+// from global memory or through S::mid, see f2_dispatch)
+static bool f2_factor(int n, int& np, int* R, int maxfirst = F2_MAXR) {
 	auto ok = [](int r) { for (int x : F2_RADICES) if (x == r) return true; return false; };
 	if (n == 1) { np = 1; R[0] = R[1] = R[2] = 1; return true; }
-	if (ok(n)) { np = 1; R[0] = n; R[1] = R[2] = 1; return true; }
+	if (ok(n) && n <= maxfirst) { np = 1; R[0] = n; R[1] = R[2] = 1; return true; }
 	int best = 1 << 30, b0 = 0, b1 = 0;
-	for (int r0 : F2_RADICES) if (n % r0 == 0 && ok(n/r0) && r0 <= n/r0) { const int m = n/r0; if (m < best) { best = m; b0 = r0; b1 = n/r0; } }
+	for (int r0 : F2_RADICES) if (r0 <= maxfirst && n % r0 == 0 && ok(n/r0) && r0 <= n/r0) { const int m = n/r0; if (m < best) { best = m; b0 = r0; b1 = n/r0; } }
 	if (b0) { np = 2; R[0] = b0; R[1] = b1; R[2] = 1; return true; }
 	int c0 = 0, c1 = 0, c2 = 0; best = 1 << 30;
-	for (int r0 : F2_RADICES) if (n % r0 == 0) for (int r1 : F2_RADICES) if ((n/r0) % r1 == 0 && r0 <= r1) {
+	for (int r0 : F2_RADICES) if (r0 <= maxfirst && n % r0 == 0) for (int r1 : F2_RADICES) if ((n/r0) % r1 == 0 && r0 <= r1) {
 		const int r2 = n/r0/r1;
 		if (!ok(r2) || r1 > r2) continue;
 		if (r2 < best) { best = r2; c0 = r0; c1 = r1; c2 = r2; }
@@ -830,7 +843,7 @@ static bool f2_factor(int n, int& np, int* R) {
 	if (!c0) return false;
 	np = 3; R[0] = c0; R[1] = c1; R[2] = c2; return true;
 }
-bool FftChain::sub_ok2(long n) { int np, R[3]; return n >= 2 && n <= CH_NMAX && smooth235(n) && f2_factor((int)n, np, R); }
+bool FftChain::sub_ok2(long n) { int np, R[3]; return n >= 2 && n <= CH_NMAX && smooth235(n) && f2_factor((int)n, np, R, F2_MAXR_FIRST); }
 
 // extra LDS cycles of one wave instruction: lanes -> 16-byte slots (-1: lane inactive)
 static int f2_read_conflicts(const int* slot) {
@@ -908,7 +921,7 @@ Fft2 FftChain::mk2(long n, int T, int NT, int kind) {
 		auto it = f2_.find(std::make_tuple(n, T, NT, kind));
 		if (it != f2_.end()) return it->second; }
 	int np, R[3];
-	PXS_REQUIRE(f2_factor((int)n, np, R), "internal: no register-radix factorisation");
+	PXS_REQUIRE(f2_factor((int)n, np, R, (kind & 9) ? F2_MAXR_FIRST : F2_MAXR), "internal: no register-radix factorisation");
 	f.n = (int)n; f.np = np; f.R0 = R[0]; f.R1 = R[1]; f.R2 = R[2];
 	f.M1 = f.n/f.R0; f.M2 = np == 3 ? f.M1/f.R1 : 1;
 	// kind: bit 0 = first pass reads global memory (elementwise loads, line-fastest), bit 1 = last pass goes to registers (line-fastest,
@@ -961,44 +974,66 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	hipLaunchKernelGGL((chain_kernel<S, CH_NT, CH_MAXE>), dim3((unsigned)nblk), dim3(CH_NT), sh, st, s);
 }
 
+// second-generation kernel: LDS image of a stage with tiles of T lines.  Layout (chain2_kernel): the two four-step twiddle tables and
+// the row buffer(s) -- the LDS-DMA destinations, which must sit below 64 KiB -- then the second transform's buffer and the W_n tables.
+struct Lds2 { Fft2 a2, b2; int RL, K0; size_t nFp, szA, dma_bytes, bytes; bool dbl; };
+template<class S> Lds2 FftChain::lds2(int na, int nb_, int T) {
+	Lds2 L; constexpr int NT = CH2_NT;
+	const int nb = S::TWO ? nb_ : 0;
+	const int kindA = (S::LOADK == 1 ? 1 : 0) | ((!S::TWO && S::STOREK == 0) ? 2 : 0) | ((!S::TWO && S::STOREK == 1) ? 4 : 0);
+	const int kindB = 8 | (S::STOREK == 0 ? 2 : 4);
+	L.a2 = mk2(na, T, NT, kindA); L.b2 = mk2(nb, T, NT, kindB);
+	const Fft2& fl = S::TWO ? L.b2 : L.a2;
+	L.RL = fl.np == 1 ? fl.R0 : (fl.np == 2 ? fl.R1 : fl.R2); L.K0 = fl.n/L.RL;
+	L.nFp = ((size_t)T*(L.K0 + L.RL) + 63) & ~(size_t)63;
+	L.szA = ((size_t)T*L.a2.ns + 63) & ~(size_t)63;
+	L.dbl = !S::TWO && S::LOADK == 0;
+	L.dma_bytes = sizeof(double2)*((S::HAS_TW ? 2*L.nFp : 0) + (L.dbl ? 2 : 1)*L.szA);
+	L.bytes = L.dma_bytes + sizeof(double2)*((S::TWO ? (size_t)T*L.b2.ns : 0) + na + nb + 2);
+	return L;
+}
+template<class S> bool FftChain::takes_v2(long n_a, long n_b) { return chain_v2_on(S::SID) && S::V2 && sub_ok2(n_a) && (!S::TWO || sub_ok2(n_b)); }
+// lines per tile of a stage: tile_lines, and for the second-generation kernel as many (in steps of mult) as leave room for TWO
+// workgroups per CU (PXS_CH2_LDS_KB, default 79.5 KiB each) with the DMA destinations below 64 KiB
+template<class S> int FftChain::tile_lines_for(long n_a, long n_b, long nlines, int mult, long tab_pts) {
+	int T = tile_lines(n_a, n_b, nlines, mult, tab_pts);
+	if (!takes_v2<S>(n_a, n_b)) return T;
+	static const size_t budget = [] { const char* e = getenv("PXS_CH2_LDS_KB"); return (size_t)((e ? atof(e) : 79.5)*1024); }();
+	auto fits = [&](int t) { const Lds2 L = lds2<S>((int)n_a, (int)n_b, t); return L.bytes <= budget && L.dma_bytes <= 65536; };
+	while (T > mult && !fits(T)) T -= mult;
+	return T;
+}
 // second-generation launch: s carries the v1 description of the stage (tiles, T, fa.n / fb.n, btw); this adds the DIF plans
 template<class S> void FftChain::launch_stage2(S& s, long ntiles, hipStream_t st) {
 	if (ntiles <= 0) return;
 	PXS_REQUIRE(ntiles < (1L << 31), "internal: chain grid too large");
-	constexpr int NT = CH2_NT_B;
+	constexpr int NT = CH2_NT;
 	const int na = s.fa.n, nb = S::TWO ? s.fb.n : 0;
-	const int kindA = (S::LOADK == 1 ? 1 : 0) | ((!S::TWO && S::STOREK == 0) ? 2 : 0) | ((!S::TWO && S::STOREK == 1) ? 4 : 0);
-	const int kindB = 8 | (S::STOREK == 0 ? 2 : 4);
-	s.a2 = mk2(na, s.T, NT, kindA);
-	s.b2 = mk2(nb, s.T, NT, kindB);
-	const Fft2& fl = S::TWO ? s.b2 : s.a2;
+	const Lds2 L = lds2<S>(na, nb, s.T);
+	s.a2 = L.a2; s.b2 = L.b2;
 	const int radA[3] = {s.a2.R0, s.a2.R1, s.a2.R2}, radB[3] = {s.b2.R0, s.b2.R1, s.b2.R2};
 	for (int q = 0; q < 3; q++) { s.dtplA[q] = make_fastdiv((uint32_t)std::max(1, na/radA[q])); s.dtplB[q] = make_fastdiv((uint32_t)std::max(1, nb/std::max(1, radB[q]))); }
-	const int RL = fl.np == 1 ? fl.R0 : (fl.np == 2 ? fl.R1 : fl.R2), K0 = fl.n/RL;
-	s.dK0 = make_fastdiv((uint32_t)K0); s.dRL = make_fastdiv((uint32_t)RL);
+	s.dK0 = make_fastdiv((uint32_t)L.K0); s.dRL = make_fastdiv((uint32_t)L.RL);
 	s.ntiles2 = (int)ntiles;
-	const size_t szA = ((size_t)s.T*s.a2.ns + 63) & ~(size_t)63;
-	const bool dbl = !S::TWO && S::LOADK == 0;
-	const size_t nF = (size_t)s.T*(K0 + RL);
-#ifndef PXS_HOST_SIM
-	PXS_REQUIRE(!(S::HAS_TW && s.btw) || nF <= (size_t)CH2_TWN*NT, "internal: four-step twiddle tables too large");
-#endif
-	const size_t sh = sizeof(double2)*((dbl ? 2 : 1)*szA + (S::TWO ? (size_t)s.T*s.b2.ns : 0) + na + nb + (S::HAS_TW ? 2*nF : 0) + 2);
+	const size_t sh = L.bytes;
 	PXS_REQUIRE(sh <= 160*1024 - 256, "internal: chain tile too large for the LDS");
-	PXS_REQUIRE(((dbl ? 2 : 1)*szA)*sizeof(double2) <= 65536, "internal: LDS-DMA destination beyond 64 KiB");
+	PXS_REQUIRE(L.dma_bytes <= 65536, "internal: LDS-DMA destination beyond 64 KiB");
+	// workgroups per CU: by LDS, by the wave slots (32 per CU) and by the register bound of the kernel (two workgroups)
 	static const int wg_cap = [] { const char* e = getenv("PXS_CH2_WGS"); return e ? atoi(e) : 0; }();
-	int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160*1024 - 256)/sh));
+	int wgs = (int)std::max<size_t>(1, std::min<size_t>(2, (160*1024 - 256)/sh));
 	if (wg_cap > 0) wgs = std::min(wgs, wg_cap);
 	const long grid = std::min<long>(ntiles, (long)device_cus()*wgs);
+	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] chain2 stage %d: na=%d (%dx%dx%d ns=%d) nb=%d (%dx%dx%d ns=%d) T=%d LDS %.1f KiB (DMA %.1f) -> %d WG/CU, %ld tiles on %ld workgroups\n",
+		S::SID, na, s.a2.R0, s.a2.R1, s.a2.R2, s.a2.ns, nb, s.b2.R0, s.b2.R1, s.b2.R2, s.b2.ns, s.T, sh/1024.0, L.dma_bytes/1024.0, wgs, ntiles, grid);
 #ifndef PXS_HOST_SIM
 	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain2_kernel<S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
 	(void)once;
 #endif
 	hipLaunchKernelGGL((chain2_kernel<S, NT>), dim3((unsigned)grid), dim3(NT), sh, st, s);
 }
-// v2 when the stage's transforms have register-radix plans, else v1
+// v2 for the stages selected by PXS_CHAIN_V2 when their transforms have register-radix plans, else v1
 template<class S> void FftChain::launch_any(S& s, long nblk, hipStream_t st) {
-	if (chain_v2_on() && S::V2 && sub_ok2(s.fa.n) && (!S::TWO || sub_ok2(s.fb.n))) launch_stage2(s, nblk, st);
+	if (takes_v2<S>(s.fa.n, S::TWO ? s.fb.n : 0)) launch_stage2(s, nblk, st);
 	else launch_stage(s, nblk, st);
 }
 
@@ -1091,7 +1126,7 @@ static long ring_chunk(long npair, long bytes_per_pair, int mult) {
 void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale) {
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
 	const long npair_all = (m.nring + 1)/2, a = ra_.a, b = ra_.b, ldY = pad8(b);
-	int T2 = tile_lines(b, 0, 2*npair_all, 8, b); if (T2 < 2) T2 = 2; T2 -= T2 % 2;
+	int T2 = tile_lines_for<StRingA2>(b, 0, 2*npair_all, 8, b); if (T2 < 2) T2 = 2; T2 -= T2 % 2;
 	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, T2/2);
 	s1_.ensure(sizeof(double2)*(size_t)nc*qchunk*a*ldY);
 	for (long q_lo = 0; q_lo < npair_all; q_lo += qchunk) {
@@ -1101,7 +1136,7 @@ void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, doubl
 			s.fa = mk(fc_, a, 8); s.fb = mk(fc_, 0, 8);
 			s.m = map_addr(m); s.m.off0 += 2*q_lo*m.ring_stride; s.m.nring = nring;
 			s.b = (int)b; s.npair = (int)npair; s.Y = s1_.as<double2>(); s.ldY = ldY; s.dnp = make_fastdiv((uint32_t)npair);
-			set_tiles(s, tile_lines(a, 0, b, 16, 2*a), b, nphi_);
+			set_tiles(s, tile_lines_for<StRingA1>(a, 0, b, 16, 2*a), b, nphi_);
 			launch_any(s, (long)nc*npair*s.ntile, st);
 		}
 		{	StRingA2 s; memset(&s, 0, sizeof(s));
@@ -1121,7 +1156,7 @@ void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& 
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
 	const long npair_all = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
 	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, 1);
-	const int T1 = tile_lines(a, 0, b, 8, 2*a), T2 = tile_lines(b, 0, a, 16, b);
+	const int T1 = tile_lines_for<StRingS1>(a, 0, b, 8, 2*a), T2 = tile_lines_for<StRingS2>(b, 0, a, 16, b);
 	s1_.ensure(sizeof(double2)*(size_t)nc*qchunk*a*ldY);
 	for (long q_lo = 0; q_lo < npair_all; q_lo += qchunk) {
 		const long npair = std::min(qchunk, npair_all - q_lo);
@@ -1175,7 +1210,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 	const long ldY1 = pad8(bN), ldZ2 = pad8(g), ldV3 = pad8(g2), ldU4 = pad8(g);
 	const size_t need1 = (size_t)npair*std::max(g*ldY1, g*ldV3), need2 = (size_t)npair*std::max(g2*ldZ2, ac*ldU4);
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
-	const int T1 = tile_lines(g, 0, bN, 8), T2 = tile_lines(bN, g2, g, 8), T3 = tile_lines(g, g, g2, 8), T4 = tile_lines(g2, ac, g, 8);
+	const int T1 = tile_lines_for<StFirst>(g, 0, bN, 8), T2 = tile_lines_for<StResize>(bN, g2, g, 8), T3 = tile_lines_for<StSigma>(g, g, g2, 8), T4 = tile_lines_for<StResize>(g2, ac, g, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
@@ -1208,7 +1243,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
-			int T = tile_lines(g, 0, 2*ac, 8); if (T < 2) T = 2; T -= T % 2;
+			int T = tile_lines_for<StSplit<0>>(g, 0, 2*ac, 8); if (T < 2) T = 2; T -= T % 2;
 			const int TH = T/2;
 			set_tiles(s, T, (long)((ac/2 + 1 + TH - 1)/TH)*T, 0);
 			s.TH = TH;
@@ -1228,20 +1263,21 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 // operator A that commutes with the reflection (E': mirror extension of the ring samples, R: restriction to the CC rings) except
 // at the CC pole rings, which E' counts twice: weight 1/2 there (w).  So: RA1, the resize N -> N_cc directly, RA5.
 void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
-                               int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w)
+                               int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w, const double2* wring)
 {
 	const long npair = (nm + 1)/2;
 	const long g = tp.g, bN = tp.bN, ac = tp.ac;
 	const long ldY1 = pad8(bN), ldU = pad8(g);
 	const size_t need1 = (size_t)npair*g*ldY1, need2 = (size_t)npair*ac*ldU;
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
-	const int T1 = tile_lines(g, 0, bN, 8), T2 = tile_lines(bN, ac, g, 8);
+	const int T1 = tile_lines_for<StFirst>(g, 0, bN, 8), T2 = tile_lines_for<StResize>(bN, ac, g, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
 		{	StFirst s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
 			s.src.leg = leg + (size_t)c0*nm*ldleg; s.src.cstride = (long)nm*ldleg; s.src.ld = ldleg; s.src.nr = nr; s.src.N = (int)tp.N; s.src.mir_c = mir_c; s.src.a_odd = spin & 1; s.src.ncol = nm;
+			s.src.w = wring;      // (quadrature weights of the map's rings: the weights form of the analysis)
 			s.b = (int)bN; s.Y = s1_.as<double2>(); s.ldY = ldY1; s.npair = (int)npair; s.dnp = make_fastdiv((uint32_t)npair);
 			set_tiles(s, T1, bN, tp.N); s.bout = blocked_on();
 			launch_any(s, ncl*npair*s.ntile, st);
@@ -1255,7 +1291,7 @@ void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double
 		}
 		{	StSplit<0> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
-			int T = tile_lines(g, 0, 2*ac, 8); if (T < 2) T = 2; T -= T % 2;
+			int T = tile_lines_for<StSplit<0>>(g, 0, 2*ac, 8); if (T < 2) T = 2; T -= T % 2;
 			const int TH = T/2;
 			set_tiles(s, T, (long)((ac/2 + 1 + TH - 1)/TH)*T, 0);
 			s.TH = TH;
@@ -1284,7 +1320,7 @@ void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2*
 	const long ldY = pad8(ac), ldZ = pad8(g), ldV = pad8(g2);
 	const size_t need1 = (size_t)npair*std::max(g*ldY, g*ldV), need2 = (size_t)npair*std::max(g2*ldZ, bN*ldZ);
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
-	const int T1 = tile_lines(g, 0, ac, 8), T2 = tile_lines(ac, g2, g, 8), T3 = tile_lines(g, g, g2, 8), T4 = tile_lines(g2, bN, g, 8);
+	const int T1 = tile_lines_for<StFirst>(g, 0, ac, 8), T2 = tile_lines_for<StResize>(ac, g2, g, 8), T3 = tile_lines_for<StSigma>(g, g, g2, 8), T4 = tile_lines_for<StResize>(g2, bN, g, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
@@ -1318,7 +1354,7 @@ void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2*
 		}
 		{	StSplit<1> s; memset(&s, 0, sizeof(s));   // pass 2 of IFFT_N, the two parities apart, rings of the map, ring-major
 			s.fa = mk(fc_, g); s.fb = mk(fc_, 0);
-			int T = tile_lines(g, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
+			int T = tile_lines_for<StSplit<1>>(g, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
 			set_tiles(s, T, bN*T, 0);         // one tile per line: ntile = bN
 			s.TH = 0;
 			s.U = s2_.as<double2>(); s.ldU = ldZ; s.a = (int)bN; s.g = (int)g; s.X = (int)tp.N; s.mir_c = mir_c; s.nr_out = nr; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
@@ -1332,14 +1368,14 @@ void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2*
 }
 
 void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
-                       int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale)
+                       int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale, const double2* wring)
 {
 	const long npair = (nm + 1)/2;
 	const long gs = tp.gs, bs = tp.bs, aN = tp.aNs;
 	const long ldY = pad8(bs), ldZ = pad8(gs);
 	const size_t need1 = (size_t)npair*gs*ldY, need2 = (size_t)npair*aN*ldZ;
 	const int cchunk = theta_comp_chunk(nc, need1, need2);
-	const int T1 = tile_lines(gs, 0, bs, 8), T2 = tile_lines(bs, aN, gs, 8);
+	const int T1 = tile_lines_for<StFirst>(gs, 0, bs, 8), T2 = tile_lines_for<StResize>(bs, aN, gs, 8);
 	s1_.ensure(sizeof(double2)*need1*cchunk); s2_.ensure(sizeof(double2)*need2*cchunk);
 	for (int c0 = 0; c0 < nc; c0 += cchunk) {
 		const long ncl = std::min(cchunk, nc - c0);
@@ -1359,13 +1395,13 @@ void FftChain::from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_c
 		}
 		{	StSplit<1> s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, gs); s.fb = mk(fc_, 0);
-			int T = tile_lines(gs, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
+			int T = tile_lines_for<StSplit<1>>(gs, 0, 2*npair, 8); if (T < 2) T = 2; T -= T % 2;
 			set_tiles(s, T, aN*T, 0);         // one tile per line: ntile = aN
 			s.TH = 0;
 			s.U = s2_.as<double2>(); s.ldU = ldZ; s.a = (int)aN; s.g = (int)gs; s.X = (int)tp.N; s.mir_c = mir_c; s.nr_out = nr; s.a_odd = spin & 1; s.ncol = nm; s.npair = (int)npair;
 			const long groups = (npair + T/2 - 1)/(T/2);
 			s.out = h + (size_t)c0*nr*ldh; s.ocstride = (long)nr*ldh; s.dnp = make_fastdiv((uint32_t)npair); s.groups = (int)groups; s.dgr = make_fastdiv((uint32_t)groups);
-			s.ld = ldh; s.w = nullptr; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)aN);
+			s.ld = ldh; s.w = wring; s.tab = tab; s.scale = scale; s.da = make_fastdiv((uint32_t)aN);
 			launch_any(s, ncl*groups*aN, st);
 		}
 	}
@@ -1392,12 +1428,12 @@ bool FftChain::fft2_real(hipStream_t st, const void* in, int in_dtype, double2* 
 		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
 		s.src.leg = s2_.as<double2>(); s.src.cstride = nm*ldF; s.src.ld = ldF; s.src.nr = (int)ny; s.src.N = (int)ny; s.src.ncol = (int)nm; s.src.plain = 1;
 		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)nm; s.dnp = make_fastdiv((uint32_t)nm);
-		set_tiles(s, tile_lines(a, 0, b, 8), b, ny);
+		set_tiles(s, tile_lines_for<StFirst>(a, 0, b, 8), b, ny);
 		launch_any(s, npre*nm*s.ntile, st);
 	}
 	{	StColOut s; memset(&s, 0, sizeof(s));
 		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
-		int T = tile_lines(b, 0, nm, 8);
+		int T = tile_lines_for<StColOut>(b, 0, nm, 8);
 		set_tiles(s, T, a*T, 0);          // one tile per line: ntile = a
 		s.Y = s1_.as<double2>(); s.ldY = ldY; s.a = (int)a; s.nm = (int)nm; s.ny = (int)ny; s.nx = (int)nx; s.conj_out = forward ? 0 : 1; s.out = out; s.scale = scale;
 		s.herm = 1; s.ldo = nx; s.ocomp = ny*nx;
@@ -1424,13 +1460,13 @@ bool FftChain::fft2_c2c(hipStream_t st, const double2* in, double2* out, long np
 		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
 		s.src.leg = src; s.src.cstride = nlines*ld; s.src.ld = ld; s.src.nr = (int)n; s.src.N = (int)n; s.src.ncol = (int)nlines; s.src.plain = 1; s.src.conj = conj;
 		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.npair = (int)nlines; s.dnp = make_fastdiv((uint32_t)nlines);
-		set_tiles(s, tile_lines(a, 0, b, 8), b, n);
+		set_tiles(s, tile_lines_for<StFirst>(a, 0, b, 8), b, n);
 		launch_any(s, npre*nlines*s.ntile, st);
 	};
 	auto second = [&](double2* dst, long nlines, long ldo, long ocomp, long a, long b, int conj, double sc) {
 		StColOut s; memset(&s, 0, sizeof(s));
 		s.fa = mk(fc_, b); s.fb = mk(fc_, 0);
-		int T = tile_lines(b, 0, nlines, 8);
+		int T = tile_lines_for<StColOut>(b, 0, nlines, 8);
 		set_tiles(s, T, a*T, 0);
 		s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.a = (int)a; s.nm = (int)nlines; s.ny = 0; s.nx = 0; s.conj_out = conj; s.herm = 0; s.out = dst; s.ldo = ldo; s.ocomp = ocomp; s.scale = sc;
 		s.groups = (int)((nlines + T - 1)/T); s.dgr = make_fastdiv((uint32_t)s.groups);

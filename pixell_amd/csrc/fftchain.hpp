@@ -10,6 +10,8 @@
 
 namespace pxs {
 
+struct Lds2;
+
 // factorisation N = a*b of a four-step transform: pass 1 = a-point transforms over the residues mod b,
 // pass 2 = b-point transforms producing the residues mod a
 struct Split { long a = 0, b = 0; };
@@ -26,7 +28,7 @@ public:
 	explicit FftChain(FftContext* fc) : fc_(fc) {}
 	// can the engine run its LDS passes on lines of this length (radices 2,3,4,5, length <= 512)?
 	static bool sub_ok(long n);
-	static bool sub_ok2(long n);      // ... and the second-generation kernel (at most three register radices <= 20)
+	static bool sub_ok2(long n);      // ... and the second-generation kernel (at most three register radices <= 10)
 	static long pad8(long n) { return (n + 7) & ~7L; }
 	// ring FFT split of nphi for analysis (map -> leg) and synthesis (h -> map); false: no usable factorisation
 	bool plan_rings(long nphi);
@@ -47,10 +49,10 @@ public:
 	           int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* wcc);
 	// band-limited leg on the CC grid -> h[c][ring][m] * conj(tab[m]) * scale on the map's rings
 	void from_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
-	             int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale);
+	             int nc, int nm, int spin, int lmax, const double2* ph_up, const double2* tab, double scale, const double2* wring = nullptr);      // wring: optional weight (.x) per output ring
 	// exact transpose of from_cc for grids without self-mirrored rings: leg on the map's rings -> leg on the CC grid (w: 1/N_cc, half at the poles)
 	void from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
-	                     int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w);
+	                     int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w, const double2* wring = nullptr);      // wring: optional weight (.x) per input ring
 	// exact adjoint of to_cc: leg on the CC grid -> h[c][ring][m] * conj(tab[m]) * scale on the map's rings (whalf: the to_cc weights, halved off the poles)
 	void to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg_cc, long ldcc, int ncc, double2* h, long ldh, int nr, int mir_c,
 	                   int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* whalf, const double2* tab, double scale);
@@ -68,6 +70,9 @@ private:
 	template<class S> void set_tiles(S& s, int T, long nlines, long X);
 	Fft2 mk2(long n, int T, int NT, int kind);
 	template<class S> void launch_stage2(S& s, long ntiles, hipStream_t st);
+	template<class S> struct Lds2 lds2(int na, int nb, int T);
+	template<class S> bool takes_v2(long n_a, long n_b);
+	template<class S> int tile_lines_for(long n_a, long n_b, long nlines, int mult, long tab_pts = -1);
 	template<class S> void launch_any(S& s, long nblk, hipStream_t st);
 	std::map<std::tuple<long, int, int, int>, Fft2> f2_;
 	std::mutex mu_;

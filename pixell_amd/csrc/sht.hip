@@ -340,6 +340,8 @@ struct pxs_plan {
 		if (gfork) (void)hipEventDestroy(gfork);
 	}
 	DevBuf wring;                // DH / F2 grids: per-ring quadrature weight / nphi (analysis = weighted adjoint synthesis)
+	int ana_weights = 0;         // pxs_plan_option("analysis"): 1 = ring weights + adjoint synthesis where ntheta >= 2 lmax + 2 (PXS_ANALYSIS=weights presets it)
+	DevBuf wgrid;                // ... its weights: get_gridweights / nphi per ring (built on first use)
 	bool syn_via_cc = false, syn_via_cc0 = false;      // synthesis through the CC grid: spin s / spin 0 (the recurrence of spin 0 is 4x cheaper per ring, the resampling is not)
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
@@ -385,6 +387,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 		const char* e = getenv("PXS_PART_GB"); if (e) p->wk.part_budget = (size_t)atol(e) << 30;
 	}
 	{ const char* e = getenv("PXS_RESAMPLE_MB"); if (e) p->resample_chunk_bytes = (size_t)atol(e) << 20; }
+	{ const char* e = getenv("PXS_ANALYSIS"); if (e && std::string(e) == "weights") p->ana_weights = 1; }
 	if (p->general) return;      // per-ring lengths and phases: see setup_general
 	std::string why;
 	if (!FftContext::supported(p->nphi, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
@@ -895,6 +898,20 @@ int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64
 
 void pxs_plan_destroy(pxs_plan* plan) { delete plan; }
 
+int pxs_plan_option(pxs_plan* p, const char* name, int64_t value) {
+	PXS_TRY
+	PXS_REQUIRE(p && name, "pxs_plan_option: null argument");
+	if (std::string(name) == "analysis") {
+		PXS_REQUIRE(value == 0 || value == 1, "pxs_plan_option: analysis takes 0 (interpolant) or 1 (weights)");
+		p->ana_weights = (int)value;
+	} else if (std::string(name) == "build_tables") {      // build the recurrence tables of spin `value` now rather than in the first transform (cold-start accounting of bench.py)
+		PXS_REQUIRE(value >= 0 && value <= p->lmax + 1, "pxs_plan_option: build_tables takes a spin");
+		PXS_HIP(hipSetDevice(p->device));
+		(void)p->table((int)value);
+	} else throw Error(PXS_ERR_ARG, std::string("pxs_plan_option: unknown option '") + name + "'");
+	PXS_CATCH
+}
+
 int pxs_plan_info(const pxs_plan* p, int* nsyn, int* nana, int64_t* scratch) {
 	if (!p) return PXS_ERR_ARG;
 	if (nsyn) *nsyn = (p->syn_via_cc && p->ncc > 0) ? p->ncc : p->nring;
@@ -976,6 +993,33 @@ int pxs_profile_read(pxs_plan* p, double* ms, int* counts, int reset) {
 	PXS_REQUIRE(p && ms && counts, "pxs_profile_read: null argument");
 	p->prof.read(ms, counts, PXS_NSTAGE, reset != 0);
 	PXS_CATCH
+}
+
+// How a pxs_analysis call runs.  Decided HERE, once, for reserve_call, the batch chunking and analysis_core.
+enum AnaPath {
+	ANA_RING_WEIGHTS,   // quadrature weights on the map's rings + (adjoint) synthesis there: DH / F2 grids; the weights option on grids without the CC detour
+	ANA_CC_WEIGHTS,     // the weights option on F1 grids with fused chains: ring weights, transposed theta upsampling, Legendre stage on the CC grid
+	ANA_CHAIN,          // exact quadrature of the theta-interpolant through the fused chains (to_cc / to_cc_adjoint)
+	ANA_UNFUSED };      // ... through the generic FFT engine on dense rows, one map at a time
+static bool adj_ana_fused() { const char* e = getenv("PXS_ADJ_ANA_FUSED"); return e ? atoi(e) != 0 : true; }      // (read per call: the tests switch it)
+static AnaPath ana_path(const pxs_plan* p, int adjoint) {
+	if (p->wring.p) return ANA_RING_WEIGHTS;
+	if (p->ana_weights && (long)p->nring >= 2L*p->lmax + 2)
+		return (p->geometry == "F1" && p->chain_theta() && p->ncc > 0) ? ANA_CC_WEIGHTS : ANA_RING_WEIGHTS;
+	if (p->chain_theta() && (!adjoint || adj_ana_fused())) return ANA_CHAIN;
+	return ANA_UNFUSED;
+}
+// per-ring weight / nphi of the ring-weights paths (DH / F2: fixed at plan time; the weights option: built on first use)
+static const double2* ring_weights(pxs_plan* p) {
+	if (p->wring.p) return p->wring.as<double2>();
+	if (!p->wgrid.p) {
+		std::vector<double> w(p->nring);
+		if (pxs_gridweights(p->geometry.c_str(), p->nring, w.data()) != 0) throw Error(PXS_ERR_ARG, get_last_error());
+		std::vector<double2> wd(p->nring);
+		for (int j = 0; j < p->nring; j++) wd[j] = make_double2(w[j]/p->nphi, 0.0);
+		p->wgrid = upload(wd);
+	}
+	return p->wgrid.as<double2>();
 }
 
 // nb maps of one call (nb > 1 only on the fused-chain paths): ring FFTs of all maps in one launch each, theta chains and
@@ -1072,15 +1116,16 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 		p->leg.ensure(c16*nct*nm*(via && p->band ? (size_t)FftChain::pad8(p->nfull) : ldm));
 		if (via) { p->leg2.ensure(c16*nct*nm*ldc); theta(1); }
 		p->chain->ring_scratch(p->nring, nct, true, r1);
-	} else if (!adjoint && !p->wring.p && th) {         // analysis_2d
-		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1)*nb);
-		p->leg.ensure(c16*nct*nm*ldm); p->leg2.ensure(c16*nct*nm*ldc); theta(0);
-		p->chain->ring_scratch(p->nring, nct, true, r1);
-	} else if (adjoint && !p->wring.p && th) {          // adjoint_analysis_2d (fused transposed chain)
-		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4)*nb);
-		p->leg2.ensure(c16*nct*nm*ldc); p->hbuf.ensure(c16*nct*nr*ldh); theta(3);
-		p->chain->ring_scratch(p->nring, nct, false, r1);
-	} else return;
+	} else {                                            // pxs_analysis: the same path decision as analysis_core
+		const AnaPath path = ana_path(p, adjoint);
+		if (path == ANA_UNFUSED) return;
+		if (adjoint) p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4)*nb); else p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1)*nb);
+		if (path == ANA_RING_WEIGHTS) { p->leg.ensure(c16*nct*nm*ldm); if (adjoint) p->hbuf.ensure(c16*nct*nr*ldh); }
+		else if (path == ANA_CC_WEIGHTS) { p->leg2.ensure(c16*nct*nm*ldc); if (adjoint) { p->hbuf.ensure(c16*nct*nr*ldh); theta(2); } else { p->leg.ensure(c16*nct*nm*ldm); theta(1); } }
+		else if (!adjoint) { p->leg.ensure(c16*nct*nm*ldm); p->leg2.ensure(c16*nct*nm*ldc); theta(0); }      // analysis_2d
+		else { p->leg2.ensure(c16*nct*nm*ldc); p->hbuf.ensure(c16*nct*nr*ldh); theta(3); }                   // adjoint_analysis_2d (fused transposed chain)
+		p->chain->ring_scratch(p->nring, nct, !adjoint, r1);
+	}
 	p->chain->reserve(std::max(c1, r1), c2);
 }
 
@@ -1124,27 +1169,57 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 	const int nc = spin == 0 ? 1 : 2, nct = nb*nc;
 	const int nm = p->mmax+1, nr = p->nring;
 	LegTables& tb = p->table(spin);
-	if (p->wring.p) {	// DH / F2: analysis = adjoint synthesis of the weighted map (its adjoint: synthesis, then the weights)
+	const AnaPath path = ana_path(p, adjoint);
+	if (path == ANA_RING_WEIGHTS) {	// DH / F2 (and the weights option off the CC detour): analysis = adjoint synthesis of the weighted map (its adjoint: synthesis, then the weights)
+		const double2* wr = ring_weights(p);
 		const long ldw = p->chain_rings ? FftChain::pad8(nr) : nr;
 		const int ncbw = nb > 1 ? nc : 0;
 		p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldw);
 		const long tot = (long)nct*nm*nr;
 		if (!adjoint) {
 			map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldw, map_bstride, ncbw);
-			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, p->wring.as<double2>());
+			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, wr);
 			leg_analysis(st, p->rs_map, tb, p->wk, p->leg.as<double2>(), alm, alm_dtype, alm_cstride,
 				p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldw, nb, alm_bstride, (long)nc*nm*ldw);
 		} else {
 			leg_synthesis(st, p->rs_map, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
 				p->leg.as<double2>(), 0, &p->prof, ldw, nb, alm_bstride, (long)nc*nm*ldw);
-			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, p->wring.as<double2>());
+			hipLaunchKernelGGL(scale_rings, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, p->leg.as<double2>(), (long)nct*nm, nr, ldw, wr);
 			leg2map(p, st, p->leg.as<double2>(), ldw, map, map_dtype, map_cstride, nct, false, map_bstride, ncbw);
 		}
 		PXS_HIP(hipGetLastError());
 		return;
 	}
-	const bool adj_fused = [] { const char* e = getenv("PXS_ADJ_ANA_FUSED"); return e ? atoi(e) != 0 : true; }();      // (read per call: the tests switch it)
-	if (adjoint && adj_fused && p->chain_theta()) {
+	if (path == ANA_CC_WEIGHTS) {
+		// the weights form on an F1 grid with at least 2 lmax + 2 rings, Legendre stage on the ~lmax + 2 rings of the CC grid: the
+		// synthesis there is (theta upsampling) o (Legendre on the CC grid), exactly, so its transpose applied to the weighted
+		// ring spectra is the reference's adjoint_synthesis(map * weights) (curvedsky.py:852-861, 1068-1084) -- three chain stages
+		// (FftChain::from_cc_adjoint, the ring weights folded into its first one) instead of the five of the interpolant (to_cc)
+		const double2* wr = ring_weights(p);
+		const long ldm = FftChain::pad8(nr), ldc = p->ld_cc(), ldh = p->ld_h();
+		const int ncb = nb > 1 ? nc : 0;
+		p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
+		if (!adjoint) {
+			p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
+			map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
+			p->prof.begin(st, PXS_STAGE_RESAMPLE);
+			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), p->wadj.as<double2>(), wr);
+			p->prof.end(st, PXS_STAGE_RESAMPLE);
+			leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
+		} else {
+			p->hbuf.ensure(sizeof(double2)*(size_t)nct*nr*ldh);
+			leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
+				p->leg2.as<double2>(), 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
+			p->prof.begin(st, PXS_STAGE_RESAMPLE);
+			p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
+				p->ph_up.as<double2>(), p->phase.as<double2>(), 1.0/(double)p->Ncc, wr);
+			p->prof.end(st, PXS_STAGE_RESAMPLE);
+			leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, ncb);
+		}
+		return;
+	}
+	if (path == ANA_CHAIN && adjoint) {
 		// adjoint_analysis_2d through the fused transposed chain: Legendre synthesis on the CC grid, FftChain::to_cc_adjoint straight
 		// into the ring-major spectra, ring FFTs -- all maps of the call in every launch
 		const long ldc = p->ld_cc(), ldh = p->ld_h();
@@ -1158,7 +1233,7 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, nb > 1 ? nc : 0);
 		return;
 	}
-	const bool th = p->chain_theta() && !adjoint;       // (PXS_ADJ_ANA_FUSED=0: the adjoint of the analysis through the unfused chain, dense rows)
+	const bool th = path == ANA_CHAIN;                  // (ANA_UNFUSED: the generic FFT engine on dense rows, one map per call)
 	const long ldm = th ? FftChain::pad8(nr) : nr, ldc = th ? p->ld_cc() : p->ncc;
 	const int ncb = nb > 1 ? nc : 0;
 	p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldm);
@@ -1194,8 +1269,7 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint, int nbatch,
 	PXS_HIP(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream;
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16, mesz = map_dtype == PX_F32 ? 4 : 8;
-	const bool adj_fused = [] { const char* e = getenv("PXS_ADJ_ANA_FUSED"); return e ? atoi(e) != 0 : true; }();
-	const int chunk = p->wring.p ? batch_chunk(p, nbatch, spin == 0 ? 1 : 2) : ((adjoint && !adj_fused) || !p->chain_theta()) ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
+	const int chunk = ana_path(p, adjoint) == ANA_UNFUSED ? 1 : batch_chunk(p, nbatch, spin == 0 ? 1 : 2);
 	reserve_call(p, spin, PXS_MODE_STANDARD, false, adjoint != 0, std::min(chunk, nbatch));
 	for (int b0 = 0; b0 < nbatch; b0 += chunk) {
 		const int nb = std::min(chunk, nbatch - b0);

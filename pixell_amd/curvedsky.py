@@ -175,12 +175,15 @@ def alm2map_adjoint(map, alm=None, spin=[0, 2], deriv=False, copy=False, method=
 	return alm2map(alm, map, spin=spin, deriv=deriv, adjoint=True, copy=copy, method=method, ainfo=ainfo, verbose=verbose, nthread=nthread, epsilon=epsilon, pix_tol=pix_tol, locinfo=locinfo)
 
 def map2alm(map, alm=None, lmax=None, spin=[0, 2], deriv=False, adjoint=False, copy=False, method="auto", ainfo=None,
-		verbose=False, nthread=None, niter=0, epsilon=None, pix_tol=1e-6, weights=None, locinfo=None, tweak=False):
-	"""Spherical harmonics analysis (curvedsky.map2alm, curvedsky.py:209-302)."""
+		verbose=False, nthread=None, niter=0, epsilon=None, pix_tol=1e-6, weights=None, locinfo=None, tweak=False, analysis=None):
+	"""Spherical harmonics analysis (curvedsky.map2alm, curvedsky.py:209-302).
+	analysis (ours, method "2d" only): None / "interpolant" = what ducc0's analysis_2d integrates; "weights" = ring quadrature weights +
+	adjoint synthesis (the reference's cyl route, curvedsky.py:852-861) on full grids with ny >= 2 lmax + 2: identical alm for
+	band-limited maps, cheaper theta resampling (see pixell_amd.sht.analysis_2d)."""
 	minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)
 	if method == "auto": method = get_method(map.shape, map.wcs, minfo=minfo)
 	if   method == "2d":
-		return map2alm_2d(map, alm, ainfo=ainfo, minfo=minfo, lmax=lmax, spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol)
+		return map2alm_2d(map, alm, ainfo=ainfo, minfo=minfo, lmax=lmax, spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol, analysis=analysis)
 	elif method == "cyl":
 		return map2alm_cyl(map, alm, ainfo=ainfo, minfo=minfo, lmax=lmax, spin=spin, deriv=deriv, copy=copy, verbose=verbose, adjoint=adjoint, nthread=nthread, niter=niter, pix_tol=pix_tol, weights=weights)
 	elif method == "general":
@@ -257,7 +260,7 @@ def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=
 	if adjoint: return alm
 	else:       return map
 
-def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], deriv=False, copy=False, verbose=False, adjoint=False, nthread=None, pix_tol=1e-6):
+def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], deriv=False, copy=False, verbose=False, adjoint=False, nthread=None, pix_tol=1e-6, analysis=None):
 	"""curvedsky.map2alm_2d + map2alm_raw_2d (curvedsky.py:822-841, 1018-1048)"""
 	if adjoint:
 		if copy and map is not None: map = map.copy()
@@ -271,7 +274,7 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 	pads = _native_pads(minfo, use_y=True)
 	if pads != ((0, 0), (0, 0)):
 		pmap = _padded_like(map, pads, fill=not adjoint)
-		res = map2alm_2d(pmap, alm=alm, ainfo=ainfo, lmax=lmax, spin=spin, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol)
+		res = map2alm_2d(pmap, alm=alm, ainfo=ainfo, lmax=lmax, spin=spin, deriv=deriv, copy=False, verbose=verbose, adjoint=adjoint, nthread=nthread, pix_tol=pix_tol, analysis=analysis)
 		if not adjoint: return res
 		_crop_into(map, pmap, pads)
 		return map
@@ -282,7 +285,7 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 	l = min(ainfo.lmax, minfo.ducc_geo.lmax)
 	m = min(ainfo.mmax, l)
 	func = sht.adjoint_analysis_2d if adjoint else sht.analysis_2d
-	kwargs = dict(phi0=minfo.phi0, lmax=l, mmax=m, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart[:m+1], lstride=ainfo.stride, flip=minfo.flip)
+	kwargs = dict(phi0=minfo.phi0, lmax=l, mmax=m, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart[:m+1], lstride=ainfo.stride, flip=minfo.flip, analysis=analysis)
 	for s, a, m in _batched_jobs(spin, alm_full, map_full): func(alm=a, map=m, spin=s, **kwargs)
 	if adjoint: return map
 	else:       return alm

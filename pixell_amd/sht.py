@@ -87,6 +87,9 @@ class Plan:
 		f = (ctypes.c_double*2)()
 		_lib.check(_lib.load().pxs_profile_flops(self.handle, f, int(bool(reset))))
 		return f[0], f[1]
+	def set_option(self, name, value):
+		"""pxs_plan_option: "analysis" = 0 (theta-interpolant) | 1 (ring weights + adjoint synthesis where ntheta >= 2 lmax + 2)"""
+		_lib.check(_lib.load().pxs_plan_option(self.handle, name.encode(), int(value)))
 	def info(self):
 		a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
 		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
@@ -187,7 +190,15 @@ def _run_syn(plan, alm, map, spin, mode, adjoint):
 		av.ptr, _DT[ad], av.cstride, av.bstride, mv.ptr, _DT[md], mv.cstride, mv.bstride, current_stream()))
 	av.finish(); mv.finish()
 
-def _run_ana(plan, map, alm, spin, adjoint):
+ANALYSIS_MODES = {"interpolant": 0, "weights": 1}
+def _analysis_mode(analysis):
+	"""analysis=None: PIXELL_AMD_ANALYSIS or "interpolant" (what ducc0's analysis_2d integrates: the theta-interpolant of the rings)"""
+	if analysis is None: analysis = os.environ.get("PIXELL_AMD_ANALYSIS", "interpolant")
+	if analysis not in ANALYSIS_MODES: raise ValueError("analysis must be 'interpolant' or 'weights', not %r" % (analysis,))
+	return ANALYSIS_MODES[analysis]
+
+def _run_ana(plan, map, alm, spin, adjoint, analysis=None):
+	plan.set_option("analysis", _analysis_mode(analysis))      # (host-side path choice of the calls that follow; plans are cached and shared)
 	ad, md = _np_dtype(alm), _np_dtype(map)
 	batched = alm.ndim == 3
 	nb = alm.shape[0] if batched else 1
@@ -214,15 +225,18 @@ def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=No
 	_run_syn(plan, alm, map, spin, mode, True)
 	return plan if return_plan else alm
 
-def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False):
-	"""ducc0.sht.experimental.analysis_2d as called at curvedsky.py:1032-1046"""
+def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False, analysis=None):
+	"""ducc0.sht.experimental.analysis_2d as called at curvedsky.py:1032-1046.
+	analysis (ours): "interpolant" (default) | "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route
+	(curvedsky.py:852-861, 1068-1084), on grids with ntheta >= 2 lmax + 2 (smaller grids keep the interpolant): the same alm for
+	band-limited maps, three resampling stages instead of five."""
 	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
-	_run_ana(plan, map, alm, spin, False)
+	_run_ana(plan, map, alm, spin, False, analysis)
 	return plan if return_plan else alm
 
-def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False):
+def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False, analysis=None):
 	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
-	_run_ana(plan, map, alm, spin, True)
+	_run_ana(plan, map, alm, spin, True, analysis)
 	return plan if return_plan else map
 
 def _ring_args(alm, map, theta, nphi, phi0, ringstart, lmax, mmax, mstart, spin, lstride, pixstride, mode):

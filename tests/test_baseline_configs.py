@@ -324,3 +324,73 @@ def test_config5_shape_gpu():
 	assert np.all(np.isfinite(b[1:])) and b.shape[-1] > 1000
 	print("\n[1x(10800x21600) lmax 6000] pixel err %.2e  max cl diff %.2e  Parseval %.2e" % (e_pix, float(np.max(np.abs(cl_out-cl_in)/cl_in)), abs(p1-p2)/p2))
 	curvedsky.sht.clear_plans(); torch.cuda.empty_cache()
+
+def alm_dot(a, b, lmax):
+	"""real inner product of two alm sets in the triangular layout: m = 0 once, m > 0 twice (the (l, -m) coefficients are implied)"""
+	torch = _torch()
+	a = alm_t(a); b = alm_t(b)
+	w = torch.full((a.shape[-1],), 2.0, dtype=torch.float64, device=a.device); w[:lmax+1] = 1.0
+	return float(((a.real*b.real+a.imag*b.imag)*w).sum().item())
+
+def check_adjointness(shape2, lmax, spins=(0, 2), seed=11, variant="fejer1"):
+	"""<analysis_2d(x), a> = <x, adjoint_analysis_2d(a)> and <synthesis_2d(a), x> = <a, adjoint_synthesis_2d(x)> for random x (NOT
+	band-limited) and random a, at full size: pins the fused transposed chains (FftChain::to_cc_adjoint, from_cc_adjoint) to the forward
+	transforms, which the oracle checks at this size (the reference's own adjointness test: tests/test_pixell.py:1051-1085).
+	Returns the worst |lhs - rhs| / (||.|| ||.||).  (torch tensors throughout: the host simulator takes CPU tensors in place.)"""
+	from pixell_amd import curvedsky, enmap, sht
+	torch = _torch(); dev = _dev()
+	shape, wcs = enmap.fullsky_geometry(shape=shape2, variant=variant)
+	mi = curvedsky.analyse_geometry(shape, wcs)
+	ainfo = curvedsky.alm_info(lmax)
+	m_of = torch.repeat_interleave(torch.arange(lmax+1, device=dev), torch.arange(lmax+1, 0, -1, device=dev))
+	l_of = torch.arange(ainfo.nelem, device=dev)-(m_of*(2*lmax+1-m_of))//2
+	worst = 0.0
+	for spin in spins:
+		nc = 1 if spin == 0 else 2
+		g = torch.Generator(device=dev); g.manual_seed(seed+spin)
+		x = torch.randn((nc,)+tuple(shape), generator=g, device=dev, dtype=torch.float64)
+		a = make_alm(lmax, nc, seed+7+spin, dev, spin2=False)*(torch.arange(ainfo.nelem, device=dev) % 7+1.0)       # no smooth spectrum
+		a[:, l_of < spin] = 0
+		kw = dict(spin=spin, lmax=lmax, mstart=ainfo.mstart, geometry=mi.ducc_geo.name, phi0=mi.phi0, flip=tuple(bool(f) for f in mi.flip))
+		nrm = lambda t: float(t.pow(2).sum().sqrt().item())
+		xn = nrm(x); an = np.sqrt(alm_dot(a, a, lmax))
+		# analysis and its adjoint
+		ax = torch.zeros_like(a); sht.analysis_2d(alm=ax, map=x, **kw)
+		aa = torch.zeros_like(x); sht.adjoint_analysis_2d(alm=a, map=aa, **kw)
+		lhs = alm_dot(ax, a, lmax); rhs = float((x*aa).sum().item())
+		n1 = max(np.sqrt(alm_dot(ax, ax, lmax))*an, xn*nrm(aa))
+		e1 = abs(lhs-rhs)/n1
+		# synthesis and its adjoint
+		sa = torch.zeros_like(x); sht.synthesis_2d(alm=a, map=sa, **kw)
+		sx = torch.zeros_like(a); sht.adjoint_synthesis_2d(alm=sx, map=x, **kw)
+		lhs2 = float((sa*x).sum().item()); rhs2 = alm_dot(a, sx, lmax)
+		n2 = max(nrm(sa)*xn, an*np.sqrt(alm_dot(sx, sx, lmax)))
+		e2 = abs(lhs2-rhs2)/n2
+		assert e1 < 1e-11, "spin %d: analysis_2d / adjoint_analysis_2d are not adjoint: %.3e (%.15g vs %.15g)" % (spin, e1, lhs, rhs)
+		assert e2 < 1e-11, "spin %d: synthesis_2d / adjoint_synthesis_2d are not adjoint: %.3e (%.15g vs %.15g)" % (spin, e2, lhs2, rhs2)
+		# the identity is informative only if the inner products are not tiny next to the product of the norms (random vectors: ~1/sqrt(n))
+		assert abs(lhs) > 1e-7*n1 and abs(lhs2) > 1e-7*n2, "degenerate inner products"
+		worst = max(worst, e1, e2)
+		del x, a, ax, aa, sa, sx
+	sht.clear_plans()
+	if _gpu(): torch.cuda.empty_cache()
+	return worst
+
+@pytest.mark.hostsim
+def test_adjointness_logic_hostsim():
+	check_adjointness((26, 52), 24); check_adjointness((40, 64), 18); check_adjointness((27, 52), 24, variant="cc")
+
+@pytest.mark.gpu
+def test_adjointness_config2_gpu():
+	"""C2 size: 5400 rings < 2 lmax + 1 (the analysis needs the exact interpolant; its adjoint is the fused to_cc_adjoint chain)"""
+	e = check_adjointness((5400, 10800), 4000)
+	print("\n[adjointness 5400x10800 lmax 4000] %.2e" % e)
+
+@pytest.mark.gpu
+def test_adjointness_config3_gpu():
+	"""C3 size: 21600 rings, lmax 10^4: synthesis and its adjoint take the CC detour (from_cc / from_cc_adjoint), analysis to_cc / to_cc_adjoint"""
+	torch = _torch()
+	free, _ = torch.cuda.mem_get_info()
+	if free < 150e9: pytest.skip("needs ~150 GB of HBM")
+	e = check_adjointness((21600, 43200), 10000)
+	print("\n[adjointness 21600x43200 lmax 10000] %.2e" % e)

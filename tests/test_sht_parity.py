@@ -465,3 +465,61 @@ def check_dh_f2():
 def test_dh_f2_hostsim(): check_dh_f2()
 @pytest.mark.gpu
 def test_dh_f2_gpu(): check_dh_f2()
+
+def check_weights_analysis(geometry, nt, nph, lmax, spin, nb=1, seed=5):
+	"""analysis="weights" (pxs_plan_option: ring quadrature weights + adjoint synthesis, the reference's cyl route, curvedsky.py:852-861,
+	1068-1084) against the oracle's restatement of the same composition -- on a band-limited map (where it must also equal the
+	interpolant form and recover the alm) and on white noise (where the two forms differ) -- and its adjoint."""
+	rng = np.random.default_rng(seed)
+	nc = 1 if spin == 0 else 2
+	assert nt >= 2*lmax+2
+	ms = so._tri_mstart(lmax, lmax)
+	kw = dict(spin=spin, lmax=lmax, geometry=geometry, phi0=0.2, mstart=ms)
+	alm = so.rand_alm_simple(lmax, nc, seed, spin=(spin,))
+	band = np.zeros((nc, nt, nph)); so.synthesis_2d(alm=alm, map=band, **kw)
+	noise = rng.standard_normal((nc, nt, nph))
+	for m, tag in ((band, "band-limited"), (noise, "noise")):
+		ref = np.zeros_like(alm); so.analysis_2d(alm=ref, map=m, weights=True, **kw)
+		got = np.zeros_like(alm); sht.analysis_2d(alm=got, map=m, analysis="weights", **kw)
+		assert relrms(got, ref) < TOL, "weights analysis, %s map: %.3e" % (tag, relrms(got, ref))
+		if tag == "band-limited":
+			assert relrms(got, alm) < TOL
+			itp = np.zeros_like(alm); sht.analysis_2d(alm=itp, map=m, **kw)
+			assert relrms(got, itp) < TOL
+		else:
+			itp = np.zeros_like(alm); sht.analysis_2d(alm=itp, map=m, analysis="interpolant", **kw)
+			assert relrms(got, itp) > 1e-6, "the two forms should differ on a map that is not band-limited"
+	ref2 = np.zeros((nc, nt, nph)); so.adjoint_analysis_2d(alm=alm, map=ref2, weights=True, **kw)
+	out2 = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=out2, analysis="weights", **kw)
+	assert rel(out2, ref2) < TOL, "adjoint of the weights analysis: %.3e" % rel(out2, ref2)
+	if nb > 1:	# batched call == single calls
+		maps = np.stack([noise*(i+1) for i in range(nb)]); a = np.zeros((nb,)+alm.shape, alm.dtype)
+		sht.analysis_2d(alm=a, map=maps, analysis="weights", **kw)
+		one = np.zeros_like(alm); sht.analysis_2d(alm=one, map=maps[nb-1], analysis="weights", **kw)
+		assert rel(a[nb-1], one) < 1e-13
+	# the option is per call: the default form is back
+	chk = np.zeros_like(alm); sht.analysis_2d(alm=chk, map=noise, **kw)
+	assert relrms(chk, itp) < 1e-14
+	with pytest.raises(ValueError): sht.analysis_2d(alm=chk, map=noise, analysis="quadrature", **kw)
+
+WEIGHTS_CASES = [("F1", 64, 128, 30, 0), ("F1", 66, 128, 31, 2), ("CC", 65, 120, 30, 2), ("MW", 64, 100, 28, 0), ("F1", 120, 240, 50, 1)]
+@pytest.mark.hostsim
+@pytest.mark.parametrize("geometry,nt,nph,lmax,spin", WEIGHTS_CASES[:3])
+def test_weights_analysis_hostsim(geometry, nt, nph, lmax, spin): check_weights_analysis(geometry, nt, nph, lmax, spin, nb=2 if spin == 0 else 1)
+@pytest.mark.gpu
+@pytest.mark.parametrize("geometry,nt,nph,lmax,spin", WEIGHTS_CASES)
+def test_weights_analysis_gpu(geometry, nt, nph, lmax, spin): check_weights_analysis(geometry, nt, nph, lmax, spin, nb=3)
+
+def test_weights_analysis_small_grid_keeps_interpolant():
+	"""below ntheta = 2 lmax + 2 ring weights are not exact: the option leaves such grids on the interpolant"""
+	lmax, nt, nph = 30, 40, 80
+	alm = so.rand_alm_simple(lmax, 1, 3, spin=(0,))
+	kw = dict(spin=0, lmax=lmax, geometry="F1", phi0=0.0, mstart=so._tri_mstart(lmax, lmax))
+	m = np.zeros((1, nt, nph)); so.synthesis_2d(alm=alm, map=m, **kw)
+	got = np.zeros_like(alm); sht.analysis_2d(alm=got, map=m, analysis="weights", **kw)
+	assert relrms(got, alm) < TOL
+
+@pytest.mark.hostsim
+def test_batched_shared_recurrence_hostsim():
+	"""five scalar maps: two groups of two through the shared-recurrence synthesis kernel (leg_syn_s0b) and one through leg_syn_s0"""
+	check_batched(nb=5, nt=20, nph=40, lmax=16)
