@@ -67,11 +67,34 @@ static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::
 
 static std::mutex g_blue_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> g_blue_scratch;
 // chain engine (and its scratch) of the 2-D real -> complex fast path, per stream like the other scratch
-static std::mutex g_f2_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<FftChain>> g_f2;
+// (each entry owns the transposed intermediate of its last transform -- 15 GB for a complex 21600 x 43200 map -- so the table is
+// bounded: beyond PXF_F2_MAX_STREAMS (4) the entry used longest ago is dropped; hipFree waits for the kernels that may still use it)
+struct F2Entry { std::unique_ptr<FftChain> ch; unsigned long stamp = 0; };
+static std::mutex g_f2_mu; static std::map<std::pair<int, hipStream_t>, F2Entry> g_f2; static unsigned long g_f2_clock = 0;
+static FftChain* f2_chain(int device, hipStream_t st, FftContext& fc) {
+	std::lock_guard<std::mutex> g(g_f2_mu);
+	static const size_t cap = [] { const char* e = getenv("PXF_F2_MAX_STREAMS"); return (size_t)std::max(1, e ? atoi(e) : 4); }();
+	auto key = std::make_pair(device, st);
+	auto it = g_f2.find(key);
+	if (it == g_f2.end()) {
+		while (g_f2.size() >= cap) {
+			auto old = g_f2.begin();
+			for (auto j = g_f2.begin(); j != g_f2.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
+			g_f2.erase(old);
+		}
+		it = g_f2.emplace(key, F2Entry()).first;
+		it->second.ch.reset(new FftChain(&fc));
+	}
+	it->second.stamp = ++g_f2_clock;
+	return it->second.ch.get();
+}
+// scratch of the multi-axis c2r transforms, per stream like the other scratch (grows only; no synchronisation in the call path)
+static std::mutex g_c2r_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> g_c2r_scratch;
 // a stream is about to be destroyed: free the scratch keyed by it (a recycled handle must not inherit a stale buffer)
 void fft_release_stream(int device, hipStream_t st) {
 	{ std::lock_guard<std::mutex> g(g_blue_mu); g_blue_scratch.erase(std::make_pair(device, st)); }
 	{ std::lock_guard<std::mutex> g(g_f2_mu); g_f2.erase(std::make_pair(device, st)); }
+	{ std::lock_guard<std::mutex> g(g_c2r_mu); g_c2r_scratch.erase(std::make_pair(device, st)); }
 	fft_context(device).release_stream(st);
 }
 
@@ -295,8 +318,7 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 			long acc = 1, npre = 1;
 			for (int k = ndim-1; k >= 0 && dense; k--) { dense = istride[k] == acc && ostride[k] == acc; acc *= shape[k]; if (k < ndim-2) npre *= shape[k]; }
 			if (dense) {
-				FftChain* ch;
-				{ std::lock_guard<std::mutex> g(g_f2_mu); auto& u = g_f2[std::make_pair(device, st)]; if (!u) u.reset(new FftChain(&fc)); ch = u.get(); }
+				FftChain* ch = f2_chain(device, st, fc);
 				if (real_in ? ch->fft2_real(st, in, in_dtype, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)
 				            : ch->fft2_c2c(st, (const double2*)in, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)) return 0;
 			}
@@ -328,10 +350,12 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 	} else {
 		// c2r: complex transforms over all but the last axis into scratch, then Hermitian c2r on the last axis
 		const void* src = in; int src_dtype = in_dtype; std::vector<int64_t> sstride(istride, istride+ndim);
-		DevBuf scratch;
 		if (naxes > 1) {
 			size_t tot = 1; for (int k = 0; k < ndim; k++) tot *= cshape[k];
-			scratch.alloc(tot*sizeof(double2));
+			DevBuf* sp;
+			{ std::lock_guard<std::mutex> g(g_c2r_mu); auto& u = g_c2r_scratch[std::make_pair(device, st)]; if (!u) u.reset(new DevBuf()); sp = u.get(); }
+			sp->ensure(tot*sizeof(double2));
+			DevBuf& scratch = *sp;
 			std::vector<int64_t> cs(ndim); long acc = 1;
 			for (int k = ndim-1; k >= 0; k--) { cs[k] = acc; acc *= cshape[k]; }
 			for (int t = 0; t < naxes-1; t++) {
@@ -350,7 +374,6 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 		std::vector<long> rshape(shape, shape+ndim);
 		// note: LD_HERM reads indices < nh directly and conj(N-e) otherwise: for even N the Nyquist bin e=N/2 < nh is read directly
 		fft_axis(fc, st, nlast, forward != 0, other_dims(last, rshape, sstride.data(), ostride), sstride[last], ostride[last], ld, stf);
-		if (naxes > 1) PXS_HIP(hipStreamSynchronize(st));   // scratch is freed on return
 	}
 	PXS_CATCH
 }

@@ -1247,6 +1247,12 @@ static LegK make_legk(const RingSet& rs, const LegTables& tb, LegWork& wk, doubl
 	return a;
 }
 
+// maps one launch can take: all maps of a launch share one grid of 8 ceil(nm / 8) nwave blocks each (a large batch of small-ring,
+// high-lmax maps goes out as several launches instead of tripping make_legk's grid check)
+static int leg_max_batch(const RingSet& rs, const LegTables& tb, int K) {
+	const long nwave = (rs.npairs + 64L*K - 1)/(64L*K), per = 8L*((tb.mmax + 1 + 7)/8)*std::max<long>(nwave, 1);
+	return (int)std::max<long>(1, std::min<long>(1 << 20, ((1L << 31) - 1)/per));
+}
 // seeds of (ring set, spin, direction, K): allocate on first use if the plan's budget allows; returns the mode for this launch
 static LegWork::Seeds* seeds_for(LegWork& wk, const RingSet& rs, const LegTables& tb, int dir, int K, LegK& a) {
 	a.seed_mode = 0; a.seed_d = nullptr; a.seed_i = nullptr;
@@ -1326,9 +1332,12 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		if (prof) prof->end(st, 0);
 		seeds_written(sb, st);
 	};
-	// spin 0, two or more maps: groups of B maps share one recurrence (leg_syn_s0b); what is left over takes the single-map kernel.
-	// PXS_SYN_SHARE = B (2 | 4; 0 / 1: off) and PXS_K_SYN0B = ring pairs per lane of that kernel override the defaults for tuning runs
-	static const int share = [] { const char* e = getenv("PXS_SYN_SHARE"); const int v = e ? atoi(e) : 2; return v >= 4 ? 4 : (v >= 2 ? 2 : 1); }();
+	// spin 0, two or more maps: groups of B maps can share one recurrence (leg_syn_s0b), what is left over takes the single-map kernel.
+	// OFF by default: measured on MI355X at C4 (64 maps 5400x10800, lmax 4000, leg_syn per step, same box, profiles/r04_syn_share_c4.txt)
+	// unshared 120.7 ms; B = 2: K = 4 119.8, K = 2 126.0, K = 1 198.9; B = 4: K = 2 127.1, K = 1 181.1 -- the 17-25 % fewer FMAs do not
+	// show: at equal (map, ring pair) units per lane the kernel runs as before, with fewer it is short of independent chains.
+	// PXS_SYN_SHARE = B (2 | 4) turns it on, PXS_K_SYN0B = ring pairs per lane (1 | 2 | 4).
+	static const int share = [] { const char* e = getenv("PXS_SYN_SHARE"); const int v = e ? atoi(e) : 1; return v >= 4 ? 4 : (v >= 2 ? 2 : 1); }();
 	static const int kshare = env_k("PXS_K_SYN0B", 2, 1, 4);
 	int b0 = 0;
 	if (tb.spin == 0 && share > 1 && nb >= share) {
@@ -1352,12 +1361,12 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		};
 		int g0 = 0;
 		if (ng > 1 && seeds_pending(wk, rs, tb, 0, K2)) { launch_groups(0, 1); g0 = 1; }      // (one wave writes each seed)
-		launch_groups(g0, ng - g0);
+		for (const int gmax = leg_max_batch(rs, tb, K2); g0 < ng; g0 += gmax) launch_groups(g0, std::min(gmax, ng - g0));
 		b0 = ng*B;
 	}
 	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
 	if (nb - b0 > 1 && seeds_pending(wk, rs, tb, 0, K)) { launch(b0, 1); b0 += 1; }
-	if (nb - b0 > 0) launch(b0, nb - b0);
+	for (const int nmax = leg_max_batch(rs, tb, K); b0 < nb; b0 += nmax) launch(b0, std::min(nmax, nb - b0));
 	PXS_HIP(hipGetLastError());
 }
 
@@ -1383,6 +1392,12 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 				leg_analysis(st, rs, tb, wk, leg + (size_t)first*leg_bstride, (char*)alm + aesz*(size_t)first*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, prof, ld, nb - first, alm_bstride, leg_bstride);
 			return;
 		}
+	}
+	if (const int nmax = leg_max_batch(rs, tb, K); nb > nmax) {      // (grid limit of one launch)
+		const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+		for (int b = 0; b < nb; b += nmax)
+			leg_analysis(st, rs, tb, wk, leg + (size_t)b*leg_bstride, (char*)alm + aesz*(size_t)b*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, prof, ld, std::min(nmax, nb - b), alm_bstride, leg_bstride);
+		return;
 	}
 	wk.mom.ensure(sizeof(double)*(size_t)n4*nb);
 	// Default: the waves of one m add their sums straight into mom with global_atomic_add_f64 -- the blocks of one m run back

@@ -1134,7 +1134,9 @@ static int batch_chunk(const pxs_plan* p, int nbatch, int ncm) {
 	if (nbatch <= 1 || !p->chain_rings) return 1;           // the unfused paths take one map at a time
 	const size_t per_map = sizeof(double2)*(size_t)ncm*((size_t)(p->mmax+1)*(p->nring + (p->ncc > 0 ? p->ncc : 0))*2 + (size_t)p->nring*p->nphi);
 	static const size_t budget = [] { const char* e = getenv("PXS_BATCH_GB"); return (size_t)(e ? atol(e) : 32) << 30; }();
-	return (int)std::max<size_t>(1, std::min<size_t>((size_t)nbatch, budget/std::max<size_t>(per_map, 1)));
+	const int cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)nbatch, budget/std::max<size_t>(per_map, 1)));
+	const int npass = (nbatch + cap - 1)/cap;
+	return (nbatch + npass - 1)/npass;      // equal passes (64 maps at 15 per pass: 13 x 4 + 12, not 15 x 4 + 4 with a last pass at 27 % of the batch dimension)
 }
 
 int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint, int nbatch,

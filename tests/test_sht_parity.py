@@ -523,3 +523,12 @@ def test_weights_analysis_small_grid_keeps_interpolant():
 def test_batched_shared_recurrence_hostsim():
 	"""five scalar maps: two groups of two through the shared-recurrence synthesis kernel (leg_syn_s0b) and one through leg_syn_s0"""
 	check_batched(nb=5, nt=20, nph=40, lmax=16)
+
+@pytest.mark.hostsim
+def test_batched_deterministic_and_seeded_hostsim(monkeypatch):
+	"""batched calls on the two paths that launch maps one at a time: the ordered (bitwise repeatable) analysis, PXS_DETERMINISTIC=1, and
+	the launch that records the recurrence seeds (the first map alone), forced on at toy size with PXS_SEED_MIN_LMAX=0"""
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(nb=3)
+	monkeypatch.delenv("PXS_DETERMINISTIC"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0"); sht.clear_plans(); check_batched(nb=3)
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(nb=3)
+	sht.clear_plans()

@@ -1,6 +1,12 @@
-# SQ counters of the Legendre kernels at the bench configuration (two passes: 8 SQ counters each)
+#!/bin/bash
+# SQ counters of the Legendre kernels on the C3 bench command (bench.py --no-cpu --steps 1 --warmup 1); separate --pmc passes with
+# kernel-trace only.  usage: pmc_leg.sh <tag>
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; CFG=${1:-c3}
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmcl1 -o p -- python $R/bench.py --config $CFG --no-cpu --steps 1 --warmup 0 > $R/gpurun_out/pmcl1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/gpurun_out/pmcl2 -o p -- python $R/bench.py --config $CFG --no-cpu --steps 1 --warmup 0 > $R/gpurun_out/pmcl2.log 2>&1
-ls $R/gpurun_out/pmcl1 $R/gpurun_out/pmcl2
+R=$GRAFT_REPO_ROOT; TAG=${1:-a}; O=$R/gpurun_out/pmcl_$TAG; mkdir -p $O
+CMD="python $R/bench.py --no-cpu --steps 1 --warmup 1"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- $CMD > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/p1 -o p -- $CMD > $O/p1.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT --output-format csv -d $O/p2 -o p -- $CMD > $O/p2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_VALU_MFMA_F64 --output-format csv -d $O/p3 -o p -- $CMD > $O/p3.log 2>&1
+python $R/tools/pmc_leg_sum.py $O > $O/summary.txt 2>&1
+cat $O/summary.txt
