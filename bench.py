@@ -508,6 +508,23 @@ def main():
 					pcie_h2d_GBps=round(h2d, 1), pcie_d2h_GBps=round(d2h, 1), note="GPU step + (map + alm bytes) in each direction at the pinned-memory copy rate measured on 2 GiB; host-buffer callers pay this, it is never `value`")
 			except Exception as e: log("pcie probe failed: %r" % (e,))
 			try:
+				# the same round trip with HOST arrays (numpy, pageable), measured: pixell_amd/hostio.py moves them in pinned double-buffered
+				# slabs and pipelines the spin groups of a call (T transforms under the upload of Q and U, maps come back while the next group runs)
+				hm = enmap.ndmap(dmap.tensor.cpu().numpy(), wcs); ha = alm_out.cpu().numpy()
+				def hstep():
+					curvedsky.map2alm(hm, alm=ha, spin=cfg["spin"], ainfo=ainfo)
+					curvedsky.alm2map(ha, hm, spin=cfg["spin"], ainfo=ainfo)
+				hstep(); torch.cuda.synchronize()
+				nh = 2; th = time.perf_counter()
+				for _ in range(nh): hstep()
+				torch.cuda.synchronize(); th = (time.perf_counter()-th)/nh
+				h_err = float(np.sqrt(np.mean(np.abs(ha-alm_in.cpu().numpy())**2)/np.mean(np.abs(ha)**2)))
+				res["h2d_inclusive"].update(measured_ms_per_step=round(th*1e3, 1), measured_value=round(maps_total/th, 4), measured_alm_rms_error=h_err,
+					measured_note="curvedsky.map2alm + alm2map on numpy arrays (pageable host memory), %d round trips after one warm-up; ms_per_step / value above are the model (resident step + PCIe time at the pinned copy rate)" % nh)
+				log("host-array round trip: %.1f ms (%.3f round trips/s), alm rms error %.2e" % (th*1e3, maps_total/th, h_err))
+				del hm, ha
+			except Exception as e: log("host-array leg failed: %r" % (e,))
+			try:
 				del alm_in; torch.cuda.empty_cache()
 				res["fft"] = fft_block(enmap.dmap(dmap.tensor[:1], wcs), enmap, torch)
 			except Exception as e: log("fft block failed: %r" % (e,)); res["fft"] = None

@@ -258,7 +258,12 @@ def alm2map_2d(alm, map, ainfo=None, minfo=None, spin=[0, 2], deriv=False, copy=
 			if adjoint: alm_full[I] = a[0]
 			else: map_full[I+(0,)] *= -1       # theta derivative -> dec derivative (curvedsky.py:919)
 	else:
-		for s, a, m in _batched_jobs(spin, alm_full, map_full): func(alm=a, map=m, spin=s, **kwargs)
+		jobs = _batched_jobs(spin, alm_full, map_full)
+		# numpy arrays: the inputs of all spin groups start uploading now, outputs come back while the next group runs (pixell_amd/hostio.py).
+		# Map -> alm: the group that is cheapest to transform goes LAST (its transform is the only one no upload hides); alm -> map: first.
+		if adjoint: jobs = sorted(jobs, key=lambda j: -j[2].shape[-3])
+		with sht.host_pipeline([m if adjoint else a for s, a, m in jobs], [a if adjoint else m for s, a, m in jobs]):
+			for s, a, m in jobs: func(alm=a, map=m, spin=s, **kwargs)
 	if adjoint: return alm
 	else:       return map
 
@@ -288,7 +293,10 @@ def map2alm_2d(map, alm=None, ainfo=None, minfo=None, lmax=None, spin=[0, 2], de
 	m = min(ainfo.mmax, l)
 	func = sht.adjoint_analysis_2d if adjoint else sht.analysis_2d
 	kwargs = dict(phi0=minfo.phi0, lmax=l, mmax=m, geometry=minfo.ducc_geo.name, mstart=ainfo.mstart[:m+1], lstride=ainfo.stride, flip=minfo.flip, analysis=analysis)
-	for s, a, m in _batched_jobs(spin, alm_full, map_full): func(alm=a, map=m, spin=s, **kwargs)
+	jobs = _batched_jobs(spin, alm_full, map_full)
+	if not adjoint: jobs = sorted(jobs, key=lambda j: -j[2].shape[-3])      # (see alm2map_2d: map -> alm takes the largest group first)
+	with sht.host_pipeline([a if adjoint else m for s, a, m in jobs], [m if adjoint else a for s, a, m in jobs]):
+		for s, a, m in jobs: func(alm=a, map=m, spin=s, **kwargs)
 	if adjoint: return map
 	else:       return alm
 

@@ -7,7 +7,7 @@ Extra keyword `flip=(flip_y, flip_x)` (ours): the map is given in its native pix
 flips of curvedsky.map2buffer/buffer2map (curvedsky.py:1384-1411) are folded into kernel
 addressing; phi0 is still that of the flipped map (analyse_geometry().phi0).
 """
-import ctypes, os
+import ctypes, os, contextlib
 import numpy as np
 from . import _lib
 
@@ -43,10 +43,26 @@ def current_stream():
 	if _lib.is_hostsim(): return None
 	return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
 
+# host-array route (pixell_amd/hostio.py): the Pipeline of the API call in progress, if any
+_pipe = None
+@contextlib.contextmanager
+def host_pipeline(inputs=(), outputs=()):
+	"""for the duration of one API call: numpy `inputs` are uploaded by a background thread, in order, starting now; numpy outputs
+	of the transforms issued inside are downloaded in the background; everything is complete when the block exits"""
+	global _pipe
+	from . import hostio
+	if _pipe is not None or _lib.is_hostsim() or not any(hostio.eligible(a) for a in list(inputs)+list(outputs)):
+		yield; return
+	_pipe = hostio.Pipeline(); _pipe.prefetch(inputs)
+	try: yield
+	finally:
+		p = _pipe; _pipe = None; p.close()
+
 class _Buf:
-	"""device view of a numpy array or torch tensor (contiguous), with optional write-back"""
-	def __init__(self, arr, writeback=False):
-		self.arr = arr; self.writeback = writeback; self.tmp = None; self.keep = None
+	"""device view of a numpy array or torch tensor (contiguous), with optional write-back.  overwrite: the call writes every
+	element (an output whose old content need not travel to the device)"""
+	def __init__(self, arr, writeback=False, overwrite=False):
+		self.arr = arr; self.writeback = writeback; self.tmp = None; self.keep = None; self.slab = False
 		if _is_tensor(arr):
 			if not arr.is_cuda and not _lib.is_hostsim(): raise ValueError("torch tensors passed to pixell_amd must live on the GPU")
 			if not arr.is_contiguous():
@@ -60,11 +76,25 @@ class _Buf:
 				self.ptr = self.keep.ctypes.data
 			else:
 				torch = _torch()
-				self.tmp = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+				from . import hostio
+				got = _pipe.take(arr) if _pipe is not None else None
+				self.slab = hostio.eligible(arr)
+				if got is not None:                      # uploaded in the background since the call began
+					self.tmp, ev = got; torch.cuda.current_stream().wait_event(ev)
+				elif self.slab and writeback and overwrite:
+					self.tmp = torch.empty(arr.shape, dtype=getattr(torch, arr.dtype.name), device="cuda")
+				elif self.slab:
+					self.tmp, ev = hostio.upload(arr); torch.cuda.current_stream().wait_event(ev)
+				else: self.tmp = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
 				self.ptr = self.tmp.data_ptr()
 	def finish(self):
 		if not self.writeback or self.tmp is None: return
 		if _lib.is_hostsim(): self.arr[...] = self.tmp
+		elif self.slab:
+			from . import hostio
+			ev = _torch().cuda.Event(); ev.record()
+			if _pipe is not None: _pipe.writeback(self.tmp, self.arr, ev)      # complete when the host_pipeline block exits
+			else: hostio.download(self.tmp, self.arr, after=ev)
 		else: self.arr[...] = self.tmp.cpu().numpy()
 
 class Plan:
@@ -165,7 +195,7 @@ class _View:
 	"""device pointer + (batch, component) strides of alm [nb?, nc, nelem] / map [nb?, nc, pixels...].  CUDA tensors are used in
 	place whenever their inner axes are contiguous (the batch and component axes may be strided views, e.g. one spin group of
 	many maps); numpy arrays and other tensors are staged contiguously (and written back for outputs)."""
-	def __init__(self, arr, inner_ndim, batched, writeback):
+	def __init__(self, arr, inner_ndim, batched, writeback, overwrite=False):
 		self.buf = None
 		if _is_tensor(arr) and (arr.is_cuda or _lib.is_hostsim()):
 			st = list(arr.stride()); sh = list(arr.shape)
@@ -174,18 +204,18 @@ class _View:
 				self.keep = arr; self.ptr = arr.data_ptr()
 				self.cstride = st[-inner_ndim-1]; self.bstride = st[0] if batched else 0
 				return
-		self.buf = _Buf(arr, writeback=writeback); self.ptr = self.buf.ptr
+		self.buf = _Buf(arr, writeback=writeback, overwrite=overwrite); self.ptr = self.buf.ptr
 		inner = int(np.prod(arr.shape[arr.ndim-inner_ndim:], dtype=np.int64))
 		self.cstride = inner; self.bstride = inner*arr.shape[-inner_ndim-1] if batched else 0
 	def finish(self):
 		if self.buf is not None: self.buf.finish()
 
-def _run_syn(plan, alm, map, spin, mode, adjoint):
+def _run_syn(plan, alm, map, spin, mode, adjoint, map_overwrite=False):
 	"""alm [nca, nelem], map [ncm, ...] -- or a batch of independent maps alm [nb, nca, nelem], map [nb, ncm, ...] in ONE library call"""
 	ad, md = _np_dtype(alm), _np_dtype(map)
 	batched = alm.ndim == 3
 	nb = alm.shape[0] if batched else 1
-	av = _View(alm, 1, batched, bool(adjoint)); mv = _View(map, map.ndim-(2 if batched else 1), batched, not adjoint)
+	av = _View(alm, 1, batched, bool(adjoint)); mv = _View(map, map.ndim-(2 if batched else 1), batched, not adjoint, overwrite=map_overwrite and not adjoint)
 	_lib.check(_lib.load().pxs_synthesis(plan.handle, int(spin), 1 if mode == "DERIV1" else 0, int(bool(adjoint)), int(nb),
 		av.ptr, _DT[ad], av.cstride, av.bstride, mv.ptr, _DT[md], mv.cstride, mv.bstride, current_stream()))
 	av.finish(); mv.finish()
@@ -197,12 +227,12 @@ def _analysis_mode(analysis):
 	if analysis not in ANALYSIS_MODES: raise ValueError("analysis must be 'interpolant' or 'weights', not %r" % (analysis,))
 	return ANALYSIS_MODES[analysis]
 
-def _run_ana(plan, map, alm, spin, adjoint, analysis=None):
+def _run_ana(plan, map, alm, spin, adjoint, analysis=None, alm_dense=False):
 	plan.set_option("analysis", _analysis_mode(analysis))      # (host-side path choice of the calls that follow; plans are cached and shared)
 	ad, md = _np_dtype(alm), _np_dtype(map)
 	batched = alm.ndim == 3
 	nb = alm.shape[0] if batched else 1
-	av = _View(alm, 1, batched, not adjoint); mv = _View(map, map.ndim-(2 if batched else 1), batched, bool(adjoint))
+	av = _View(alm, 1, batched, not adjoint, overwrite=alm_dense and not adjoint); mv = _View(map, map.ndim-(2 if batched else 1), batched, bool(adjoint), overwrite=bool(adjoint))      # (a grid plan writes every pixel)
 	_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), int(nb), mv.ptr, _DT[md], mv.cstride, mv.bstride,
 		av.ptr, _DT[ad], av.cstride, av.bstride, current_stream()))
 	av.finish(); mv.finish()
@@ -217,7 +247,7 @@ def _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode
 def synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False), return_plan=False):
 	"""ducc0.sht.experimental.synthesis_2d as called at curvedsky.py:907-924"""
 	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip)
-	_run_syn(plan, alm, map, spin, mode, False)
+	_run_syn(plan, alm, map, spin, mode, False, map_overwrite=True)      # (a grid plan writes every pixel of the map)
 	return plan if return_plan else map
 
 def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, mode="STANDARD", flip=(False, False), return_plan=False):
@@ -231,7 +261,9 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	(curvedsky.py:852-861, 1068-1084), on grids with ntheta >= 2 lmax + 2 (smaller grids keep the interpolant): the same alm for
 	band-limited maps, three resampling stages instead of five."""
 	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
-	_run_ana(plan, map, alm, spin, False, analysis)
+	# (an alm array that is exactly the triangular layout is written in full: a host array of it need not be uploaded first)
+	dense = lstride == 1 and (mmax is None or mmax == lmax) and alm.shape[-1] == (lmax+1)*(lmax+2)//2 and (mstart is None or int(np.asarray(mstart)[-1]) + lmax + 1 == alm.shape[-1])
+	_run_ana(plan, map, alm, spin, False, analysis, alm_dense=dense)
 	return plan if return_plan else alm
 
 def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False, analysis=None):

@@ -356,3 +356,43 @@ def test_repeatable_and_cyl_equals_2d_gpu(monkeypatch):
 	assert np.max(np.abs(res[0][1]-alm.cpu().numpy())) < 1e-11
 	assert np.max(np.abs(res[0][3]-res[0][0])) < 1e-11                                  # cyl and 2d agree
 	assert np.max(np.abs(res[0][4]-res[0][2])) < 1e-11*np.max(np.abs(res[0][2]))
+
+@pytest.mark.gpu
+def test_host_array_route_gpu(monkeypatch):
+	"""numpy maps / alm through the slab route (pixell_amd/hostio.py: pinned double-buffered transfers, the spin groups of a call
+	pipelined in the background) give the bytes the device-resident call gives; small slabs so that many of them are in play"""
+	import torch
+	from pixell_amd import hostio
+	monkeypatch.setattr(hostio, "SLAB_BYTES", 24 << 20); monkeypatch.setattr(hostio, "MIN_BYTES", 16 << 20)
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1")      # (the default analysis adds with atomics: equal to rounding, not bit for bit, even between two device-resident calls)
+	lmax = 1500
+	shape, wcs = enmap.fullsky_geometry(shape=(2000, 4000))
+	ainfo = curvedsky.alm_info(lmax)
+	rng = np.random.default_rng(4)
+	alm = (rng.standard_normal((3, ainfo.nelem))+1j*rng.standard_normal((3, ainfo.nelem)))/(1.0+np.arange(ainfo.nelem) % 97)
+	alm[:, :lmax+1] = alm[:, :lmax+1].real
+	# device-resident reference
+	d_alm = torch.from_numpy(alm).cuda()
+	d_map = enmap.dmap(torch.zeros((3,)+shape, dtype=torch.float64, device="cuda"), wcs)
+	curvedsky.alm2map(d_alm, d_map, spin=[0, 2], ainfo=ainfo)
+	d_back = torch.zeros_like(d_alm); curvedsky.map2alm(d_map, alm=d_back, spin=[0, 2], ainfo=ainfo)
+	# host arrays (every array here is above MIN_BYTES except the T alm)
+	h_map = enmap.ndmap(np.full((3,)+shape, np.nan), wcs)
+	curvedsky.alm2map(alm.copy(), h_map, spin=[0, 2], ainfo=ainfo)
+	assert np.array_equal(np.asarray(h_map), d_map.tensor.cpu().numpy())
+	h_back = np.full_like(alm, np.nan); curvedsky.map2alm(h_map, alm=h_back, spin=[0, 2], ainfo=ainfo)
+	assert np.array_equal(h_back, d_back.cpu().numpy())
+	# the ducc-shaped route (one call per spin group, no pipeline) through the same slabs
+	from pixell_amd import sht
+	mi = curvedsky.analyse_geometry(h_map.shape, wcs)
+	kw = dict(lmax=lmax, mstart=ainfo.mstart, geometry=mi.ducc_geo.name, phi0=mi.phi0, flip=tuple(bool(f) for f in mi.flip))
+	m2 = np.full((2,)+shape, np.nan); sht.synthesis_2d(alm=alm[1:], map=m2, spin=2, **kw)
+	assert np.array_equal(m2, d_map.tensor[1:].cpu().numpy())
+	a2 = np.zeros_like(alm[1:]); sht.analysis_2d(alm=a2, map=m2, spin=2, **kw)
+	assert np.array_equal(a2, d_back[1:].cpu().numpy())
+	# float32 maps, adjoint directions
+	x = rng.standard_normal((1,)+shape).astype(np.float32)
+	ax_h = np.zeros((1, ainfo.nelem), np.complex64); curvedsky.alm2map_adjoint(enmap.ndmap(x, wcs), alm=ax_h, spin=[0], ainfo=ainfo)
+	ax_d = torch.zeros((1, ainfo.nelem), dtype=torch.complex64, device="cuda"); curvedsky.alm2map_adjoint(enmap.dmap(torch.from_numpy(x).cuda(), wcs), alm=ax_d, spin=[0], ainfo=ainfo)
+	assert np.array_equal(ax_h, ax_d.cpu().numpy())
+	sht.clear_plans(); torch.cuda.empty_cache()
