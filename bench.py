@@ -122,7 +122,7 @@ def measured_traffic(config, dom):
 	profiles/r02_traffic_<config>.json; FETCH_SIZE corrected per access pattern -- x2 for 16-byte-per-lane row reads as the gfx950 note
 	of MI355X_MICROARCH.md prescribes, x1 where the known array sizes of the chain kernels show full counting -- WRITE_SIZE as reported).
 	Counters cannot be read from inside this process: null when no profile of this config is committed."""
-	for tag in ("r03", "r02", "r01"):
+	for tag in ("r04", "r03", "r02", "r01"):
 		path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config))
 		if os.path.exists(path): break
 	else: return dict(traffic=None)
@@ -438,7 +438,7 @@ def main():
 	# the grid has >= 2 lmax + 2 rings: same alm for band-limited maps, three theta-resampling stages instead of five.  Reported beside
 	# the default (the interpolant, which is what ducc0's analysis_2d integrates); never `value`.
 	ana_w = None
-	if ny >= 2*lmax+2 and world == 1 and not batched:
+	if ny >= 2*lmax+2 and world == 1 and not batched and not os.environ.get("PXS_BENCH_NO_WEIGHTS"):
 		try:
 			aw = torch.zeros_like(alm_out)
 			def wstep():

@@ -51,7 +51,7 @@ EXPORTS = ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_plan_destroy", "pxs_synthes
 	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxs_debug_chain", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]
 
 def lib_path():
-	# PIXELL_AMD_LIB: another build of the same library (kernel A/B experiments, tools/chain_exp*.sh)
+	# PIXELL_AMD_LIB: another build of the same library (kernel A/B experiments, tools/build_variants.sh, tools/gpu_v2lab.sh, tools/gpu_leg_ab.sh)
 	return os.environ.get("PIXELL_AMD_LIB") or os.path.join(HERE, "libpxsht.so")
 
 def load():

@@ -23,7 +23,7 @@ def fetch_factor(k):
 		if key in k: return f
 	return 2.0
 cfg, tag = sys.argv[1], sys.argv[2]
-ROUND_TRIPS = 2   # tools/pmc_traffic.sh runs bench.py --steps 1 --warmup 0: one validation round trip in setup + one timed
+ROUND_TRIPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3   # bench.py --steps 1 --warmup 0 with PXS_BENCH_NO_WEIGHTS=1: two round trips in the setup (cold call, second round trip) + one timed
 f = load(f"gpurun_out/pmc_fetch_{cfg}/f_counter_collection.csv", "FETCH_SIZE")
 w = load(f"gpurun_out/pmc_write_{cfg}/w_counter_collection.csv", "WRITE_SIZE")
 res = {}
