@@ -763,7 +763,8 @@ static LdsFft mk(FftContext* fc, long n, int maxr = 9) {
 	if (n <= 0) return f;
 	auto v = fc->view(n, maxr);
 	static const int nofft = [] { const char* e = getenv("PXS_CH_NOFFT"); return e ? atoi(e) : 0; }();     // timing experiments only (wrong results)
-	f.n = v.n; f.nfac = nofft ? 0 : v.nfac; f.ns = v.ns; f.generic = v.generic; f.pass = (const PassDesc*)v.pass; f.perm = v.perm; f.tw = v.tw; f.dn = make_fastdiv((uint32_t)n);
+	static const int nspad = [] { const char* e = getenv("PXS_CH_NS_PAD"); return e ? atoi(e) : 0; }();     // experiments: line stride (n | 1) + pad
+	f.n = v.n; f.nfac = nofft ? 0 : v.nfac; f.ns = v.ns + nspad; f.generic = v.generic; f.pass = (const PassDesc*)v.pass; f.perm = v.perm; f.tw = v.tw; f.dn = make_fastdiv((uint32_t)n);
 	return f;
 }
 

@@ -394,3 +394,58 @@ def test_adjointness_config3_gpu():
 	if free < 150e9: pytest.skip("needs ~150 GB of HBM")
 	e = check_adjointness((21600, 43200), 10000)
 	print("\n[adjointness 21600x43200 lmax 10000] %.2e" % e)
+
+def check_weights_analysis_fullsize(shape2, lmax, seed=21):
+	"""analysis="weights" (pxs_plan_option "analysis" = 1: ring weights + transposed theta upsampling, the reference's cyl route,
+	curvedsky.py:852-861, 1068-1084) at full size: (i) on a band-limited map it recovers the alm and equals the interpolant form; (ii) on
+	white noise it equals its definition, adjoint_synthesis_2d(map x get_gridweights / nphi) -- adjoint_synthesis_2d being checked against
+	the CPU at this size -- and differs from the interpolant form; (iii) its adjoint is adjoint to it."""
+	from pixell_amd import curvedsky, enmap, sht
+	torch = _torch(); dev = _dev()
+	shape, wcs = enmap.fullsky_geometry(shape=shape2)
+	ny, nx = shape; assert ny >= 2*lmax+2
+	mi = curvedsky.analyse_geometry(shape, wcs); ainfo = curvedsky.alm_info(lmax)
+	w = torch.as_tensor(sht.get_gridweights(mi.ducc_geo.name, ny)/nx, device=dev)
+	worst = 0.0
+	for spin in (0, 2):
+		nc = 1 if spin == 0 else 2
+		kw = dict(spin=spin, lmax=lmax, mstart=ainfo.mstart, geometry=mi.ducc_geo.name, phi0=mi.phi0, flip=tuple(bool(f) for f in mi.flip))
+		alm = make_alm(lmax, 3, seed+spin, dev)[:nc] if spin == 0 else make_alm(lmax, 3, seed+spin, dev)[1:]
+		m = torch.zeros((nc,)+tuple(shape), dtype=torch.float64, device=dev); sht.synthesis_2d(alm=alm, map=m, **kw)
+		aw = torch.zeros_like(alm); sht.analysis_2d(alm=aw, map=m, analysis="weights", **kw)
+		ai = torch.zeros_like(alm); sht.analysis_2d(alm=ai, map=m, **kw)
+		nrm = lambda t: float(t.abs().pow(2).mean().sqrt().item())
+		e1 = nrm(aw-alm)/nrm(alm); e2 = nrm(aw-ai)/nrm(alm)
+		assert e1 < TOL and e2 < 1e-11, "spin %d band-limited: %.3e from the alm, %.3e from the interpolant form" % (spin, e1, e2)
+		g = torch.Generator(device=dev); g.manual_seed(seed+5+spin)
+		x = torch.randn(m.shape, generator=g, device=dev, dtype=torch.float64)
+		sht.analysis_2d(alm=aw, map=x, analysis="weights", **kw)
+		ref = torch.zeros_like(alm); sht.adjoint_synthesis_2d(alm=ref, map=x*w[None, :, None], **kw)
+		e3 = nrm(aw-ref)/nrm(ref)
+		assert e3 < 1e-11, "spin %d noise: weights analysis differs from adjoint_synthesis_2d(map x weights) by %.3e" % (spin, e3)
+		sht.analysis_2d(alm=ai, map=x, **kw)
+		dform = nrm(aw-ai)/nrm(ai)      # the two forms are different estimators off band-limited input (1.5e-7 on white noise at C3, 1e-3 near ny = 2 lmax + 2)
+		assert dform > 1e-10, "the weights form and the interpolant form should differ on a map that is not band-limited"
+		back = torch.zeros_like(x); sht.adjoint_analysis_2d(alm=alm, map=back, analysis="weights", **kw)
+		lhs = alm_dot(aw, alm, lmax); rhs = float((x*back).sum().item())
+		e4 = abs(lhs-rhs)/max(np.sqrt(alm_dot(aw, aw, lmax)*alm_dot(alm, alm, lmax)), float(x.pow(2).sum().sqrt().item()*back.pow(2).sum().sqrt().item()))
+		assert e4 < 1e-11, "spin %d: adjoint of the weights analysis: %.3e" % (spin, e4)
+		worst = max(worst, e1, e2, e3, e4)
+		print("\n[weights analysis %dx%d spin %d] band-limited %.2e / %.2e, definition %.2e, adjoint %.2e; forms differ by %.2e on white noise" % (ny, nx, spin, e1, e2, e3, e4, dform))
+		del m, x, back, aw, ai, ref
+	sht.clear_plans()
+	if _gpu(): torch.cuda.empty_cache()
+	return worst
+
+@pytest.mark.hostsim
+def test_weights_analysis_fullsize_logic_hostsim():
+	check_weights_analysis_fullsize((64, 128), 30)
+
+@pytest.mark.gpu
+def test_weights_analysis_config3_gpu():
+	"""BASELINE config 3's grid (21600 rings >= 2 lmax + 2 at lmax 10^4)"""
+	torch = _torch()
+	free, _ = torch.cuda.mem_get_info()
+	if free < 150e9: pytest.skip("needs ~150 GB of HBM")
+	e = check_weights_analysis_fullsize((21600, 43200), 10000)
+	print("\n[weights analysis 21600x43200 lmax 10000] worst %.2e" % e)
