@@ -398,6 +398,9 @@ def main():
 	# north_star: alm must come back to < 1e-8 relative rms.  A throughput number of a transform that does not is worthless.
 	if not (rt_err < 1e-8) and not os.environ.get("PXS_BENCH_NOCHECK"): raise SystemExit("bench.py: round-trip rms error %.3e exceeds 1e-8 -- refusing to time a wrong transform" % rt_err)
 	info = plan.info()
+	# what map2alm integrates (include/pxsht.h, pxs_plan_option "analysis"): the default is ducc0's route as published
+	aform = dict(form={0: "interpolant", 1: "weights", 2: "ducc0"}[plan.query("analysis_form")], ncc_circle=plan.query("ncc_circle"), ducc_ncc_circle=plan.query("ducc_ncc_circle"),
+		note="ducc0 = the route of ducc0's analysis_2d as published (theta-interpolant, low-passed to |k| < N_cc, on the CC grid of N_cc + 1 rings, that grid's weights, transposed upsampling to the N_cc/2 + 1 rings of the Legendre stage); ncc_circle is the N_cc this plan runs, ducc_ncc_circle = 2 good_size_complex(lmax + 1)")
 	gather = None; side = None; ranks_seen = None
 	if (world > 1 or force_pg) and not args.no_gather:
 		rows = [ncomp*(pdist.shard_range(ntot, r, world)[1]-pdist.shard_range(ntot, r, world)[0]) for r in range(world)] if batched else [ncomp]*world
@@ -434,26 +437,31 @@ def main():
 	maps_total = ntot if batched else world
 	value = maps_total*args.steps/dt
 	cold["steady_ms"] = round(ms_step, 3)
-	# ---- the weights form of the analysis (pxs_plan_option "analysis" = 1; the reference's cyl route, curvedsky.py:852-861, 1068-1084) where
-	# the grid has >= 2 lmax + 2 rings: same alm for band-limited maps, three theta-resampling stages instead of five.  Reported beside
-	# the default (the interpolant, which is what ducc0's analysis_2d integrates); never `value`.
-	ana_w = None
-	if ny >= 2*lmax+2 and world == 1 and not batched and not os.environ.get("PXS_BENCH_NO_WEIGHTS"):
-		try:
-			aw = torch.zeros_like(alm_out)
-			def wstep():
-				curvedsky.map2alm(dmap, alm=aw, spin=cfg["spin"], ainfo=ainfo, analysis="weights")
-				curvedsky.alm2map(aw, dmap, spin=cfg["spin"], ainfo=ainfo)
-			wstep(); torch.cuda.synchronize()
-			w_err = float((aw-alm_out).abs().pow(2).mean().sqrt()/alm_out.abs().pow(2).mean().sqrt())
-			plan.profile(True); torch.cuda.synchronize(); tw = time.perf_counter()
-			for _ in range(args.steps): wstep()
-			torch.cuda.synchronize(); dtw = time.perf_counter()-tw
-			pw = plan.profile_read(reset=True); plan.profile_flops(reset=True); plan.profile(False)
-			ana_w = dict(ms_per_step=round(dtw/args.steps*1e3, 3), value=round(args.steps/dtw, 4), unit="round-trips/s", stage_ms_per_step={k: round(v[0]/args.steps, 3) for k, v in pw.items()},
-				alm_rms_difference_from_default=w_err, note="map2alm(..., analysis='weights') + alm2map; an option, not the default: on maps that are not band-limited the two forms differ")
-			del aw
-		except Exception as e: log("weights-analysis leg failed: %r" % (e,))
+	# ---- the other forms of the analysis (pxs_plan_option "analysis", include/pxsht.h), reported beside the default (ducc0's route as
+	# published: the fine-CC form); never `value`.  All give the same alm on the band-limited input of this bench.
+	#   "interpolant": exact quadrature of the full theta-interpolant (the default of rounds 1-3; a fine circle of M > N + 2 lmax points);
+	#   "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route (curvedsky.py:852-861, 1068-1084), where the
+	#              grid has >= 2 lmax + 2 rings: three theta-resampling stages instead of five.
+	ana_forms = None
+	if world == 1 and not batched and not os.environ.get("PXS_BENCH_NO_WEIGHTS"):
+		ana_forms = {}
+		for form in ["interpolant"]+(["weights"] if ny >= 2*lmax+2 else []):
+			try:
+				aw = torch.zeros_like(alm_out)
+				def wstep():
+					curvedsky.map2alm(dmap, alm=aw, spin=cfg["spin"], ainfo=ainfo, analysis=form)
+					curvedsky.alm2map(aw, dmap, spin=cfg["spin"], ainfo=ainfo)
+				wstep(); torch.cuda.synchronize()
+				w_err = float((aw-alm_out).abs().pow(2).mean().sqrt()/alm_out.abs().pow(2).mean().sqrt())
+				plan.profile(True); torch.cuda.synchronize(); tw = time.perf_counter()
+				for _ in range(args.steps): wstep()
+				torch.cuda.synchronize(); dtw = time.perf_counter()-tw
+				pw = plan.profile_read(reset=True); plan.profile_flops(reset=True); plan.profile(False)
+				ana_forms[form] = dict(ms_per_step=round(dtw/args.steps*1e3, 3), value=round(args.steps/dtw, 4), unit="round-trips/s", stage_ms_per_step={k: round(v[0]/args.steps, 3) for k, v in pw.items()},
+					alm_rms_difference_from_default=w_err)
+				del aw
+			except Exception as e: log("analysis form %s: leg failed: %r" % (form, e))
+		ana_forms["note"] = "map2alm(..., analysis=<form>) + alm2map; options, not the default (ducc0's route): on maps that are not band-limited the forms differ"
 
 	# ---- roofline of the dominant kernel family (Legendre; FP64 FMA bound) ----
 	R_syn, R_ana = info["nring_syn"], info["nring_ana"]
@@ -495,7 +503,7 @@ def main():
 		stage_note="stages run back to back on one stream (hipEvent-bracketed inside the library)",
 		plan_state="data-independent tables built with the plan or by its first transform (untimed warm-up): recurrence coefficients, twiddles, CC quadrature, and the recurrence seeds of DESIGN.md section 4; every timed step runs the full transform on the resident map",
 		hbm_algorithmic_GBps=round(hbm_gbs, 1), hbm_frac_of_8TBps=round(hbm_gbs/HBM_PEAK_GBS, 5),
-		cold_start=cold, analysis_weights=ana_w,
+		cold_start=cold, analysis_form=aform, analysis_other_forms=ana_forms,
 		roundtrip_rms_error=rt_err, ducc0=probe_ducc0())
 	if ranks_seen is not None: res["rccl_ranks_seen"] = ranks_seen; res["collective"] = gather.describe()
 	if rank == 0:

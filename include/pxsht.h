@@ -72,19 +72,31 @@ int pxs_synthesis(pxs_plan* plan, int spin, int mode, int adjoint, int nbatch,
                   void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride, void* stream);
 
 /* map -> alm (adjoint = 0: analysis_2d) or alm -> map (adjoint = 1: adjoint_analysis_2d).
- * Only for grid2d plans: exact quadrature of the theta-interpolant (curvedsky.py:1018-1048; batch loop :1038-1046). */
+ * Only for grid2d plans (curvedsky.py:1018-1048; batch loop :1038-1046); how the integral over theta is taken: pxs_plan_option. */
 int pxs_analysis(pxs_plan* plan, int spin, int adjoint, int nbatch,
                  void* map, int map_dtype, int64_t map_cstride, int64_t map_bstride,
                  void* alm, int alm_dtype, int64_t alm_cstride, int64_t alm_bstride, void* stream);
 
-/* Plan options.  "analysis": how pxs_analysis integrates over theta on grid2d plans --
- *   0 (default) "interpolant": exact quadrature of the theta-interpolant, exact down to ntheta = lmax + 1 (curvedsky.py:1018-1048);
+/* Plan options.  "analysis": how pxs_analysis integrates over theta on grid2d plans (CC, F1, MW, MWflip; DH and F2 always take ring
+ * weights) -- all forms give the same alm for band-limited maps and differ at the 1e-3 level on maps that are not --
+ *   2 (default) "ducc0": the route of ducc0's analysis_2d as published (ducc0 >= 0.36, src/ducc0/sht/sht.cc: analysis_2d ->
+ *     resample_to_prepared_CC; the reference calls it at curvedsky.py:1032-1046).  The theta-interpolant of the rings -- low-passed to
+ *     |k| < N_cc where the grid's circle has at least 2 N_cc samples -- is evaluated on the Clenshaw-Curtis grid of N_cc + 1 rings,
+ *     multiplied by that grid's quadrature weights and carried to the N_cc/2 + 1 rings of the Legendre stage by the transposed
+ *     band-limited upsampling; N_cc = 2 good_size_complex(lmax + 1) (ducc0's) whenever the grid's circle shares a usable factor with
+ *     it (pxs_plan_query "ncc_circle" tells).  A CC grid with ntheta >= 2 lmax + 2 is multiplied by its own weights directly (ducc0:
+ *     need_first_resample = false).  Plans without fused theta chains run the same form through the generic FFT engine.
+ *   0 "interpolant": exact quadrature of the full theta-interpolant (its product with |sin| on a circle of M > N + 2 lmax points);
  *   1 "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route (curvedsky.py:852-861, 1068-1084:
- *     get_gridweights / nphi, then adjoint_synthesis), applied when ntheta >= 2 lmax + 2, where it is exact for band-limited maps
- *     (smaller grids keep the interpolant).  The adjoint (adjoint = 1) follows the same choice: synthesis, then the weights.
- * Takes effect for the calls issued after it returns.
+ *     get_gridweights / nphi, then adjoint_synthesis), applied when ntheta >= 2 lmax + 2 (smaller grids take the default).
+ * The adjoint (adjoint = 1) is the exact transpose of the chosen form.  Takes effect for the calls issued after it returns.
  * "build_tables" (value = spin): builds the recurrence tables of that spin now instead of inside the first transform that needs them. */
 int pxs_plan_option(pxs_plan* plan, const char* name, int64_t value);
+
+/* What a plan does: "analysis_form" = the form pxs_analysis runs now (0 interpolant, 1 ring weights, 2 fine-CC form of ducc0's
+ * route), "ncc_circle" = N_cc, the circle of the CC grid of the Legendre stage (0: none), "ducc_ncc_circle" = ducc0's N_cc for
+ * the plan's lmax. */
+int pxs_plan_query(const pxs_plan* plan, const char* name, int64_t* value);
 
 /* ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855): out[ntheta], sum = 4 pi. Host memory. */
 int pxs_gridweights(const char* geometry, int ntheta, double* out);

@@ -91,8 +91,11 @@ def _resample_tables(geometry, ntheta, lmax):
 	_TABLES[key] = t
 	return t
 
-def theta_resample(L, par, geometry, ntheta, lmax, workers=None):
+def theta_resample(L, par, geometry, ntheta, lmax, workers=None, fine_cc=None):
 	"""Exact |sin|-weighted integration of the theta-interpolant, as samples on a CC grid.
+	fine_cc = N_cc: the fine-CC form instead (sht_oracle.analysis_2d, ducc0's route): the interpolant, low-passed to |k| < N_cc when
+	the circle has at least 2 N_cc samples, evaluated on the CC grid of N_cc + 1 rings and multiplied by that grid's quadrature
+	weights; the returned grid is that fine grid.
 
 	L[ncol, ntheta]: ring values of one m column each (any complex numbers: NOT required to be band limited);
 	par[ncol]: parity (m+spin) % 2 of each column.  Returns (theta_cc[ncc], G[ncol, ncc]) such that
@@ -119,6 +122,20 @@ def theta_resample(L, par, geometry, ntheta, lmax, workers=None):
 		X = F[:, K2]                                                  # (1/N) sum_j f_j (-1)^j
 		cspec[:, 0]  = 0.5*X*np.exp(+1j*K2*th0)                       # k = -N/2
 		cspec[:, -1] = 0.5*X*np.exp(-1j*K2*th0)                       # k = +N/2
+	if fine_cc:
+		Nf = int(fine_cc); M2 = 2*Nf
+		k = T["k"]
+		if M2 <= N: cspec = np.where((np.abs(k) < Nf)[None, :], cspec, 0)        # low pass (the Nyquist pair of N goes with it)
+		keep = np.abs(k) <= min(K2, Nf)
+		spec = np.zeros((ncol, M2), np.complex128)
+		np.add.at(spec, (slice(None), k[keep] % M2), cspec[:, keep])               # (|k| = N/2 < N_cc: the two halves of the Nyquist term land on k and -k)
+		fc = ifft(spec, axis=1)*M2                                                # f(2 pi j / M2)
+		nfr = Nf+1
+		psgn = np.where(par == 1, -1.0, 1.0)[:, None]
+		fpar = 0.5*(fc[:, :nfr]+psgn*fc[:, (-np.arange(nfr)) % M2])
+		w = so.get_gridweights("CC", nfr)/(2*np.pi)                               # sum = 2
+		theta_f = np.pi*np.arange(nfr)/Nf
+		return theta_f, fpar*w[None, :]
 	# h = f |sin|: Fourier coefficients |k| <= lmax by convolution with the |sin| series (full convolution via zero-padded FFTs)
 	H = ifft(fft(cspec, T["nf"], axis=1)*T["sfft"][None, :], axis=1)
 	# index i of H <-> k = i - K2 - Q
@@ -137,11 +154,11 @@ def theta_resample(L, par, geometry, ntheta, lmax, workers=None):
 	theta_cc = 2*np.pi*np.arange(ncc)/Ncc; theta_cc[-1] = np.pi
 	return theta_cc, G
 
-def analysis_columns(L, msel, spin, lmax, geometry, ntheta, nphi):
+def analysis_columns(L, msel, spin, lmax, geometry, ntheta, nphi, fine_cc=None):
 	"""analysis_2d restricted to the m columns msel.  L[len(msel), nc, ntheta] = sum_x ring[x] e^{-i m phi_x}
-	(the ring-FFT output, phi0 included).  Returns alm columns [len(msel), nc, lmax+1]."""
+	(the ring-FFT output, phi0 included).  Returns alm columns [len(msel), nc, lmax+1].  fine_cc = N_cc: the fine-CC form (ducc0's route)."""
 	L = np.asarray(L, np.complex128); nms, nc, nt = L.shape
 	par = (np.asarray(msel)+spin) % 2
-	th_cc, G = theta_resample(L.reshape(nms*nc, nt), np.repeat(par, nc), geometry, ntheta, lmax)
+	th_cc, G = theta_resample(L.reshape(nms*nc, nt), np.repeat(par, nc), geometry, ntheta, lmax, fine_cc=fine_cc)
 	G = G.reshape(nms, nc, -1)*(2*np.pi/nphi)
 	return sht_port.leg(spin, lmax, np.asarray(msel), th_cc, leg=G)

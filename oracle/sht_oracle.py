@@ -24,10 +24,14 @@ libsharp conventions, which docs/usage.rst:401-402 of the reference asserts):
             map[0] +- i map[1] = sum_lm (+-s a_lm) (+-s Y_lm)   (Goldberg sYlm).
   DERIV1  : spin-1 transform of E = sqrt(l(l+1)) a_lm, B = 0  -> (d_theta f, d_phi f / sin theta).
   adjoint_synthesis  = exact transpose of synthesis (a_lm = sum_pix map Y*_lm, no weights).
-  analysis_2d        = exact integration over the full theta circle, against |sin theta| Y*_lm,
-                       of the trigonometric interpolant of the parity-extended ring-FFT of the map: the left inverse of
-                       synthesis_2d for band-limited maps whenever the grid carries
-                       enough rings (curvedsky.py:1349-1353 get_ducc_maxlmax).
+  analysis_2d        = quadrature of the trigonometric interpolant (in theta) of the parity-extended ring-FFT of the map
+                       against Y*_lm: the left inverse of synthesis_2d for band-limited maps whenever the grid carries
+                       enough rings (curvedsky.py:1349-1353 get_ducc_maxlmax).  Default: ducc0's own route as its published
+                       source has it (Clenshaw-Curtis weights on the grid of 2 good_size_complex(lmax+1) + 1 rings, see
+                       analysis_2d below); fine_cc=False: the exact integral of the full interpolant against |sin theta|;
+                       weights=True: the grid's own quadrature weights.  The three agree on band-limited maps (pinned by the
+                       reference's round-trip tests, tests/golden/make_golden.py); on other maps they differ and which one
+                       ducc0 computes is NOT pinned by anything in the reference tree: parity unpinned there.
   adjoint_analysis_2d= exact transpose of analysis_2d.
 
 It is deliberately written differently from the HIP implementation so that agreement is
@@ -423,15 +427,18 @@ def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=No
 	return adjoint_synthesis(map=m2, alm=alm, theta=th, nphi=nphi, phi0=p0, ringstart=rs, lmax=lmax,
 		mmax=mmax, mstart=mstart, spin=spin, lstride=lstride, mode=mode)
 
-def _interp_matrix(geometry, ntheta, theta_out):
+def _interp_matrix(geometry, ntheta, theta_out, kcut=None):
 	"""Dense matrix M[g, j'] evaluating at theta_out the canonical trigonometric
-	interpolant through N full-circle samples at theta0 + 2 pi j'/N."""
+	interpolant through N full-circle samples at theta0 + 2 pi j'/N.
+	kcut (2 kcut <= N): the interpolant low-passed to |k| < kcut."""
 	g = grid_info(geometry, ntheta); N = g["N"]; t0 = float(g["theta0"])
 	d = np.asarray(theta_out, np.float64)[:, None] - (t0 + 2*np.pi*np.arange(N)/N)[None, :]
 	K = (N-1)//2
+	lowpass = kcut is not None and 2*kcut <= N
+	if lowpass: K = min(K, kcut-1)
 	M = np.ones_like(d)
 	for k in range(1, K+1): M += 2*np.cos(k*d)
-	if N % 2 == 0:
+	if N % 2 == 0 and not lowpass:
 		# Nyquist term: X_{N/2} cos((N/2)(theta-theta0)), X_{N/2} = sum_j g_j (-1)^j
 		sgn = 1-2*(np.arange(N) % 2)
 		M += np.cos((N//2)*(np.asarray(theta_out, np.float64)[:, None]-t0))*sgn[None, :]
@@ -450,11 +457,39 @@ def _gl(nq):
 	x, w = roots_legendre(nq)
 	return np.arccos(x)[::-1].copy(), w[::-1].copy()
 
+def good_size_complex(n):
+	"""smallest 2^a 3^b 5^c 7^d 11^e >= n (ducc0's good_size_complex; used for the ring count of its Legendre stage)"""
+	n = int(n)
+	while True:
+		m = n
+		for f in (2, 3, 5, 7, 11):
+			while m % f == 0: m //= f
+		if m == 1: return n
+		n += 1
+
+def _fine_cc_nodes(lmax, fine_cc):
+	"""circle length N_cc of the Legendre-stage CC grid of the fine-CC form, nodes and weights of the CC grid of N_cc + 1 rings the
+	weights are applied on.  fine_cc=True: ducc0's sizes (N_cc = 2 good_size_complex(lmax + 1)); an integer: that N_cc."""
+	Ncc = 2*good_size_complex(lmax+1) if fine_cc is True else int(fine_cc)
+	nf = Ncc+1
+	return Ncc, np.pi*np.arange(nf)/Ncc, get_gridweights("CC", nf)/(2*np.pi)
+
 def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0,
-		nthreads=0, lstride=1, weights=False):
-	"""ducc0.sht.experimental.analysis_2d (curvedsky.py:1032-1046): exact integration of
-	the theta-interpolant, evaluated here on Gauss-Legendre nodes.
-	weights=True (ours, the product's analysis="weights"): ring quadrature weights + adjoint synthesis, the reference's cyl route
+		nthreads=0, lstride=1, weights=False, fine_cc=True):
+	"""ducc0.sht.experimental.analysis_2d (curvedsky.py:1032-1046).
+	fine_cc=True (default) or an N_cc (the product's analysis="ducc0"): ducc0's own route for the CC / F1 / MW / MWflip grids as
+	published (ducc0 >= 0.36 is a PyPI dependency of the reference and is absent here; src/ducc0/sht/sht.cc, analysis_2d ->
+	resample_to_prepared_CC): the theta-interpolant of the rings -- low-passed to |k| < N_cc where the grid's circle has at least
+	2 N_cc samples -- is evaluated on the Clenshaw-Curtis grid of N_cc + 1 rings (circle of 2 N_cc points) and integrated with that
+	grid's quadrature weights; N_cc = 2 good_size_complex(lmax + 1) unless given.  (ducc0 then carries the weighted samples to the
+	N_cc/2 + 1 rings of its Legendre stage with the transposed band-limited upsampling, which changes nothing in exact arithmetic:
+	lambda_lm is band-limited to lmax < N_cc/2.)  Restated here as the direct sum over the N_cc + 1 rings.  A CC grid with
+	nt >= 2 lmax + 2 is multiplied by its own quadrature weights directly (ducc0: need_first_resample = false), i.e. weights=True.
+	On maps that are not band-limited the forms differ at the 1e-3 level, and no test or fixture of the reference pins which one
+	ducc0 computes: parity unpinned against ducc0 itself for such maps; on band-limited maps all forms agree and are pinned
+	(tests/golden/make_golden.py).
+	fine_cc=False (the product's analysis="interpolant"): exact integration of the full theta-interpolant, evaluated on Gauss-Legendre nodes.
+	weights=True (the product's analysis="weights"): ring quadrature weights + adjoint synthesis, the reference's cyl route
 	(curvedsky.py:852-861, 1068-1084); exact for band-limited maps on grids with nt >= 2 lmax + 2."""
 	map = np.asarray(map)
 	nc, nt, nph = map.shape
@@ -462,6 +497,7 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	if mstart is None: mstart = _tri_mstart(lmax, mmax)
 	if lmax > grid_maxlmax(geometry, nt):
 		raise ValueError("too few rings for analysis up to requested lmax")
+	if fine_cc is True and geometry == "CC" and nt >= 2*lmax+2: weights = True
 	if geometry in ("DH", "F2") or weights:
 		w = get_gridweights(geometry, nt)/nph
 		return adjoint_synthesis_2d(alm=alm, map=map*w[None, :, None], spin=spin, lmax=lmax,
@@ -469,10 +505,15 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	th, nphi, p0, rs = _grid_rings(geometry, nt, nph, phi0)
 	leg = map2leg(map.reshape(nc, -1), nphi, p0, rs, mmax)          # [nc, nt, nm]
 	N = grid_info(geometry, nt)["N"]
-	nq = (N//2 + lmax)//2 + 2
-	thq, wq = _gl(nq)
-	Ma = _interp_matrix(geometry, nt, thq)                          # [nq, N]  at theta_q
-	Mb = _interp_matrix(geometry, nt, 2*np.pi-thq)                  # at the mirror points 2pi - theta_q
+	if fine_cc:
+		Ncc, thq, wq = _fine_cc_nodes(lmax, fine_cc)
+		kcut = Ncc; nq = len(thq)
+	else:
+		nq = (N//2 + lmax)//2 + 2
+		thq, wq = _gl(nq)
+		kcut = None
+	Ma = _interp_matrix(geometry, nt, thq, kcut)                    # [nq, N]  at theta_q
+	Mb = _interp_matrix(geometry, nt, 2*np.pi-thq, kcut)            # at the mirror points 2pi - theta_q
 	ring, mirrored = _extension(geometry, nt, None)
 	par = ((np.arange(mmax+1)+spin) % 2)
 	sign = np.where(mirrored[:, None] & (par[None, :] == 1), -1.0, 1.0)   # [N, nm]
@@ -489,11 +530,12 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	return alm
 
 def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0,
-		nthreads=0, lstride=1, weights=False):
-	"""Exact transpose of analysis_2d (curvedsky.py:1032); weights=True: of its weights form (synthesis, then the ring weights)."""
+		nthreads=0, lstride=1, weights=False, fine_cc=True):
+	"""Exact transpose of analysis_2d (curvedsky.py:1032), form by form (same keywords)."""
 	nc, nt, nph = map.shape
 	if mmax is None: mmax = lmax
 	if mstart is None: mstart = _tri_mstart(lmax, mmax)
+	if fine_cc is True and geometry == "CC" and nt >= 2*lmax+2: weights = True
 	if geometry in ("DH", "F2") or weights:
 		w = get_gridweights(geometry, nt)/nph
 		synthesis_2d(alm=alm, map=map, spin=spin, lmax=lmax, geometry=geometry, mmax=mmax,
@@ -502,10 +544,15 @@ def adjoint_analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=Non
 		return map
 	th, nphi, p0, rs = _grid_rings(geometry, nt, nph, phi0)
 	N = grid_info(geometry, nt)["N"]
-	nq = (N//2 + lmax)//2 + 2
-	thq, wq = _gl(nq)
-	Ma = _interp_matrix(geometry, nt, thq)
-	Mb = _interp_matrix(geometry, nt, 2*np.pi-thq)
+	if fine_cc:
+		Ncc, thq, wq = _fine_cc_nodes(lmax, fine_cc)
+		kcut = Ncc; nq = len(thq)
+	else:
+		nq = (N//2 + lmax)//2 + 2
+		thq, wq = _gl(nq)
+		kcut = None
+	Ma = _interp_matrix(geometry, nt, thq, kcut)
+	Mb = _interp_matrix(geometry, nt, 2*np.pi-thq, kcut)
 	ring, mirrored = _extension(geometry, nt, None)
 	par = ((np.arange(mmax+1)+spin) % 2)
 	sign = np.where(mirrored[:, None] & (par[None, :] == 1), -1.0, 1.0)

@@ -477,7 +477,7 @@ long FftContext::good_size(long n) {
 static std::vector<int> factorize_comp(long n, int maxr) {
 	static const std::vector<int> allowed = [] {
 		std::vector<int> a; const char* e = getenv("PXS_FFT_RADICES");
-		std::string s = e ? e : "16,15,12,10,9,8,6,5,4,3,2";
+		std::string s = e ? e : "16,15,12,10,9,8,7,6,5,4,3,2";
 		size_t pos = 0;
 		while (pos < s.size()) { size_t c = s.find(',', pos); if (c == std::string::npos) c = s.size(); int v = atoi(s.substr(pos, c-pos).c_str()); if (v >= 2 && (v <= 5 || v <= PXS_COMP_MAXR)) a.push_back(v); pos = c+1; }
 		return a; }();
@@ -485,7 +485,7 @@ static std::vector<int> factorize_comp(long n, int maxr) {
 	std::function<void(long, size_t)> rec = [&](long m, size_t from) {
 		if (m == 1) { if (best.empty() || cur.size() < best.size()) best = cur; return; }
 		if (!best.empty() && cur.size()+1 >= best.size()) return;
-		for (size_t i = from; i < allowed.size(); i++) if (m % allowed[i] == 0 && (allowed[i] <= 5 || allowed[i] <= maxr)) { cur.push_back(allowed[i]); rec(m/allowed[i], i); cur.pop_back(); }
+		for (size_t i = from; i < allowed.size(); i++) if (m % allowed[i] == 0 && (allowed[i] == 7 ? maxr >= 9 : (allowed[i] <= 5 || allowed[i] <= maxr))) { cur.push_back(allowed[i]); rec(m/allowed[i], i); cur.pop_back(); }
 	};
 	rec(n, 0);
 	if (best.empty()) return factorize(n);
@@ -509,7 +509,8 @@ std::shared_ptr<FftSub> FftContext::sub(long n, bool comp, int maxr) {
 	for (int p = 0; p < s->nfac; p++) {
 		int R = s->fac[p];
 		const bool comp_r = comp && R <= maxr && (R == 6 || R == 8 || R == 9 || R == 10 || R == 12 || R == 15 || R == 16);
-		if (R != 2 && R != 3 && R != 4 && R != 5 && !comp_r) s->generic = true;
+		const bool seven = comp && R == 7 && maxr >= 9;      // plain radix 7 of the chain kernels' theta stages (fft_dev.hpp)
+		if (R != 2 && R != 3 && R != 4 && R != 5 && !comp_r && !seven) s->generic = true;
 		PassDesc& ps = s->pass[p];
 		ps.R = R; ps.L = L; ps.tws = (int)(n/((long)L*R));
 		ps.dL = make_fastdiv(L); ps.dnb = make_fastdiv((uint32_t)(n/R));

@@ -54,6 +54,27 @@ template<> __device__ __forceinline__ void butterfly<5>(double2* v) {
 	v[2] = cadd(m2, iu2); v[3] = csub(m2, iu2);
 }
 
+// (radix 7: only in the theta stages of the chain kernels -- ducc0's ring counts good_size_complex(lmax + 1) often carry a factor 7,
+// e.g. 10080 for lmax = 10000 and 4032 for lmax = 4000)
+template<> __device__ __forceinline__ void butterfly<7>(double2* v) {
+	const double c1 = 0.62348980185873353053, c2 = -0.22252093395631440429, c3 = -0.90096886790241912624;
+	const double s1 = 0.78183148246802980871, s2 = 0.97492791218182360702, s3 = 0.43388373911755812048;
+	const double2 a = v[0];
+	const double2 t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
+	const double2 d1 = csub(v[1], v[6]), d2 = csub(v[2], v[5]), d3 = csub(v[3], v[4]);
+	const double2 m1 = make_double2(a.x + c1*t1.x + c2*t2.x + c3*t3.x, a.y + c1*t1.y + c2*t2.y + c3*t3.y);
+	const double2 m2 = make_double2(a.x + c2*t1.x + c3*t2.x + c1*t3.x, a.y + c2*t1.y + c3*t2.y + c1*t3.y);
+	const double2 m3 = make_double2(a.x + c3*t1.x + c1*t2.x + c2*t3.x, a.y + c3*t1.y + c1*t2.y + c2*t3.y);
+	const double2 u1 = make_double2(s1*d1.x + s2*d2.x + s3*d3.x, s1*d1.y + s2*d2.y + s3*d3.y);
+	const double2 u2 = make_double2(s2*d1.x - s3*d2.x - s1*d3.x, s2*d1.y - s3*d2.y - s1*d3.y);
+	const double2 u3 = make_double2(s3*d1.x - s1*d2.x + s2*d3.x, s3*d1.y - s1*d2.y + s2*d3.y);
+	const double2 iu1 = mulmi(u1), iu2 = mulmi(u2), iu3 = mulmi(u3);   // -i*u
+	v[0] = make_double2(a.x + t1.x + t2.x + t3.x, a.y + t1.y + t2.y + t3.y);
+	v[1] = cadd(m1, iu1); v[6] = csub(m1, iu1);
+	v[2] = cadd(m2, iu2); v[5] = csub(m2, iu2);
+	v[3] = cadd(m3, iu3); v[4] = csub(m3, iu3);
+}
+
 // workgroup barrier that only waits for LDS traffic: __syncthreads() also drains vmcnt, which would stall on the
 // global loads the pipelined kernel keeps in flight for its next tile
 #ifdef PXS_HOST_SIM
@@ -164,6 +185,7 @@ template<int NT, int MAXR = PXS_COMP_MAXR> __device__ __forceinline__ void lds_f
 			case 4: radix_pass_t<4, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 5: radix_pass_t<5, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 6: if constexpr (MAXR >= 6) radix_pass_comp<3, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
+			case 7: if constexpr (MAXR >= 9) radix_pass_t<7, NT>(buf, tw, f.n, f.ns, T, ps); break;      // (theta stages only; FftContext::sub plans a 7 only for maxr >= 9)
 			case 8: if constexpr (MAXR >= 8) radix_pass_comp<4, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 9: if constexpr (MAXR >= 9) radix_pass_comp<3, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #if PXS_COMP_MAXR >= 10

@@ -1081,28 +1081,46 @@ static long smooth_at_least(long n, bool even_product_with = false, long g = 1) 
 	for (long m = std::max<long>(n, 2);; m++) if (smooth235(m) && (!even_product_with || ((m*g) % 2 == 0))) return m;
 }
 
+// lengths the theta stages (StFirst, StResize, StSigma, StSplit: lds_fft with MAXR = 9) transform: radix 7 next to 2, 3, 5
+static bool smooth2357(long n) { if (n < 1) return false; for (int p : {2, 3, 5, 7}) while (n % p == 0) n /= p; return n == 1; }
+static bool sub_ok7(long n) { return n >= 2 && n <= CH_NMAX && smooth2357(n); }
+// ducc0's good_size_complex: the smallest 2^a 3^b 5^c 7^d 11^e >= n.  Its analysis_2d / synthesis_2d run the Legendre stage on a CC grid of
+// good_size_complex(lmax + 1) + 1 rings, i.e. a circle of N_cc = 2 good_size_complex(lmax + 1) points.
+bool FftChain::sub_ok_theta(long n) { return sub_ok7(n); }
+long FftChain::ducc_ncc(int lmax) {
+	for (long n = std::max<long>(lmax + 1, 1);; n++) { long r = n; for (int p : {2, 3, 5, 7, 11}) while (r % p == 0) r /= p; if (r == 1) return 2*n; }
+}
+
 ThetaPlan FftChain::plan_theta(long N, int lmax) {
 	ThetaPlan best; double bestc = 1e300;
 	static const long gforce = [] { const char* e = getenv("PXS_THETA_G"); return e ? atol(e) : 0L; }();     // experiments: force the shared modulus
-	for (long g = 2; g <= 1024 && g <= N/2; g++) if (N % g == 0 && sub_ok(g) && sub_ok(N/g) && (!gforce || g == gforce)) {
-		ThetaPlan t; t.N = N; t.g = g; t.bN = N/g;
+	static const bool ducc_size = [] { const char* e = getenv("PXS_THETA_DUCC_NCC"); return e ? atoi(e) != 0 : true; }();     // 0: the planner's own N_cc only (rounds 1-3)
+	const long Nd = ducc_ncc(lmax);
+	auto consider = [&](long g, long ac) {
+		ThetaPlan t; t.N = N; t.g = g; t.bN = N/g; t.ac = ac; t.Ncc = g*ac;
 		t.g2 = smooth_at_least((N + 2L*lmax + 2 + g - 1)/g); t.M = g*t.g2;
-		t.ac = smooth_at_least((2L*lmax + 2 + g - 1)/g, true, g); t.Ncc = g*t.ac;
-		if (!sub_ok(t.g2) || !sub_ok(t.ac)) continue;
+		if ((t.Ncc & 1) || !sub_ok(t.g2) || !sub_ok7(t.ac)) return;
 		// synthesis split: gs divides both Ncc and N
 		long gs_best = 0; double gsc = 1e300;
-		for (long gs = 2; gs <= 1024; gs++) if (t.Ncc % gs == 0 && N % gs == 0 && sub_ok(gs) && sub_ok(t.Ncc/gs) && sub_ok(N/gs)) {
+		for (long gs = 2; gs <= 1024; gs++) if (t.Ncc % gs == 0 && N % gs == 0 && sub_ok7(gs) && sub_ok7(t.Ncc/gs) && sub_ok7(N/gs)) {
 			const double c = std::max({(double)gs, (double)(t.Ncc/gs), (double)(N/gs)});
 			if (c < gsc) { gsc = c; gs_best = gs; }
 		}
-		if (!gs_best) continue;
+		if (!gs_best) return;
 		t.gs = gs_best; t.bs = t.Ncc/gs_best; t.aNs = N/gs_best;
-		// cost: a CC ring costs far more (Legendre stage) than a point of FFT traffic; then traffic; then tile balance
+		// cost: a CC ring costs far more (Legendre stage) than a point of FFT traffic; then traffic; then tile balance.
+		// ducc0's own N_cc wins whenever some g realises it: the fine-CC form of the analysis then cuts the theta spectrum of a map
+		// that is not band-limited where ducc0 does (sht.hip, ana_set), and it is the smallest size ducc0 considers good.
 		const double lmin = 2.0*lmax + 2;
 		double c = 60.0*(t.Ncc - lmin)/lmin + (3.0*N + 4.0*t.M + 3.0*t.Ncc)/(3.0*N + 4.0*(N + lmin) + 3.0*lmin);
 		const double big = (double)std::max({t.g, t.bN, t.g2, t.ac});
 		if (big > 320) c += 0.05*(big - 320)/320;
+		if (ducc_size && t.Ncc == Nd) c -= 1000.0;
 		if (c < bestc) { bestc = c; best = t; best.ok = true; }
+	};
+	for (long g = 2; g <= 1024 && g <= N/2; g++) if (N % g == 0 && sub_ok7(g) && sub_ok7(N/g) && (!gforce || g == gforce)) {
+		consider(g, smooth_at_least((2L*lmax + 2 + g - 1)/g, true, g));
+		if (ducc_size && Nd % g == 0) consider(g, Nd/g);
 	}
 	return best;
 }
@@ -1224,7 +1242,10 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));
 			s.fa = mk(fc_, bN); s.fb = mk(fc_, g2);
-			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.M; s.kmax = -1; s.nyq = 1;
+			s.Y = s1_.as<double2>(); s.ldY = ldY1; s.Z = s2_.as<double2>(); s.ldZ = ldZ2; s.g = (int)g; s.X1 = (int)tp.N; s.X2 = (int)tp.M;
+			// M > N (the interpolant form; the fine-CC form on grids below ~2 lmax rings): zero padding, Nyquist bin of N split;
+			// M <= N (the fine-CC form on larger grids): low pass, |k| < M/2 kept
+			s.kmax = tp.M > tp.N ? -1 : (int)(tp.M/2 - 1); s.nyq = tp.M > tp.N ? 1 : 0;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
 			launch_any(s, ncl*npair*s.ntile, st);
@@ -1348,7 +1369,7 @@ void FftChain::to_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2*
 		}
 		{	StResize s; memset(&s, 0, sizeof(s));     // pass 2 of FFT_M, transposed padding M -> N (conjugate phase, Nyquist bins combined), pass 1 of IFFT_N
 			s.fa = mk(fc_, g2); s.fb = mk(fc_, bN);
-			s.Y = s1_.as<double2>(); s.ldY = ldV; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.N; s.kmax = -1; s.nyq = 0; s.adj = 1;
+			s.Y = s1_.as<double2>(); s.ldY = ldV; s.Z = s2_.as<double2>(); s.ldZ = ldZ; s.g = (int)g; s.X1 = (int)tp.M; s.X2 = (int)tp.N; s.kmax = tp.M > tp.N ? -1 : (int)(tp.M/2 - 1); s.nyq = 0; s.adj = 1;      // (M <= N: transpose of the low pass = zero padding of |k| < M/2)
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
 			set_tiles(s, T4, g, tp.N); s.bin = mk_blk(T3, g2, T4);      // (plain rows out: the transposing split takes one line of many pairs)
 			launch_any(s, ncl*npair*s.ntile, st);

@@ -28,12 +28,14 @@ public:
 	explicit FftChain(FftContext* fc) : fc_(fc) {}
 	// can the engine run its LDS passes on lines of this length (radices 2,3,4,5, length <= 512)?
 	static bool sub_ok(long n);
+	static bool sub_ok_theta(long n); // ... of the theta stages: radix 7 as well
 	static bool sub_ok2(long n);      // ... and the second-generation kernel (at most three register radices <= 10)
 	static long pad8(long n) { return (n + 7) & ~7L; }
 	// ring FFT split of nphi for analysis (map -> leg) and synthesis (h -> map); false: no usable factorisation
 	bool plan_rings(long nphi);
 	// theta chain sizes for a grid with N circle samples; picks Ncc (even, > 2 lmax + 1) and M (> N + 2 lmax)
 	static ThetaPlan plan_theta(long N, int lmax);
+	static long ducc_ncc(int lmax);     // 2 good_size_complex(lmax + 1): the circle of the CC grid ducc0 runs its Legendre stage on
 	bool rings_ok() const { return ra_.a > 0; }
 	std::string describe() const { return "analysis " + std::to_string(ra_.a) + "x" + std::to_string(ra_.b) + ", synthesis " + std::to_string(rs_.a) + "x" + std::to_string(rs_.b); }
 

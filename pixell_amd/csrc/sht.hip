@@ -340,8 +340,15 @@ struct pxs_plan {
 		if (gfork) (void)hipEventDestroy(gfork);
 	}
 	DevBuf wring;                // DH / F2 grids: per-ring quadrature weight / nphi (analysis = weighted adjoint synthesis)
-	int ana_weights = 0;         // pxs_plan_option("analysis"): 1 = ring weights + adjoint synthesis where ntheta >= 2 lmax + 2 (PXS_ANALYSIS=weights presets it)
-	DevBuf wgrid;                // ... its weights: get_gridweights / nphi per ring (built on first use)
+	int ana_weights = 2;         // pxs_plan_option("analysis"): 2 = ducc0's route (default: the fine-CC form; ring weights on CC grids with ntheta >= 2 lmax + 2),
+	                             // 0 = interpolant (|sin| series on the M circle), 1 = ring weights + adjoint synthesis where ntheta >= 2 lmax + 2;
+	                             // PXS_ANALYSIS=ducc0|interpolant|weights presets it
+	// the fine-CC form of the analysis (ducc0's resample_to_prepared_CC as published: the theta-interpolant, low-passed where the grid
+	// has more than 2 N_cc circle samples, is evaluated on the CC grid of N_cc + 1 rings, multiplied by that grid's quadrature weights
+	// and carried to the N_cc/2 + 1 rings of the Legendre stage by the transposed upsampling): the chain of the interpolant form with
+	// M = 2 N_cc and the weights as the pointwise table
+	ThetaPlan tpf; DevBuf sigma_f, wcc_f, whalf_f; long Mf = 0;      // tpf.ok: through the fused chains; Mf > 0: the tables exist (the unfused engine takes any plan)
+	DevBuf wgrid, wgrid_ext, wunit_ext;     // ... its weights: get_gridweights / nphi per ring (built on first use); _ext: self-mirrored rings doubled (ring_weights_ext)
 	bool syn_via_cc = false, syn_via_cc0 = false;      // synthesis through the CC grid: spin s / spin 0 (the recurrence of spin 0 is 4x cheaper per ring, the resampling is not)
 	bool ring_pairs = true;      // transform two real rings per complex FFT (PXS_RING_PAIRS=0 disables)
 	FftContext* fc = nullptr;
@@ -387,7 +394,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 		const char* e = getenv("PXS_PART_GB"); if (e) p->wk.part_budget = (size_t)atol(e) << 30;
 	}
 	{ const char* e = getenv("PXS_RESAMPLE_MB"); if (e) p->resample_chunk_bytes = (size_t)atol(e) << 20; }
-	{ const char* e = getenv("PXS_ANALYSIS"); if (e && std::string(e) == "weights") p->ana_weights = 1; }
+	{ const char* e = getenv("PXS_ANALYSIS"); if (e) { const std::string v(e); p->ana_weights = v == "weights" ? 1 : (v == "ducc0" ? 2 : (v == "interpolant" ? 0 : p->ana_weights)); } }
 	if (p->general) return;      // per-ring lengths and phases: see setup_general
 	std::string why;
 	if (!FftContext::supported(p->nphi, &why)) throw Error(PXS_ERR_UNSUPPORTED, why);
@@ -410,6 +417,11 @@ void setup_resampling(pxs_plan* p) {
 	p->Ncc = FftContext::good_size(std::max<long>(2L*lmax + 2, 4));
 	if (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
 	while (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
+	{	// ducc0's own N_cc = 2 good_size_complex(lmax + 1) where the FFT engine takes it and twice it (the fused chains decide for themselves below)
+		static const bool ducc_size = [] { const char* e = getenv("PXS_THETA_DUCC_NCC"); return e ? atoi(e) != 0 : true; }();
+		const long nd = FftChain::ducc_ncc(lmax);
+		if (ducc_size && nd >= 4 && FftContext::supported(nd) && FftContext::supported(2*nd)) p->Ncc = nd;
+	}
 	p->M = FftContext::good_size(p->N + 2L*lmax + 2);
 	{ const char* e = getenv("PXS_M_FINE"); if (e && atol(e) >= p->M && FftContext::supported(atol(e))) p->M = atol(e); }   // experiments: a larger fine grid with friendlier factors
 	if (p->chain_rings) {	// the fused theta chains need N, M and Ncc to share a modulus: let their planner pick M and Ncc
@@ -463,6 +475,25 @@ void setup_resampling(pxs_plan* p) {
 		std::vector<double2> wa(p->ncc);
 		for (int j = 0; j < p->ncc; j++) wa[j] = make_double2(((j == 0 || j == p->ncc-1) ? 0.5 : 1.0)/(double)p->Ncc, 0.0);
 		p->wadj = upload(wa); }
+	if (FftContext::supported(2*p->Ncc)) {	// the fine-CC form: M = 2 N_cc (through the fused chains: = g * (2 ac))
+		if (p->tp.ok && FftChain::sub_ok_theta(2*p->tp.ac)) { p->tpf = p->tp; p->tpf.g2 = 2*p->tp.ac; p->tpf.M = 2*p->Ncc; } else p->tpf.ok = false;
+		const long Mf = p->Mf = 2*p->Ncc; const int nf = (int)(Mf/2 + 1);
+		std::vector<double> gw(nf);
+		if (pxs_gridweights("CC", nf, gw.data()) != 0) throw Error(PXS_ERR_ARG, get_last_error());
+		// table on the circle: (Mf / 2 pi) x the weight of the full-circle rule int g |sin| = sum_i t_i g(theta_i): ring weight
+		// (sum over the rings = 2) at both images of a ring, twice that at the two poles, which the circle holds once
+		std::vector<double2> sg(Mf);
+		for (long i = 0; i < Mf; i++) {
+			const long r = std::min(i, Mf - i);
+			const LDb wr = (LDb)gw[r]/(2*PIl)*((r == 0 || r == Mf/2) ? 2 : 1);
+			sg[i] = make_double2((double)(wr*(LDb)Mf/(2*PIl)), 0.0);
+		}
+		p->sigma_f = upload(sg);
+		const double f = (double)p->M/(double)Mf;       // the FFT normalisation 1/(N M) of the weights, for this M
+		std::vector<double2> wf(w), whf(w);
+		for (int j = 0; j < p->ncc; j++) { wf[j].x *= f; whf[j].x *= (j == 0 || j == p->ncc-1) ? f : 0.5*f; }
+		p->wcc_f = upload(wf); p->whalf_f = upload(whf);
+	}
 }
 
 // tables of a general ring set: groups of equal length, z offsets, the block table of the gen_* kernels
@@ -642,12 +673,14 @@ void leg2map(pxs_plan* p, hipStream_t st, const double2* leg, long ldleg, void* 
 // Columns m and m+1 have opposite theta-parity, so their mirror extensions are the even and the odd part
 // of ONE sequence: each pair shares the whole 4-FFT chain (every stage is linear and commutes with the
 // reflection theta -> -theta) and is separated again at the end -- half the FFT work.
-void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2* leg_cc, int nc, int spin) {
+// (M, sigma, w: the fine circle, the pointwise table on it and the CC weights of the form of the analysis -- the |sin| series on
+// M > N + 2 lmax points, or ducc0's route: the CC weights on M = 2 N_cc points, with the spectrum cut to |k| < M/2 when M <= N)
+void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2* leg_cc, int nc, int spin, long M, const double2* sigma, const double2* wcc) {
 	const int nm = p->mmax+1, nr = p->nring;
 	const long npair_all = (nm + 1)/2;
-	const long chunk = std::max<long>(32, std::min<long>(npair_all, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->M))));
+	const long chunk = std::max<long>(32, std::min<long>(npair_all, (long)(p->resample_chunk_bytes/(sizeof(double2)*M))));
 	p->b1.ensure(sizeof(double2)*(size_t)chunk*std::max(p->N, p->Ncc));
-	p->b2.ensure(sizeof(double2)*(size_t)chunk*p->M);
+	p->b2.ensure(sizeof(double2)*(size_t)chunk*M);
 	p->prof.begin(st, PXS_STAGE_RESAMPLE);
 	for (int c = 0; c < nc; c++)
 	for (long p0 = 0; p0 < npair_all; p0 += chunk) {
@@ -661,27 +694,27 @@ void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2*
 			p->fc->exec(st, p->N, true, d, ld, sf);
 		}
 		{	// (b) shift to theta0 = 0, pad to M, backward FFT_M, multiply by the |sin| series
-			FftDims d; d.n_i = np; d.is_i = p->N; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
-			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->N; ld.nyq_half = 1; ld.mul = p->ph_shift.as<double2>();
-			FftStore sf; sf.ptr = p->b2.p; sf.mul = p->sigma.as<double2>();
-			p->fc->exec(st, p->M, false, d, ld, sf);
+			FftDims d; d.n_i = np; d.is_i = p->N; d.os_i = M; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->N; ld.nyq_half = M > p->N ? 1 : 0; ld.kmax = M > p->N ? -1 : M/2 - 1; ld.mul = p->ph_shift.as<double2>();
+			FftStore sf; sf.ptr = p->b2.p; sf.mul = sigma;
+			p->fc->exec(st, M, false, d, ld, sf);
 		}
 		{	// (c) forward FFT_M in place; only |k| <= lmax are needed
-			FftDims d; d.n_i = np; d.is_i = p->M; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftDims d; d.n_i = np; d.is_i = M; d.os_i = M; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b2.p;
 			FftStore sf; sf.ptr = p->b2.p; sf.two_sided_k = p->lmax;
-			p->fc->exec(st, p->M, true, d, ld, sf);
+			p->fc->exec(st, M, true, d, ld, sf);
 		}
 		{	// (d) truncate to |k| <= lmax, backward FFT_Ncc onto the full CC circle
-			FftDims d; d.n_i = np; d.is_i = p->M; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
-			FftLoad ld; ld.ptr = p->b2.p; ld.mode = LD_SPEC; ld.ne = p->M; ld.kmax = p->lmax;
+			FftDims d; d.n_i = np; d.is_i = M; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b2.p; ld.mode = LD_SPEC; ld.ne = M; ld.kmax = p->lmax;
 			FftStore sf; sf.ptr = p->b1.p;
 			p->fc->exec(st, p->Ncc, false, d, ld, sf);
 		}
 		{	// (e) separate the pair by reflection symmetry, keep rings 0..ncc-1, apply the quadrature weights
 			const long tot = np*p->ncc;
 			hipLaunchKernelGGL(split_pair, dim3((unsigned)((tot+255)/256)), dim3(256), 0, st, (const double2*)p->b1.p,
-				leg_cc + ((size_t)c*nm + m0)*p->ncc, p->ncc, p->Ncc, 0, np, nlines, (spin + (int)m0) & 1, p->wcc.as<double2>(), 1.0);
+				leg_cc + ((size_t)c*nm + m0)*p->ncc, p->ncc, p->Ncc, 0, np, nlines, (spin + (int)m0) & 1, wcc, 1.0);
 		}
 	}
 	p->prof.end(st, PXS_STAGE_RESAMPLE);
@@ -689,36 +722,37 @@ void resample_to_cc(pxs_plan* p, hipStream_t st, const double2* leg_in, double2*
 }
 
 // exact transpose of resample_to_cc: leg on the CC grid [c][m][ncc] -> leg on the map's rings [c][m][nring]
-void resample_to_cc_adjoint(pxs_plan* p, hipStream_t st, const double2* leg_cc, double2* leg_out, int nc, int spin) {
+void resample_to_cc_adjoint(pxs_plan* p, hipStream_t st, const double2* leg_cc, double2* leg_out, int nc, int spin, long M, const double2* sigma, const double2* wcc) {
 	const int nm = p->mmax+1, nr = p->nring;
-	const long chunk = std::max<long>(32, std::min<long>(nm, (long)(p->resample_chunk_bytes/(sizeof(double2)*p->M))));
+	const long chunk = std::max<long>(32, std::min<long>(nm, (long)(p->resample_chunk_bytes/(sizeof(double2)*M))));
 	p->b1.ensure(sizeof(double2)*(size_t)chunk*std::max(p->N, p->Ncc));
-	p->b2.ensure(sizeof(double2)*(size_t)chunk*p->M);
+	p->b2.ensure(sizeof(double2)*(size_t)chunk*M);
 	p->prof.begin(st, PXS_STAGE_RESAMPLE);
 	for (int c = 0; c < nc; c++)
 	for (long m0 = 0; m0 < nm; m0 += chunk) {
 		const long nl = std::min<long>(chunk, nm - m0);
 		{	// (d)^H: weights, zero-extend the rings to the Ncc circle, forward FFT_Ncc
 			FftDims d; d.n_i = nl; d.is_i = p->ncc; d.os_i = p->Ncc; d.is_e = 1; d.os_e = 1;
-			FftLoad ld; ld.ptr = leg_cc + ((size_t)c*nm + m0)*p->ncc; ld.ne = p->ncc; ld.mul = p->wcc.as<double2>();
+			FftLoad ld; ld.ptr = leg_cc + ((size_t)c*nm + m0)*p->ncc; ld.ne = p->ncc; ld.mul = wcc;
 			FftStore sf; sf.ptr = p->b1.p;
 			p->fc->exec(st, p->Ncc, true, d, ld, sf);
 		}
 		{	// (c)^H: embed |k| <= lmax into the M spectrum, backward FFT_M, multiply by the |sin| series
-			FftDims d; d.n_i = nl; d.is_i = p->Ncc; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftDims d; d.n_i = nl; d.is_i = p->Ncc; d.os_i = M; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b1.p; ld.mode = LD_SPEC; ld.ne = p->Ncc; ld.kmax = p->lmax;
-			FftStore sf; sf.ptr = p->b2.p; sf.mul = p->sigma.as<double2>();
-			p->fc->exec(st, p->M, false, d, ld, sf);
+			FftStore sf; sf.ptr = p->b2.p; sf.mul = sigma;
+			p->fc->exec(st, M, false, d, ld, sf);
 		}
 		{	// (b)^H first half: forward FFT_M in place (only |k| <= N/2 needed)
-			FftDims d; d.n_i = nl; d.is_i = p->M; d.os_i = p->M; d.is_e = 1; d.os_e = 1;
+			FftDims d; d.n_i = nl; d.is_i = M; d.os_i = M; d.is_e = 1; d.os_e = 1;
 			FftLoad ld; ld.ptr = p->b2.p;
-			FftStore sf; sf.ptr = p->b2.p; sf.two_sided_k = p->N/2;
-			p->fc->exec(st, p->M, true, d, ld, sf);
+			FftStore sf; sf.ptr = p->b2.p; sf.two_sided_k = M > p->N ? p->N/2 : -1;
+			p->fc->exec(st, M, true, d, ld, sf);
 		}
 		{	// (b)^H second half + (a)^H FFT: truncate M -> N with the Nyquist combination and conj phase, backward FFT_N
-			FftDims d; d.n_i = nl; d.is_i = p->M; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
-			FftLoad ld; ld.ptr = p->b2.p; ld.mode = LD_SPEC_ADJ; ld.ne = p->M; ld.nyq_half = 1; ld.mul = p->ph_shift.as<double2>();
+			// (M <= N: the transpose of the low pass, zero padding of |k| < M/2)
+			FftDims d; d.n_i = nl; d.is_i = M; d.os_i = p->N; d.is_e = 1; d.os_e = 1;
+			FftLoad ld; ld.ptr = p->b2.p; ld.mode = LD_SPEC_ADJ; ld.ne = M; ld.nyq_half = M > p->N ? 1 : 0; ld.kmax = M > p->N ? -1 : M/2 - 1; ld.mul = p->ph_shift.as<double2>();
 			FftStore sf; sf.ptr = p->b1.p;
 			p->fc->exec(st, p->N, false, d, ld, sf);
 		}
@@ -902,13 +936,25 @@ int pxs_plan_option(pxs_plan* p, const char* name, int64_t value) {
 	PXS_TRY
 	PXS_REQUIRE(p && name, "pxs_plan_option: null argument");
 	if (std::string(name) == "analysis") {
-		PXS_REQUIRE(value == 0 || value == 1, "pxs_plan_option: analysis takes 0 (interpolant) or 1 (weights)");
+		PXS_REQUIRE(value >= 0 && value <= 2, "pxs_plan_option: analysis takes 0 (interpolant), 1 (weights) or 2 (ducc0)");
 		p->ana_weights = (int)value;
 	} else if (std::string(name) == "build_tables") {      // build the recurrence tables of spin `value` now rather than in the first transform (cold-start accounting of bench.py)
 		PXS_REQUIRE(value >= 0 && value <= p->lmax + 1, "pxs_plan_option: build_tables takes a spin");
 		PXS_HIP(hipSetDevice(p->device));
 		(void)p->table((int)value);
 	} else throw Error(PXS_ERR_ARG, std::string("pxs_plan_option: unknown option '") + name + "'");
+	PXS_CATCH
+}
+
+static int ana_form_now(const pxs_plan* p);
+int pxs_plan_query(const pxs_plan* p, const char* name, int64_t* value) {
+	PXS_TRY
+	PXS_REQUIRE(p && name && value, "pxs_plan_query: null argument");
+	const std::string n(name);
+	if (n == "analysis_form") *value = ana_form_now(p);
+	else if (n == "ncc_circle") *value = p->ncc > 0 ? p->Ncc : 0;
+	else if (n == "ducc_ncc_circle") *value = FftChain::ducc_ncc(p->lmax);
+	else throw Error(PXS_ERR_ARG, std::string("pxs_plan_query: unknown name '") + name + "'");
 	PXS_CATCH
 }
 
@@ -947,8 +993,9 @@ int pxs_debug_chain(pxs_plan* p, int kind, int nc, int spin, int reps, double* m
 		switch (kind) {
 		case 0: p->chain->map2leg(st, md, nc, p->mmax, p->leg.as<double2>(), ldm, p->phase.as<double2>(), 1.0); break;
 		case 1: p->chain->h2map(st, p->hbuf.as<double2>(), ldh, md, nc, p->mmax); break;
-		case 2: p->chain->to_cc(st, p->tp, p->leg.as<double2>(), ldm, p->nring, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, (int)nm, spin, p->lmax,
-				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>()); break;
+		case 2: { const bool f = p->ana_weights != 0 && p->Mf > 0 && p->tpf.ok;      // (the form the plan's analysis option selects)
+			p->chain->to_cc(st, f ? p->tpf : p->tp, p->leg.as<double2>(), ldm, p->nring, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, (int)nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), (f ? p->sigma_f : p->sigma).as<double2>(), (f ? p->wcc_f : p->wcc).as<double2>()); } break;
 		case 3: p->chain->from_cc(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, p->nring, p->mir_c, nc, (int)nm, spin, p->lmax,
 				p->ph_up.as<double2>(), p->phase.as<double2>(), 1.0/(double)p->Ncc); break;
 		default: p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldm, p->nring, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nc, (int)nm, spin, p->lmax,
@@ -1004,10 +1051,24 @@ enum AnaPath {
 static bool adj_ana_fused() { const char* e = getenv("PXS_ADJ_ANA_FUSED"); return e ? atoi(e) != 0 : true; }      // (read per call: the tests switch it)
 static AnaPath ana_path(const pxs_plan* p, int adjoint) {
 	if (p->wring.p) return ANA_RING_WEIGHTS;
-	if (p->ana_weights && (long)p->nring >= 2L*p->lmax + 2)
-		return (p->geometry == "F1" && p->chain_theta() && p->ncc > 0) ? ANA_CC_WEIGHTS : ANA_RING_WEIGHTS;
-	if (p->chain_theta() && (!adjoint || adj_ana_fused())) return ANA_CHAIN;
-	return ANA_UNFUSED;
+	// ring weights on the map's own rings: the weights option, and ducc0's route on CC grids with >= 2 lmax + 2 rings (its
+	// resample_to_prepared_CC multiplies such a grid by its weights directly: need_first_resample is false for it)
+	if ((p->ana_weights == 1 || (p->ana_weights == 2 && p->geometry == "CC")) && (long)p->nring >= 2L*p->lmax + 2)
+		return (p->chain_theta() && p->ncc > 0) ? ANA_CC_WEIGHTS : ANA_RING_WEIGHTS;
+	const bool fine = p->ana_weights != 0 && p->Mf > 0;        // the fine-CC form (default; the weights option on a grid below 2 lmax + 2 rings takes it too)
+	if (p->chain_theta() && (fine ? p->tpf.ok : (!adjoint || adj_ana_fused()))) return ANA_CHAIN;
+	return ANA_UNFUSED;      // (also: the fine-CC form on a plan whose chains cannot hold the circle of 2 N_cc points)
+}
+// tables of the interpolating forms of the analysis (fused chains or the unfused engine): the fine-CC form, else the interpolant form
+struct AnaSet { const ThetaPlan* tp; const double2* sigma; const double2* wcc; const double2* whalf; long M; bool fine; };
+static AnaSet ana_set(const pxs_plan* p) {
+	if (p->ana_weights != 0 && p->Mf > 0) return AnaSet{&p->tpf, p->sigma_f.as<double2>(), p->wcc_f.as<double2>(), p->whalf_f.as<double2>(), p->Mf, true};
+	return AnaSet{&p->tp, p->sigma.as<double2>(), p->wcc.as<double2>(), p->whalf.as<double2>(), p->M, false};
+}
+static int ana_form_now(const pxs_plan* p) {
+	const AnaPath path = ana_path(p, 0);
+	if (path == ANA_RING_WEIGHTS || path == ANA_CC_WEIGHTS) return 1;
+	return ana_set(p).fine ? 2 : 0;
 }
 // per-ring weight / nphi of the ring-weights paths (DH / F2: fixed at plan time; the weights option: built on first use)
 static const double2* ring_weights(pxs_plan* p) {
@@ -1020,6 +1081,31 @@ static const double2* ring_weights(pxs_plan* p) {
 		p->wgrid = upload(wd);
 	}
 	return p->wgrid.as<double2>();
+}
+// ... for the transposed theta upsampling (FftChain::from_cc_adjoint): its first stage extends the weighted ring samples to the circle
+// by reflection, which holds a self-mirrored ring (the pole rings of CC, one of MW / MWflip) once and every other ring twice -- the
+// zero extension it stands for is half the sum of the symmetric and the antisymmetric one, so the self-mirrored rings count double
+static const double2* ring_weights_ext(pxs_plan* p) {
+	const double2* w = ring_weights(p);
+	if (p->geometry == "F1") return w;
+	if (!p->wgrid_ext.p) {
+		std::vector<double2> wd(p->nring);
+		PXS_HIP(hipMemcpy(wd.data(), w, sizeof(double2)*p->nring, hipMemcpyDeviceToHost));
+		for (int r = 0; r < p->nring; r++) { const long t = 2L*r + p->mir_c; if (t == 0 || t == p->N || t == 2*p->N) wd[r].x *= 2; }
+		p->wgrid_ext = upload(wd);
+	}
+	return p->wgrid_ext.as<double2>();
+}
+
+// unit weights for the transposed theta upsampling on grids with self-mirrored rings (see ring_weights_ext); null on F1 grids
+static const double2* unit_weights_ext(pxs_plan* p) {
+	if (p->geometry == "F1" || p->band) return nullptr;
+	if (!p->wunit_ext.p) {
+		std::vector<double2> wd(p->nring, make_double2(1, 0));
+		for (int r = 0; r < p->nring; r++) { const long t = 2L*r + p->mir_c; if (t == 0 || t == p->N || t == 2*p->N) wd[r].x = 2; }
+		p->wunit_ext = upload(wd);
+	}
+	return p->wunit_ext.as<double2>();
 }
 
 // nb maps of one call (nb > 1 only on the fused-chain paths): ring FFTs of all maps in one launch each, theta chains and
@@ -1064,10 +1150,11 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 			leg2map(p, st, p->leg.as<double2>(), ldm, map, map_dtype, map_cstride, nct, false, map_bstride, ncb);
 		}
 	} else {
-		// the transpose of the synthesis through the CC grid, where that is the cheaper synthesis: F1 grids (no self-mirrored rings)
-		// and bands of them (rows outside the band are zero)
+		// the transpose of the synthesis through the CC grid, where that is the cheaper synthesis: grids (self-mirrored rings of
+		// CC / MW / MWflip count double in the reflection that stands for the zero extension, unit_weights_ext) and bands of F1 grids
+		// (rows outside the band are zero)
 		static const bool adj_cc = [] { const char* e = getenv("PXS_ADJ_VIA_CC"); return e ? atoi(e) != 0 : true; }();
-		const bool via = adj_cc && (p->is_grid || p->band) && th && p->geometry == "F1" && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
+		const bool via = adj_cc && (p->is_grid || p->band) && th && (p->is_grid || p->geometry == "F1") && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
 		if (via && p->band) {
 			const long ldf = FftChain::pad8(p->nfull);
 			p->leg.ensure(sizeof(double2)*(size_t)nct*nm*ldf);
@@ -1079,7 +1166,7 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 			p->leg2.ensure(sizeof(double2)*(size_t)nct*nm*ldc);
 			p->prof.begin(st, PXS_STAGE_RESAMPLE);
 			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldin, p->band ? p->nfull : nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
-				p->ph_shift.as<double2>(), p->wadj.as<double2>());
+				p->ph_shift.as<double2>(), p->wadj.as<double2>(), unit_weights_ext(p));
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
 			leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
 				mode == PXS_MODE_DERIV1, &p->prof, ldc, nb, alm_bstride, (long)ncm*nm*ldc);
@@ -1103,7 +1190,7 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 	const bool via_cc = (p->is_grid || (p->band && th)) && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
 	LegTables& tb = p->table(spin);
 	size_t c1 = 0, c2 = 0, r1 = 0;
-	auto theta = [&](int kind) { if (th) FftChain::theta_scratch(p->tp, (int)nm, nct, kind, c1, c2); };
+	auto theta = [&](int kind) { if (th) FftChain::theta_scratch((kind == 0 || kind == 3) ? *ana_set(p).tp : p->tp, (int)nm, nct, kind, c1, c2); };
 	if (synthesis && !adjoint) {                        // alm -> map
 		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4)*nb);
 		p->leg.ensure(c16*nct*nm*ldm);
@@ -1112,7 +1199,7 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 		p->chain->ring_scratch(p->nring, nct, false, r1);
 	} else if (synthesis) {                             // map -> alm, transpose of the synthesis
 		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1)*nb);
-		const bool via = (p->is_grid || p->band) && th && p->geometry == "F1" && via_cc;
+		const bool via = (p->is_grid || p->band) && th && (p->is_grid || p->geometry == "F1") && via_cc;
 		p->leg.ensure(c16*nct*nm*(via && p->band ? (size_t)FftChain::pad8(p->nfull) : ldm));
 		if (via) { p->leg2.ensure(c16*nct*nm*ldc); theta(1); }
 		p->chain->ring_scratch(p->nring, nct, true, r1);
@@ -1172,6 +1259,7 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 	const int nm = p->mmax+1, nr = p->nring;
 	LegTables& tb = p->table(spin);
 	const AnaPath path = ana_path(p, adjoint);
+	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] analysis path %d (0 ring weights, 1 weights via the CC grid, 2 chain, 3 unfused), option %d, adjoint %d\n", (int)path, p->ana_weights, adjoint);
 	if (path == ANA_RING_WEIGHTS) {	// DH / F2 (and the weights option off the CC detour): analysis = adjoint synthesis of the weighted map (its adjoint: synthesis, then the weights)
 		const double2* wr = ring_weights(p);
 		const long ldw = p->chain_rings ? FftChain::pad8(nr) : nr;
@@ -1206,7 +1294,7 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 			map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
 			p->prof.begin(st, PXS_STAGE_RESAMPLE);
 			p->chain->from_cc_adjoint(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
-				p->ph_shift.as<double2>(), p->wadj.as<double2>(), wr);
+				p->ph_shift.as<double2>(), p->wadj.as<double2>(), ring_weights_ext(p));
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
 			leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
 		} else {
@@ -1229,8 +1317,9 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride,
 			p->leg2.as<double2>(), 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
 		p->prof.begin(st, PXS_STAGE_RESAMPLE);
-		p->chain->to_cc_adjoint(st, p->tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
-			p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->whalf.as<double2>(), p->phase.as<double2>(), 2.0);
+		const AnaSet as = ana_set(p);
+		p->chain->to_cc_adjoint(st, *as.tp, p->leg2.as<double2>(), ldc, p->ncc, p->hbuf.as<double2>(), ldh, nr, p->mir_c, nct, nm, spin, p->lmax,
+			p->ph_shift.as<double2>(), as.sigma, as.whalf, p->phase.as<double2>(), 2.0);
 		p->prof.end(st, PXS_STAGE_RESAMPLE);
 		leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, nb > 1 ? nc : 0);
 		return;
@@ -1244,16 +1333,17 @@ static void analysis_core(pxs_plan* p, int spin, int adjoint, int nb, void* map,
 		map2leg(p, st, map, map_dtype, map_cstride, nct, p->leg.as<double2>(), 1.0, ldm, map_bstride, ncb);
 		if (th) {
 			p->prof.begin(st, PXS_STAGE_RESAMPLE);
-			p->chain->to_cc(st, p->tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
-				p->ph_shift.as<double2>(), p->sigma.as<double2>(), p->wcc.as<double2>());
+			const AnaSet as = ana_set(p);
+			p->chain->to_cc(st, *as.tp, p->leg.as<double2>(), ldm, nr, p->mir_c, p->leg2.as<double2>(), ldc, p->ncc, nct, nm, spin, p->lmax,
+				p->ph_shift.as<double2>(), as.sigma, as.wcc);
 			p->prof.end(st, PXS_STAGE_RESAMPLE);
-		} else { PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path"); resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin); }
+		} else { PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path"); const AnaSet as = ana_set(p); resample_to_cc(p, st, p->leg.as<double2>(), p->leg2.as<double2>(), nc, spin, as.M, as.sigma, as.wcc); }
 		leg_analysis(st, p->rs_cc, tb, p->wk, p->leg2.as<double2>(), alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, 0, &p->prof, ldc, nb, alm_bstride, (long)nc*nm*ldc);
 	} else {
 		// adjoint_analysis_2d: the exact transpose, stage by stage in reverse
 		PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path");
 		leg_synthesis(st, p->rs_cc, tb, p->wk, alm, alm_dtype, alm_cstride, p->d_mstart.as<uint64_t>(), p->lstride, p->leg2.as<double2>(), 0, &p->prof, ldc);
-		resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin);
+		{ const AnaSet as = ana_set(p); resample_to_cc_adjoint(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), nc, spin, as.M, as.sigma, as.wcc); }
 		leg2map(p, st, p->leg.as<double2>(), nr, map, map_dtype, map_cstride, nc);
 	}
 }

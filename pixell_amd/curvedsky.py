@@ -177,9 +177,9 @@ def alm2map_adjoint(map, alm=None, spin=[0, 2], deriv=False, copy=False, method=
 def map2alm(map, alm=None, lmax=None, spin=[0, 2], deriv=False, adjoint=False, copy=False, method="auto", ainfo=None,
 		verbose=False, nthread=None, niter=0, epsilon=None, pix_tol=1e-6, weights=None, locinfo=None, tweak=False, analysis=None, weights_order="reference"):
 	"""Spherical harmonics analysis (curvedsky.map2alm, curvedsky.py:209-302).
-	analysis (ours, method "2d" only): None / "interpolant" = what ducc0's analysis_2d integrates; "weights" = ring quadrature weights +
-	adjoint synthesis (the reference's cyl route, curvedsky.py:852-861) on full grids with ny >= 2 lmax + 2: identical alm for
-	band-limited maps, cheaper theta resampling (see pixell_amd.sht.analysis_2d).
+	analysis (ours, method "2d" only): None / "ducc0" = the route ducc0's analysis_2d takes as published; "interpolant" = exact
+	quadrature of the full theta-interpolant; "weights" = ring quadrature weights + adjoint synthesis (the reference's cyl route,
+	curvedsky.py:852-861) on full grids with ny >= 2 lmax + 2: identical alm for band-limited maps (see pixell_amd.sht.analysis_2d).
 	weights_order (ours, method "cyl" only): "reference" (default) applies weights to rows exactly as the reference does, including its
 	mirrored pixel areas for maps stored north-to-south off a named grid; "map": weight i belongs to map row i (see map2alm_cyl)."""
 	minfo = analyse_geometry(map.shape, map.wcs, tol=pix_tol)

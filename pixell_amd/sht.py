@@ -118,8 +118,13 @@ class Plan:
 		_lib.check(_lib.load().pxs_profile_flops(self.handle, f, int(bool(reset))))
 		return f[0], f[1]
 	def set_option(self, name, value):
-		"""pxs_plan_option: "analysis" = 0 (theta-interpolant) | 1 (ring weights + adjoint synthesis where ntheta >= 2 lmax + 2)"""
+		"""pxs_plan_option: "analysis" = 2 (ducc0's route, the default) | 0 (full theta-interpolant) | 1 (ring weights + adjoint synthesis where ntheta >= 2 lmax + 2)"""
 		_lib.check(_lib.load().pxs_plan_option(self.handle, name.encode(), int(value)))
+	def query(self, name):
+		"""pxs_plan_query: "analysis_form", "ncc_circle", "ducc_ncc_circle" """
+		v = ctypes.c_int64()
+		_lib.check(_lib.load().pxs_plan_query(self.handle, name.encode(), ctypes.byref(v)))
+		return int(v.value)
 	def info(self):
 		a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
 		_lib.check(_lib.load().pxs_plan_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
@@ -220,12 +225,21 @@ def _run_syn(plan, alm, map, spin, mode, adjoint, map_overwrite=False):
 		av.ptr, _DT[ad], av.cstride, av.bstride, mv.ptr, _DT[md], mv.cstride, mv.bstride, current_stream()))
 	av.finish(); mv.finish()
 
-ANALYSIS_MODES = {"interpolant": 0, "weights": 1}
+ANALYSIS_MODES = {"ducc0": 2, "interpolant": 0, "weights": 1}
 def _analysis_mode(analysis):
-	"""analysis=None: PIXELL_AMD_ANALYSIS or "interpolant" (what ducc0's analysis_2d integrates: the theta-interpolant of the rings)"""
-	if analysis is None: analysis = os.environ.get("PIXELL_AMD_ANALYSIS", "interpolant")
-	if analysis not in ANALYSIS_MODES: raise ValueError("analysis must be 'interpolant' or 'weights', not %r" % (analysis,))
+	"""analysis=None: PIXELL_AMD_ANALYSIS or "ducc0" (the route of ducc0's analysis_2d as published, see include/pxsht.h pxs_plan_option)"""
+	if analysis is None: analysis = os.environ.get("PIXELL_AMD_ANALYSIS", "ducc0")
+	if analysis not in ANALYSIS_MODES: raise ValueError("analysis must be 'ducc0', 'interpolant' or 'weights', not %r" % (analysis,))
 	return ANALYSIS_MODES[analysis]
+
+def analysis_form(geometry, ntheta, nphi, lmax, mmax=None, mstart=None, phi0=0.0, lstride=1, flip=(False, False), analysis=None):
+	"""What analysis_2d does on this grid with this option (pxs_plan_query): dict(form="ducc0" (its fine-CC form) | "weights" |
+	"interpolant", ncc_circle=N_cc of the Legendre-stage CC grid (0: none), ducc_ncc_circle=ducc0's own N_cc for this lmax)"""
+	if mmax is None: mmax = lmax
+	if mstart is None: mstart = tri_mstart(lmax, mmax)
+	plan = grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride)
+	plan.set_option("analysis", _analysis_mode(analysis))
+	return dict(form={0: "interpolant", 1: "weights", 2: "ducc0"}[plan.query("analysis_form")], ncc_circle=plan.query("ncc_circle"), ducc_ncc_circle=plan.query("ducc_ncc_circle"))
 
 def _run_ana(plan, map, alm, spin, adjoint, analysis=None, alm_dense=False):
 	plan.set_option("analysis", _analysis_mode(analysis))      # (host-side path choice of the calls that follow; plans are cached and shared)
@@ -257,9 +271,11 @@ def adjoint_synthesis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=No
 
 def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0, nthreads=0, lstride=1, flip=(False, False), return_plan=False, analysis=None):
 	"""ducc0.sht.experimental.analysis_2d as called at curvedsky.py:1032-1046.
-	analysis (ours): "interpolant" (default) | "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route
-	(curvedsky.py:852-861, 1068-1084), on grids with ntheta >= 2 lmax + 2 (smaller grids keep the interpolant): the same alm for
-	band-limited maps, three resampling stages instead of five."""
+	analysis (ours): "ducc0" (default): the route ducc0's analysis_2d takes as published -- the theta-interpolant of the rings, low-passed
+	to |k| < N_cc where the grid is finer, evaluated on the CC grid of N_cc + 1 rings and integrated with that grid's weights (a CC
+	grid with ntheta >= 2 lmax + 2: its own weights directly) | "interpolant": exact quadrature of the full interpolant |
+	"weights": ring quadrature weights + adjoint synthesis, the reference's cyl route (curvedsky.py:852-861, 1068-1084), on grids
+	with ntheta >= 2 lmax + 2.  The same alm for band-limited maps (include/pxsht.h, pxs_plan_option)."""
 	plan = _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, "STANDARD", flip)
 	# (an alm array that is exactly the triangular layout is written in full: a host array of it need not be uploaded first)
 	dense = lstride == 1 and (mmax is None or mmax == lmax) and alm.shape[-1] == (lmax+1)*(lmax+2)//2 and (mstart is None or int(np.asarray(mstart)[-1]) + lmax + 1 == alm.shape[-1])

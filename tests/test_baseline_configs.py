@@ -133,7 +133,7 @@ def build_map_from_profiles(shape, wcs, F, msel, dtype=None):
 def check_analysis_sparse_m(shape, wcs, lmax, spins, seed=1, band_limited=True):
 	"""map2alm of a torch-assembled map with a dozen m against the CPU; returns (rms error over the selected m, max |alm| elsewhere / rms)"""
 	from oracle import sht_fast as sf, sht_port
-	from pixell_amd import curvedsky
+	from pixell_amd import curvedsky, sht
 	torch = _torch()
 	rng = np.random.default_rng(seed)
 	ny, nx = shape[-2:]
@@ -157,7 +157,11 @@ def check_analysis_sparse_m(shape, wcs, lmax, spins, seed=1, band_limited=True):
 			leg = rng.standard_normal((len(msel), nc, ny))+1j*rng.standard_normal((len(msel), nc, ny))
 			leg[msel == 0] = leg[msel == 0].real
 			# ring FFT output of the assembled map: nx F_m (m = 0: nx Re F_0); 0 < m < nx/2 for every selected m
-			expect.append(sf.analysis_columns(leg*nx, msel, s, lmax, "F1" if _is_f1(shape, wcs) else "CC", ny, nx))
+			# (the form map2alm takes on this grid: ducc0's route at the N_cc the plan realised, else the full interpolant)
+			mi = curvedsky.analyse_geometry(shape, wcs); ai = curvedsky.alm_info(lmax)
+			form = sht.analysis_form(mi.ducc_geo.name, ny, nx, lmax, phi0=mi.phi0, flip=mi.flip, mstart=ai.mstart)
+			assert form["form"] in ("ducc0", "interpolant"), form
+			expect.append(sf.analysis_columns(leg*nx, msel, s, lmax, "F1" if _is_f1(shape, wcs) else "CC", ny, nx, fine_cc=form["ncc_circle"] if form["form"] == "ducc0" else None))
 		F[ci:ci+nc] = np.transpose(leg, (1, 0, 2))[:, :, inv]
 		ci += nc
 	dmap = build_map_from_profiles(shape, wcs, F, msel)

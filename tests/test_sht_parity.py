@@ -16,6 +16,12 @@ TOL = 1e-11
 def rel(a, b): return np.max(np.abs(a-b))/max(np.max(np.abs(b)), 1e-300)
 def relrms(a, b): return np.sqrt(np.mean(np.abs(a-b)**2))/max(np.sqrt(np.mean(np.abs(b)**2)), 1e-300)
 
+def oracle_form(geometry, nt, nph, lmax, analysis=None, **plan_kw):
+	"""keywords that make the oracle's analysis_2d restate the form the product's analysis_2d takes on this grid (the default is ducc0's
+	route; the product reports the form and the N_cc it realised, sht.analysis_form, and the oracle is asked for exactly that)"""
+	f = sht.analysis_form(geometry, nt, nph, lmax, analysis=analysis, **plan_kw)
+	return {"ducc0": dict(fine_cc=f["ncc_circle"]), "weights": dict(weights=True), "interpolant": dict(fine_cc=False)}[f["form"]]
+
 def check_grid(geometry, nt, nph, lmax, spin, phi0=0.3, seed=3, random_map=True, mmax=None):
 	nc = 1 if spin == 0 else 2
 	mmax = lmax if mmax is None else mmax
@@ -37,13 +43,16 @@ def check_grid(geometry, nt, nph, lmax, spin, phi0=0.3, seed=3, random_map=True,
 		for m in range(mmax+1): sel[int(ms[m])+m:int(ms[m])+lmax+1] = True
 		if mmax == lmax and 2*mmax < nph: assert relrms(oa[:, sel], alm[:, sel]) < TOL, "round trip"   # (no exact inverse when m aliases)
 		ref2 = np.zeros((nc, nt, nph)); out2 = np.zeros((nc, nt, nph))
-		if nt <= 64:
-			so.adjoint_analysis_2d(alm=alm, map=ref2, **kw); sht.adjoint_analysis_2d(alm=alm, map=out2, **kw)
-			assert rel(out2, ref2) < TOL, "adjoint_analysis_2d"
-		if random_map:
-			ra = np.zeros_like(alm); so.analysis_2d(alm=ra, map=pix, **kw)
-			oa = np.zeros_like(alm); sht.analysis_2d(alm=oa, map=pix, **kw)
-			assert relrms(oa, ra) < TOL, "analysis_2d on a non-band-limited map"
+		from pixell_amd import _lib
+		for form in (None, "interpolant") if (nt <= 24 or not _lib.is_hostsim()) else (None,):      # the default (ducc0's route) and the full-interpolant option (simulator: small grids only, for time)
+			okw = oracle_form(geometry, nt, nph, lmax, analysis=form, mmax=mmax, mstart=ms[:mmax+1], phi0=phi0)
+			if nt <= 64:
+				so.adjoint_analysis_2d(alm=alm, map=ref2, **kw, **okw); sht.adjoint_analysis_2d(alm=alm, map=out2, analysis=form, **kw)
+				assert rel(out2, ref2) < TOL, "adjoint_analysis_2d (%s)" % form
+			if random_map:
+				ra = np.zeros_like(alm); so.analysis_2d(alm=ra, map=pix, **kw, **okw)
+				oa = np.zeros_like(alm); sht.analysis_2d(alm=oa, map=pix, analysis=form, **kw)
+				assert relrms(oa, ra) < TOL, "analysis_2d on a non-band-limited map (%s)" % form
 
 SMALL = [("F1", 20, 41, 19, 0), ("F1", 20, 41, 19, 2), ("F1", 32, 61, 30, 1), ("CC", 21, 40, 19, 0), ("CC", 21, 48, 19, 2),
 	("MW", 16, 33, 15, 0), ("MWflip", 16, 33, 15, 2), ("F1", 24, 64, 12, 0), ("F1", 24, 64, 12, 3),
@@ -104,7 +113,7 @@ def check_adjoint_analysis_fused(geometry, nt, nph, lmax, monkeypatch, nb=1):
 	for spin in (0, 2):
 		nc = 1 if spin == 0 else 2
 		alm = np.stack([so.rand_alm_simple(lmax, nc, 50+i, spin=(spin,)) for i in range(nb)])
-		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.25)
+		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.25, analysis="interpolant")      # (the only form with an unfused transpose)
 		monkeypatch.setenv("PXS_ADJ_ANA_FUSED", "1")
 		a = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=a, **kw)
 		monkeypatch.setenv("PXS_ADJ_ANA_FUSED", "0")
@@ -291,7 +300,7 @@ def check_seeds(lmax, nt, nph, reps=3):
 @pytest.mark.hostsim
 def test_seeds_hostsim(monkeypatch):
 	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0")
-	check_seeds(56, 60, 120, reps=2)
+	check_seeds(28, 30, 60, reps=2)
 @pytest.mark.gpu
 def test_seeds_gpu(monkeypatch):
 	monkeypatch.setenv("PXS_DETERMINISTIC", "1")           # (bitwise comparison of the analysis needs the ordered accumulation)
@@ -428,10 +437,13 @@ def check_batched(nb=3, geometry="F1", nt=24, nph=48, lmax=20):
 
 @pytest.mark.hostsim
 def test_batched_hostsim(): check_batched()
-# 2 x 28 rings = 7 x 8: the ring FFTs (64 pixels) are chained, the theta resampling is not -- a batched synthesis through the CC grid
-# has to fall back to one map per pass there (round 2 raised "batched call on an unfused path")
+# 2 x 26 rings = 4 x 13: the ring FFTs (64 pixels) are chained, the theta resampling is not -- a batched synthesis through the CC grid
+# has to fall back to one map per pass there (round 2 raised "batched call on an unfused path"); the analysis takes ducc0's route
+# through the generic FFT engine (N_cc = 28, radix 7 there too)
 @pytest.mark.hostsim
-def test_batched_unfused_theta_hostsim(): check_batched(2, "F1", 28, 64, 12)
+def test_batched_unfused_theta_hostsim():
+	assert sht.analysis_form("F1", 26, 64, 12, phi0=0.2) == dict(form="ducc0", ncc_circle=28, ducc_ncc_circle=28)
+	check_batched(2, "F1", 26, 64, 12)
 @pytest.mark.gpu
 def test_batched_gpu():
 	check_batched(); check_batched(5, "CC", 130, 300, 128); check_batched(2, "F1", 28, 64, 12); check_batched(3, "F1", 154, 320, 60)
@@ -450,11 +462,11 @@ def test_batched_gpu():
 	assert float((back-alm).abs().max()) < 1e-11
 
 
-def check_dh_f2():
+def check_dh_f2(cases=(("DH", 22), ("F2", 21), ("DH", 41), ("F2", 40))):
 	"""Driscoll-Healy and Fejer-2 grids (get_ducc_geo can return them, curvedsky.py:1329-1342): synthesis on their rings, analysis
 	by Fejer's second rule, exact up to get_ducc_maxlmax = (n-2)//2 resp. (n-1)//2; adjoints; error beyond the limit"""
 	from pixell_amd._lib import PxsError
-	for g, nt in [("DH", 22), ("F2", 21), ("DH", 41), ("F2", 40)]:
+	for g, nt in cases:
 		lmax = so.grid_maxlmax(g, nt); assert sht.grid_maxlmax(g, nt) == lmax
 		for spin in (0, 2):
 			check_grid(g, nt, 2*lmax+3, lmax, spin)
@@ -462,7 +474,7 @@ def check_dh_f2():
 			sht.analysis_2d(alm=np.zeros((1, so.nalm(lmax+1)), complex), map=np.zeros((1, nt, 64)), spin=0, lmax=lmax+1, mstart=so._tri_mstart(lmax+1, lmax+1), geometry=g)
 
 @pytest.mark.hostsim
-def test_dh_f2_hostsim(): check_dh_f2()
+def test_dh_f2_hostsim(): check_dh_f2((("DH", 22), ("F2", 21)))
 @pytest.mark.gpu
 def test_dh_f2_gpu(): check_dh_f2()
 
@@ -497,9 +509,10 @@ def check_weights_analysis(geometry, nt, nph, lmax, spin, nb=1, seed=5):
 		sht.analysis_2d(alm=a, map=maps, analysis="weights", **kw)
 		one = np.zeros_like(alm); sht.analysis_2d(alm=one, map=maps[nb-1], analysis="weights", **kw)
 		assert rel(a[nb-1], one) < 1e-13
-	# the option is per call: the default form is back
+	# the option is per call: the default form (ducc0's route) is back
 	chk = np.zeros_like(alm); sht.analysis_2d(alm=chk, map=noise, **kw)
-	assert relrms(chk, itp) < 1e-14
+	dflt = np.zeros_like(alm); so.analysis_2d(alm=dflt, map=noise, **kw, **oracle_form(geometry, nt, nph, lmax, phi0=0.2, mstart=ms))
+	assert relrms(chk, dflt) < TOL
 	with pytest.raises(ValueError): sht.analysis_2d(alm=chk, map=noise, analysis="quadrature", **kw)
 
 WEIGHTS_CASES = [("F1", 64, 128, 30, 0), ("F1", 66, 128, 31, 2), ("CC", 65, 120, 30, 2), ("MW", 64, 100, 28, 0), ("F1", 120, 240, 50, 1)]
@@ -510,14 +523,66 @@ def test_weights_analysis_hostsim(geometry, nt, nph, lmax, spin): check_weights_
 @pytest.mark.parametrize("geometry,nt,nph,lmax,spin", WEIGHTS_CASES)
 def test_weights_analysis_gpu(geometry, nt, nph, lmax, spin): check_weights_analysis(geometry, nt, nph, lmax, spin, nb=3)
 
-def test_weights_analysis_small_grid_keeps_interpolant():
-	"""below ntheta = 2 lmax + 2 ring weights are not exact: the option leaves such grids on the interpolant"""
+def check_ducc0_route(geometry, nt, nph, lmax, spin, expect_ducc_size=None, seed=7):
+	"""The default analysis: ducc0's route as published (analysis_2d -> resample_to_prepared_CC), restated by the oracle as the direct
+	sum over the CC grid of N_cc + 1 rings of (quadrature weight) x (theta-interpolant, low-passed to |k| < N_cc on finer grids) x
+	lambda_lm.  White noise and a band-limited map, the adjoint, and -- where the plan realises ducc0's own N_cc =
+	2 good_size_complex(lmax + 1), radix 7 included -- the oracle at ducc0's sizes (fine_cc=True)."""
+	nc = 1 if spin == 0 else 2
+	ms = so._tri_mstart(lmax, lmax)
+	kw = dict(spin=spin, lmax=lmax, geometry=geometry, phi0=0.2, mstart=ms)
+	f = sht.analysis_form(geometry, nt, nph, lmax, phi0=0.2, mstart=ms)
+	assert f["form"] == "ducc0" and f["ducc_ncc_circle"] == 2*so.good_size_complex(lmax+1)
+	if expect_ducc_size is not None: assert (f["ncc_circle"] == f["ducc_ncc_circle"]) == expect_ducc_size, f
+	alm = so.rand_alm_simple(lmax, nc, seed, spin=(spin,))
+	band = np.zeros((nc, nt, nph)); so.synthesis_2d(alm=alm, map=band, **kw)
+	noise = np.random.default_rng(seed).standard_normal((nc, nt, nph))
+	for m, tag in ((band, "band-limited"), (noise, "noise")):
+		ref = np.zeros_like(alm); so.analysis_2d(alm=ref, map=m, fine_cc=f["ncc_circle"], **kw)
+		got = np.zeros_like(alm); sht.analysis_2d(alm=got, map=m, **kw)
+		assert relrms(got, ref) < TOL, "%s: %.3e" % (tag, relrms(got, ref))
+		if tag == "band-limited": assert relrms(got, alm) < TOL
+		if f["ncc_circle"] == f["ducc_ncc_circle"]:
+			ref = np.zeros_like(alm); so.analysis_2d(alm=ref, map=m, fine_cc=True, **kw)
+			assert relrms(got, ref) < TOL
+	ref2 = np.zeros((nc, nt, nph)); so.adjoint_analysis_2d(alm=alm, map=ref2, fine_cc=f["ncc_circle"], **kw)
+	out2 = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=out2, **kw)
+	assert rel(out2, ref2) < TOL
+
+# (grid, rings, nphi, lmax, spin, ducc0's N_cc realised?)  N > 2 N_cc: low pass; N < 2 N_cc: zero padding; N = 2 N_cc; radix 7 in N_cc (lmax 20, 27)
+DUCC0_CASES = [("F1", 120, 240, 30, 0, True), ("F1", 96, 192, 20, 2, True), ("F1", 40, 80, 30, 1, True), ("F1", 64, 128, 30, 2, True),
+	("CC", 49, 100, 27, 0, True), ("MW", 63, 100, 20, 0, False), ("MWflip", 63, 100, 40, 1, None)]
+@pytest.mark.hostsim
+@pytest.mark.parametrize("geometry,nt,nph,lmax,spin,ds", DUCC0_CASES[:5])
+def test_ducc0_route_hostsim(geometry, nt, nph, lmax, spin, ds): check_ducc0_route(geometry, nt, nph, lmax, spin, ds)
+@pytest.mark.gpu
+@pytest.mark.parametrize("geometry,nt,nph,lmax,spin,ds", DUCC0_CASES+[("F1", 300, 600, 127, 2, True), ("F1", 540, 1080, 250, 0, True), ("F1", 400, 1000, 399, 1, True), ("CC", 301, 800, 200, 2, None)])
+def test_ducc0_route_gpu(geometry, nt, nph, lmax, spin, ds): check_ducc0_route(geometry, nt, nph, lmax, spin, ds)
+
+def check_ducc0_route_cc_weights(geometry="CC", nt=65, nph=120, lmax=30, spin=2):
+	"""a CC grid with at least 2 lmax + 2 rings: ducc0 multiplies it by its own weights (need_first_resample = false), i.e. the weights
+	form; here through the transposed theta upsampling with the pole rings counted double in the mirror extension"""
+	nc = 1 if spin == 0 else 2
+	ms = so._tri_mstart(lmax, lmax); kw = dict(spin=spin, lmax=lmax, geometry=geometry, phi0=0.1, mstart=ms)
+	assert sht.analysis_form(geometry, nt, nph, lmax, phi0=0.1, mstart=ms)["form"] == "weights"
+	noise = np.random.default_rng(2).standard_normal((nc, nt, nph))
+	ref = np.zeros((nc, so.nalm(lmax)), complex); so.analysis_2d(alm=ref, map=noise, weights=True, **kw)
+	got = np.zeros_like(ref); sht.analysis_2d(alm=got, map=noise, **kw)
+	assert relrms(got, ref) < TOL
+@pytest.mark.hostsim
+def test_ducc0_route_cc_weights_hostsim(): check_ducc0_route_cc_weights()
+@pytest.mark.gpu
+def test_ducc0_route_cc_weights_gpu(): check_ducc0_route_cc_weights(); check_ducc0_route_cc_weights("CC", 601, 1200, 250, 0)
+
+def test_weights_analysis_small_grid_takes_the_default():
+	"""below ntheta = 2 lmax + 2 ring weights are not exact: the option leaves such grids on the default form"""
 	lmax, nt, nph = 30, 40, 80
 	alm = so.rand_alm_simple(lmax, 1, 3, spin=(0,))
 	kw = dict(spin=0, lmax=lmax, geometry="F1", phi0=0.0, mstart=so._tri_mstart(lmax, lmax))
 	m = np.zeros((1, nt, nph)); so.synthesis_2d(alm=alm, map=m, **kw)
 	got = np.zeros_like(alm); sht.analysis_2d(alm=got, map=m, analysis="weights", **kw)
 	assert relrms(got, alm) < TOL
+	assert sht.analysis_form("F1", nt, nph, lmax, analysis="weights")["form"] == sht.analysis_form("F1", nt, nph, lmax)["form"]
 
 @pytest.mark.hostsim
 def test_batched_shared_recurrence_hostsim():
@@ -528,7 +593,8 @@ def test_batched_shared_recurrence_hostsim():
 def test_batched_deterministic_and_seeded_hostsim(monkeypatch):
 	"""batched calls on the two paths that launch maps one at a time: the ordered (bitwise repeatable) analysis, PXS_DETERMINISTIC=1, and
 	the launch that records the recurrence seeds (the first map alone), forced on at toy size with PXS_SEED_MIN_LMAX=0"""
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(nb=3)
-	monkeypatch.delenv("PXS_DETERMINISTIC"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0"); sht.clear_plans(); check_batched(nb=3)
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(nb=3)
+	small = dict(nb=2, nt=18, nph=36, lmax=14)
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(**small)
+	monkeypatch.delenv("PXS_DETERMINISTIC"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0"); sht.clear_plans(); check_batched(**small)
+	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(**small)
 	sht.clear_plans()
