@@ -22,6 +22,7 @@
 #include "fftchain.hpp"
 #include "fft2_dev.hpp"
 #include <algorithm>
+#include <set>
 #include <type_traits>
 #include <cmath>
 
@@ -107,7 +108,9 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 	PXS_SHARED(double2, lds);
 	const int na = s.fa.n, nb = s.fb.n;
 	const int nlast = S::TWO ? nb : na, nslast = S::TWO ? s.fb.ns : s.fa.ns;
-	double2* twa = lds; double2* twb = lds + na; double2* twx = twb + nb; double2* buf = twx + (S::HAS_TW ? nlast : 0);
+	// (two transforms of one length share the W_n table: StSigma at g = 320 then fits three times on a CU instead of twice)
+	const bool same_tw = S::TWO && nb == na;
+	double2* twa = lds; double2* twb = same_tw ? lds : lds + na; double2* twx = lds + na + (same_tw ? 0 : nb); double2* buf = twx + (S::HAS_TW ? nlast : 0);
 	TileC c;
 	if (!s.decode((int)blockIdx.x, c)) return;
 	const bool have_tw = S::HAS_TW && s.btw != nullptr;
@@ -129,7 +132,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 			}
 		}
 		for (int k = threadIdx.x; k < na; k += NT) twa[k] = s.fa.tw[k];
-		for (int k = threadIdx.x; k < nb; k += NT) twb[k] = s.fb.tw[k];
+		if (!same_tw) for (int k = threadIdx.x; k < nb; k += NT) twb[k] = s.fb.tw[k];
 		if (have_tw) for (int k = threadIdx.x; k < nlast; k += NT) twx[k] = s.btw[(long)c.t0*k];
 #pragma unroll
 		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
@@ -966,8 +969,13 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	if (nblk <= 0) return;
 	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= CH_TILE_PTS, "internal: chain tile too large");
 	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
-	size_t sh = sizeof(double2)*((size_t)s.fa.n + s.fb.n + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
+	size_t sh = sizeof(double2)*((size_t)s.fa.n + (S::TWO && s.fb.n == s.fa.n ? 0 : s.fb.n) + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
 	{ static const size_t pad = [] { const char* e = getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
+	if (getenv("PXS_CHAIN_VERBOSE")) {
+		static std::mutex mu; static std::set<std::tuple<int, int, int, int>> seen; std::lock_guard<std::mutex> g(mu);
+		if (seen.insert(std::make_tuple(S::SID, s.fa.n, s.fb.n, s.T)).second)
+			fprintf(stderr, "[pxsht] chain stage %d: na=%d nb=%d T=%d LDS %.1f KiB -> %d WG/CU by LDS, %ld workgroups\n", S::SID, s.fa.n, s.fb.n, s.T, sh/1024.0, (int)((160*1024)/sh), nblk);
+	}
 #ifndef PXS_HOST_SIM
 	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, CH_NT, CH_MAXE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
 	(void)once;
