@@ -175,7 +175,7 @@ template<int A, int B, int NT> __device__ __forceinline__ void radix_pass_comp(d
 }
 
 // all passes of f on T lines (radices 2,3,4,5 and the composite ones); ends with a barrier
-template<int NT, int MAXR = PXS_COMP_MAXR> __device__ __forceinline__ void lds_fft(double2* buf, const double2* tw, const LdsFft& f, int T) {
+template<int NT, int MAXR = PXS_COMP_MAXR, bool R7 = true> __device__ __forceinline__ void lds_fft(double2* buf, const double2* tw, const LdsFft& f, int T) {
 	static_assert(MAXR <= PXS_COMP_MAXR, "composite radix not compiled in");
 	for (int p = 0; p < f.nfac; p++) {
 		const PassDesc ps = f.pass[p];
@@ -185,7 +185,9 @@ template<int NT, int MAXR = PXS_COMP_MAXR> __device__ __forceinline__ void lds_f
 			case 4: radix_pass_t<4, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 5: radix_pass_t<5, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 6: if constexpr (MAXR >= 6) radix_pass_comp<3, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
-			case 7: if constexpr (MAXR >= 9) radix_pass_t<7, NT>(buf, tw, f.n, f.ns, T, ps); break;      // (theta stages only; FftContext::sub plans a 7 only for maxr >= 9)
+#ifndef PXS_NO_RADIX7   /* (A/B builds without the radix-7 code: tools/fft2_ab.sh) */
+			case 7: if constexpr (MAXR >= 9 && R7) radix_pass_t<7, NT>(buf, tw, f.n, f.ns, T, ps); break;      // (theta stages only; FftContext::sub plans a 7 only for maxr >= 9)
+#endif
 			case 8: if constexpr (MAXR >= 8) radix_pass_comp<4, 2, NT>(buf, tw, f.n, f.ns, T, ps); break;
 			case 9: if constexpr (MAXR >= 9) radix_pass_comp<3, 3, NT>(buf, tw, f.n, f.ns, T, ps); break;
 #if PXS_COMP_MAXR >= 10

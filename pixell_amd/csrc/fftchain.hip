@@ -66,6 +66,9 @@ struct BlkIn {
 };
 
 struct StageBase {
+	// radix 7 compiled into the stage's kernel (MAXR = 9 stages): the theta stages, for ducc0's ring counts.  Its code costs the kernels
+	// that hold it 2-4 % (same box, tools/fft2_ab.sh: enmap.fft 17.3 -> 17.7 ms, enmap.ifft 32.2 -> 33.7), so the 2-D FFT stages leave it out
+	static constexpr bool R7 = true;
 	LdsFft fa, fb;
 	BlkIn bin; int bout;       // input in the blocked layout (bin.Tw > 0); write the output blocked
 	int T; int ntile;
@@ -138,7 +141,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
 	}
 	PXS_LDS_BARRIER();
-	lds_fft<NT, S::MAXR>(buf, twa, s.fa, T);
+	lds_fft<NT, S::MAXR, S::R7>(buf, twa, s.fa, T);
 	if (S::TWO) {	// ---- second transform on the same lines: pull its inputs out of the first one's output (lines fastest across lanes)
 		const int total = T*nb;
 		double2 v[MAXE]; int pos[MAXE];
@@ -156,7 +159,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 #pragma unroll
 		for (int u = 0; u < MAXE; u++) if (pos[u] >= 0) buf[pos[u]] = v[u];
 		PXS_LDS_BARRIER();
-		lds_fft<NT, S::MAXR>(buf, twb, s.fb, T);
+		lds_fft<NT, S::MAXR, S::R7>(buf, twb, s.fb, T);
 	}
 	{	// ---- store
 		const int total = T*nlast;
@@ -426,6 +429,9 @@ struct StFirst : StageBase {
 		const long o = bout ? ((long)c.outer*b + c.t0)*fa.n + (long)e*c.nl + li : ((long)c.outer*fa.n + e)*ldY + c.t0 + li;
 		Y[o] = cmul(val(li, e), w); }
 };
+
+// ... of the 2-D FFTs (plain mode; lengths are 2-3-5-smooth there, split_balanced)
+struct StFirst2D : StFirst { static constexpr bool R7 = false; };
 
 // pass 2 of transform X1 (forward, b1 points) + spectrum resize + pass 1 of transform X2 (backward, a2 points); shared modulus g.
 // in: Y[outer][k1 < g][j2 < b1]; out: Z[outer][k1' < a2][k1 < g] (row stride ldZ).
@@ -721,6 +727,7 @@ struct StRingS2 : StageBase {
 // out[(ny - ky) % ny][nx - kx] = conj
 struct StColOut : StageBase {
 	static constexpr int SID = 9;
+	static constexpr bool R7 = false;
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out, herm; double2* out; long ldo, ocomp; double scale; FastDiv dgr;
@@ -1454,11 +1461,11 @@ bool FftChain::fft2_real(hipStream_t st, const void* in, int in_dtype, double2* 
 	MapDesc m; m.ptr = in; m.dtype = in_dtype; m.cstride = ny*nx; m.ring_off0 = 0; m.ring_stride = nx; m.pix_stride = 1; m.nring = (int)ny; m.nphi = nx;
 	map2leg(st, m, (int)npre, (int)(nm - 1), s2_.as<double2>(), ldF, nullptr, 1.0);
 	s1_.ensure(sizeof(double2)*(size_t)npre*nm*a*ldY);
-	{	StFirst s; memset(&s, 0, sizeof(s));
+	{	StFirst2D s; memset(&s, 0, sizeof(s));
 		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
 		s.src.leg = s2_.as<double2>(); s.src.cstride = nm*ldF; s.src.ld = ldF; s.src.nr = (int)ny; s.src.N = (int)ny; s.src.ncol = (int)nm; s.src.plain = 1;
 		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = ldY; s.npair = (int)nm; s.dnp = make_fastdiv((uint32_t)nm);
-		set_tiles(s, tile_lines_for<StFirst>(a, 0, b, 8), b, ny);
+		set_tiles(s, tile_lines_for<StFirst2D>(a, 0, b, 8), b, ny);
 		launch_any(s, npre*nm*s.ntile, st);
 	}
 	{	StColOut s; memset(&s, 0, sizeof(s));
@@ -1486,11 +1493,11 @@ bool FftChain::fft2_c2c(hipStream_t st, const double2* in, double2* out, long np
 	s1_.ensure(sizeof(double2)*(size_t)npre*std::max(ny*ax*pad8(bx), nx*ay*pad8(by)));
 	s2_.ensure(sizeof(double2)*(size_t)npre*nx*ldF);
 	auto first = [&](const double2* src, long nlines, long ld, long n, long a, long b, int conj) {
-		StFirst s; memset(&s, 0, sizeof(s));
+		StFirst2D s; memset(&s, 0, sizeof(s));
 		s.fa = mk(fc_, a); s.fb = mk(fc_, 0);
 		s.src.leg = src; s.src.cstride = nlines*ld; s.src.ld = ld; s.src.nr = (int)n; s.src.N = (int)n; s.src.ncol = (int)nlines; s.src.plain = 1; s.src.conj = conj;
 		s.b = (int)b; s.Y = s1_.as<double2>(); s.ldY = pad8(b); s.npair = (int)nlines; s.dnp = make_fastdiv((uint32_t)nlines);
-		set_tiles(s, tile_lines_for<StFirst>(a, 0, b, 8), b, n);
+		set_tiles(s, tile_lines_for<StFirst2D>(a, 0, b, 8), b, n);
 		launch_any(s, npre*nlines*s.ntile, st);
 	};
 	auto second = [&](double2* dst, long nlines, long ldo, long ocomp, long a, long b, int conj, double sc) {
