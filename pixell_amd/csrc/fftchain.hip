@@ -69,6 +69,9 @@ struct StageBase {
 	// radix 7 compiled into the stage's kernel (MAXR = 9 stages): the theta stages, for ducc0's ring counts.  Its code costs the kernels
 	// that hold it 2-4 % (same box, tools/fft2_ab.sh: enmap.fft 17.3 -> 17.7 ms, enmap.ifft 32.2 -> 33.7), so the 2-D FFT stages leave it out
 	static constexpr bool R7 = true;
+	// threads per workgroup.  Per-stage A/B at C3 (tools/gpu_ntlab.sh, profiles/r04b_ntlab_c3.txt): 512 wins for every stage (256: ring stages
+	// +15-25 %, StResize / StSigma +5-9 %; 384: 0 to +10 %) except the transposing split StSplit<1>: from_cc 12.27 -> 11.45 ms with 256
+	static constexpr int NT = CH_NT;
 	LdsFft fa, fb;
 	BlkIn bin; int bout;       // input in the blocked layout (bin.Tw > 0); write the output blocked
 	int T; int ntile;
@@ -511,6 +514,9 @@ struct StSigma : StageBase {
 //         out = h[t*ld + col] * conj(tab[col]) * scale                      (synthesis: ring-major rows for the ring FFT)
 template<int MODE> struct StSplit : StageBase {
 	static constexpr int SID = 3 + MODE;
+#ifndef PXS_HOST_SIM
+	static constexpr int NT = MODE == 1 ? 256 : CH_NT;
+#endif
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
@@ -984,10 +990,20 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 			fprintf(stderr, "[pxsht] chain stage %d: na=%d nb=%d T=%d LDS %.1f KiB -> %d WG/CU by LDS, %ld workgroups\n", S::SID, s.fa.n, s.fb.n, s.T, sh/1024.0, (int)((160*1024)/sh), nblk);
 	}
 #ifndef PXS_HOST_SIM
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, CH_NT, CH_MAXE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
+#ifdef PXS_CH_NT2      /* experiment builds: stages whose bit SID is set in PXS_CH_NT2_MASK run with PXS_CH_NT2 threads per workgroup */
+	static const long mask2 = [] { const char* e = getenv("PXS_CH_NT2_MASK"); return e ? strtol(e, nullptr, 0) : 0L; }();
+	if ((mask2 >> S::SID) & 1) {
+		constexpr int NT2 = PXS_CH_NT2, MAXE2 = (PXS_CH_PTS + NT2 - 1)/NT2;
+		static const bool once2 = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, NT2, MAXE2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
+		(void)once2;
+		hipLaunchKernelGGL((chain_kernel<S, NT2, MAXE2>), dim3((unsigned)nblk), dim3(NT2), sh, st, s);
+		return;
+	}
+#endif
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, S::NT, (PXS_CH_PTS + S::NT - 1)/S::NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
 	(void)once;
 #endif
-	hipLaunchKernelGGL((chain_kernel<S, CH_NT, CH_MAXE>), dim3((unsigned)nblk), dim3(CH_NT), sh, st, s);
+	hipLaunchKernelGGL((chain_kernel<S, S::NT, (PXS_CH_PTS + S::NT - 1)/S::NT>), dim3((unsigned)nblk), dim3(S::NT), sh, st, s);
 }
 
 // second-generation kernel: LDS image of a stage with tiles of T lines.  Layout (chain2_kernel): the two four-step twiddle tables and

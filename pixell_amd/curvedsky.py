@@ -193,8 +193,9 @@ def map2alm(map, alm=None, lmax=None, spin=[0, 2], deriv=False, adjoint=False, c
 	else:
 		raise ValueError("Unrecognized alm2map method '%s'" % str(method))
 
-def map2alm_adjoint(alm, map, lmax=None, spin=[0, 2], deriv=False, copy=False, method="auto", ainfo=None, verbose=False, nthread=None, niter=0, epsilon=1e-6, pix_tol=1e-6, weights=None, locinfo=None):
-	return map2alm(map=map, alm=alm, lmax=lmax, spin=spin, deriv=deriv, adjoint=True, copy=copy, method=method, ainfo=ainfo, verbose=verbose, nthread=nthread, niter=niter, epsilon=epsilon, pix_tol=pix_tol, weights=weights, locinfo=locinfo)
+def map2alm_adjoint(alm, map, lmax=None, spin=[0, 2], deriv=False, copy=False, method="auto", ainfo=None, verbose=False, nthread=None, niter=0, epsilon=1e-6, pix_tol=1e-6, weights=None, locinfo=None, analysis=None):
+	"""curvedsky.map2alm_adjoint (curvedsky.py:304-310); analysis (ours): the form of map2alm whose transpose this is"""
+	return map2alm(map=map, alm=alm, lmax=lmax, spin=spin, deriv=deriv, adjoint=True, copy=copy, method=method, ainfo=ainfo, verbose=verbose, nthread=nthread, niter=niter, epsilon=epsilon, pix_tol=pix_tol, weights=weights, locinfo=locinfo, analysis=analysis)
 
 # ---- 2d ---------------------------------------------------------------------------------
 def _check_shapes(alm_full, map_full, deriv):

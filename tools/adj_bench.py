@@ -16,11 +16,9 @@ for shp, lmax in [((5400, 10800), 4000), ((21600, 43200), 10000)]:
 	g = torch.Generator(device="cuda"); g.manual_seed(1)
 	alm = torch.randn((3, ainfo.nelem), dtype=torch.complex128, device="cuda", generator=g)
 	m = enmap.dmap(torch.zeros((3,)+tuple(shape), dtype=torch.float64, device="cuda"), wcs)
-	import os
-	for fused in ("1", "0"):
-		os.environ["PXS_ADJ_ANA_FUSED"] = fused
+	for form in ("ducc0", "interpolant"):      # the default form and the full-interpolant option, each through its fused transposed chain
 		for rep in range(2):
 			torch.cuda.synchronize(); t0 = time.perf_counter()
-			curvedsky.map2alm_adjoint(alm, m, spin=[0, 2], ainfo=ainfo); torch.cuda.synchronize(); dt = time.perf_counter()-t0
-		print("map2alm_adjoint (adjoint_analysis_2d) 3x%dx%d lmax %d, %s: %.1f ms" % (shp[0], shp[1], lmax, "fused transposed chain" if fused == "1" else "unfused stage-by-stage transpose", dt*1e3), flush=True)
+			curvedsky.map2alm_adjoint(alm, m, spin=[0, 2], ainfo=ainfo, analysis=form); torch.cuda.synchronize(); dt = time.perf_counter()-t0
+		print("map2alm_adjoint (adjoint_analysis_2d) 3x%dx%d lmax %d, analysis=%s: %.1f ms" % (shp[0], shp[1], lmax, form, dt*1e3), flush=True)
 	del m; torch.cuda.empty_cache()
