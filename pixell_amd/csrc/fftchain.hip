@@ -72,6 +72,8 @@ struct StageBase {
 	// threads per workgroup.  Per-stage A/B at C3 (tools/gpu_ntlab.sh, profiles/r04b_ntlab_c3.txt): 512 wins for every stage (256: ring stages
 	// +15-25 %, StResize / StSigma +5-9 %; 384: 0 to +10 %) except the transposing split StSplit<1>: from_cc 12.27 -> 11.45 ms with 256
 	static constexpr int NT = CH_NT;
+	// most points a tile of the stage may hold (the kernel's per-thread element count follows from it)
+	static constexpr int PTS = CH_TILE_PTS;
 	LdsFft fa, fb;
 	BlkIn bin; int bout;       // input in the blocked layout (bin.Tw > 0); write the output blocked
 	int T; int ntile;
@@ -597,6 +599,10 @@ struct MapAddr { void* ptr; int dtype; long cstride, bstride, off0, rstride, pst
 // MA1: two real rings as one complex line z = ring(2q) + i ring(2q+1); pixel x = b*j1 + j2, line = j2, a-point FFT over j1
 struct StRingA1 : StageBase {
 	static constexpr int SID = 5;
+	// MA1 reads the map in runs of T reals: 16 lines make whole 128-byte lines.  Where 2560 points hold fewer (C3: 180-point lines, T = 14) the
+	// tile may grow to 2880 points (profiles/r04b_tile2880_ab.txt: map2leg of the Q/U pair 14.74 -> 13.76 ms, enmap.fft 17.65 -> 16.78 ms;
+	// 2880-point tiles for every stage: nothing elsewhere at C3, +2 % at C4)
+	static constexpr int PTS = 2880;
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	MapAddr m; int b, npair; double2* Y; long ldY; FastDiv dnp;
@@ -980,7 +986,7 @@ static int device_cus() {
 
 template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st) {
 	if (nblk <= 0) return;
-	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= CH_TILE_PTS, "internal: chain tile too large");
+	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= S::PTS, "internal: chain tile too large");
 	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
 	size_t sh = sizeof(double2)*((size_t)s.fa.n + (S::TWO && s.fb.n == s.fa.n ? 0 : s.fb.n) + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
 	{ static const size_t pad = [] { const char* e = getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
@@ -993,17 +999,17 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 #ifdef PXS_CH_NT2      /* experiment builds: stages whose bit SID is set in PXS_CH_NT2_MASK run with PXS_CH_NT2 threads per workgroup */
 	static const long mask2 = [] { const char* e = getenv("PXS_CH_NT2_MASK"); return e ? strtol(e, nullptr, 0) : 0L; }();
 	if ((mask2 >> S::SID) & 1) {
-		constexpr int NT2 = PXS_CH_NT2, MAXE2 = (PXS_CH_PTS + NT2 - 1)/NT2;
+		constexpr int NT2 = PXS_CH_NT2, MAXE2 = (S::PTS + NT2 - 1)/NT2;
 		static const bool once2 = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, NT2, MAXE2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
 		(void)once2;
 		hipLaunchKernelGGL((chain_kernel<S, NT2, MAXE2>), dim3((unsigned)nblk), dim3(NT2), sh, st, s);
 		return;
 	}
 #endif
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, S::NT, (PXS_CH_PTS + S::NT - 1)/S::NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, S::NT, (S::PTS + S::NT - 1)/S::NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
 	(void)once;
 #endif
-	hipLaunchKernelGGL((chain_kernel<S, S::NT, (PXS_CH_PTS + S::NT - 1)/S::NT>), dim3((unsigned)nblk), dim3(S::NT), sh, st, s);
+	hipLaunchKernelGGL((chain_kernel<S, S::NT, (S::PTS + S::NT - 1)/S::NT>), dim3((unsigned)nblk), dim3(S::NT), sh, st, s);
 }
 
 // second-generation kernel: LDS image of a stage with tiles of T lines.  Layout (chain2_kernel): the two four-step twiddle tables and
@@ -1029,6 +1035,8 @@ template<class S> bool FftChain::takes_v2(long n_a, long n_b) { return chain_v2_
 // workgroups per CU (PXS_CH2_LDS_KB, default 79.5 KiB each) with the DMA destinations below 64 KiB
 template<class S> int FftChain::tile_lines_for(long n_a, long n_b, long nlines, int mult, long tab_pts) {
 	int T = tile_lines(n_a, n_b, nlines, mult, tab_pts);
+	// a stage with a larger cap takes it only to reach `mult` lines (whole 128-byte lines on its strided side)
+	if (S::PTS > CH_TILE_PTS && T < mult && (long)mult*std::max(n_a, n_b) <= S::PTS && nlines >= mult) T = mult;
 	if (!takes_v2<S>(n_a, n_b)) return T;
 	static const size_t budget = [] { const char* e = getenv("PXS_CH2_LDS_KB"); return (size_t)((e ? atof(e) : 79.5)*1024); }();
 	auto fits = [&](int t) { const Lds2 L = lds2<S>((int)n_a, (int)n_b, t); return L.bytes <= budget && L.dma_bytes <= 65536; };
