@@ -1130,6 +1130,16 @@ long FftChain::ducc_ncc(int lmax) {
 	for (long n = std::max<long>(lmax + 1, 1);; n++) { long r = n; for (int p : {2, 3, 5, 7, 11}) while (r % p == 0) r /= p; if (r == 1) return 2*n; }
 }
 
+// How full the tiles of a stage with lines of n points are (tiles hold a multiple of 8 lines, at most CH_TILE_PTS points); lines too long
+// for 8 of them (strided side in runs below 128 bytes) count as a quarter less.  Sweeps of the shared moduli with tools/gpu_sweep.sh
+// (profiles/r04b_theta_modulus_sweep.txt) follow sum(points of a stage / fill) to ~5 %: C3 analysis 29.8 ms (g = 160, 144, 288, 320) against
+// 34-40 (g = 180, 192, 240: half-empty tiles; 480: five-line tiles), C5 3.6-3.75 (72, 96, 288) against 3.9-4.0 (108, 144, 216, 432).
+static double tile_fill(long n) {
+	long T = CH_TILE_PTS / n; if (T >= 8) T -= T % 8; if (T < 1) T = 1;
+	return (double)(T*n)/(double)CH_TILE_PTS*(T >= 8 ? 1.0 : 0.8);
+}
+// among moduli whose tiles fill alike: 64 ... 160 (16 or more lines per tile in the g-point stages) before larger or much smaller ones
+static double modulus_pref(long g) { return 1.0 + 0.02*std::max(0.0, std::log2((double)g/160.0)) + 0.04*std::max(0.0, std::log2(64.0/(double)g)); }
 ThetaPlan FftChain::plan_theta(long N, int lmax) {
 	ThetaPlan best; double bestc = 1e300;
 	static const long gforce = [] { const char* e = getenv("PXS_THETA_G"); return e ? atol(e) : 0L; }();     // experiments: force the shared modulus
@@ -1139,21 +1149,23 @@ ThetaPlan FftChain::plan_theta(long N, int lmax) {
 		ThetaPlan t; t.N = N; t.g = g; t.bN = N/g; t.ac = ac; t.Ncc = g*ac;
 		t.g2 = smooth_at_least((N + 2L*lmax + 2 + g - 1)/g); t.M = g*t.g2;
 		if ((t.Ncc & 1) || !sub_ok(t.g2) || !sub_ok7(t.ac)) return;
-		// synthesis split: gs divides both Ncc and N
+		// synthesis split: gs divides both Ncc and N; RS1 and RS3 run gs-point lines, RS2 lines of max(bs, aNs) points
 		long gs_best = 0; double gsc = 1e300;
-		for (long gs = 2; gs <= 1024; gs++) if (t.Ncc % gs == 0 && N % gs == 0 && sub_ok7(gs) && sub_ok7(t.Ncc/gs) && sub_ok7(N/gs)) {
-			const double c = std::max({(double)gs, (double)(t.Ncc/gs), (double)(N/gs)});
+		static const long gsforce = [] { const char* e = getenv("PXS_THETA_GS"); return e ? atol(e) : 0L; }();     // experiments: force the modulus of the synthesis chain
+		for (long gs = 2; gs <= 1024; gs++) if (t.Ncc % gs == 0 && N % gs == 0 && sub_ok7(gs) && sub_ok7(t.Ncc/gs) && sub_ok7(N/gs) && (!gsforce || gs == gsforce)) {
+			const double c = ((2.0*t.Ncc + 1.5*N)/tile_fill(gs) + (double)(t.Ncc + N)/tile_fill(std::max(t.Ncc/gs, N/gs)))*modulus_pref(gs);
 			if (c < gsc) { gsc = c; gs_best = gs; }
 		}
 		if (!gs_best) return;
 		t.gs = gs_best; t.bs = t.Ncc/gs_best; t.aNs = N/gs_best;
-		// cost: a CC ring costs far more (Legendre stage) than a point of FFT traffic; then traffic; then tile balance.
+		// cost: a CC ring costs far more (Legendre stage) than a point of FFT traffic; then the points the stages of the default analysis
+		// (the fine-CC form: middle circle of 2 N_cc points) and of the synthesis move, each over the fill of its tiles, with a slight
+		// preference among equals for moduli of 64 ... 160 (modulus_pref).
 		// ducc0's own N_cc wins whenever some g realises it: the fine-CC form of the analysis then cuts the theta spectrum of a map
 		// that is not band-limited where ducc0 does (sht.hip, ana_set), and it is the smallest size ducc0 considers good.
-		const double lmin = 2.0*lmax + 2;
-		double c = 60.0*(t.Ncc - lmin)/lmin + (3.0*N + 4.0*t.M + 3.0*t.Ncc)/(3.0*N + 4.0*(N + lmin) + 3.0*lmin);
-		const double big = (double)std::max({t.g, t.bN, t.g2, t.ac});
-		if (big > 320) c += 0.05*(big - 320)/320;
+		const double lmin = 2.0*lmax + 2, M2 = 2.0*t.Ncc;
+		const double ana = (2.0*N + 2.0*M2 + 1.5*t.Ncc)/tile_fill(g) + (N + M2)/tile_fill(std::max(t.bN, 2*t.ac)) + (M2 + t.Ncc)/tile_fill(2*t.ac);
+		double c = 60.0*(t.Ncc - lmin)/lmin + (ana*modulus_pref(g) + gsc)/(3.0*N + 4.0*M2 + 2.5*t.Ncc + 3.0*t.Ncc + 2.5*N);
 		if (ducc_size && t.Ncc == Nd) c -= 1000.0;
 		if (c < bestc) { bestc = c; best = t; best.ok = true; }
 	};
