@@ -598,3 +598,18 @@ def test_batched_deterministic_and_seeded_hostsim(monkeypatch):
 	monkeypatch.delenv("PXS_DETERMINISTIC"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0"); sht.clear_plans(); check_batched(**small)
 	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(**small)
 	sht.clear_plans()
+
+def check_baseline_analysis_forms():
+	"""what map2alm integrates at the BASELINE configurations: ducc0's route, at ducc0's own N_cc = 2 good_size_complex(lmax + 1) wherever
+	the grid's circle shares a usable modulus with it (C2 ... C5; C1's 2048-point circle does not: the planner's 1080 against 1050)"""
+	for name, (nt, nph, lmax), realised in [("C1", (1024, 2048, 512), False), ("C2/C4", (5400, 10800, 4000), True), ("C3", (21600, 43200, 10000), True), ("C5", (10800, 21600, 6000), True)]:
+		f = sht.analysis_form("F1", nt, nph, lmax)
+		assert f["form"] == "ducc0" and f["ducc_ncc_circle"] == 2*so.good_size_complex(lmax+1), (name, f)
+		assert (f["ncc_circle"] == f["ducc_ncc_circle"]) == realised, (name, f)
+		assert sht.analysis_form("F1", nt, nph, lmax, analysis="interpolant")["form"] == "interpolant"
+		assert sht.analysis_form("F1", nt, nph, lmax, analysis="weights")["form"] == ("weights" if nt >= 2*lmax+2 else "ducc0")
+	sht.clear_plans()
+@pytest.mark.hostsim
+def test_baseline_analysis_forms_hostsim(): check_baseline_analysis_forms()
+@pytest.mark.gpu
+def test_baseline_analysis_forms_gpu(): check_baseline_analysis_forms()
