@@ -1298,6 +1298,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			// M <= N (the fine-CC form on larger grids): low pass, |k| < M/2 kept
 			s.kmax = tp.M > tp.N ? -1 : (int)(tp.M/2 - 1); s.nyq = tp.M > tp.N ? 1 : 0;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
+			{ static const int noph = [] { const char* e = getenv("PXS_CH_NOPH"); return e ? atoi(e) : 0; }(); if (noph) s.ph = nullptr; }     // timing experiments only (wrong results)
 			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
 			launch_any(s, ncl*npair*s.ntile, st);
 		}
