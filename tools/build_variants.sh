@@ -1,5 +1,6 @@
 # builds a variant of libpxsht.so for same-box kernel A/B runs (selected with PIXELL_AMD_LIB=variants/libpxsht_<name>.so)
 # usage: tools/build_variants.sh <name> "<extra hipcc flags>" <source stems to recompile...>     e.g.  r10 "-DPXS_COMP_MAXR=10" fftchain fft
+# (variants/ is in .gpurunignore: copy the .so under tools/ for the GPU call -- *.so is git-ignored -- as tools/fft2_ab.sh and tools/gpu_ntlab.sh expect, and delete it afterwards)
 set -e
 cd "$(dirname "$0")/.."; mkdir -p variants/obj
 name=$1; flags=$2; shift; shift

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The fine-CC form of the analysis (analysis="finecc") against the oracle's restatement, at the N_cc the plan chose, on band-limited
+"""The default form of the analysis (analysis="ducc0": ducc0's route, its fine-CC form) against the oracle's restatement, at the N_cc the plan chose, on band-limited
 maps and white noise, and its adjoint.  usage: tools/finecc_check.py [small|big]"""
 import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,10 +22,10 @@ for geometry, nt, nph, lmax, spin in cases:
 	res = []
 	for m in (band, noise):
 		ref = np.zeros_like(alm); so.analysis_2d(alm=ref, map=m, fine_cc=Ncc, **kw)
-		got = np.zeros_like(alm); sht.analysis_2d(alm=got, map=m, analysis="finecc", **kw)
+		got = np.zeros_like(alm); sht.analysis_2d(alm=got, map=m, analysis="ducc0", **kw)
 		res.append(relrms(got, ref))
 	ref2 = np.zeros((nc, nt, nph)); so.adjoint_analysis_2d(alm=alm, map=ref2, fine_cc=Ncc, **kw)
-	out2 = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=out2, analysis="finecc", **kw)
+	out2 = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=out2, analysis="ducc0", **kw)
 	res.append(np.max(np.abs(out2-ref2))/np.max(np.abs(ref2)))
 	worst = max(worst, max(res))
 	print(geometry, nt, nph, lmax, spin, "N_cc %d (ducc0's: %d) g %d ac %d | band %.1e noise %.1e adjoint %.1e" % (Ncc, 2*so.good_size_complex(lmax+1), tp[1], tp[5], *res))
