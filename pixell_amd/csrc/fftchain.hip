@@ -445,7 +445,10 @@ struct StFirst2D : StFirst { static constexpr bool R7 = false; };
 struct StResize : StageBase {
 	static constexpr int SID = 1;
 	static constexpr bool TWO = true, INV_A = false, INV_B = true, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
-	static constexpr int MAXR = 9, MINW = 1;
+	#ifndef PXS_RESIZE_MINW
+#define PXS_RESIZE_MINW 1      /* 8 (at most 64 VGPRs, 20 bytes of scratch per lane, four workgroups per CU where the LDS allows) measured: to_cc 29.9 -> 34.1 ms at C3, 11.4 -> 13.0 at C4 */
+#endif
+	static constexpr int MAXR = 9, MINW = PXS_RESIZE_MINW;
 	const double2* Y; long ldY; double2* Z; long ldZ;
 	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
 	int adj;      // transposed padding rule (X1 > X2): conjugate phase, and the Nyquist slot of X2 collects 1/2 of both +-X2/2 bins of X1
