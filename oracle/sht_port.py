@@ -152,7 +152,7 @@ def time_sample(cfg, budget_s=20.0):
 		extrapolation=dict(legendre={"m_values_timed": {str(k): v for k, v in nsel_used.items()}, "of": lmax+1, "scaled_by": "sum over m of (lmax - max(m, spin) + 1)"},
 			ring_fft={"rings_timed": nr, "of": cfg["ncomp"]*ny, "scaled_by": "rings"}, theta_resampling=res_info),
 		sample="oracle/sht_port.c (C, f64, OpenMP x%d, -O3 -march=native): Legendre synthesis+adjoint on the CC grid of %d rings for %s of %d m values "
-			"(extrapolated by sum(lmax-m+1)); scipy.fft rfft+irfft (workers=%d) on %d of %d rings; exact theta resampling (oracle/sht_fast.py: "
+			"(extrapolated by sum(lmax-m+1)); scipy.fft rfft+irfft (workers=%d) on %d of %d rings; theta resampling in the full-interpolant form (oracle/sht_fast.py; the fine-CC form of the default analysis runs the same transforms on a shorter middle circle: "
 			"pocketfft via scipy, one block of columns per host thread) timed at two sample sizes, fixed + per-column cost extrapolated to %d columns, both directions. "
 			"A restatement of the same algorithm on the CPU, NOT ducc0." % (ncores, R, str(nsel_used), lmax+1, ncores, nr, cfg["ncomp"]*ny, cfg["ncomp"]*(lmax+1)))
 
