@@ -57,7 +57,8 @@ def check_grid(geometry, nt, nph, lmax, spin, phi0=0.3, seed=3, random_map=True,
 SMALL = [("F1", 20, 41, 19, 0), ("F1", 20, 41, 19, 2), ("F1", 32, 61, 30, 1), ("CC", 21, 40, 19, 0), ("CC", 21, 48, 19, 2),
 	("MW", 16, 33, 15, 0), ("MWflip", 16, 33, 15, 2), ("F1", 24, 64, 12, 0), ("F1", 24, 64, 12, 3),
 	("CC", 20, 12, 18, 0), ("F1", 20, 38, 19, 2),   # these two alias m onto the rings (mmax >= nphi/2), as the golden CC 181x360 lmax=400 case does
-	("F1", 96, 200, 30, 0), ("F1", 96, 200, 30, 2), ("F1", 120, 240, 50, 1)]   # many more rings than lmax: synthesis AND its adjoint go through the CC grid (from_cc / from_cc_adjoint)
+	("F1", 96, 200, 30, 0), ("F1", 96, 200, 30, 2), ("F1", 120, 240, 50, 1),   # many more rings than lmax: synthesis AND its adjoint go through the CC grid (from_cc / from_cc_adjoint)
+	("CC", 97, 200, 30, 2), ("MW", 113, 200, 30, 1)]   # ... on grids with self-mirrored rings (counted double in the mirror extension of the transposed upsampling); CC: analysis by the grid's own weights
 
 @pytest.mark.hostsim
 @pytest.mark.parametrize("geometry,nt,nph,lmax,spin", SMALL)
