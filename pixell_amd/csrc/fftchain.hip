@@ -449,6 +449,9 @@ struct StResize : StageBase {
 #define PXS_RESIZE_MINW 1      /* 8 (at most 64 VGPRs, 20 bytes of scratch per lane, four workgroups per CU where the LDS allows) measured: to_cc 29.9 -> 34.1 ms at C3, 11.4 -> 13.0 at C4 */
 #endif
 	static constexpr int MAXR = 9, MINW = PXS_RESIZE_MINW;
+#ifdef PXS_RESIZE_PTS      /* experiment: a larger tile cap (2880) so that lines of 321 ... 360 points still get 8 per tile: to_cc 11.2 -> 12.45 ms at C4, 4.3 -> 4.8 at C2 (74 VGPRs, more LDS per workgroup), nothing at C3 / C5 */
+	static constexpr int PTS = PXS_RESIZE_PTS;
+#endif
 	const double2* Y; long ldY; double2* Z; long ldZ;
 	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
 	int adj;      // transposed padding rule (X1 > X2): conjugate phase, and the Nyquist slot of X2 collects 1/2 of both +-X2/2 bins of X1
