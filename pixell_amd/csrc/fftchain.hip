@@ -84,6 +84,12 @@ struct StageBase {
 	const double2* btw; const double2* tws;
 	// second-generation kernel (chain2_kernel): DIF transforms with large register radices, tiles walked by persistent workgroups
 	Fft2 a2, b2; int ntiles2;
+	// Prefetch ahead: a workgroup of a stage that loads whole rows touches the rows of the tile `pf` workgroups ahead (one dword per
+	// 128-byte line, issued after its own loads, consumed by nothing until the kernel ends), so that tile's loads hit the L2 when its
+	// workgroup starts -- on the same XCD: workgroups go round-robin to the 8 XCDs and pf is a multiple of 8.  Measured at C3 / C4
+	// (tools/chain_lab.py, 5 repetitions, profiles/r04b_prefetch_ahead.txt): pf = 24, 48: +2 %; 96: -0.5 %; 128 ... 256: -2.5 % (to_cc
+	// 30.0 -> 28.4 ms, C4 11.6 -> 10.8); 384 ... 768: -2 % (from_cc 17.1 -> 16.5); 1536: 0; 3072: +6 %.  PXS_CH_PF overrides (0: off).
+	int pf;
 	FastDiv dtplA[3], dtplB[3];     // tasks per line of every pass
 	FastDiv dK0, dRL;               // four-step twiddle tables of the stored transform: K0 = n / R_last, R_last
 };
@@ -123,6 +129,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 	if (!s.decode((int)blockIdx.x, c)) return;
 	const bool have_tw = S::HAS_TW && s.btw != nullptr;
 	const int T = s.T;
+	int pf_val = 0;
 	{	// ---- load: every global load of the tile is in flight before the first LDS write
 		const int total = T*na;
 		double2 v[MAXE]; int pos[MAXE];
@@ -137,6 +144,15 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 				v[u] = s.load(c, (int)li, (int)e);
 				if (S::INV_A) v[u].y = -v[u].y;
 				pos[u] = (int)li*s.fa.ns + s.fa.perm[e];
+			}
+		}
+		if (S::LOADK == 0 && s.pf > 0) {	// (issued after the tile's own loads: the wait before the LDS writes below does not include it)
+			const int per = (na*16 + 127) >> 7, i = threadIdx.x;
+			TileC c2;
+			if ((long)blockIdx.x + s.pf < (long)gridDim.x && i < T*per && s.decode((int)blockIdx.x + s.pf, c2)) {
+				const int li = i/per, seg = i - li*per;
+				const double2* r = s.row(c2, li);
+				if (r) pf_val = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(r) + seg*128);
 			}
 		}
 		for (int k = threadIdx.x; k < na; k += NT) twa[k] = s.fa.tw[k];
@@ -177,6 +193,9 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 			s.store(c, (int)li, (int)e, [&](int l2, int e2) { return buf[l2*nslast + e2]; }, w);
 		}
 	}
+#ifndef PXS_HOST_SIM
+	if (S::LOADK == 0) asm volatile("" :: "v"(pf_val));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -996,6 +1015,7 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
 	size_t sh = sizeof(double2)*((size_t)s.fa.n + (S::TWO && s.fb.n == s.fa.n ? 0 : s.fb.n) + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
 	{ static const size_t pad = [] { const char* e = getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
+	{ static const int pf = [] { const char* e = getenv("PXS_CH_PF"); return e ? atoi(e) : 256; }(); const_cast<S&>(s).pf = pf; }
 	if (getenv("PXS_CHAIN_VERBOSE")) {
 		static std::mutex mu; static std::set<std::tuple<int, int, int, int>> seen; std::lock_guard<std::mutex> g(mu);
 		if (seen.insert(std::make_tuple(S::SID, s.fa.n, s.fb.n, s.T)).second)
