@@ -90,6 +90,7 @@ struct StageBase {
 	// (tools/chain_lab.py, 5 repetitions, profiles/r04b_prefetch_ahead.txt): pf = 24, 48: +2 %; 96: -0.5 %; 128 ... 256: -2.5 % (to_cc
 	// 30.0 -> 28.4 ms, C4 11.6 -> 10.8); 384 ... 768: -2 % (from_cc 17.1 -> 16.5); 1536: 0; 3072: +6 %.  PXS_CH_PF overrides (0: off).
 	int pf;
+	static constexpr int PF = 256;
 	FastDiv dtplA[3], dtplB[3];     // tasks per line of every pass
 	FastDiv dK0, dRL;               // four-step twiddle tables of the stored transform: K0 = n / R_last, R_last
 };
@@ -544,6 +545,7 @@ template<int MODE> struct StSplit : StageBase {
 #ifndef PXS_HOST_SIM
 	static constexpr int NT = MODE == 1 ? 256 : CH_NT;
 #endif
+	static constexpr int PF = MODE == 1 ? 512 : 256;      // (per-stage sweep, profiles/r04b_prefetch_ahead.txt: from_cc 16.9 -> 16.3 ms at 512 ... 768)
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* U; long ldU; int a, g, X, mir_c, nr_out, a_odd, ncol, npair;
@@ -654,6 +656,7 @@ struct StRingA1 : StageBase {
 // partner bin nphi - k (in the mirror line) into the spectra of the two rings and written as leg[m][2q], leg[m][2q+1]
 struct StRingA2 : StageBase {
 	static constexpr int SID = 6;
+	static constexpr int PF = 512;      // (map2leg 21.1 -> 20.75 ms against 256)
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, X, npair, groups, nring, mmax; double2* leg; long ldleg; int nm; const double2* tab; double scale; FastDiv da, dgr;
@@ -1015,7 +1018,10 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
 	size_t sh = sizeof(double2)*((size_t)s.fa.n + (S::TWO && s.fb.n == s.fa.n ? 0 : s.fb.n) + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
 	{ static const size_t pad = [] { const char* e = getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
-	{ static const int pf = [] { const char* e = getenv("PXS_CH_PF"); return e ? atoi(e) : 256; }(); const_cast<S&>(s).pf = pf; }
+	{ static const int pf = [] {      // PXS_CH_PF: every stage; PXS_CH_PF_SID<k>: the stage with S::SID = k
+		const std::string name = "PXS_CH_PF_SID" + std::to_string(S::SID);
+		const char* e1 = getenv(name.c_str()); const char* e = getenv("PXS_CH_PF");
+		return e1 ? atoi(e1) : (e ? atoi(e) : S::PF); }(); const_cast<S&>(s).pf = pf; }
 	if (getenv("PXS_CHAIN_VERBOSE")) {
 		static std::mutex mu; static std::set<std::tuple<int, int, int, int>> seen; std::lock_guard<std::mutex> g(mu);
 		if (seen.insert(std::make_tuple(S::SID, s.fa.n, s.fb.n, s.T)).second)
