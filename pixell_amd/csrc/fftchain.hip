@@ -91,6 +91,11 @@ struct StageBase {
 	// 30.0 -> 28.4 ms, C4 11.6 -> 10.8); 384 ... 768: -2 % (from_cc 17.1 -> 16.5); 1536: 0; 3072: +6 %.  PXS_CH_PF overrides (0: off).
 	int pf;
 	static constexpr int PF = 256;
+	// stages that load strided runs name the 128-byte lines of a tile themselves (pfaddr), PFI per thread at most.  Only the first stage of
+	// the 2-D FFTs does: for StFirst of the theta chains and the ring stages MA1 / MS1 it was measured and lost (the ring stages, held to
+	// 64 VGPRs, spill with it: profiles/r04b_prefetch_ahead.txt); enmap.ifft of 21600 x 43200: 32.2 -> 30.2 ms.
+	static constexpr int PFI = 0;
+	__device__ __forceinline__ const void* pfaddr(const TileC&, int) const { return nullptr; }
 	FastDiv dtplA[3], dtplB[3];     // tasks per line of every pass
 	FastDiv dK0, dRL;               // four-step twiddle tables of the stored transform: K0 = n / R_last, R_last
 };
@@ -147,13 +152,23 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 				pos[u] = (int)li*s.fa.ns + s.fa.perm[e];
 			}
 		}
-		if (S::LOADK == 0 && s.pf > 0) {	// (issued after the tile's own loads: the wait before the LDS writes below does not include it)
-			const int per = (na*16 + 127) >> 7, i = threadIdx.x;
+		if ((S::LOADK == 0 || S::PFI > 0) && s.pf > 0 && (long)blockIdx.x + s.pf < (long)gridDim.x) {	// (issued after the tile's own loads: the wait before the LDS writes below does not include it)
 			TileC c2;
-			if ((long)blockIdx.x + s.pf < (long)gridDim.x && i < T*per && s.decode((int)blockIdx.x + s.pf, c2)) {
-				const int li = i/per, seg = i - li*per;
-				const double2* r = s.row(c2, li);
-				if (r) pf_val = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(r) + seg*128);
+			if (s.decode((int)blockIdx.x + s.pf, c2)) {
+				if (S::LOADK == 0) {	// whole rows: one dword per 128-byte line
+					const int per = (na*16 + 127) >> 7, i = threadIdx.x;
+					if (i < T*per) {
+						const int li = i/per, seg = i - li*per;
+						const double2* r = s.row(c2, li);
+						if (r) pf_val = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(r) + seg*128);
+					}
+				} else {	// runs of T elements at a stride: the stage names the lines, at most S::PFI per thread
+#pragma unroll
+					for (int it = 0; it < S::PFI; it++) {
+						const void* q = s.pfaddr(c2, (int)threadIdx.x + it*NT);
+						if (q) pf_val += *reinterpret_cast<const int*>(q);
+					}
+				}
 			}
 		}
 		for (int k = threadIdx.x; k < na; k += NT) twa[k] = s.fa.tw[k];
@@ -195,7 +210,7 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 		}
 	}
 #ifndef PXS_HOST_SIM
-	if (S::LOADK == 0) asm volatile("" :: "v"(pf_val));
+	if (S::LOADK == 0 || S::PFI > 0) asm volatile("" :: "v"(pf_val));
 #endif
 }
 
@@ -456,7 +471,15 @@ struct StFirst : StageBase {
 };
 
 // ... of the 2-D FFTs (plain mode; lengths are 2-3-5-smooth there, split_balanced)
-struct StFirst2D : StFirst { static constexpr bool R7 = false; };
+struct StFirst2D : StFirst {
+	static constexpr bool R7 = false;
+	// the tile's samples are runs of nl elements at j = b e + t0 of row q0: every 8th element names a 128-byte line
+	static constexpr int PFI = 2;
+	__device__ __forceinline__ const void* pfaddr(const TileC& c, int i) const {
+		const int segs = (c.nl + 7) >> 3;
+		const int e = i/segs; if (e >= fa.n) return nullptr;
+		return src.leg + (long)c.comp*src.cstride + (long)c.q0*src.ld + (b*e + c.t0 + 8*(i - e*segs)); }
+};
 
 // pass 2 of transform X1 (forward, b1 points) + spectrum resize + pass 1 of transform X2 (backward, a2 points); shared modulus g.
 // in: Y[outer][k1 < g][j2 < b1]; out: Z[outer][k1' < a2][k1 < g] (row stride ldZ).
