@@ -84,6 +84,7 @@ struct LegK {
 	// maps of a batched call in one launch: the waves of one m of ALL maps sit next to each other in an XCD's queue, so the maps
 	// share the coefficient rows in L2 and the scalar cache.  Strides in elements of leg (double2), almt and mom (double).
 	int nb; long leg_bs, almt_bs, mom_bs;
+	int nmaps;                          // MFMA kernels (leg_ana_s0_mm): nb counts GROUPS of maps there, nmaps the maps themselves
 };
 // (PXS_NCOUNT slots, one picked by the block index: 200 000 waves adding to ONE address cost ~10 ms per C3 step and 24 ms per C4 step)
 #define PXS_NCOUNT 1024
@@ -778,6 +779,181 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	if (kk > 0) leg_flush(red, pout + 4*kbase, lane, kk, a.atomic);
 }
 
+
+// ---- batched spin-0 analysis as an FP64-MFMA GEMM (round 5) -----------------------------------------------------------------------
+// For the maps of a batched call the per-m problem is  mom[k][map, c] = sum_ring p_k(ring) D[ring][map, c]  with the SAME p_k(ring) for
+// every map (c = the four real right-hand sides of leg_ana_s0: re / im of the ring-pair sum, re / im of the difference x cos theta):
+// the ring axis is the K dimension of v_mfma_f64_16x16x4_f64, M = 16 consecutive recurrence steps, N = 16 = 4 maps x 4 sides.
+// The reference loops over the maps, one ducc0 call each (pixell/curvedsky.py:1038-1046); here a wave runs ONE Ishioka recurrence per
+// ring pair (lane = ring pair, phases A / B as in leg_ana_s0; a lane below scale 0 contributes p = 0), parks 16 steps of it in a
+// [16][64] LDS tile (row stride 66 doubles: the write is 64 consecutive doubles, the read in the A-operand layout -- lane (i, kk)
+// takes step i of ring 4q + kk -- touches 64 distinct banks per 32-lane group), and issues 16 MFMAs per tile and group of 4 maps
+// against B operands (the ring data, 16 x 2 VGPRs per group) that stay in registers for the whole l loop.  What the VALU form pays per
+// map -- the recurrence (2 of 6 FMAs), the 64-lane reduce-scatter (10 of ~58 VALU per step) and the three-VGPR-operand FMA rate --
+// is paid once per 4 NG maps or not at all.
+// A workgroup is W waves over 64 W consecutive ring pairs, dealt round-robin (pair = base + slot W + wave) so that the waves of a
+// workgroup become live at the same step; the tiles of a workgroup are aligned to multiples of 16 steps, every wave adds its
+// 16 x 16 accumulators into an LDS tile (ds_add_f64), and after one barrier per tile the waves share out the flush: one
+// global_atomic_add_f64 per (ring chunk of 64 W pairs, row, map) -- the same count as leg_ana_s0<8>.
+#define MM_PSTRIDE 66
+#define MM_WAVES 8
+#ifdef PXS_HOST_SIM
+struct mm_acc { double v[4]; double& operator[](int i) { return v[i]; } };
+static inline mm_acc mm_mfma(double av, double bv, mm_acc c) {      // D[4r + lane/16][lane%16] += sum_kk A[i][kk] B[kk][j], A at lane i + 16 kk, B at lane j + 16 kk
+	pxsim::BlockCtx* cx = pxsim::t_ctx; const int w = pxsim::wave_id(), l = pxsim::lane_id();
+	uint64_t* s = cx->wslot->data() + (size_t)w*128;
+	memcpy(&s[l], &av, 8); memcpy(&s[64 + l], &bv, 8); cx->wbar[w]->wait();
+	for (int r = 0; r < 4; r++) {
+		const int i = 4*r + (l >> 4), j = l & 15;
+		double sum = c.v[r];
+		for (int kk = 0; kk < 4; kk++) { double x, y; memcpy(&x, &s[i + 16*kk], 8); memcpy(&y, &s[64 + j + 16*kk], 8); sum = fma(x, y, sum); }
+		c.v[r] = sum;
+	}
+	cx->wbar[w]->wait();
+	return c;
+}
+static inline void mm_lds_add(double* p, double v) { atomicAdd(p, v); }
+#define MM_WAVE_SYNC() pxsim::t_ctx->wbar[pxsim::wave_id()]->wait()
+#else
+typedef double mm_acc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mm_acc mm_mfma(double av, double bv, mm_acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0); }
+__device__ __forceinline__ void mm_lds_add(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define MM_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+static inline size_t mm_ana_lds(int NG, int W) { return sizeof(double)*((size_t)W*16*MM_PSTRIDE + 2*(size_t)NG*4*64) + 16; }
+
+template<int NG, int W> __global__ __launch_bounds__(64*W, W/2) void leg_ana_s0_mm(const LegK a)
+{
+	PXS_SHARED(double, sh);
+	constexpr int K = 1;
+	double* __restrict__ ptile = sh;                              // [W][16][MM_PSTRIDE]
+	double* __restrict__ red = sh + W*16*MM_PSTRIDE;              // [2][4 NG][64]: the accumulators of a tile summed over the waves
+	int* __restrict__ s_kmin = reinterpret_cast<int*>(red + 2*NG*4*64);
+	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6);
+	int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
+	const int nk = (a.lmax - m)/2 + 1;
+	const double4_t* __restrict__ coef = a.coef + row0;
+	const int pbase = wv*64*W;
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64*W, a.npairs) - 1]; return c*c > 0.5; }();
+	double csq[K], lam1[K], lam2[K]; int sc[K];
+	bool alive;
+	{
+		const int p = pbase + lane*W + w;
+		const bool valid = p < a.npairs;
+		const double x = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0;
+		csq[0] = polar ? -sth*sth : x*x;
+		alive = valid && ((double)m <= a.lmax*sth + a.ofs);
+		lam1[0] = 0; lam2[0] = 0; sc[0] = 0;
+		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[0], sc[0]); }
+	}
+	for (int i = tid; i < 2*NG*4*64; i += 64*W) red[i] = 0.0;
+	if (tid == 0) *s_kmin = nk;
+	__syncthreads();
+	// phase A, per wave: recurrence only until the first lane of the wave is at scale 0; kw = the first step this wave contributes to
+	int k = 0;
+	const bool wave_alive = __any(alive);
+	if (wave_alive) { S0_PHASE_A }
+	const int kw = wave_alive ? PXS_UNIFORM_INT(k) : nk + 16;
+	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	if (lane == 0) atomicMin(s_kmin, kw);
+	__syncthreads();
+	const int kmin = PXS_UNIFORM_INT(*s_kmin);
+	if (kmin >= nk) return;      // (workgroup-uniform) no ring of this chunk carries signal at this m
+	// B operands: lane (j, kk) of MFMA q holds side j & 3 of map 4 (bb NG + g) + (j >> 2) on ring slot 4 q + kk
+	double breg[NG][16];
+	{
+		const int comp = lane & 3, mloc = (lane & 15) >> 2, kk4 = lane >> 4;
+#pragma unroll
+		for (int q = 0; q < 16; q++) {
+			const int pp = pbase + (4*q + kk4)*W + w;
+			const bool ok = pp < a.npairs;
+			const int rn = ok ? a.ring_n[pp] : -1, rs = ok ? a.ring_s[pp] : -1;
+			const double x = ok ? a.cth[pp] : 0.0;
+#pragma unroll
+			for (int g = 0; g < NG; g++) {
+				const int map = (bb*NG + g)*4 + mloc;
+				const double* __restrict__ in = reinterpret_cast<const double*>(a.leg + (long)map*a.leg_bs + (long)m*a.ld) + (comp & 1);
+				const bool okm = map < a.nmaps;
+				const double vn = (okm && rn >= 0) ? in[2*rn] : 0.0, vs = (okm && rs >= 0) ? in[2*rs] : 0.0;
+				breg[g][q] = comp < 2 ? vn + vs : (vn - vs)*x;
+			}
+		}
+	}
+	bool pend = __any(sc[0] < 0);
+	double* __restrict__ pmine = ptile + w*16*MM_PSTRIDE;
+	const double* __restrict__ pread = pmine + (lane & 15)*MM_PSTRIDE + (lane >> 4);
+	long ntile = 0;
+	for (int t = kmin >> 4; 16*t < nk; t++) {
+		const int k0 = 16*t;
+		double* __restrict__ redt = red + (t & 1)*NG*4*64;
+		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
+			ntile++;
+#pragma unroll
+			for (int q4 = 0; q4 < 4; q4++) {
+				const int kq = k0 + 4*q4;
+				if (kq >= kw && kq < nk) {
+					const double4_t c0 = LDC(coef, kq), c1 = LDC(coef, kq+1), c2 = LDC(coef, kq+2), c3 = LDC(coef, kq+3);
+					const double b0 = polar ? c0.c : c0.b, b1 = polar ? c1.c : c1.b, b2 = polar ? c2.c : c2.b, b3 = polar ? c3.c : c3.b;
+					double p0 = lam2[0];
+					lam1[0] = fma(fma(c0.a, csq[0], b0), lam2[0], lam1[0]);
+					double p1 = lam1[0];
+					lam2[0] = fma(fma(c1.a, csq[0], b1), lam1[0], lam2[0]);
+					double p2 = lam2[0];
+					lam1[0] = fma(fma(c2.a, csq[0], b2), lam2[0], lam1[0]);
+					double p3 = lam1[0];
+					lam2[0] = fma(fma(c3.a, csq[0], b3), lam1[0], lam2[0]);
+					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
+						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
+						pend = __any(sc[0] < 0);
+					}
+					// rows beyond the last step of this m stay out of the sums (their table rows belong to the next m)
+					pmine[(4*q4 + 0)*MM_PSTRIDE + lane] = p0;
+					pmine[(4*q4 + 1)*MM_PSTRIDE + lane] = (kq + 1 < nk) ? p1 : 0.0;
+					pmine[(4*q4 + 2)*MM_PSTRIDE + lane] = (kq + 2 < nk) ? p2 : 0.0;
+					pmine[(4*q4 + 3)*MM_PSTRIDE + lane] = (kq + 3 < nk) ? p3 : 0.0;
+				} else {
+#pragma unroll
+					for (int i = 0; i < 4; i++) pmine[(4*q4 + i)*MM_PSTRIDE + lane] = 0.0;
+				}
+			}
+			MM_WAVE_SYNC();
+			mm_acc acc[NG];
+#pragma unroll
+			for (int g = 0; g < NG; g++) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
+#pragma unroll
+			for (int q = 0; q < 16; q++) {
+				const double av = pread[4*q];
+#pragma unroll
+				for (int g = 0; g < NG; g++) acc[g] = mm_mfma(av, breg[g][q], acc[g]);
+			}
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) mm_lds_add(redt + (g*4 + r)*64 + lane, acc[g][r]);
+			MM_WAVE_SYNC();
+		}
+		__syncthreads();
+		// flush: register r of group g holds rows 4 r + lane / 16 of the tile, column lane % 16 = 4 (map in the group) + side
+		for (int c = w; c < 4*NG; c += W) {
+			const int g = c >> 2, r = c & 3;
+			double* rp = redt + c*64 + lane;
+			const double v = *rp; *rp = 0.0;
+			const int krow = k0 + 4*r + (lane >> 4), map = (bb*NG + g)*4 + ((lane & 15) >> 2);
+			if (krow < nk && map < a.nmaps) {
+				double* dst = a.mom + (long)map*a.mom_bs + 4*(row0 + krow) + (lane & 3);
+#ifdef PXS_HOST_SIM
+				atomicAdd(dst, v);
+#else
+				unsafeAtomicAdd(dst, v);
+#endif
+			}
+		}
+	}
+	PXS_COUNT(1, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
+}
+
 // ---------------------------------------------------------------------------------
 // spin-s kernels.  rows l = l0..lmax.  chains G+ (spin +s) and G- (spin -s) of the NORTH ring;
 // south ring: F+_S = (-1)^(l+m) F-_N, F-_S = (-1)^(l+m) F+_N.
@@ -1370,12 +1546,56 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	PXS_HIP(hipGetLastError());
 }
 
+// spin-0 analysis of nb >= PXS_ANA_MM_MIN (4) maps: the FP64-MFMA form (leg_ana_s0_mm), 8 maps per workgroup; a remainder of <= 4 maps
+// takes 4-map workgroups, a single left-over map the VALU kernel.  Summation order differs from the single-map kernel: a batched
+// call equals its single-map calls to rounding (1e-13), not bit for bit.
+static int ana_mm_min() { static int v = [] { const char* e = getenv("PXS_ANA_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
+static bool leg_deterministic() { const char* det = getenv("PXS_DETERMINISTIC"); return det && atoi(det) != 0; }
+static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
+                  const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
+                  LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
+{
+	constexpr int W = MM_WAVES;
+	const int nm = tb.mmax+1;
+	const long n4 = leg_mom_stride(tb);
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+	int nmm = nb;
+	if (nb % 8 == 1) nmm = nb - 1;      // (a lone map in a 4-map workgroup costs more than the VALU kernel)
+	wk.mom.ensure(sizeof(double)*(size_t)n4*nmm);
+	PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nmm, st));
+	auto launch = [&](int b0, int nmaps, int ng) {      // maps [b0, b0 + nmaps) in groups of 4 ng
+		const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
+		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg) + (size_t)b0*leg_bstride, ld, W, ngroups, leg_bstride);
+		a.mom = wk.mom.as<double>() + (size_t)b0*a.mom_bs; a.part = a.mom; a.atomic = 1; a.nmaps = nmaps;
+		if (prof) prof->begin(st, 1);
+		const dim3 grid = leg_grid(a);
+		if (ng == 2) {
+			static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<2, MM_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
+			hipLaunchKernelGGL((leg_ana_s0_mm<2, W>), grid, dim3(64*W), mm_ana_lds(2, W), st, a);
+		} else {
+			static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<1, MM_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
+			hipLaunchKernelGGL((leg_ana_s0_mm<1, W>), grid, dim3(64*W), mm_ana_lds(1, W), st, a);
+		}
+		if (prof) prof->end(st, 1);
+	};
+	const int gmax = std::max(1, leg_max_batch(rs, tb, W));      // groups one launch can take (grid limit)
+	const int r = nmm % 8, n8 = nmm - r;
+	for (int b0 = 0; b0 < n8; b0 += 8*gmax) launch(b0, std::min(8*gmax, n8 - b0), 2);
+	if (r > 4) launch(n8, r, 2); else if (r > 0) launch(n8, r, 1);
+	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, 0, alm_bstride);
+	hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm, nmm), dim3(256), 0, st, ak);
+	PXS_HIP(hipGetLastError());
+	if (nmm < nb)
+		leg_analysis(st, rs, tb, wk, leg + (size_t)nmm*leg_bstride, (char*)alm + aesz*(size_t)nmm*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, 0, prof, ld, 1, 0, 0);
+}
+
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   int deriv1, LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
+	if (tb.spin == 0 && nb >= ana_mm_min() && !leg_deterministic()) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	const int K = tb.spin == 0 ? k_ana0() : k_anas();
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
