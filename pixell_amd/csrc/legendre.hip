@@ -59,6 +59,16 @@ __device__ __forceinline__ double4_t ldc_row(const double4_t* p, long i) {
 }
 #define LDC(p, i) ldc_row((p), (i))
 #endif
+// one double of a wave-uniform table through the constant address space (s_load_dwordx2)
+#ifdef PXS_HOST_SIM
+#define LDCD(p, i) ((p)[i])
+#else
+__device__ __forceinline__ double ldc_double(const double* p, long i) {
+	const __attribute__((address_space(4))) double* c = (const __attribute__((address_space(4))) double*)(unsigned long long)p;
+	return c[i];
+}
+#define LDCD(p, i) ldc_double((p), (i))
+#endif
 
 struct LegK {
 	int lmax, mmax, spin, nm, npairs, nring, nwave;
@@ -85,6 +95,7 @@ struct LegK {
 	// share the coefficient rows in L2 and the scalar cache.  Strides in elements of leg (double2), almt and mom (double).
 	int nb; long leg_bs, almt_bs, mom_bs;
 	int nmaps;                          // MFMA kernels (leg_ana_s0_mm): nb counts GROUPS of maps there, nmaps the maps themselves
+	const double2* coef2; const double2* coef2p;      // compact step table (a, b) / (a, a + b) of the MFMA kernels (LegTables::coef2)
 };
 // (PXS_NCOUNT slots, one picked by the block index: 200 000 waves adding to ONE address cost ~10 ms per C3 step and 24 ms per C4 step)
 #define PXS_NCOUNT 1024
@@ -786,17 +797,25 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 // the ring axis is the K dimension of v_mfma_f64_16x16x4_f64, M = 16 consecutive recurrence steps, N = 16 = 4 maps x 4 sides.
 // The reference loops over the maps, one ducc0 call each (pixell/curvedsky.py:1038-1046); here a wave runs ONE Ishioka recurrence per
 // ring pair (lane = ring pair, phases A / B as in leg_ana_s0; a lane below scale 0 contributes p = 0), parks 16 steps of it in a
-// [16][64] LDS tile (row stride 66 doubles: the write is 64 consecutive doubles, the read in the A-operand layout -- lane (i, kk)
-// takes step i of ring 4q + kk -- touches 64 distinct banks per 32-lane group), and issues 16 MFMAs per tile and group of 4 maps
-// against B operands (the ring data, 16 x 2 VGPRs per group) that stay in registers for the whole l loop.  What the VALU form pays per
-// map -- the recurrence (2 of 6 FMAs), the 64-lane reduce-scatter (10 of ~58 VALU per step) and the three-VGPR-operand FMA rate --
-// is paid once per 4 NG maps or not at all.
-// A workgroup is W waves over 64 W consecutive ring pairs, dealt round-robin (pair = base + slot W + wave) so that the waves of a
-// workgroup become live at the same step; the tiles of a workgroup are aligned to multiples of 16 steps, every wave adds its
-// 16 x 16 accumulators into an LDS tile (ds_add_f64), and after one barrier per tile the waves share out the flush: one
-// global_atomic_add_f64 per (ring chunk of 64 W pairs, row, map) -- the same count as leg_ana_s0<8>.
-#define MM_PSTRIDE 66
+// [16][64] LDS tile and issues 16 MFMAs per tile and group of 4 maps against B operands (the ring data, 16 x 2 VGPRs per group) that
+// stay in registers for the whole l loop.  What the VALU form pays per map -- the recurrence (2 of 6 FMAs), the 64-lane
+// reduce-scatter (10 of ~58 VALU per step) and the three-VGPR-operand FMA rate -- is paid once per 4 NG maps or not at all.
+//  * Workgroup = 8 waves over 512 consecutive ring pairs, wave w the pairs [64 w, 64 w + 64): polar waves join at the tile where their
+//    first lane reaches scale 0.  Tiles are aligned to multiples of 16 steps of the m; every wave adds its 16 x 16 accumulators
+//    into an LDS tile (ds_add_f64) and after ONE barrier per tile the waves share out the flush: one global_atomic_add_f64 per
+//    (chunk of 512 pairs, row, map) -- the count of leg_ana_s0<8>.
+//  * Recurrence lane L is MFMA slot (kk, q) = (L >> 4, L & 15): the P row is written as 64 consecutive doubles and lane (i, kk)
+//    reads its 16 A operands P[i][16 kk + q] from rows of 65 doubles -- conflict-free for ds_read_b64 and ds_read2_b64 alike.
+//  * The ring data reach the B registers through the LDS: the 512 threads read the rows leg[map][m][ring] of 4 maps coalesced (one
+//    ring pair per thread), park (sum, difference x cos) as 16 doubles per pair (17-double entries: lane (j, kk) of MFMA q then reads
+//    entry 64 w + 16 kk + q, double j, conflict-free), and every lane picks its 16 operands.  (First form: per-lane gathers straight
+//    from global memory -- 16 % of the kernel's wave time, tools/mm_time.sh.)
+//  * Step coefficients come from a compact table (a, b) resp. (a, a + b) per step (LegTables::coef2), the 16 steps of the NEXT tile
+//    requested with four s_load_dwordx16 before the MFMAs of the current one (first form: the 32-byte rows of the VALU kernels,
+//    requested and awaited group by group -- four scalar-load round trips per tile, 38 % of the wave time).
+#define MM_PSTRIDE 65
 #define MM_WAVES 8
+#define MM_ESTRIDE 17
 #ifdef PXS_HOST_SIM
 struct mm_acc { double v[4]; double& operator[](int i) { return v[i]; } };
 static inline mm_acc mm_mfma(double av, double bv, mm_acc c) {      // D[4r + lane/16][lane%16] += sum_kk A[i][kk] B[kk][j], A at lane i + 16 kk, B at lane j + 16 kk
@@ -817,18 +836,44 @@ static inline void mm_lds_add(double* p, double v) { atomicAdd(p, v); }
 #else
 typedef double mm_acc __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mm_acc mm_mfma(double av, double bv, mm_acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0); }
+#ifdef PXS_LAB_NOLDSADD
+__device__ __forceinline__ void mm_lds_add(double* p, double v) { *p = v; }      // timing experiment (wrong results)
+#else
 __device__ __forceinline__ void mm_lds_add(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
 #define MM_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
-static inline size_t mm_ana_lds(int NG, int W) { return sizeof(double)*((size_t)W*16*MM_PSTRIDE + 2*(size_t)NG*4*64) + 16; }
+// lab build (-DPXS_LAB_MMTIME): shader-clock time of the phases of leg_ana_s0_mm, summed over the waves (tools/mm_time.sh)
+#if defined(PXS_LAB_MMTIME) && !defined(PXS_HOST_SIM)
+__device__ unsigned long long mm_prof[16];
+#define MM_T0 long long tprev_ = clock64(); unsigned long long tacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MM_TICK(i) { const long long tn_ = clock64(); tacc_[i] += (unsigned long long)(tn_ - tprev_); tprev_ = tn_; }
+#define MM_TDUMP if (lane == 0) { for (int i_ = 0; i_ < 14; i_++) atomicAdd(&mm_prof[i_], tacc_[i_]); atomicAdd(&mm_prof[15], 1ull); }
+#else
+#define MM_T0
+#define MM_TICK(i)
+#define MM_TDUMP
+#endif
+// LDS: [W][16][MM_PSTRIDE] P tiles + [2][4 NG][64] reduction tiles (the staging area of the prologue, 64 W entries of MM_ESTRIDE doubles, lies over both)
+__host__ __device__ constexpr int mm_lds_doubles(int NG, int W) { return W*16*MM_PSTRIDE + 2*NG*4*64 > 64*W*MM_ESTRIDE ? W*16*MM_PSTRIDE + 2*NG*4*64 : 64*W*MM_ESTRIDE; }
+static inline size_t mm_ana_lds(int NG, int W) { return sizeof(double)*(size_t)mm_lds_doubles(NG, W) + 16; }
 
-template<int NG, int W> __global__ __launch_bounds__(64*W, W/2) void leg_ana_s0_mm(const LegK a)
+// compact step table: (a, b) or (a, a + b) of the rows of LegTables::coef; 32 rows of padding (a tile reads 16 steps whatever nk is)
+__global__ __launch_bounds__(256) void coef2_kernel(const double4_t* __restrict__ coef, long nrows, double2* __restrict__ c2, double2* __restrict__ c2p) {
+	const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= nrows + 32) return;
+	if (i < nrows) { const double4_t c = coef[i]; c2[i] = make_double2(c.a, c.b); c2p[i] = make_double2(c.a, c.c); }
+	else { c2[i] = make_double2(0, 0); c2p[i] = make_double2(0, 0); }
+}
+
+template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_s0_mm(const LegK a)
 {
 	PXS_SHARED(double, sh);
 	constexpr int K = 1;
+	MM_T0
 	double* __restrict__ ptile = sh;                              // [W][16][MM_PSTRIDE]
 	double* __restrict__ red = sh + W*16*MM_PSTRIDE;              // [2][4 NG][64]: the accumulators of a tile summed over the waves
-	int* __restrict__ s_kmin = reinterpret_cast<int*>(red + 2*NG*4*64);
+	int* __restrict__ s_kmin = reinterpret_cast<int*>(sh + mm_lds_doubles(NG, W));
 	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6);
 	int wv, m, bb;
 	if (!leg_block(a, wv, m, bb)) return;
@@ -840,7 +885,7 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, W/2) void leg_ana_s0_
 	double csq[K], lam1[K], lam2[K]; int sc[K];
 	bool alive;
 	{
-		const int p = pbase + lane*W + w;
+		const int p = pbase + tid;      // pair of this recurrence lane: wave w owns the pairs [64 w, 64 w + 64) of the chunk
 		const bool valid = p < a.npairs;
 		const double x = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0;
 		csq[0] = polar ? -sth*sth : x*x;
@@ -848,109 +893,152 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, W/2) void leg_ana_s0_
 		lam1[0] = 0; lam2[0] = 0; sc[0] = 0;
 		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[0], sc[0]); }
 	}
-	for (int i = tid; i < 2*NG*4*64; i += 64*W) red[i] = 0.0;
 	if (tid == 0) *s_kmin = nk;
 	__syncthreads();
+	MM_TICK(0)
 	// phase A, per wave: recurrence only until the first lane of the wave is at scale 0; kw = the first step this wave contributes to
 	int k = 0;
 	const bool wave_alive = __any(alive);
 	if (wave_alive) { S0_PHASE_A }
 	const int kw = wave_alive ? PXS_UNIFORM_INT(k) : nk + 16;
-	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	MM_TICK(1)
 	if (lane == 0) atomicMin(s_kmin, kw);
 	__syncthreads();
 	const int kmin = PXS_UNIFORM_INT(*s_kmin);
-	if (kmin >= nk) return;      // (workgroup-uniform) no ring of this chunk carries signal at this m
-	// B operands: lane (j, kk) of MFMA q holds side j & 3 of map 4 (bb NG + g) + (j >> 2) on ring slot 4 q + kk
+	MM_TICK(2)
+	if (kmin >= nk) { MM_TDUMP return; }      // (workgroup-uniform) no ring of this chunk carries signal at this m
+	// B operands through the LDS: thread = ring pair, 4 maps per round
 	double breg[NG][16];
 	{
-		const int comp = lane & 3, mloc = (lane & 15) >> 2, kk4 = lane >> 4;
+		const int p = pbase + tid;
+		const bool ok = p < a.npairs;
+		const int rn = ok ? a.ring_n[p] : -1, rs = ok ? a.ring_s[p] : -1;
+		const double x = ok ? a.cth[p] : 0.0;
+		MM_TICK(8)
+		double* __restrict__ ent = sh + tid*MM_ESTRIDE;
+		const double* __restrict__ rd = sh + (64*w + 16*(lane >> 4))*MM_ESTRIDE + (lane & 15);
 #pragma unroll
-		for (int q = 0; q < 16; q++) {
-			const int pp = pbase + (4*q + kk4)*W + w;
-			const bool ok = pp < a.npairs;
-			const int rn = ok ? a.ring_n[pp] : -1, rs = ok ? a.ring_s[pp] : -1;
-			const double x = ok ? a.cth[pp] : 0.0;
+		for (int g = 0; g < NG; g++) {
+			double2 vn[4], vs[4];
 #pragma unroll
-			for (int g = 0; g < NG; g++) {
-				const int map = (bb*NG + g)*4 + mloc;
-				const double* __restrict__ in = reinterpret_cast<const double*>(a.leg + (long)map*a.leg_bs + (long)m*a.ld) + (comp & 1);
+			for (int mm = 0; mm < 4; mm++) {
+				const int map = (bb*NG + g)*4 + mm;
+				const double2* __restrict__ in = a.leg + (long)map*a.leg_bs + (long)m*a.ld;
 				const bool okm = map < a.nmaps;
-				const double vn = (okm && rn >= 0) ? in[2*rn] : 0.0, vs = (okm && rs >= 0) ? in[2*rs] : 0.0;
-				breg[g][q] = comp < 2 ? vn + vs : (vn - vs)*x;
+				vn[mm] = (okm && rn >= 0) ? in[rn] : make_double2(0, 0); vs[mm] = (okm && rs >= 0) ? in[rs] : make_double2(0, 0);
 			}
-		}
-	}
-	bool pend = __any(sc[0] < 0);
-	double* __restrict__ pmine = ptile + w*16*MM_PSTRIDE;
-	const double* __restrict__ pread = pmine + (lane & 15)*MM_PSTRIDE + (lane >> 4);
-	long ntile = 0;
-	for (int t = kmin >> 4; 16*t < nk; t++) {
-		const int k0 = 16*t;
-		double* __restrict__ redt = red + (t & 1)*NG*4*64;
-		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
-			ntile++;
+			MM_TICK(9)
+			if (g > 0) __syncthreads();      // the reads of the previous round
 #pragma unroll
-			for (int q4 = 0; q4 < 4; q4++) {
-				const int kq = k0 + 4*q4;
-				if (kq >= kw && kq < nk) {
-					const double4_t c0 = LDC(coef, kq), c1 = LDC(coef, kq+1), c2 = LDC(coef, kq+2), c3 = LDC(coef, kq+3);
-					const double b0 = polar ? c0.c : c0.b, b1 = polar ? c1.c : c1.b, b2 = polar ? c2.c : c2.b, b3 = polar ? c3.c : c3.b;
-					double p0 = lam2[0];
-					lam1[0] = fma(fma(c0.a, csq[0], b0), lam2[0], lam1[0]);
-					double p1 = lam1[0];
-					lam2[0] = fma(fma(c1.a, csq[0], b1), lam1[0], lam2[0]);
-					double p2 = lam2[0];
-					lam1[0] = fma(fma(c2.a, csq[0], b2), lam2[0], lam1[0]);
-					double p3 = lam1[0];
-					lam2[0] = fma(fma(c3.a, csq[0], b3), lam1[0], lam2[0]);
-					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
-						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
-						pend = __any(sc[0] < 0);
-					}
-					// rows beyond the last step of this m stay out of the sums (their table rows belong to the next m)
-					pmine[(4*q4 + 0)*MM_PSTRIDE + lane] = p0;
-					pmine[(4*q4 + 1)*MM_PSTRIDE + lane] = (kq + 1 < nk) ? p1 : 0.0;
-					pmine[(4*q4 + 2)*MM_PSTRIDE + lane] = (kq + 2 < nk) ? p2 : 0.0;
-					pmine[(4*q4 + 3)*MM_PSTRIDE + lane] = (kq + 3 < nk) ? p3 : 0.0;
-				} else {
-#pragma unroll
-					for (int i = 0; i < 4; i++) pmine[(4*q4 + i)*MM_PSTRIDE + lane] = 0.0;
-				}
+			for (int mm = 0; mm < 4; mm++) {
+				ent[4*mm + 0] = vn[mm].x + vs[mm].x; ent[4*mm + 1] = vn[mm].y + vs[mm].y;
+				ent[4*mm + 2] = (vn[mm].x - vs[mm].x)*x; ent[4*mm + 3] = (vn[mm].y - vs[mm].y)*x;
 			}
+			__syncthreads();
+			MM_TICK(10)
+#pragma unroll
+			for (int q = 0; q < 16; q++) breg[g][q] = rd[q*MM_ESTRIDE];
 			MM_WAVE_SYNC();
-			mm_acc acc[NG];
-#pragma unroll
-			for (int g = 0; g < NG; g++) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
-#pragma unroll
-			for (int q = 0; q < 16; q++) {
-				const double av = pread[4*q];
-#pragma unroll
-				for (int g = 0; g < NG; g++) acc[g] = mm_mfma(av, breg[g][q], acc[g]);
-			}
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) mm_lds_add(redt + (g*4 + r)*64 + lane, acc[g][r]);
-			MM_WAVE_SYNC();
+			MM_TICK(11)
 		}
 		__syncthreads();
-		// flush: register r of group g holds rows 4 r + lane / 16 of the tile, column lane % 16 = 4 (map in the group) + side
+		for (int i = tid; i < 2*NG*4*64; i += 64*W) red[i] = 0.0;
+		__syncthreads();
+	}
+	MM_TICK(3)
+	const double* __restrict__ tab = reinterpret_cast<const double*>(polar ? a.coef2p : a.coef2) + 2*row0;      // (a, b') of step k at tab[2 k]
+	bool pend = __any(sc[0] < 0);
+	double* __restrict__ pmine = ptile + w*16*MM_PSTRIDE;
+	const double* __restrict__ pread = pmine + (lane & 15)*MM_PSTRIDE + 16*(lane >> 4);
+	double cf[32]; int cf_tile = -1;      // coefficients of the 16 steps of tile cf_tile, requested a tile ahead
+	long ntile = 0;
+	// flush of tile tf (after the barrier that ends it): register r of group g holds rows 4 r + lane / 16 of the tile, column lane % 16 =
+	// 4 (map in the group) + side.  It is issued behind the MFMAs of the NEXT tile (the two reduction tiles alternate), off the path
+	// from the barrier to that tile's recurrence.
+	auto mm_flush = [&](int tf) {
+		double* __restrict__ redf = red + (tf & 1)*NG*4*64;
 		for (int c = w; c < 4*NG; c += W) {
 			const int g = c >> 2, r = c & 3;
-			double* rp = redt + c*64 + lane;
+			double* rp = redf + c*64 + lane;
 			const double v = *rp; *rp = 0.0;
-			const int krow = k0 + 4*r + (lane >> 4), map = (bb*NG + g)*4 + ((lane & 15) >> 2);
+			const int krow = 16*tf + 4*r + (lane >> 4), map = (bb*NG + g)*4 + ((lane & 15) >> 2);
 			if (krow < nk && map < a.nmaps) {
 				double* dst = a.mom + (long)map*a.mom_bs + 4*(row0 + krow) + (lane & 3);
 #ifdef PXS_HOST_SIM
 				atomicAdd(dst, v);
+#elif defined(PXS_LAB_NOATOM)
+				if (v == 12345.678) *dst = v;      // timing experiment (wrong results)
 #else
 				unsafeAtomicAdd(dst, v);
 #endif
 			}
 		}
+	};
+	int tlast = -1;
+	for (int t = kmin >> 4; 16*t < nk; t++) {
+		const int k0 = 16*t;
+		double* __restrict__ redt = red + (t & 1)*NG*4*64;
+		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
+			ntile++;
+			if (cf_tile != t) {
+#pragma unroll
+				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*k0 + i);
+			}
+#pragma unroll
+			for (int q4 = 0; q4 < 4; q4++) {
+				const int kq = k0 + 4*q4;
+				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+				if (kq >= kw && kq < nk) {
+					p0 = lam2[0]; lam1[0] = fma(fma(cf[8*q4 + 0], csq[0], cf[8*q4 + 1]), lam2[0], lam1[0]);
+					p1 = lam1[0]; lam2[0] = fma(fma(cf[8*q4 + 2], csq[0], cf[8*q4 + 3]), lam1[0], lam2[0]);
+					p2 = lam2[0]; lam1[0] = fma(fma(cf[8*q4 + 4], csq[0], cf[8*q4 + 5]), lam2[0], lam1[0]);
+					p3 = lam1[0]; lam2[0] = fma(fma(cf[8*q4 + 6], csq[0], cf[8*q4 + 7]), lam1[0], lam2[0]);
+					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
+						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
+						pend = __any(sc[0] < 0);
+					}
+					// rows beyond the last step of this m stay out of the sums (their table rows belong to the next m)
+					if (kq + 1 >= nk) p1 = 0.0;
+					if (kq + 2 >= nk) p2 = 0.0;
+					if (kq + 3 >= nk) p3 = 0.0;
+				}
+				pmine[(4*q4 + 0)*MM_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MM_PSTRIDE + lane] = p1;
+				pmine[(4*q4 + 2)*MM_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MM_PSTRIDE + lane] = p3;
+			}
+			MM_WAVE_SYNC();
+			MM_TICK(4)
+			double av[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) av[q] = pread[q];
+			MM_WAVE_SYNC();
+			if (k0 + 16 < nk) {      // the rows of the next tile, on their way during the MFMAs (requested after the first A operands have landed)
+#pragma unroll
+				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
+				cf_tile = t + 1;
+			}
+			mm_acc acc[NG];
+#pragma unroll
+			for (int g = 0; g < NG; g++) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
+#pragma unroll
+			for (int q = 0; q < 16; q++) {
+				const double aq = q < 4 ? av[q] : pread[q];
+#pragma unroll
+				for (int g = 0; g < NG; g++) acc[g] = mm_mfma(aq, breg[g][q], acc[g]);
+			}
+			if (tlast >= 0) { mm_flush(tlast); tlast = -1; }
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) mm_lds_add(redt + (g*4 + r)*64 + lane, acc[g][r]);
+			MM_TICK(5)
+		}
+		if (tlast >= 0) mm_flush(tlast);
+		tlast = t;
+		__syncthreads();
+		MM_TICK(6)
 	}
+	if (tlast >= 0) mm_flush(tlast);
+	MM_TDUMP
 	PXS_COUNT(1, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
 }
 
@@ -1551,11 +1639,24 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 // call equals its single-map calls to rounding (1e-13), not bit for bit.
 static int ana_mm_min() { static int v = [] { const char* e = getenv("PXS_ANA_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
 static bool leg_deterministic() { const char* det = getenv("PXS_DETERMINISTIC"); return det && atoi(det) != 0; }
+template<int NG, int W> static void mm_launch1(dim3 grid, hipStream_t st, const LegK& a) {
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<NG, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
+	hipLaunchKernelGGL((leg_ana_s0_mm<NG, W>), grid, dim3(64*W), mm_ana_lds(NG, W), st, a);
+#if defined(PXS_LAB_MMTIME) && !defined(PXS_HOST_SIM)
+	{	unsigned long long h[16]; PXS_HIP(hipStreamSynchronize(st)); PXS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(mm_prof), sizeof(h)));
+		static const char* nm_[14] = {"init", "phaseA", "kmin_barrier", "B_final_barriers", "P_phase", "mfma+ds_add", "barrier", "flush", "B_index", "B_data_loads", "B_lds_write+barrier", "B_lds_read", "-", "-"};
+		double tot = 0; for (int i = 0; i < 14; i++) tot += (double)h[i];
+		fprintf(stderr, "[mm_prof] waves %llu, cycles per wave %.0f:", h[15], tot/std::max(1.0, (double)h[15]));
+		for (int i = 0; i < 12; i++) fprintf(stderr, " %s %.1f%%", nm_[i], 100.0*h[i]/tot);
+		fprintf(stderr, "\n"); memset(h, 0, sizeof(h)); PXS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mm_prof), h, sizeof(h))); }
+#endif
+}
+template<int W> static void mm_launch(int ng, dim3 grid, hipStream_t st, const LegK& a) { if (ng == 2) mm_launch1<2, W>(grid, st, a); else mm_launch1<1, W>(grid, st, a); }
 static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
-	constexpr int W = MM_WAVES;
+	static const int W = [] { const int v = env_k("PXS_ANA_MM_W", MM_WAVES, 2, 16); return v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : 2)); }();      // waves per workgroup (tuning: 2 | 4 | 8 | 16)
 	const int nm = tb.mmax+1;
 	const long n4 = leg_mom_stride(tb);
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
@@ -1563,24 +1664,27 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 	if (nb % 8 == 1) nmm = nb - 1;      // (a lone map in a 4-map workgroup costs more than the VALU kernel)
 	wk.mom.ensure(sizeof(double)*(size_t)n4*nmm);
 	PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nmm, st));
+	if (!tb.d_coef2.p) {      // compact step table, built by the first batched analysis on the plan
+		tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
+		hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
+	}
 	auto launch = [&](int b0, int nmaps, int ng) {      // maps [b0, b0 + nmaps) in groups of 4 ng
 		const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg) + (size_t)b0*leg_bstride, ld, W, ngroups, leg_bstride);
 		a.mom = wk.mom.as<double>() + (size_t)b0*a.mom_bs; a.part = a.mom; a.atomic = 1; a.nmaps = nmaps;
+		a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 		if (prof) prof->begin(st, 1);
 		const dim3 grid = leg_grid(a);
-		if (ng == 2) {
-			static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<2, MM_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
-			hipLaunchKernelGGL((leg_ana_s0_mm<2, W>), grid, dim3(64*W), mm_ana_lds(2, W), st, a);
-		} else {
-			static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<1, MM_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
-			hipLaunchKernelGGL((leg_ana_s0_mm<1, W>), grid, dim3(64*W), mm_ana_lds(1, W), st, a);
-		}
+		if (W == 16)     mm_launch<16>(ng, grid, st, a);
+		else if (W == 8) mm_launch<8>(ng, grid, st, a);
+		else if (W == 4) mm_launch<4>(ng, grid, st, a);
+		else             mm_launch<2>(ng, grid, st, a);
 		if (prof) prof->end(st, 1);
 	};
 	const int gmax = std::max(1, leg_max_batch(rs, tb, W));      // groups one launch can take (grid limit)
-	const int r = nmm % 8, n8 = nmm - r;
-	for (int b0 = 0; b0 < n8; b0 += 8*gmax) launch(b0, std::min(8*gmax, n8 - b0), 2);
+	static const int ngmax = env_k("PXS_ANA_MM_NG", 2, 1, 2);      // groups of 4 maps per workgroup (tuning)
+	const int mper = 4*ngmax, r = nmm % mper, n8 = nmm - r;
+	for (int b0 = 0; b0 < n8; b0 += mper*gmax) launch(b0, std::min(mper*gmax, n8 - b0), ngmax);
 	if (r > 4) launch(n8, r, 2); else if (r > 0) launch(n8, r, 1);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, 0, alm_bstride);
 	hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm, nmm), dim3(256), 0, st, ak);

@@ -23,6 +23,7 @@ struct LegTables {
 	std::vector<long> row;      // row[m]: first row of m; rows = k-steps (spin 0: two l per row) or l-steps (spin s)
 	long nrows = 0;
 	DevBuf d_row, d_coef, d_alpha;   // coef[row] = (a,b); alpha[row] = scaling folded into the alm
+	mutable DevBuf d_coef2, d_coef2p; // spin 0, batched analysis (leg_ana_s0_mm): compact rows (a, b) / (a, a + b), built on first use
 	void build(int lmax, int mmax, int spin);
 };
 

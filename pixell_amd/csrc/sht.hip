@@ -1222,6 +1222,10 @@ static int batch_chunk(const pxs_plan* p, int nbatch, int ncm) {
 	const size_t per_map = sizeof(double2)*(size_t)ncm*((size_t)(p->mmax+1)*(p->nring + (p->ncc > 0 ? p->ncc : 0))*2 + (size_t)p->nring*p->nphi);
 	static const size_t budget = [] { const char* e = getenv("PXS_BATCH_GB"); return (size_t)(e ? atol(e) : 32) << 30; }();
 	const int cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)nbatch, budget/std::max<size_t>(per_map, 1)));
+	if (ncm == 1 && cap >= 8 && nbatch > cap) {      // scalar maps: the batched Legendre analysis works on groups of 8 maps (leg_ana_s0_mm)
+		const int cap8 = cap & ~7, npass = (nbatch + cap8 - 1)/cap8;
+		return std::min(cap8, (((nbatch + npass - 1)/npass + 7)/8)*8);
+	}
 	const int npass = (nbatch + cap - 1)/cap;
 	return (nbatch + npass - 1)/npass;      // equal passes (64 maps at 15 per pass: 13 x 4 + 12, not 15 x 4 + 4 with a last pass at 27 % of the batch dimension)
 }
