@@ -35,6 +35,7 @@ CONFIGS = {
 	"c5":  dict(ncomp=1, shape=(10800, 21600), lmax=6000,  spin=[0],    name="C5 100x[rand_alm -> alm2map -> enmap.fft -> ps2d -> lbin | map2alm -> alm2cl], 1x(10800x21600), lmax=6000", nreal_total=100),
 	"ref": dict(ncomp=1, shape=(900, 1800),    lmax=750,   spin=[0],    name="reference benchmark shape 1x(900x1800) lmax=750"),
 }
+FRAC_DEFINITION = "frac: SURVEY 8(d) F_alg = (4 n0 + 12 n2) R nalm flop per direction over the kernel family's time / 78.6 TFLOP/s; frac_hw: the FP64 flops the kernels executed (recurrence + accumulation FMAs / MFMAs of the steps the waves ran, counted in the kernels) over the same time"
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
 
@@ -219,46 +220,62 @@ def dry_run(args, rank, world, backend):
 
 def run_c5(args, torch, dist, rank, world, local, device, backend):
 	"""BASELINE config 5 (SURVEY 8d recipe): the mixed SHT + 2-D FFT power-spectrum pipeline over independent realisations.
-	One step = every rank works through its contiguous shard of the realisations; nothing but the spectra leaves a rank."""
+	One step = every rank works through its contiguous shard of the realisations, PXS_BENCH_C5_BATCH (8) at a time: the two SHTs of a
+	batch are ONE call each (the batched Legendre kernels; the reference loops over the maps, curvedsky.py:763-765, 1038-1046);
+	nothing but the spectra leaves a rank.  Returns the result line (rank 0 emits it)."""
 	from pixell_amd import curvedsky, enmap, sht, dist as pdist
 	cfg = CONFIGS["c5"]; lmax = cfg["lmax"]; ny, nx = cfg["shape"]
 	ntot = int(os.environ.get("PXS_BENCH_NREAL", cfg["nreal_total"]))
 	lo, hi = pdist.shard_range(ntot, rank, world); nloc = hi-lo
+	nbc = max(1, min(int(os.environ.get("PXS_BENCH_C5_BATCH", "8")), nloc))
 	shape, wcs = enmap.fullsky_geometry(shape=(ny, nx))
 	ainfo = curvedsky.alm_info(lmax)
 	cl_in = 1.0/(np.arange(lmax+1)+1.0)**2
-	m = enmap.dmap(torch.zeros((1, ny, nx), dtype=torch.float64, device=device), wcs)
+	m = enmap.dmap(torch.zeros((nbc, ny, nx), dtype=torch.float64, device=device), wcs)
 	fbuf = enmap.dmap(torch.empty((1, ny, nx), dtype=torch.complex128, device=device), wcs)
-	alm_out = torch.zeros((1, nalm(lmax)), dtype=torch.complex128, device=device)
+	alm_in = torch.zeros((nbc, nalm(lmax)), dtype=torch.complex128, device=device)
+	alm_out = torch.zeros((nbc, nalm(lmax)), dtype=torch.complex128, device=device)
 	stages = ["rand_alm", "alm2map", "enmap_fft", "ps2d_lbin", "map2alm", "alm2cl"]
-	def realisation(i, ev=None):
+	minfo = curvedsky.analyse_geometry(m.shape, wcs)
+	plan = sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1)
+	def batch(i0, n, ev=None):
+		"""realisations i0 .. i0 + n of this rank's shard; returns (binned 2-D spectra, bin centres, C_l [n, lmax + 1])"""
 		def mark():
 			if ev is not None: e = torch.cuda.Event(enable_timing=True); e.record(); ev.append(e)
-		mark(); alm = curvedsky.rand_alm(cl_in, ainfo=ainfo, seed=200+i, rng="device")[None]
-		mark(); curvedsky.alm2map(alm, m, spin=[0], ainfo=ainfo)
-		mark(); f = enmap.fft(m, omap=fbuf, normalize="phys")
-		mark(); ps = enmap.calc_ps2d(f); b, l = enmap.lbin(ps)
-		mark(); curvedsky.map2alm(m, alm=alm_out, spin=[0], ainfo=ainfo)
-		mark(); cl = curvedsky.alm2cl(alm_out[0], ainfo=ainfo)
 		mark()
-		return alm, b, l, cl
+		for j in range(n): alm_in[j] = curvedsky.rand_alm(cl_in, ainfo=ainfo, seed=200+i0+j, rng="device")
+		mark(); curvedsky.alm2map(alm_in[:n], enmap.dmap(m.tensor[:n], wcs), spin=[0], ainfo=ainfo)
+		bs = []; t_fft = []
+		for j in range(n):
+			e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+			e0.record(); f = enmap.fft(enmap.dmap(m.tensor[j:j+1], wcs), omap=fbuf, normalize="phys")
+			e1.record(); ps = enmap.calc_ps2d(f); b, l = enmap.lbin(ps); e2.record()
+			bs.append(b); t_fft.append((e0, e1, e2))
+		mark(); mark()      # (the FFT / spectrum stages of the n maps alternate: their split comes from the inner events)
+		curvedsky.map2alm(enmap.dmap(m.tensor[:n], wcs), alm=alm_out[:n], spin=[0], ainfo=ainfo)
+		mark(); cl = torch.stack([curvedsky.alm2cl(alm_out[j], ainfo=ainfo) for j in range(n)])
+		mark()
+		if ev is not None: ev.append(t_fft)
+		return bs, l, cl
 	t0 = time.time()
-	alm, b, l, cl = realisation(lo)                       # builds the plans; checks below
+	bs, l, cl = batch(lo, nbc)                       # builds the plans; checks below
 	torch.cuda.synchronize()
-	rt_err = float((alm_out-alm).abs().pow(2).mean().sqrt()/alm.abs().pow(2).mean().sqrt())
-	cl_ref = curvedsky.alm2cl(alm[0], ainfo=ainfo)
-	cl_err = float(((cl-cl_ref).abs().max()/cl_ref.abs().max()).item())
+	rt_err = float((alm_out-alm_in).abs().pow(2).mean().sqrt()/alm_in.abs().pow(2).mean().sqrt())
+	cl_ref = curvedsky.alm2cl(alm_in[0], ainfo=ainfo)
+	cl_err = float(((cl[0]-cl_ref).abs().max()/cl_ref.abs().max()).item())
+	b = bs[0]
 	ok = np.isfinite(b[0]) & (l > 200) & (l < 0.5*lmax)
 	flat_ratio = float(np.median(b[0][ok]/np.interp(l[ok], np.arange(lmax+1), cl_in)))       # flat-sky estimate of a full-sky CAR map: order of magnitude only
-	log("[rank %d] c5 setup %.1fs; %d realisation(s) per step; round-trip rms %.2e, alm2cl invariance %.2e, binned 2-D spectrum / C_l (median) %.2f"
-		% (rank, time.time()-t0, nloc, rt_err, cl_err, flat_ratio))
+	log("[rank %d] c5 setup %.1fs; %d realisation(s) per step in batches of %d; round-trip rms %.2e, alm2cl invariance %.2e, binned 2-D spectrum / C_l (median) %.2f"
+		% (rank, time.time()-t0, nloc, nbc, rt_err, cl_err, flat_ratio))
 	if not (rt_err < 1e-8 and cl_err < 1e-9): raise SystemExit("bench.py c5: pipeline check failed (round trip %.3e, alm2cl %.3e)" % (rt_err, cl_err))
 	cls = torch.zeros((max(pdist.shard_sizes(ntot, world)), lmax+1), dtype=torch.float64, device=device)
 	gathered = torch.zeros((world,)+tuple(cls.shape), dtype=torch.float64, device=device) if world > 1 else None
 	def step(ev=None):
-		for k in range(nloc):
-			_, b, l, cl = realisation(lo+k, ev)
-			cls[k] = cl
+		for k in range(0, nloc, nbc):
+			n = min(nbc, nloc-k)
+			_, _, cl = batch(lo+k, n, ev)
+			cls[k:k+n] = cl
 		if gathered is not None:
 			if backend == "nccl": dist.all_gather_into_tensor(gathered.view(world, -1), cls.view(-1))
 			else:
@@ -266,6 +283,7 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 	for _ in range(args.warmup): step()
 	torch.cuda.synchronize()
 	if world > 1: dist.barrier()
+	plan.profile(True)
 	torch.cuda.synchronize()
 	evs = []
 	t0 = time.perf_counter()
@@ -274,89 +292,49 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 	if world > 1: dist.barrier()
 	torch.cuda.synchronize()
 	dt = time.perf_counter()-t0
+	prof = plan.profile_read(reset=True); fl_syn, fl_ana = plan.profile_flops(reset=True); plan.profile(False)
 	if world > 1:
 		t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 	stage_ms = {k: 0.0 for k in stages}
-	for r in range(len(evs)//7):
-		for j, k in enumerate(stages): stage_ms[k] += evs[7*r+j].elapsed_time(evs[7*r+j+1])
+	for r in range(len(evs)//8):
+		e = evs[8*r:8*r+8]
+		stage_ms["rand_alm"] += e[0].elapsed_time(e[1]); stage_ms["alm2map"] += e[1].elapsed_time(e[2])
+		stage_ms["map2alm"] += e[4].elapsed_time(e[5]); stage_ms["alm2cl"] += e[5].elapsed_time(e[6])
+		for e0, e1, e2 in e[7]: stage_ms["enmap_fft"] += e0.elapsed_time(e1); stage_ms["ps2d_lbin"] += e1.elapsed_time(e2)
 	nre = max(1, args.steps*nloc)
 	stage_ms = {k: round(v/nre, 3) for k, v in stage_ms.items()}
 	ms_step = dt/args.steps*1e3
 	# algorithmic bytes / flops per realisation: SHT round trip 2 F_alg, 2 (map + alm) bytes; the 2-D FFT reads the real map and writes the complex one
-	R_alg = min(ny, lmax+2); F = 2*4*R_alg*nalm(lmax); B_fft = ny*nx*(8+16)
-	leg_ms = stage_ms["alm2map"]+stage_ms["map2alm"]
+	R_alg = min(ny, lmax+2); F_dir = 4*R_alg*nalm(lmax); B_fft = ny*nx*(8+16)
+	leg = {k: prof[k][0]/nre for k in ("leg_syn", "leg_ana")}      # Legendre kernel ms per realisation, hipEvents inside the library (pxs_profile)
+	dom = "leg_ana" if leg["leg_ana"] >= leg["leg_syn"] else "leg_syn"
+	exe = {"leg_syn": fl_syn/nre, "leg_ana": fl_ana/nre}
+	frac_hw = {k: (round(exe[k]/(leg[k]*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if leg[k] > 0 else 0.0) for k in leg}
 	res = dict(metric="power-spectrum pipeline realisations/sec (rand_alm + alm2map + enmap.fft + ps2d/lbin + map2alm + alm2cl)", value=round(ntot*args.steps/dt, 4), unit="realisations/s",
 		n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
 		config=dict(workload=cfg["name"] if ntot == cfg["nreal_total"] else cfg["name"].replace("100x", "%dx" % ntot), geometry="CAR fejer1 %dx%d" % (ny, nx), lmax=lmax,
-			realisations_total=ntot, realisations_per_gpu=nloc, rng="device (torch Philox); the legacy-numpy recipe pinned to the reference costs ~0.5 s per realisation on the host",
+			realisations_total=ntot, realisations_per_gpu=nloc, realisations_per_call=nbc, rng="device (torch Philox); the legacy-numpy recipe pinned to the reference costs ~0.5 s per realisation on the host",
 			parallelism=("independent realisations sharded contiguously over the ranks; RCCL all-gather of the C_l only" if world > 1 else "single GPU")),
 		ms_per_realisation=round(ms_step/max(nloc, 1), 3), stage_ms_per_realisation=stage_ms,
-		roofline=dict(bound="fp64_valu", kernel="the two SHTs of a realisation (alm2map + map2alm, all their kernels incl. the FFT stages)", achieved=round(F/(leg_ms*1e-3)/1e12, 3) if leg_ms > 0 else 0.0,
-			peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=round(F/(leg_ms*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if leg_ms > 0 else 0.0, traffic=None, algorithmic_flops_per_realisation=F),
+		roofline=dict(bound="mfma" if (dom == "leg_ana" and nbc >= 4) else "fp64_valu", kernel="leg_ana_* (Legendre analysis of a batch)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis of a batch)",
+			achieved=round(F_dir/(leg[dom]*1e-3)/1e12, 3) if leg[dom] > 0 else 0.0, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+			frac=round(F_dir/(leg[dom]*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if leg[dom] > 0 else 0.0, frac_hw=frac_hw[dom], frac_hw_both=frac_hw, frac_definition=FRAC_DEFINITION, traffic=None,
+			kernel_ms_per_realisation={k: round(v, 3) for k, v in leg.items()}, algorithmic_flops_per_realisation_direction=F_dir, executed_flops_per_realisation=exe),
 		fft=dict(bound="hbm", kernel="enmap.fft real -> complex, 10800x21600", ms=stage_ms["enmap_fft"], achieved=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9, 1) if stage_ms["enmap_fft"] > 0 else 0.0,
 			peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9/HBM_PEAK_GBS, 4) if stage_ms["enmap_fft"] > 0 else 0.0),
 		checks=dict(roundtrip_rms_error=rt_err, alm2cl_invariance=cl_err, binned_ps2d_over_cl_median=flat_ratio), ducc0=probe_ducc0())
 	if world > 1: res["rccl_ranks_seen"] = world
-	if rank == 0: emit(res)
+	del m, fbuf, alm_in, alm_out
+	return res
 
-def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument("--gpus", type=int, default=1)
-	ap.add_argument("--steps", type=int, default=3)
-	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-	ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / fft / h2d legs")
-	ap.add_argument("--no-gather", action="store_true", help="skip the alm all-gather (N>1)")
-	ap.add_argument("--dry", action="store_true", help="rank plumbing only (launch, sharding, gather), no transforms: runs without a GPU over gloo")
-	args = ap.parse_args()
-	if args.gpus < 1: raise SystemExit("bench.py: --gpus must be >= 1")
-	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-		sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))        # one process per GPU; the children come back here with WORLD_SIZE set
-	import torch
-	import torch.distributed as dist
-	rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-	if world != args.gpus:
-		raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s): refusing to report a line whose n_gpus is not what was asked for" % (args.gpus, world))
-	# PXS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the gather goes
-	# through host memory); the driver's runs use nccl (= RCCL) with one rank per GPU
-	backend = os.environ.get("PXS_BENCH_BACKEND", "gloo" if args.dry else "nccl")
-	if args.dry:
-		if world > 1:
-			os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-			dist.init_process_group(backend)
-		try: dry_run(args, rank, world, backend)
-		finally:
-			if world > 1: dist.destroy_process_group()
-		return
-	assert torch.cuda.is_available(), "bench.py needs a GPU"
-	if backend == "nccl" and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
-		raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible: RCCL needs one GPU per rank (PXS_BENCH_BACKEND=gloo shares devices for rehearsals)"
-			% (int(os.environ.get("LOCAL_WORLD_SIZE", world)), torch.cuda.device_count()))
-	if backend != "nccl": local = local % torch.cuda.device_count()
-	torch.cuda.set_device(local)             # before the process group: RCCL binds the communicator to the current device
-	device = torch.device("cuda", local)
-	# PXS_BENCH_FORCE_PG=1: a process group (and the alm gather) even with one rank -- exercises the RCCL calls of the N > 1 path on a one-GPU box
-	force_pg = world == 1 and os.environ.get("PXS_BENCH_FORCE_PG") == "1"
-	if force_pg:
-		os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
-		os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-	if world > 1 or force_pg:
-		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		# RCCL logs to stdout (this image sets NCCL_DEBUG=VERSION: a banner, from libc's buffer, i.e. at process exit, AFTER the JSON
-		# line): send its log to stderr and keep stdout to the one line the driver parses
-		os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-		dist.init_process_group(backend)
-		dist.barrier()                               # creates the communicator now; anything it printed leaves libc's buffer before the timed part
-		try:
-			import ctypes; ctypes.CDLL(None).fflush(None)
-		except Exception: pass
-	if args.config == "c5":
-		try: run_c5(args, torch, dist, rank, world, local, device, backend)
-		finally:
-			if world > 1 or force_pg: dist.destroy_process_group()
-		return
+def run_sht(args, ctx):
+	"""One SHT configuration (args.config, args.steps, args.warmup): K timed round trips of map2alm + alm2map on device-resident maps; returns the
+	result line.  args.primary (default True): with the legs that belong to the headline line only (other analysis forms; host arrays, 2-D FFT and
+	CPU baseline unless args.no_cpu)."""
 	from pixell_amd import curvedsky, enmap, sht, dist as pdist
+	torch, dist, rank, world, local, device, backend, force_pg = ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.local, ctx.device, ctx.backend, ctx.force_pg
+	primary = getattr(args, "primary", True)
 	cfg = CONFIGS[args.config]
 	batched = "nbatch_total" in cfg
 	ntot = int(os.environ.get("PXS_BENCH_NBATCH", cfg.get("nbatch_total", 0))) if batched else 0     # (smaller batches for rehearsals)
@@ -443,7 +421,7 @@ def main():
 	#   "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route (curvedsky.py:852-861, 1068-1084), where the
 	#              grid has >= 2 lmax + 2 rings: three theta-resampling stages instead of five.
 	ana_forms = None
-	if world == 1 and not batched and not os.environ.get("PXS_BENCH_NO_WEIGHTS"):
+	if primary and world == 1 and not batched and not os.environ.get("PXS_BENCH_NO_WEIGHTS"):
 		ana_forms = {}
 		for form in ["interpolant"]+(["weights"] if ny >= 2*lmax+2 else []):
 			try:
@@ -471,12 +449,15 @@ def main():
 	dom_ms_per_step = prof[dom][0]/args.steps
 	achieved = flops_dir/(dom_ms_per_step*1e-3)/1e12 if dom_ms_per_step > 0 else 0.0
 	exe = (fl_ana if dom == "leg_ana" else fl_syn)/max(args.steps, 1)        # flops the kernels of that family executed per step (counted in the kernels)
-	roof = dict(bound="fp64_valu", pipe="FP64 vector FMA (v_fma_f64): the contraction is 4 right-hand sides wide per map, too narrow for the 16x16x4 f64 MFMA, whose dense peak equals the vector peak; no MFMA instruction is issued",
+	# batched scalar maps: the analysis of 4 or more maps per call is the FP64-MFMA kernel (leg_ana_s0_mm); everything else is plain v_fma_f64
+	mm = batched and nmaps >= 4 and dom == "leg_ana"
+	roof = dict(bound="mfma" if mm else "fp64_valu",
+		pipe=("FP64 MFMA (v_mfma_f64_16x16x4_f64): the maps of a batch share one recurrence per ring pair, rings are the K dimension, 16 columns = 4 maps x 4 real right-hand sides; its dense peak equals the vector peak on MI355X"
+			if mm else "FP64 vector FMA (v_fma_f64): the contraction is 4 right-hand sides wide per map, too narrow for the 16x16x4 f64 MFMA, whose dense peak equals the vector peak; no MFMA instruction is issued"),
 		kernel="leg_ana_* (Legendre analysis, all launches of a step)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis, all launches of a step)",
-		achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved/FP64_PEAK_TFLOPS, 4), traffic=None,
+		achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved/FP64_PEAK_TFLOPS, 4),
+		frac_hw=round(exe/(dom_ms_per_step*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if dom_ms_per_step > 0 else 0.0, frac_definition=FRAC_DEFINITION, traffic=None,
 		algorithmic_flops_per_step_direction=flops_dir, executed_flops_per_step_direction=exe,
-		frac_hw=round(exe/(dom_ms_per_step*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if dom_ms_per_step > 0 else 0.0,
-		frac_note="frac credits SURVEY 8(d)'s algorithmic count (4 / 12 flop per (l,m,ring) on R_algorithmic rings); frac_hw is what the FMA pipe really did: recurrence + accumulation FMAs of the steps the waves ran (spin 0 needs 3, not 4, flop per (l,m,ring); polar-dead rings and phase A are skipped), counted by the kernels",
 		executed_flops_both={"leg_syn": fl_syn/max(args.steps, 1), "leg_ana": fl_ana/max(args.steps, 1)},
 		frac_hw_both={k: (round(v/max(args.steps, 1)/(prof[k][0]/args.steps*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if prof[k][0] > 0 else 0.0) for k, v in (("leg_syn", fl_syn), ("leg_ana", fl_ana))},
 		kernel_ms_per_step=round(dom_ms_per_step, 3),
@@ -540,8 +521,120 @@ def main():
 				res["cpu_baseline"] = cpu_baseline(dict(cfg, ncomp=ncomp))
 			except Exception as e:   # the baseline must never take the GPU number down with it
 				log("cpu_baseline failed: %r" % (e,)); res["cpu_baseline"] = None
-		emit(res)
-	if world > 1 or force_pg: dist.destroy_process_group()
+	del dmap, alm_out
+	return res
+
+
+class Ctx: pass
+
+LEG_KEYS = ("ms_per_step", "value", "unit", "steps", "stage_ms_per_step", "roundtrip_rms_error")
+def compact_leg(res):
+	"""what a secondary configuration contributes to the one line: its time, throughput, stage split, roofline fractions and round-trip error"""
+	out = {k: res[k] for k in LEG_KEYS if k in res}
+	out["workload"] = res["config"]["workload"]
+	if "ms_per_realisation" in res: out.update(ms_per_realisation=res["ms_per_realisation"], stage_ms_per_realisation=res["stage_ms_per_realisation"], roundtrip_rms_error=res["checks"]["roundtrip_rms_error"], realisations_per_call=res["config"]["realisations_per_call"])
+	r = res["roofline"]
+	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_hw", "frac_hw_both", "frac_definition", "kernel_ms_per_step", "kernel_ms_per_realisation") if k in r}
+	if "fft_chain" in res: out["fft_chain"] = {k: res["fft_chain"][k] for k in ("bound", "achieved", "unit", "frac", "kernel_ms_per_step")}
+	if "fft" in res and res["fft"] and "frac" in res["fft"]: out["fft"] = res["fft"]
+	return out
+
+def secondary_legs(args, ctx):
+	"""After the timed headline loop (never inside it, never in `value`): the other BASELINE configurations and the reference's own benchmark
+	shape, a few steps each, so that every configuration has a driver-run number in the one line.  N > 1: the batched configuration (C4, 64
+	maps sharded over the ranks -- strong scaling, north_star's "batched-map scaling") beside the weak-scaling headline."""
+	torch = ctx.torch
+	from pixell_amd import sht
+	legs = {}
+	plan = [("c4", dict(config="c4", steps=2, warmup=1))] if ctx.world > 1 else [
+		("c2", dict(config="c2", steps=3, warmup=1)),
+		("c4_share", dict(config="c4", steps=3, warmup=1, nbatch=8)),
+		("c4", dict(config="c4", steps=2, warmup=1)),
+		("c5", dict(config="c5", steps=1, warmup=0, nreal=8)),
+		("ref", dict(config="ref", steps=40, warmup=2))]
+	for name, kw in plan:
+		t0 = time.time()
+		leg = argparse.Namespace(**vars(args)); leg.config = kw["config"]; leg.steps = kw["steps"]; leg.warmup = kw["warmup"]; leg.no_cpu = True; leg.primary = False
+		try:
+			sht.clear_plans(); torch.cuda.empty_cache()
+			if "nbatch" in kw: os.environ["PXS_BENCH_NBATCH"] = str(kw["nbatch"])
+			if "nreal" in kw: os.environ["PXS_BENCH_NREAL"] = str(kw["nreal"])
+			res = run_c5(leg, ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.local, ctx.device, ctx.backend) if kw["config"] == "c5" else run_sht(leg, ctx)
+			legs[name] = compact_leg(res); legs[name]["leg_wall_s"] = round(time.time()-t0, 1)
+			if name == "ref": legs[name]["note"] = "the reference's own benchmark shape (scripts/benchmark_pixell_runner.py:13-27: 900x1800, lmax 750, 40 iterations): wall time per round trip including the Python layer"
+		except Exception as e:
+			if ctx.world > 1: raise          # (a rank that skipped a leg's collectives would hang the others)
+			log("secondary leg %s failed: %r" % (name, e)); legs[name] = dict(error=repr(e))
+		finally:
+			os.environ.pop("PXS_BENCH_NBATCH", None) if "nbatch" in kw else None
+			os.environ.pop("PXS_BENCH_NREAL", None) if "nreal" in kw else None
+	return legs
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=3)
+	ap.add_argument("--warmup", type=int, default=1)
+	ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+	ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / fft / h2d legs")
+	ap.add_argument("--no-legs", action="store_true", help="skip the secondary configurations (`configs` block) after the headline loop")
+	ap.add_argument("--no-gather", action="store_true", help="skip the alm all-gather (N>1)")
+	ap.add_argument("--dry", action="store_true", help="rank plumbing only (launch, sharding, gather), no transforms: runs without a GPU over gloo")
+	args = ap.parse_args()
+	if args.gpus < 1: raise SystemExit("bench.py: --gpus must be >= 1")
+	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))        # one process per GPU; the children come back here with WORLD_SIZE set
+	import torch
+	import torch.distributed as dist
+	rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+	if world != args.gpus:
+		raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d rank(s): refusing to report a line whose n_gpus is not what was asked for" % (args.gpus, world))
+	# PXS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the gather goes
+	# through host memory); the driver's runs use nccl (= RCCL) with one rank per GPU
+	backend = os.environ.get("PXS_BENCH_BACKEND", "gloo" if args.dry else "nccl")
+	if args.dry:
+		if world > 1:
+			os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+			dist.init_process_group(backend)
+		try: dry_run(args, rank, world, backend)
+		finally:
+			if world > 1: dist.destroy_process_group()
+		return
+	assert torch.cuda.is_available(), "bench.py needs a GPU"
+	if backend == "nccl" and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+		raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible: RCCL needs one GPU per rank (PXS_BENCH_BACKEND=gloo shares devices for rehearsals)"
+			% (int(os.environ.get("LOCAL_WORLD_SIZE", world)), torch.cuda.device_count()))
+	if backend != "nccl": local = local % torch.cuda.device_count()
+	torch.cuda.set_device(local)             # before the process group: RCCL binds the communicator to the current device
+	device = torch.device("cuda", local)
+	# PXS_BENCH_FORCE_PG=1: a process group (and the alm gather) even with one rank -- exercises the RCCL calls of the N > 1 path on a one-GPU box
+	force_pg = world == 1 and os.environ.get("PXS_BENCH_FORCE_PG") == "1"
+	if force_pg:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+		os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+	if world > 1 or force_pg:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		# RCCL logs to stdout (this image sets NCCL_DEBUG=VERSION: a banner, from libc's buffer, i.e. at process exit, AFTER the JSON
+		# line): send its log to stderr and keep stdout to the one line the driver parses
+		os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+		dist.init_process_group(backend)
+		dist.barrier()                               # creates the communicator now; anything it printed leaves libc's buffer before the timed part
+		try:
+			import ctypes; ctypes.CDLL(None).fflush(None)
+		except Exception: pass
+	ctx = Ctx(); ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.local, ctx.device, ctx.backend, ctx.force_pg = torch, dist, rank, world, local, device, backend, force_pg
+	try:
+		t_all = time.time()
+		res = run_c5(args, torch, dist, rank, world, local, device, backend) if args.config == "c5" else run_sht(args, ctx)
+		# the other BASELINE configurations, after the headline loop: only beside the default headline (c3), so that `--config X` stays a
+		# short single-configuration run for profiling
+		if args.config == "c3" and res["config"]["lmax"] == CONFIGS["c3"]["lmax"] and not args.no_legs and not os.environ.get("PXS_BENCH_NO_LEGS"):
+			res["configs"] = secondary_legs(args, ctx)
+			res["configs_note"] = "secondary configurations run after the timed loop of the headline configuration, each on freshly built plans; never part of `value`"
+		res["bench_wall_s"] = round(time.time()-t_all, 1)
+		if rank == 0: emit(res)
+	finally:
+		if world > 1 or force_pg: dist.destroy_process_group()
 
 if __name__ == "__main__":
 	main()
