@@ -547,7 +547,9 @@ const double2* FftContext::bigtw(long n) {
 
 static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	k.n = s.n; k.nfac = s.nfac; k.generic = s.generic;
+#ifdef PXS_LAB
 	{ static const int nopass = [] { const char* e = getenv("PXS_FFT_DEBUG_NOPASS"); return e ? atoi(e) : 0; }(); if (nopass) k.nfac = 0; }   // timing experiments only: wrong results
+#endif
 	k.pass = s.d_pass.as<PassDesc>();
 	k.perm = s.perm.as<int>(); k.tw = s.tw.as<double2>();
 	int bufs = s.generic ? 2 : 1;

@@ -20,7 +20,7 @@
 // on MI355X with tools/stride_bw.hip).  All global loads of a tile are issued before the first LDS write.
 // Replaces ducc0's ring FFTs / resample_theta inside synthesis_2d / analysis_2d (pixell/curvedsky.py:907-924, 1032-1046).
 #include "fftchain.hpp"
-#include "fft2_dev.hpp"
+#include "fft_dev.hpp"
 #include <algorithm>
 #include <set>
 #include <type_traits>
@@ -82,8 +82,6 @@ struct StageBase {
 	// from the full table btw (into LDS), the second comes from a small table tws[e][li] shared by all tiles (coalesced reads).
 	// (One gather per point from the full table made every wave instruction touch 64 cache lines.)
 	const double2* btw; const double2* tws;
-	// second-generation kernel (chain2_kernel): DIF transforms with large register radices, tiles walked by persistent workgroups
-	Fft2 a2, b2; int ntiles2;
 	// Prefetch ahead: a workgroup of a stage that loads whole rows touches the rows of the tile `pf` workgroups ahead (one dword per
 	// 128-byte line, issued after its own loads, consumed by nothing until the kernel ends), so that tile's loads hit the L2 when its
 	// workgroup starts -- on the same XCD: workgroups go round-robin to the 8 XCDs and pf is a multiple of 8.  Measured at C3 / C4
@@ -96,8 +94,6 @@ struct StageBase {
 	// 64 VGPRs, spill with it: profiles/r04b_prefetch_ahead.txt); enmap.ifft of 21600 x 43200: 32.2 -> 30.2 ms.
 	static constexpr int PFI = 0;
 	__device__ __forceinline__ const void* pfaddr(const TileC&, int) const { return nullptr; }
-	FastDiv dtplA[3], dtplB[3];     // tasks per line of every pass
-	FastDiv dK0, dRL;               // four-step twiddle tables of the stored transform: K0 = n / R_last, R_last
 };
 
 __device__ __forceinline__ double2 cscale(double2 a, double f) { return make_double2(a.x*f, a.y*f); }
@@ -215,215 +211,6 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// second-generation chain kernel (round 4)
-// ---------------------------------------------------------------------------------------------------------------
-// What limited chain_kernel (SQ counters of round 4, profiles/r04_chain_sq_v1.txt): the VALU ~50 % busy, the LDS ~50 % busy with
-// 44-52 % of its active cycles lost to bank conflicts, waves parked at barriers / waitcnt 65-73 % of their time -- per tile the
-// VALU time (2.6 us), the LDS time (2.6 us) and the memory latency ADD UP instead of overlapping: ten barriered sweeps, one
-// radix <= 9 butterfly per thread and sweep.  This kernel:
-//   * persistent workgroups walk over the tiles; a tile whose lines are contiguous rows (S::LOADK == 0) arrives by LDS-DMA
-//     (global_load_lds_dwordx4, 64 x 16 bytes per wave instruction, natural order -- the transforms are decimation in frequency)
-//     while the previous tile is still being worked on; raw s_barrier + lgkmcnt-only waits keep the DMA in flight, the one
-//     vmcnt(0) sits where the tile is needed.  Nothing between the DMA issue and that wait consumes a global load (the four-step
-//     twiddles of the store come from two small per-tile LDS tables fetched BEFORE the DMA is issued): a later load cannot return
-//     before an earlier one, so any such use would wait for the whole tile;
-//   * at most three passes per transform with register radices up to 25 (fft2_dev.hpp): 4 barriers per two-transform tile
-//     instead of 10, a third of the LDS store traffic;
-//   * the last pass hands its results to the store in registers (S::STOREK == 0), the first pass of an elementwise-loading stage
-//     (S::LOADK == 1) takes its inputs straight from global memory, the second transform of a two-transform stage pulls its
-//     inputs through S::mid from the first one's output;
-//   * layouts are padded (Fft2::rs, ns: chosen on the host by counting bank conflicts of every pass with the ds_read_b128 /
-//     ds_write_b128 lane groups of gfx950).
-// Four-step twiddle of output k = k0 + K0*i (i: register index of the last pass) of line L = t0 + li:
-//   W_X^{L k} = F1[li][k0] * F2[li][i],  F1 = W_X^{L k0},  F2 = W_X^{L K0 i}:  T*(K0 + R_last) table entries per tile.
-#ifdef PXS_HOST_SIM
-#define PXS_DMA16(gp, lbase, lane) ((lbase)[lane] = *(gp))
-#define PXS_WAIT_VM0()
-static constexpr int CH2_NT = 1;
-#define PXS_CH2_BOUNDS
-#else
-__device__ __forceinline__ void pxs_dma16(const double2* g, double2* l) {
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-#define PXS_DMA16(gp, lbase, lane) pxs_dma16((gp), (lbase))
-#define PXS_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#ifndef PXS_CH2_NT
-#define PXS_CH2_NT 512
-#endif
-static constexpr int CH2_NT = PXS_CH2_NT;
-// two workgroups per CU (each ~75 KiB of LDS): 2 NT / 64 waves on 4 SIMDs = NT / 128 waves per SIMD -> 128 VGPRs at 512 threads
-#define PXS_CH2_BOUNDS __launch_bounds__(NT, (NT >= 128 ? NT/128 : 1))
-#endif
-
-// (a kernel holds the butterflies of every radix a pass may take, and its register allocation is the maximum over them: the passes
-// that pull their inputs from global memory or through S::mid -- many address registers next to the data -- take radices up to
-// F2_MAXR_FIRST only, see f2_factor)
-template<int MAXR, class F> __device__ __forceinline__ void f2_dispatch(int R, F&& f) {
-	switch (R) {
-		case 2: f(std::integral_constant<int, 2>{}); break;   case 3: f(std::integral_constant<int, 3>{}); break;
-		case 4: f(std::integral_constant<int, 4>{}); break;   case 5: f(std::integral_constant<int, 5>{}); break;
-		case 6: f(std::integral_constant<int, 6>{}); break;
-		case 8: if constexpr (MAXR >= 8) f(std::integral_constant<int, 8>{}); break;
-		case 9: if constexpr (MAXR >= 9) f(std::integral_constant<int, 9>{}); break;
-		default: break;
-	}
-}
-
-// one pass of transform f on T lines: in(task, i) -> input i of the butterfly, out(task, i, value) <- output i
-template<int NT, int MAXR, class In, class Out>
-__device__ __forceinline__ void f2_pass(const Fft2& f, int q, int T, FastDiv dT, FastDiv dtpl, bool line_fast, const double2* tw, In&& in, Out&& out) {
-	const int R = f2_radix(f, q), tpl = f.n / R, total = T*tpl;
-	const bool twd = q + 1 < f.np;
-	f2_dispatch<MAXR>(R, [&](auto Rc) {
-		constexpr int RR = decltype(Rc)::value;
-		for (int t = threadIdx.x; t < total; t += NT) {
-			F2Task k; int tl;
-			if (line_fast) { tl = (int)fdiv((uint32_t)t, dT); k.li = t - tl*T; } else { k.li = (int)fdiv((uint32_t)t, dtpl); tl = t - k.li*tpl; }
-			f2_decode(f, q, tl, k);
-			double2 v[RR];
-#pragma unroll
-			for (int i = 0; i < RR; i++) v[i] = in(k, i);
-			dft_reg<RR>(v);
-			if (twd && k.step != 0) {
-#pragma unroll
-				for (int i = 1; i < RR; i++) v[i] = cmul(v[i], tw[i*k.step]);
-			}
-#pragma unroll
-			for (int i = 0; i < RR; i++) out(k, i, v[i]);
-		}
-	});
-}
-
-template<class S, int NT> __global__ PXS_CH2_BOUNDS void chain2_kernel(const S s)
-{
-	PXS_SHARED(double2, lds);
-	const Fft2& fa = s.a2; const Fft2& fb = s.b2;
-	const Fft2& fl = S::TWO ? fb : fa;               // the transform whose output is stored
-	const int na = fa.n, nb = S::TWO ? fb.n : 0;
-	const int T = s.T;
-	const FastDiv dT = s.dT;
-	const int szA = ((T*fa.ns + 63) & ~63);           // DMA granularity: whole wave instructions
-	const bool dbl = !S::TWO && S::LOADK == 0;        // two input buffers: the next tile arrives while this one is transformed in place
-	const int K0 = fl.n / f2_radix(fl, fl.np - 1), RL = f2_radix(fl, fl.np - 1);
-	const bool have_tw = S::HAS_TW && s.btw != nullptr;
-	const int nF = T*(K0 + RL), nFp = (nF + 63) & ~63;           // F1[li][k0] | F2[li][i]
-	// DMA destinations first (they must sit below 64 KiB): the two four-step twiddle tables (tile parity), then the row buffer(s)
-	double2* ftw = lds;
-	double2* bufA = ftw + (S::HAS_TW ? 2*nFp : 0);
-	double2* bufB = bufA + (dbl ? 2 : 1)*szA;
-	double2* twa = bufB + (S::TWO ? T*fb.ns : 0); double2* twb = twa + na;
-	for (int k = threadIdx.x; k < na; k += NT) twa[k] = fa.tw[k];
-	if (S::TWO) for (int k = threadIdx.x; k < nb; k += NT) twb[k] = fb.tw[k];
-
-	TileC c, cn;
-	const int ntiles = s.ntiles2;
-	auto next_valid = [&](int t, TileC& cc) { while (t < ntiles && !s.decode(t, cc)) t += (int)gridDim.x; return t; };
-	auto fetch_rows = [&](const TileC& cc, double2* dst) {
-		// slot S of the buffer <- point (li, e) of the tile; padding slots and absent lines are skipped
-		for (int S0 = threadIdx.x; S0 < szA; S0 += NT) {
-			const uint32_t li = fdiv((uint32_t)S0, fa.dns), sl = S0 - li*fa.ns;
-			const uint32_t blk = fdiv(sl, fa.drs), r = sl - blk*fa.rs;
-			const double2* rp = ((int)li < T && (int)r < fa.M1 && (int)blk < fa.R0) ? s.row(cc, (int)li) : nullptr;
-			if (rp) PXS_DMA16(rp + blk*fa.M1 + r, dst + (S0 - (int)(threadIdx.x & 63)), (int)(threadIdx.x & 63));
-		}
-	};
-	// four-step twiddle tables of a tile: gathered from the full table straight into LDS (no registers; padding slots and absent
-	// lines fetch entry 0)
-	auto fetch_tw = [&](const TileC& cc, double2* Fd) {
-		for (int i0 = threadIdx.x; i0 < nFp; i0 += NT) {
-			const double2* src = s.btw;
-			if (i0 < nF) {
-				const bool second = i0 >= T*K0;
-				const int j = second ? i0 - T*K0 : i0, per = second ? RL : K0;
-				const int li = (int)fdiv((uint32_t)j, second ? s.dRL : s.dK0), kk = j - li*per;
-				if (li < cc.nl) src = s.btw + (long)(cc.t0 + li)*(second ? K0*kk : kk);
-			}
-			PXS_DMA16(src, Fd + (i0 - (int)(threadIdx.x & 63)), (int)(threadIdx.x & 63));
-		}
-	};
-	int tile = next_valid((int)blockIdx.x, c), par = 0;
-	if (tile < ntiles) { if (have_tw) fetch_tw(c, ftw); if (S::LOADK == 0) fetch_rows(c, bufA); }
-	while (tile < ntiles) {
-		double2* A = bufA + (dbl ? par*szA : 0);
-		const double2* F = ftw + par*nFp;
-		PXS_WAIT_VM0();
-		PXS_LDS_BARRIER();
-		const int tnext = next_valid(tile + (int)gridDim.x, cn);
-		if (!S::TWO && tnext < ntiles) {        // (single-transform stages: the other buffers are free from here on)
-			if (have_tw) fetch_tw(cn, ftw + (par ^ 1)*nFp);
-			if (dbl) fetch_rows(cn, bufA + (par ^ 1)*szA);
-		}
-		// output of the stored transform: value X[k] of line li, k = task.k0 + i*task.kstride
-		auto emit = [&](const F2Task& k, int i, double2 v) {
-			const int e = k.k0 + i*k.kstride;
-			double2 w = make_double2(1, 0);
-			if (have_tw) w = cmul(F[k.li*K0 + k.k0], F[T*K0 + k.li*RL + i]);
-			s.store(c, k.li, e, [&](int, int) { return v; }, w);
-		};
-		// ---- first transform (only the input / output combinations a stage can take are instantiated: each one is a set of
-		// register-radix butterflies)
-		for (int q = 0; q < fa.np; q++) {
-			const bool first = q == 0, last = q + 1 == fa.np;
-			const FastDiv dA = q == 0 ? s.dtplA[0] : (q == 1 ? s.dtplA[1] : s.dtplA[2]);      // (a run-time index into the by-value argument would put it in scratch)
-			constexpr bool CAN_REGS = !S::TWO && S::STOREK == 0;
-			const bool to_regs = CAN_REGS && last;
-			auto in_lds = [&](const F2Task& k, int i) { double2 v = A[k.li*fa.ns + k.base + i*k.istride]; if (S::INV_A && first) v.y = -v.y; return v; };
-			auto out_lds = [&](const F2Task& k, int i, double2 v) { A[k.li*fa.ns + k.base + i*k.istride] = v; };
-			bool done = false;
-			if constexpr (S::LOADK == 1) {
-				if (first) {
-					auto in_glb = [&](const F2Task& k, int i) { double2 v = s.load(c, k.li, k.base + i*(fa.np == 1 ? 1 : fa.M1)); if (S::INV_A) v.y = -v.y; return v; };
-					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT, F2_MAXR_FIRST>(fa, q, T, dT, dA, true, twa, in_glb, emit); done = true; } }
-					if (!done) { f2_pass<NT, F2_MAXR_FIRST>(fa, q, T, dT, dA, true, twa, in_glb, out_lds); done = true; }
-				}
-			}
-			if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT, F2_MAXR>(fa, q, T, dT, dA, true, twa, in_lds, emit); done = true; } }
-			if (!done) f2_pass<NT, F2_MAXR>(fa, q, T, dT, dA, false, twa, in_lds, out_lds);
-			if (!to_regs) PXS_LDS_BARRIER();
-		}
-		// ---- second transform: inputs pulled through S::mid from the first one's output
-		if constexpr (S::TWO) {
-			for (int q = 0; q < fb.np; q++) {
-				const bool first = q == 0, last = q + 1 == fb.np;
-				const FastDiv dB = q == 0 ? s.dtplB[0] : (q == 1 ? s.dtplB[1] : s.dtplB[2]);
-				constexpr bool CAN_REGS = S::STOREK == 0;
-				const bool to_regs = CAN_REGS && last;
-				auto in_mid = [&](const F2Task& k, int i) {
-					const double2* Al = A + k.li*fa.ns;
-					double2 v = s.mid(c, k.li, k.base + i*(fb.np == 1 ? 1 : fb.M1), [&](int kk) { return Al[fa.slot_out(kk)]; });
-					if (S::INV_B) v.y = -v.y;
-					return v; };
-				auto in_lds = [&](const F2Task& k, int i) { return bufB[k.li*fb.ns + k.base + i*k.istride]; };
-				auto out_lds = [&](const F2Task& k, int i, double2 v) { bufB[k.li*fb.ns + k.base + i*k.istride] = v; };
-				bool done = false;
-				if (first) {
-					if constexpr (CAN_REGS) { if (to_regs) { f2_pass<NT, F2_MAXR_FIRST>(fb, q, T, dT, dB, true, twb, in_mid, emit); done = true; } }
-					if (!done) { f2_pass<NT, F2_MAXR_FIRST>(fb, q, T, dT, dB, false, twb, in_mid, out_lds); done = true; }
-				}
-				if constexpr (CAN_REGS) { if (!done && to_regs) { f2_pass<NT, F2_MAXR>(fb, q, T, dT, dB, true, twb, in_lds, emit); done = true; } }
-				if (!done) f2_pass<NT, F2_MAXR>(fb, q, T, dT, dB, false, twb, in_lds, out_lds);
-				if (!to_regs || first) PXS_LDS_BARRIER();
-				if (first && tnext < ntiles) {      // the input buffer is free (and nothing below consumes a global load): the next tile's twiddles and rows
-					if (have_tw) fetch_tw(cn, ftw + (par ^ 1)*nFp);
-					if (S::LOADK == 0) fetch_rows(cn, bufA);
-				}
-			}
-		}
-		if (S::STOREK == 1) {      // stores that combine two lines read the finished transform from LDS
-			const double2* Bf = S::TWO ? bufB : A;
-			const int nl_ = fl.n, total = T*nl_;
-			const FastDiv dl = S::TWO ? s.dnb : s.dna;
-			for (int idx = threadIdx.x; idx < total; idx += NT) {
-				uint32_t li, e;
-				if (S::STORE_LINE_FAST) { e = fdiv((uint32_t)idx, dT); li = idx - e*T; } else { li = fdiv((uint32_t)idx, dl); e = idx - li*nl_; }
-				s.store(c, (int)li, (int)e, [&](int l2, int e2) { return Bf[l2*fl.ns + fl.slot_out(e2)]; }, make_double2(1, 0));
-			}
-		}
-		c = cn; tile = tnext; par ^= 1;
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // theta chains
 // ---------------------------------------------------------------------------------------------------------------
 // value of circle sample j of the packed pair of columns (2p, 2p+1): even + odd extension (cf. LD_MIRROR_PAIR in fft.hip)
@@ -455,7 +242,7 @@ struct StFirst : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	PairSrc src; int b; double2* Y; long ldY; int npair; FastDiv dnp;       // outer = comp*npair + pair
-	static constexpr bool V2 = true; static constexpr int LOADK = 1, STOREK = 0;
+	static constexpr int LOADK = 1, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC&, int) const { return nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
@@ -498,7 +285,7 @@ struct StResize : StageBase {
 	const double2* Y; long ldY; double2* Z; long ldZ;
 	int g, X1, X2, kmax, nyq; const double2* ph; FastDiv dg;
 	int adj;      // transposed padding rule (X1 > X2): conjugate phase, and the Nyquist slot of X2 collects 1/2 of both +-X2/2 bins of X1
-	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	static constexpr int LOADK = 0, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return li < c.nl ? Y + ((long)c.outer*g + c.t0 + li)*ldY : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g - c.t0); return true; }
@@ -541,7 +328,7 @@ struct StSigma : StageBase {
 	static constexpr bool TWO = true, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Z; long ldZ; double2* V; long ldV; int g, g2; const double2* sigma;
-	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	static constexpr int LOADK = 0, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return li < c.nl ? Z + ((long)c.outer*g2 + c.t0 + li)*ldZ : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, g2 - c.t0); return true; }
@@ -575,7 +362,7 @@ template<int MODE> struct StSplit : StageBase {
 	double2* out; long ld; const double2* w; const double2* tab; double scale; int TH; FastDiv da;
 	long ocstride; int groups; FastDiv dnp, dgr;      // components of a launch: output stride; MODE 0: outer = comp*npair + pair, MODE 1: outer = comp*groups + group
 	int self_half;     // self-mirrored output rings get weight 1/2 (adjoint of a mirror extension, which reads them once)
-	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 1;
+	static constexpr int LOADK = 0, STOREK = 1;
 	__device__ __forceinline__ const double2* row(const TileC& c, int li) const {
 		int line, pair; slot(c, li, line, pair);
 		return line >= 0 ? U + (((long)c.comp*npair + pair)*a + line)*ldU : nullptr; }
@@ -656,7 +443,7 @@ struct StRingA1 : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	MapAddr m; int b, npair; double2* Y; long ldY; FastDiv dnp;
-	static constexpr bool V2 = true; static constexpr int LOADK = 1, STOREK = 0;
+	static constexpr int LOADK = 1, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC&, int) const { return nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
@@ -683,7 +470,7 @@ struct StRingA2 : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, X, npair, groups, nring, mmax; double2* leg; long ldleg; int nm; const double2* tab; double scale; FastDiv da, dgr;
-	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 1;
+	static constexpr int LOADK = 0, STOREK = 1;
 	__device__ __forceinline__ const double2* row(const TileC& c, int li) const {
 		int line, q; slot(c, li, line, q);
 		return line >= 0 ? Y + (((long)c.comp*npair + q)*a + line)*ldY : nullptr; }
@@ -733,7 +520,7 @@ struct StRingS1 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = true, STORE_LINE_FAST = true, HAS_TW = true;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* h; long ldh, hcomp; int b, X, npair, nring, mmax; double2* Y; long ldY; FastDiv dnp;      // hcomp: rows of h per component
-	static constexpr bool V2 = true; static constexpr int LOADK = 1, STOREK = 0;
+	static constexpr int LOADK = 1, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC&, int) const { return nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, b - c.t0);
@@ -764,7 +551,7 @@ struct StRingS2 : StageBase {
 	static constexpr bool TWO = false, INV_A = true, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 8, MINW = 8;
 	const double2* Y; long ldY; int a, npair; MapAddr m; FastDiv dnp;
-	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	static constexpr int LOADK = 0, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return li < c.nl ? Y + ((long)c.outer*a + c.t0 + li)*ldY : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = (bx - c.outer*ntile)*T; c.nl = min(T, a - c.t0);
@@ -794,7 +581,7 @@ struct StColOut : StageBase {
 	static constexpr bool TWO = false, INV_A = false, INV_B = false, LOAD_LINE_FAST = false, STORE_LINE_FAST = true, HAS_TW = false;
 	static constexpr int MAXR = 9, MINW = 1;
 	const double2* Y; long ldY; int a, nm, ny, nx, groups, conj_out, herm; double2* out; long ldo, ocomp; double scale; FastDiv dgr;
-	static constexpr bool V2 = true; static constexpr int LOADK = 0, STOREK = 0;
+	static constexpr int LOADK = 0, STOREK = 0;
 	__device__ __forceinline__ const double2* row(const TileC& c, int li) const { return c.q0 + li < nm ? Y + (((long)c.comp*nm + c.q0 + li)*a + c.t0)*ldY : nullptr; }
 	__device__ __forceinline__ bool decode(int bx, TileC& c) const {
 		c.outer = fdiv(bx, dnt); c.t0 = bx - c.outer*ntile; c.nl = T;
@@ -819,15 +606,6 @@ struct StColOut : StageBase {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-// Which stages take the second-generation kernel: bit SID of PXS_CHAIN_V2 (0: none, -1: all; StFirst 0, StResize 1, StSigma 2,
-// StSplit<0> 3, StSplit<1> 4, RingA1 5, RingA2 6, RingS1 7, RingS2 8, ColOut 9).  History: the first form of this kernel (radices up
-// to 20 dispatched at run time, 256 threads) cost 256 VGPRs -- one wave per SIMD -- and ran the C3 chain stages in 289 ms against 107 ms
-// for chain_kernel (profiles/r04_chain_lab_v2.jsonl).
-#ifndef PXS_CHAIN_V2_DEFAULT
-#define PXS_CHAIN_V2_DEFAULT 0
-#endif
-static long chain_v2_mask() { static const long m = [] { const char* e = getenv("PXS_CHAIN_V2"); return e ? strtol(e, nullptr, 0) : (long)PXS_CHAIN_V2_DEFAULT; }(); return m; }
-static bool chain_v2_on(int sid) { return sid >= 0 && ((chain_v2_mask() >> sid) & 1) != 0; }
 static bool smooth235(long n) { if (n < 1) return false; for (int p : {2, 3, 5}) while (n % p == 0) n /= p; return n == 1; }
 bool FftChain::sub_ok(long n) { return n >= 2 && n <= CH_NMAX && smooth235(n); }
 
@@ -835,7 +613,11 @@ static LdsFft mk(FftContext* fc, long n, int maxr = 9) {
 	LdsFft f; memset(&f, 0, sizeof(f));
 	if (n <= 0) return f;
 	auto v = fc->view(n, maxr);
-	static const int nofft = [] { const char* e = getenv("PXS_CH_NOFFT"); return e ? atoi(e) : 0; }();     // timing experiments only (wrong results)
+#ifdef PXS_LAB
+	static const int nofft = [] { const char* e = getenv("PXS_CH_NOFFT"); return e ? atoi(e) : 0; }();     // lab builds only: timing experiments (wrong results)
+#else
+	constexpr int nofft = 0;
+#endif
 	static const int nspad = [] { const char* e = getenv("PXS_CH_NS_PAD"); return e ? atoi(e) : 0; }();     // experiments: line stride (n | 1) + pad
 	f.n = v.n; f.nfac = nofft ? 0 : v.nfac; f.ns = v.ns + nspad; f.generic = v.generic; f.pass = (const PassDesc*)v.pass; f.perm = v.perm; f.tw = v.tw; f.dn = make_fastdiv((uint32_t)n);
 	return f;
@@ -843,8 +625,9 @@ static LdsFft mk(FftContext* fc, long n, int maxr = 9) {
 
 // W_X^{li e}, e < n, li < T, laid out [e][li] (see StageBase)
 const double2* FftChain::small_tw(long X, int n, int T) {
-	static const int notw = [] { const char* e = getenv("PXS_CH_NOTW"); return e ? atoi(e) : 0; }();     // timing experiments only (wrong results)
-	if (notw) return nullptr;
+#ifdef PXS_LAB
+	{ static const int notw = [] { const char* e = getenv("PXS_CH_NOTW"); return e ? atoi(e) : 0; }(); if (notw) return nullptr; }     // lab builds only: timing experiments (wrong results)
+#endif
 	std::lock_guard<std::mutex> g(mu_);
 	auto key = std::make_tuple(X, n, T);
 	auto it = stw_.find(key);
@@ -900,140 +683,6 @@ static BlkIn mk_blk(int Tw, long na, int T) {
 static const int F2_RADICES[] = {2, 3, 4, 5, 6, 8, 9};
 // n as a product of at most three register radices: fewest passes, then the smallest largest radix; ascending order (the first
 // pass works on the longest rows, which wastes the least padding).  maxfirst: cap on the first radix (passes that pull their inputs
-// from global memory or through S::mid, see f2_dispatch)
-static bool f2_factor(int n, int& np, int* R, int maxfirst = F2_MAXR) {
-	auto ok = [](int r) { for (int x : F2_RADICES) if (x == r) return true; return false; };
-	if (n == 1) { np = 1; R[0] = R[1] = R[2] = 1; return true; }
-	if (ok(n) && n <= maxfirst) { np = 1; R[0] = n; R[1] = R[2] = 1; return true; }
-	int best = 1 << 30, b0 = 0, b1 = 0;
-	for (int r0 : F2_RADICES) if (r0 <= maxfirst && n % r0 == 0 && ok(n/r0) && r0 <= n/r0) { const int m = n/r0; if (m < best) { best = m; b0 = r0; b1 = n/r0; } }
-	if (b0) { np = 2; R[0] = b0; R[1] = b1; R[2] = 1; return true; }
-	int c0 = 0, c1 = 0, c2 = 0; best = 1 << 30;
-	for (int r0 : F2_RADICES) if (r0 <= maxfirst && n % r0 == 0) for (int r1 : F2_RADICES) if ((n/r0) % r1 == 0 && r0 <= r1) {
-		const int r2 = n/r0/r1;
-		if (!ok(r2) || r1 > r2) continue;
-		if (r2 < best) { best = r2; c0 = r0; c1 = r1; c2 = r2; }
-	}
-	if (!c0) return false;
-	np = 3; R[0] = c0; R[1] = c1; R[2] = c2; return true;
-}
-bool FftChain::sub_ok2(long n) { int np, R[3]; return n >= 2 && n <= CH_NMAX && smooth235(n) && f2_factor((int)n, np, R, F2_MAXR_FIRST); }
-
-// extra LDS cycles of one wave instruction: lanes -> 16-byte slots (-1: lane inactive)
-static int f2_read_conflicts(const int* slot) {
-	static const int G[4][16] = { {0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27}, {4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31},
-	                              {32,33,34,35,44,45,46,47,52,53,54,55,56,57,58,59}, {36,37,38,39,40,41,42,43,48,49,50,51,60,61,62,63} };
-	int extra = 0;
-	for (int g = 0; g < 4; g++) {
-		int cnt[16] = {0}, seen[16][16], mx = 0;
-		for (int i = 0; i < 16; i++) {
-			const int sl = slot[G[g][i]]; if (sl < 0) continue;
-			const int b = sl & 15; bool dup = false;
-			for (int j = 0; j < cnt[b]; j++) if (seen[b][j] == sl) dup = true;       // identical addresses broadcast
-			if (!dup) seen[b][cnt[b]++] = sl;
-			mx = std::max(mx, cnt[b]);
-		}
-		extra += std::max(0, mx - 1);
-	}
-	return extra;
-}
-static int f2_write_conflicts(const int* slot) {      // ds_write_b128: 8 groups of 8 contiguous lanes, 32 banks = 8 slots
-	int extra = 0;
-	for (int g = 0; g < 8; g++) {
-		int cnt[8] = {0}, mx = 0;
-		for (int i = 0; i < 8; i++) { const int sl = slot[8*g + i]; if (sl >= 0) mx = std::max(mx, ++cnt[sl & 7]); }
-		extra += std::max(0, mx - 1);
-	}
-	return extra;
-}
-static void f2_host_decode(const Fft2& f, int q, int tl, int& base) {
-	if (q == 0) { base = f.np == 1 ? 0 : tl; return; }
-	if (f.np == 2) { base = tl*f.rs; return; }
-	if (q == 1) { const int k1 = tl / f.M2, r = tl % f.M2; base = k1*f.rs + r; return; }
-	{ const int k1 = tl / f.R1, k2 = tl % f.R1; base = k1*f.rs + k2*f.M2; }
-}
-static int f2_host_slot_out(const Fft2& f, int k) {
-	if (f.np == 1) return k;
-	const int q = k / f.R0, k1 = k % f.R0;
-	if (f.np == 2) return k1*f.rs + q;
-	return k1*f.rs + (q % f.R1)*f.M2 + q / f.R1;
-}
-// lf[q]: tasks of pass q dealt line-fastest; rd[q] / wr[q]: the pass reads / writes the LDS buffer; store_lds: a final read sweep in
-// store order (line fastest, frequency next)
-static double f2_layout_cost(const Fft2& f, int T, int NT, const bool* lf, const bool* rd, const bool* wr, bool store_lds) {
-	double cost = 0; int slot[64];
-	const int radix[3] = {f.R0, f.R1, f.R2};
-	for (int q = 0; q < f.np; q++) {
-		const int tpl = f.n/radix[q], total = T*tpl;
-		for (int t0 = 0; t0 < total && t0 < NT; t0 += 64) {
-			for (int l = 0; l < 64; l++) {
-				const int t = t0 + l;
-				if (t >= total) { slot[l] = -1; continue; }
-				int li, tl; if (lf[q]) { tl = t / T; li = t % T; } else { li = t / tpl; tl = t % tpl; }
-				int base; f2_host_decode(f, q, tl, base);
-				slot[l] = li*f.ns + base;
-			}
-			if (rd[q]) cost += f2_read_conflicts(slot)*radix[q];
-			if (wr[q]) cost += 0.5*f2_write_conflicts(slot)*radix[q];
-		}
-	}
-	if (store_lds) {
-		const int total = T*f.n;
-		for (int t0 = 0; t0 < total && t0 < NT; t0 += 64) {
-			for (int l = 0; l < 64; l++) { const int t = t0 + l; slot[l] = t < total ? (t % T)*f.ns + f2_host_slot_out(f, t / T) : -1; }
-			cost += f2_read_conflicts(slot);
-		}
-	}
-	return cost;
-}
-
-// plan of an n-point transform for tiles of T lines: radices and the padded layout with the fewest bank conflicts
-Fft2 FftChain::mk2(long n, int T, int NT, int kind) {
-	Fft2 f; memset(&f, 0, sizeof(f));
-	if (n <= 0) { f.n = 0; f.np = 0; f.R0 = f.R1 = f.R2 = 1; return f; }
-	{	std::lock_guard<std::mutex> g(mu_);
-		auto it = f2_.find(std::make_tuple(n, T, NT, kind));
-		if (it != f2_.end()) return it->second; }
-	int np, R[3];
-	PXS_REQUIRE(f2_factor((int)n, np, R, (kind & 9) ? F2_MAXR_FIRST : F2_MAXR), "internal: no register-radix factorisation");
-	f.n = (int)n; f.np = np; f.R0 = R[0]; f.R1 = R[1]; f.R2 = R[2];
-	f.M1 = f.n/f.R0; f.M2 = np == 3 ? f.M1/f.R1 : 1;
-	// kind: bit 0 = first pass reads global memory (elementwise loads, line-fastest), bit 1 = last pass goes to registers (line-fastest,
-	// no LDS write), bit 2 = a store sweep reads the result from LDS, bit 3 = the first pass pulls through S::mid (irregular reads of
-	// ANOTHER buffer: not modelled)
-	bool lf[3] = {false, false, false}, rd[3] = {true, true, true}, wr[3] = {true, true, true};
-	if (kind & 1) { lf[0] = true; rd[0] = false; }
-	if (kind & 8) rd[0] = false;
-	if (kind & 2) { lf[np-1] = true; wr[np-1] = false; }
-	double best = 1e300; int brs = f.M1, bns = f.n;
-	static const int nopad = [] { const char* e = getenv("PXS_CH2_NOPAD"); return e ? atoi(e) : 0; }();       // experiments
-	const int rs_hi = (np == 1 || nopad) ? f.M1 : f.M1 + 1;
-	for (int rs = f.M1; rs <= rs_hi; rs++) {
-		const int row = np == 1 ? f.n : f.R0*rs;
-		for (int ns = row; ns <= (nopad ? row : row + 16); ns++) {
-			f.rs = rs; f.ns = ns;
-			const double c = f2_layout_cost(f, T, NT, lf, rd, wr, (kind & 4) != 0) + 0.02*(ns - f.n);      // a little for the LDS footprint
-			if (c < best) { best = c; brs = rs; bns = ns; }
-		}
-	}
-	f.rs = brs; f.ns = bns;
-	f.dM1 = make_fastdiv((uint32_t)f.M1); f.dM2 = make_fastdiv((uint32_t)std::max(f.M2, 1)); f.dR0 = make_fastdiv((uint32_t)f.R0); f.dR1 = make_fastdiv((uint32_t)f.R1);
-	f.drs = make_fastdiv((uint32_t)f.rs); f.dns = make_fastdiv((uint32_t)f.ns);
-	f.tw = fc_->twiddle_table(n);
-	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] fft2 n=%ld T=%d kind=%d: %d x %d x %d, rs=%d (M1=%d) ns=%d, conflict cost %.1f\n", n, T, kind, f.R0, f.R1, f.R2, f.rs, f.M1, f.ns, best - 0.02*(f.ns - f.n));
-	std::lock_guard<std::mutex> g(mu_);
-	f2_[std::make_tuple(n, T, NT, kind)] = f;
-	return f;
-}
-
-static int device_cus() {
-#ifdef PXS_HOST_SIM
-	return 2;
-#else
-	static const int n = [] { int d = 0, v = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v > 0 ? v : 256; }();
-	return n;
-#endif
-}
 
 template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st) {
 	if (nblk <= 0) return;
@@ -1067,70 +716,14 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	hipLaunchKernelGGL((chain_kernel<S, S::NT, (S::PTS + S::NT - 1)/S::NT>), dim3((unsigned)nblk), dim3(S::NT), sh, st, s);
 }
 
-// second-generation kernel: LDS image of a stage with tiles of T lines.  Layout (chain2_kernel): the two four-step twiddle tables and
-// the row buffer(s) -- the LDS-DMA destinations, which must sit below 64 KiB -- then the second transform's buffer and the W_n tables.
-struct Lds2 { Fft2 a2, b2; int RL, K0; size_t nFp, szA, dma_bytes, bytes; bool dbl; };
-template<class S> Lds2 FftChain::lds2(int na, int nb_, int T) {
-	Lds2 L; constexpr int NT = CH2_NT;
-	const int nb = S::TWO ? nb_ : 0;
-	const int kindA = (S::LOADK == 1 ? 1 : 0) | ((!S::TWO && S::STOREK == 0) ? 2 : 0) | ((!S::TWO && S::STOREK == 1) ? 4 : 0);
-	const int kindB = 8 | (S::STOREK == 0 ? 2 : 4);
-	L.a2 = mk2(na, T, NT, kindA); L.b2 = mk2(nb, T, NT, kindB);
-	const Fft2& fl = S::TWO ? L.b2 : L.a2;
-	L.RL = fl.np == 1 ? fl.R0 : (fl.np == 2 ? fl.R1 : fl.R2); L.K0 = fl.n/L.RL;
-	L.nFp = ((size_t)T*(L.K0 + L.RL) + 63) & ~(size_t)63;
-	L.szA = ((size_t)T*L.a2.ns + 63) & ~(size_t)63;
-	L.dbl = !S::TWO && S::LOADK == 0;
-	L.dma_bytes = sizeof(double2)*((S::HAS_TW ? 2*L.nFp : 0) + (L.dbl ? 2 : 1)*L.szA);
-	L.bytes = L.dma_bytes + sizeof(double2)*((S::TWO ? (size_t)T*L.b2.ns : 0) + na + nb + 2);
-	return L;
-}
-template<class S> bool FftChain::takes_v2(long n_a, long n_b) { return chain_v2_on(S::SID) && S::V2 && sub_ok2(n_a) && (!S::TWO || sub_ok2(n_b)); }
-// lines per tile of a stage: tile_lines, and for the second-generation kernel as many (in steps of mult) as leave room for TWO
-// workgroups per CU (PXS_CH2_LDS_KB, default 79.5 KiB each) with the DMA destinations below 64 KiB
+// lines per tile of a stage
 template<class S> int FftChain::tile_lines_for(long n_a, long n_b, long nlines, int mult, long tab_pts) {
 	int T = tile_lines(n_a, n_b, nlines, mult, tab_pts);
 	// a stage with a larger cap takes it only to reach `mult` lines (whole 128-byte lines on its strided side)
 	if (S::PTS > CH_TILE_PTS && T < mult && (long)mult*std::max(n_a, n_b) <= S::PTS && nlines >= mult) T = mult;
-	if (!takes_v2<S>(n_a, n_b)) return T;
-	static const size_t budget = [] { const char* e = getenv("PXS_CH2_LDS_KB"); return (size_t)((e ? atof(e) : 79.5)*1024); }();
-	auto fits = [&](int t) { const Lds2 L = lds2<S>((int)n_a, (int)n_b, t); return L.bytes <= budget && L.dma_bytes <= 65536; };
-	while (T > mult && !fits(T)) T -= mult;
 	return T;
 }
-// second-generation launch: s carries the v1 description of the stage (tiles, T, fa.n / fb.n, btw); this adds the DIF plans
-template<class S> void FftChain::launch_stage2(S& s, long ntiles, hipStream_t st) {
-	if (ntiles <= 0) return;
-	PXS_REQUIRE(ntiles < (1L << 31), "internal: chain grid too large");
-	constexpr int NT = CH2_NT;
-	const int na = s.fa.n, nb = S::TWO ? s.fb.n : 0;
-	const Lds2 L = lds2<S>(na, nb, s.T);
-	s.a2 = L.a2; s.b2 = L.b2;
-	const int radA[3] = {s.a2.R0, s.a2.R1, s.a2.R2}, radB[3] = {s.b2.R0, s.b2.R1, s.b2.R2};
-	for (int q = 0; q < 3; q++) { s.dtplA[q] = make_fastdiv((uint32_t)std::max(1, na/radA[q])); s.dtplB[q] = make_fastdiv((uint32_t)std::max(1, nb/std::max(1, radB[q]))); }
-	s.dK0 = make_fastdiv((uint32_t)L.K0); s.dRL = make_fastdiv((uint32_t)L.RL);
-	s.ntiles2 = (int)ntiles;
-	const size_t sh = L.bytes;
-	PXS_REQUIRE(sh <= 160*1024 - 256, "internal: chain tile too large for the LDS");
-	PXS_REQUIRE(L.dma_bytes <= 65536, "internal: LDS-DMA destination beyond 64 KiB");
-	// workgroups per CU: by LDS, by the wave slots (32 per CU) and by the register bound of the kernel (two workgroups)
-	static const int wg_cap = [] { const char* e = getenv("PXS_CH2_WGS"); return e ? atoi(e) : 0; }();
-	int wgs = (int)std::max<size_t>(1, std::min<size_t>(2, (160*1024 - 256)/sh));
-	if (wg_cap > 0) wgs = std::min(wgs, wg_cap);
-	const long grid = std::min<long>(ntiles, (long)device_cus()*wgs);
-	if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] chain2 stage %d: na=%d (%dx%dx%d ns=%d) nb=%d (%dx%dx%d ns=%d) T=%d LDS %.1f KiB (DMA %.1f) -> %d WG/CU, %ld tiles on %ld workgroups\n",
-		S::SID, na, s.a2.R0, s.a2.R1, s.a2.R2, s.a2.ns, nb, s.b2.R0, s.b2.R1, s.b2.R2, s.b2.ns, s.T, sh/1024.0, L.dma_bytes/1024.0, wgs, ntiles, grid);
-#ifndef PXS_HOST_SIM
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)chain2_kernel<S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
-	(void)once;
-#endif
-	hipLaunchKernelGGL((chain2_kernel<S, NT>), dim3((unsigned)grid), dim3(NT), sh, st, s);
-}
-// v2 for the stages selected by PXS_CHAIN_V2 when their transforms have register-radix plans, else v1
-template<class S> void FftChain::launch_any(S& s, long nblk, hipStream_t st) {
-	if (takes_v2<S>(s.fa.n, S::TWO ? s.fb.n : 0)) launch_stage2(s, nblk, st);
-	else launch_stage(s, nblk, st);
-}
+template<class S> void FftChain::launch_any(S& s, long nblk, hipStream_t st) { launch_stage(s, nblk, st); }
 
 // balanced split n = a*b with both factors usable
 static bool split_balanced(long n, Split& s, long amax = 320) {
@@ -1353,7 +946,9 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 			// M <= N (the fine-CC form on larger grids): low pass, |k| < M/2 kept
 			s.kmax = tp.M > tp.N ? -1 : (int)(tp.M/2 - 1); s.nyq = tp.M > tp.N ? 1 : 0;
 			s.ph = ph_shift; s.dg = make_fastdiv((uint32_t)g);
+#ifdef PXS_LAB
 			{ static const int noph = [] { const char* e = getenv("PXS_CH_NOPH"); return e ? atoi(e) : 0; }(); if (noph) s.ph = nullptr; }     // timing experiments only (wrong results)
+#endif
 			set_tiles(s, T2, g, tp.M); s.bin = mk_blk(T1, bN, T2); s.bout = blocked_on();
 			launch_any(s, ncl*npair*s.ntile, st);
 		}

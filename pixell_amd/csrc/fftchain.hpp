@@ -3,7 +3,6 @@
 // array is written once and read once.
 #pragma once
 #include "fft.hpp"
-#include "fft2_dev.hpp"
 #include <tuple>
 #include <map>
 #include <mutex>
@@ -29,7 +28,6 @@ public:
 	// can the engine run its LDS passes on lines of this length (radices 2,3,4,5, length <= 512)?
 	static bool sub_ok(long n);
 	static bool sub_ok_theta(long n); // ... of the theta stages: radix 7 as well
-	static bool sub_ok2(long n);      // ... and the second-generation kernel (at most three register radices <= 10)
 	static long pad8(long n) { return (n + 7) & ~7L; }
 	// ring FFT split of nphi for analysis (map -> leg) and synthesis (h -> map); false: no usable factorisation
 	bool plan_rings(long nphi);
@@ -70,13 +68,8 @@ public:
 private:
 	const double2* small_tw(long X, int n, int T);
 	template<class S> void set_tiles(S& s, int T, long nlines, long X);
-	Fft2 mk2(long n, int T, int NT, int kind);
-	template<class S> void launch_stage2(S& s, long ntiles, hipStream_t st);
-	template<class S> struct Lds2 lds2(int na, int nb, int T);
-	template<class S> bool takes_v2(long n_a, long n_b);
 	template<class S> int tile_lines_for(long n_a, long n_b, long nlines, int mult, long tab_pts = -1);
 	template<class S> void launch_any(S& s, long nblk, hipStream_t st);
-	std::map<std::tuple<long, int, int, int>, Fft2> f2_;
 	std::mutex mu_;
 	std::map<std::tuple<long, int, int>, DevBuf> stw_;
 	FftContext* fc_;

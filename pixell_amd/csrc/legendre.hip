@@ -463,127 +463,6 @@ template<int K> __global__ __launch_bounds__(64, (K == 4 ? 7 : 1)) void leg_syn_
 	}
 }
 
-// ---- spin-0 synthesis of B maps with ONE recurrence (batched calls) -------------------------------------------------------------
-// The recurrence p_k(x) does not depend on the map: a lane that owns K ring pairs advances K chains and feeds the accumulators of B
-// maps from them -- 4B + 2 FMAs per ring pair and step instead of 6B (B = 2: 17 % fewer, B = 4: 25 %), and at equal (map, ring pair)
-// units per lane fewer registers (K = 2, B = 2: 48 of state against 64 for K = 4, B = 1).  The pre-scaled alm rows of the B maps are B
-// scalar loads per step.  Each accumulator sees exactly the FMA sequence of leg_syn_s0, so a map comes out as from its own call.
-// Replaces the per-map loop of the reference (pixell/curvedsky.py:763-765, 910-924) for batches; the analysis has no such form
-// that pays: it needs one lane reduction per map and step whatever B is.
-#define S0_SYNB_HALF(cq, LA, LB, A) { \
-	PXS_VCOPY(vb_, polar ? cq.c : cq.b); \
-	_Pragma("unroll") for (int s = 0; s < K; s++) { \
-		_Pragma("unroll") for (int b = 0; b < B; b++) { \
-			p1r[b][s] = fma(LA[s], A[b].a, p1r[b][s]); p1i[b][s] = fma(LA[s], A[b].b, p1i[b][s]); \
-			p2r[b][s] = fma(LA[s], A[b].c, p2r[b][s]); p2i[b][s] = fma(LA[s], A[b].d, p2i[b][s]); \
-		} \
-		LB[s] = fma(fma(cq.a, csq[s], vb_), LA[s], LB[s]); \
-	} }
-#define S0_SYNB_PAIR(c0, c1, A0, A1) { S0_SYNB_HALF(c0, lam2, lam1, A0) S0_SYNB_HALF(c1, lam1, lam2, A1) }
-
-template<int K, int B> __global__ __launch_bounds__(64) void leg_syn_s0b(const LegK a)
-{
-	const int lane = threadIdx.x; int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;      // bb: group of B consecutive maps (a.nb groups)
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int nk = (a.lmax - m)/2 + 1;
-	const double4_t* __restrict__ coef = a.coef + row0;
-	const double4_t* __restrict__ at[B];
-#pragma unroll
-	for (int b = 0; b < B; b++) at[b] = reinterpret_cast<const double4_t*>(a.almt + ((long)bb*B + b)*a.almt_bs) + row0;
-	double csq[K], lam1[K], lam2[K], p1r[B][K], p1i[B][K], p2r[B][K], p2i[B][K];
-	int sc[K];
-	bool alive_any = false;
-	const bool polar = leg_wave_polar(a, wv, K);
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		const double x = valid ? a.cth[p] : 0.0;
-		const double sth = valid ? a.sth[p] : 0.0;
-		csq[s] = polar ? -sth*sth : x*x;
-		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
-		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
-		if (alive && a.seed_mode != 2) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
-#pragma unroll
-		for (int b = 0; b < B; b++) p1r[b][s] = p1i[b][s] = p2r[b][s] = p2i[b][s] = 0;
-		alive_any |= alive;
-	}
-	int k = 0;
-	if (__any(alive_any)) {
-		S0_SEEDED_PHASE_A
-		k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
-		PXS_COUNT(0, (long)(nk - k)*K*(4*B + 2) + (a.seed_mode != 2 ? (long)k*K*2 : 0L));
-		// phase B (see leg_syn_s0): ungated fast steps, lanes below scale 0 rescaled every 4 steps, their sums reset on arrival
-		while (k + 1 < nk) {
-			bool pend = false;
-#pragma unroll
-			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
-			if (!__any(pend)) break;
-			for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
-				const double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1);
-				double4_t A0[B], A1[B];
-#pragma unroll
-				for (int b = 0; b < B; b++) { A0[b] = LDC(at[b], k); A1[b] = LDC(at[b], k+1); }
-				S0_SYNB_PAIR(c0, c1, A0, A1)
-			}
-#pragma unroll
-			for (int s = 0; s < K; s++)
-				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) {
-					lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL;
-					if (++sc[s] == 0) {
-#pragma unroll
-						for (int b = 0; b < B; b++) p1r[b][s] = p1i[b][s] = p2r[b][s] = p2i[b][s] = 0;
-					}
-				}
-		}
-#pragma unroll
-		for (int s = 0; s < K; s++) if (sc[s] < 0) {      // never reached scale 0
-			lam1[s] = lam2[s] = 0;
-#pragma unroll
-			for (int b = 0; b < B; b++) p1r[b][s] = p1i[b][s] = p2r[b][s] = p2i[b][s] = 0;
-		}
-		// phase C: the first rows of the next pair are fetched a pair ahead, the second ones while the first half-step runs (all of
-		// them ahead would need 2 (2B + 2) rows of 8 SGPRs)
-		double4_t c0 = LDC(coef, k), A0[B];
-#pragma unroll
-		for (int b = 0; b < B; b++) A0[b] = LDC(at[b], k);
-		for (; k + 1 < nk; k += 2) {
-			const double4_t c1 = LDC(coef, k+1);
-			double4_t A1[B];
-#pragma unroll
-			for (int b = 0; b < B; b++) A1[b] = LDC(at[b], k+1);
-			S0_SYNB_HALF(c0, lam2, lam1, A0)
-			c0 = LDC(coef, k+2);
-#pragma unroll
-			for (int b = 0; b < B; b++) A0[b] = LDC(at[b], k+2);
-			S0_SYNB_HALF(c1, lam1, lam2, A1)
-		}
-		if (k < nk) {
-#pragma unroll
-			for (int s = 0; s < K; s++)
-#pragma unroll
-				for (int b = 0; b < B; b++) {
-					p1r[b][s] = fma(lam2[s], A0[b].a, p1r[b][s]); p1i[b][s] = fma(lam2[s], A0[b].b, p1i[b][s]);
-					p2r[b][s] = fma(lam2[s], A0[b].c, p2r[b][s]); p2i[b][s] = fma(lam2[s], A0[b].d, p2i[b][s]);
-				}
-		}
-	}
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		const int rn_ = valid ? a.ring_n[p] : -1, rs_ = valid ? a.ring_s[p] : -1;
-		const double x_ = valid ? a.cth[p] : 0.0;
-#pragma unroll
-		for (int b = 0; b < B; b++) {
-			double2* __restrict__ out = a.leg + ((long)bb*B + b)*a.leg_bs + (long)m*a.ld;
-			if (rn_ >= 0) out[rn_] = make_double2(p1r[b][s] + x_*p2r[b][s], p1i[b][s] + x_*p2i[b][s]);
-			if (rs_ >= 0) out[rs_] = make_double2(p1r[b][s] - x_*p2r[b][s], p1i[b][s] - x_*p2i[b][s]);
-		}
-	}
-}
-
 // Workgroups are ONE wave: lanes run in lockstep and a wave's LDS operations execute in order, so
 // cross-lane visibility of the LDS tile only needs the LDS counter drained -- not an s_barrier, whose
 // compiler-inserted s_waitcnt vmcnt(0) would also wait for the (slow, fire-and-forget) global store
@@ -1596,38 +1475,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		if (prof) prof->end(st, 0);
 		seeds_written(sb, st);
 	};
-	// spin 0, two or more maps: groups of B maps can share one recurrence (leg_syn_s0b), what is left over takes the single-map kernel.
-	// OFF by default: measured on MI355X at C4 (64 maps 5400x10800, lmax 4000, leg_syn per step, same box, profiles/r04_syn_share_c4.txt)
-	// unshared 120.7 ms; B = 2: K = 4 119.8, K = 2 126.0, K = 1 198.9; B = 4: K = 2 127.1, K = 1 181.1 -- the 17-25 % fewer FMAs do not
-	// show: at equal (map, ring pair) units per lane the kernel runs as before, with fewer it is short of independent chains.
-	// PXS_SYN_SHARE = B (2 | 4) turns it on, PXS_K_SYN0B = ring pairs per lane (1 | 2 | 4).
-	static const int share = [] { const char* e = getenv("PXS_SYN_SHARE"); const int v = e ? atoi(e) : 1; return v >= 4 ? 4 : (v >= 2 ? 2 : 1); }();
-	static const int kshare = env_k("PXS_K_SYN0B", 2, 1, 4);
 	int b0 = 0;
-	if (tb.spin == 0 && share > 1 && nb >= share) {
-		const int B = share, K2 = (kshare >= 4 ? 4 : (kshare >= 2 ? 2 : 1)), ng = nb / B;
-		auto launch_groups = [&](int g0, int n) {      // groups [g0, g0 + n) of B maps
-			LegK a = make_legk(rs, tb, wk, leg + (size_t)g0*B*leg_bstride, ld, K2, n, leg_bstride);
-			a.almt += (size_t)g0*B*a.almt_bs;
-			LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K2, a); seeds_wait(sb, st);
-			if (prof) prof->begin(st, 0);
-			const dim3 grid = leg_grid(a);
-			if (B == 2) {
-				if (K2 == 4)      hipLaunchKernelGGL((leg_syn_s0b<4, 2>), grid, dim3(64), 0, st, a);
-				else if (K2 == 2) hipLaunchKernelGGL((leg_syn_s0b<2, 2>), grid, dim3(64), 0, st, a);
-				else              hipLaunchKernelGGL((leg_syn_s0b<1, 2>), grid, dim3(64), 0, st, a);
-			} else {
-				if (K2 >= 2)      hipLaunchKernelGGL((leg_syn_s0b<2, 4>), grid, dim3(64), 0, st, a);
-				else              hipLaunchKernelGGL((leg_syn_s0b<1, 4>), grid, dim3(64), 0, st, a);
-			}
-			if (prof) prof->end(st, 0);
-			seeds_written(sb, st);
-		};
-		int g0 = 0;
-		if (ng > 1 && seeds_pending(wk, rs, tb, 0, K2)) { launch_groups(0, 1); g0 = 1; }      // (one wave writes each seed)
-		for (const int gmax = leg_max_batch(rs, tb, K2); g0 < ng; g0 += gmax) launch_groups(g0, std::min(gmax, ng - g0));
-		b0 = ng*B;
-	}
 	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
 	if (nb - b0 > 1 && seeds_pending(wk, rs, tb, 0, K)) { launch(b0, 1); b0 += 1; }
 	for (const int nmax = leg_max_batch(rs, tb, K); b0 < nb; b0 += nmax) launch(b0, std::min(nmax, nb - b0));

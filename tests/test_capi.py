@@ -54,6 +54,14 @@ def test_product_package_does_not_import_oracle():
 		assert "import oracle" not in src and "from oracle" not in src, f
 
 
+def test_default_build_carries_no_lab_switches():
+	"""The switches that turn parts of a transform OFF (timing experiments: wrong results) and the experimental kernel families exist in
+	lab builds only (-DPXS_LAB, tools/build_variants.sh): the library __graft_entry__.build() makes must not even contain their names."""
+	from pixell_amd import _build
+	blob = open(_build.build(), "rb").read()
+	for name in (b"PXS_CH_NOFFT", b"PXS_CH_NOTW", b"PXS_CH_NOPH", b"PXS_FFT_DEBUG_NOPASS", b"PXS_CHAIN_V2", b"PXS_CH2_", b"PXS_SYN_SHARE", b"chain2_kernel", b"leg_syn_s0b"):
+		assert name not in blob, name
+
 def test_docs_agree_with_the_header():
 	"""the entry-point count quoted in INTEGRATION.md / DESIGN.md / README.md is the number of declarations in include/pxsht.h,
 	and every declared symbol is in the loader's export list"""

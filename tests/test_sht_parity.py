@@ -590,7 +590,8 @@ def test_weights_analysis_small_grid_takes_the_default():
 
 @pytest.mark.hostsim
 def test_batched_shared_recurrence_hostsim():
-	"""five scalar maps: two groups of two through the shared-recurrence synthesis kernel (leg_syn_s0b) and one through leg_syn_s0"""
+	"""five scalar maps in one call: the analysis through the shared-recurrence FP64-MFMA kernel (leg_ana_s0_mm: one 8-map workgroup shape
+	with three columns groups masked), the synthesis map by map"""
 	check_batched(nb=5, nt=20, nph=40, lmax=16)
 
 def check_mm_analysis(nbs=(4, 9, 12, 13), lmax=40, grid=None):
