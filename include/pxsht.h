@@ -90,7 +90,11 @@ int pxs_analysis(pxs_plan* plan, int spin, int adjoint, int nbatch,
  *   1 "weights": ring quadrature weights + adjoint synthesis, the reference's cyl route (curvedsky.py:852-861, 1068-1084:
  *     get_gridweights / nphi, then adjoint_synthesis), applied when ntheta >= 2 lmax + 2 (smaller grids take the default).
  * The adjoint (adjoint = 1) is the exact transpose of the chosen form.  Takes effect for the calls issued after it returns.
- * "build_tables" (value = spin): builds the recurrence tables of that spin now instead of inside the first transform that needs them. */
+ * "build_tables" (value = spin): builds the recurrence tables of that spin now instead of inside the first transform that needs them.
+ * "deterministic" (0 | 1; default 0, or 1 when PXS_DETERMINISTIC=1 is set as the plan is made): the Legendre analysis (pxs_analysis,
+ *   adjoint synthesis) sums the contributions of the ring chunks of an m with atomic adds in arrival order -- results repeat from
+ *   run to run to ~1e-14 of their size, not bit for bit (ducc0 on the CPU is bitwise repeatable).  1 selects ordered sums through
+ *   per-chunk partial moments (<= 2 GB of scratch, m in passes; batched calls one map at a time): bitwise repeatable, slower. */
 int pxs_plan_option(pxs_plan* plan, const char* name, int64_t value);
 
 /* What a plan does: "analysis_form" = the form pxs_analysis runs now (0 interpolant, 1 ring weights, 2 fine-CC form of ducc0's

@@ -69,24 +69,31 @@ static std::mutex g_blue_mu; static std::map<std::pair<int, hipStream_t>, std::u
 // chain engine (and its scratch) of the 2-D real -> complex fast path, per stream like the other scratch
 // (each entry owns the transposed intermediate of its last transform -- 15 GB for a complex 21600 x 43200 map -- so the table is
 // bounded: beyond PXF_F2_MAX_STREAMS (4) the entry used longest ago is dropped; hipFree waits for the kernels that may still use it)
-struct F2Entry { std::unique_ptr<FftChain> ch; unsigned long stamp = 0; };
+// Entries are shared_ptr: the caller holds one for the duration of its transform, so an eviction (or fft_release_stream) on another
+// thread only drops the table's reference -- the chain and its scratch go when the last user is done.  The cap counts the streams of
+// ONE device (a process driving 8 GPUs keeps 4 per GPU), and an entry somebody holds is never the one evicted.
+struct F2Entry { std::shared_ptr<FftChain> ch; unsigned long stamp = 0; };
 static std::mutex g_f2_mu; static std::map<std::pair<int, hipStream_t>, F2Entry> g_f2; static unsigned long g_f2_clock = 0;
-static FftChain* f2_chain(int device, hipStream_t st, FftContext& fc) {
+static std::shared_ptr<FftChain> f2_chain(int device, hipStream_t st, FftContext& fc) {
 	std::lock_guard<std::mutex> g(g_f2_mu);
 	static const size_t cap = [] { const char* e = getenv("PXF_F2_MAX_STREAMS"); return (size_t)std::max(1, e ? atoi(e) : 4); }();
 	auto key = std::make_pair(device, st);
 	auto it = g_f2.find(key);
 	if (it == g_f2.end()) {
-		while (g_f2.size() >= cap) {
-			auto old = g_f2.begin();
-			for (auto j = g_f2.begin(); j != g_f2.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
+		for (;;) {
+			size_t ndev = 0; auto old = g_f2.end();
+			for (auto j = g_f2.begin(); j != g_f2.end(); ++j) if (j->first.first == device) {
+				ndev++;
+				if (j->second.ch.use_count() == 1 && (old == g_f2.end() || j->second.stamp < old->second.stamp)) old = j;      // (idle: only the table holds it)
+			}
+			if (ndev < cap || old == g_f2.end()) break;
 			g_f2.erase(old);
 		}
 		it = g_f2.emplace(key, F2Entry()).first;
-		it->second.ch.reset(new FftChain(&fc));
+		it->second.ch = std::make_shared<FftChain>(&fc);
 	}
 	it->second.stamp = ++g_f2_clock;
-	return it->second.ch.get();
+	return it->second.ch;
 }
 // scratch of the multi-axis c2r transforms, per stream like the other scratch (grows only; no synchronisation in the call path)
 static std::mutex g_c2r_mu; static std::map<std::pair<int, hipStream_t>, std::unique_ptr<DevBuf>> g_c2r_scratch;
@@ -318,7 +325,7 @@ int pxf_fft_nd(int ndim, const int64_t* shape, const int64_t* istride, const int
 			long acc = 1, npre = 1;
 			for (int k = ndim-1; k >= 0 && dense; k--) { dense = istride[k] == acc && ostride[k] == acc; acc *= shape[k]; if (k < ndim-2) npre *= shape[k]; }
 			if (dense) {
-				FftChain* ch = f2_chain(device, st, fc);
+				const std::shared_ptr<FftChain> ch = f2_chain(device, st, fc);
 				if (real_in ? ch->fft2_real(st, in, in_dtype, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)
 				            : ch->fft2_c2c(st, (const double2*)in, (double2*)out, npre, shape[ndim-2], shape[ndim-1], forward != 0, scale)) return 0;
 			}

@@ -1486,7 +1486,6 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 // takes 4-map workgroups, a single left-over map the VALU kernel.  Summation order differs from the single-map kernel: a batched
 // call equals its single-map calls to rounding (1e-13), not bit for bit.
 static int ana_mm_min() { static int v = [] { const char* e = getenv("PXS_ANA_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
-static bool leg_deterministic() { const char* det = getenv("PXS_DETERMINISTIC"); return det && atoi(det) != 0; }
 template<int NG, int W> static void mm_launch1(dim3 grid, hipStream_t st, const LegK& a) {
 	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<NG, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
 	hipLaunchKernelGGL((leg_ana_s0_mm<NG, W>), grid, dim3(64*W), mm_ana_lds(NG, W), st, a);
@@ -1547,17 +1546,16 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
-	if (tb.spin == 0 && nb >= ana_mm_min() && !leg_deterministic()) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
+	if (tb.spin == 0 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	const int K = tb.spin == 0 ? k_ana0() : k_anas();
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = leg_mom_stride(tb);
 	{	// the ordered (bitwise repeatable) scheme and the launch that records the seeds take one map at a time
-		const char* det0 = getenv("PXS_DETERMINISTIC");
-		const bool one_by_one = (det0 && atoi(det0) != 0) || seeds_pending(wk, rs, tb, 1, K);
+		const bool one_by_one = wk.deterministic || seeds_pending(wk, rs, tb, 1, K);
 		if (nb > 1 && one_by_one) {
 			const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
-			const int first = (det0 && atoi(det0) != 0) ? nb : 1;
+			const int first = wk.deterministic ? nb : 1;
 			for (int b = 0; b < first; b++)
 				leg_analysis(st, rs, tb, wk, leg + (size_t)b*leg_bstride, (char*)alm + aesz*(size_t)b*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, prof, ld, 1, 0, 0);
 			if (first < nb)
@@ -1574,10 +1572,9 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	wk.mom.ensure(sizeof(double)*(size_t)n4*nb);
 	// Default: the waves of one m add their sums straight into mom with global_atomic_add_f64 -- the blocks of one m run back
 	// to back on one XCD (leg_block), so the row they share sits in that XCD's L2 while they do.  The order of those additions
-	// is not fixed: results repeat to rounding, not bit for bit.  PXS_DETERMINISTIC=1 selects the former scheme instead
+	// is not fixed: results repeat to rounding, not bit for bit.  pxs_plan_option("deterministic", 1) (or PXS_DETERMINISTIC=1 when the plan is made) selects the former scheme instead
 	// (per-wave partial moments in scratch, summed in wave order by reduce_partials), for callers that need bitwise repeats.
-	const char* det = getenv("PXS_DETERMINISTIC");
-	const bool atomic = !(det && atoi(det) != 0);
+	const bool atomic = !wk.deterministic;
 	std::vector<int> cuts; cuts.push_back(0);
 	if (atomic) {
 		cuts.push_back(nm);

@@ -39,7 +39,8 @@ struct LegProfile {
 };
 
 struct LegWork {     // scratch owned by the SHT plan
-	size_t part_budget = size_t(8) << 30;   // bytes of per-wave partial moments per launch (PXS_PART_GB overrides)
+	size_t part_budget = size_t(2) << 30;   // bytes of per-wave partial moments per launch of the ordered analysis (PXS_PART_GB overrides): m goes in chunks that fit
+	bool deterministic = false;             // ordered (bitwise repeatable) analysis sums: pxs_plan_option("deterministic"); default from PXS_DETERMINISTIC when the plan is made
 	DevBuf almt;     // [nrows][4] doubles
 	DevBuf part;     // [nwave][nrows][4] doubles (analysis partial moments)
 	DevBuf mom;      // [nrows][4] reduced moments

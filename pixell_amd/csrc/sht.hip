@@ -19,6 +19,7 @@
 #include <map>
 #include <memory>
 #include <cmath>
+#include <mutex>
 #include <algorithm>
 
 namespace pxs {
@@ -311,6 +312,9 @@ __global__ __launch_bounds__(256) void split_pair_transposed(const double2* __re
 using namespace pxs;
 
 struct pxs_plan {
+	// a plan serves one call at a time (it owns the scratch of the call, and the analysis option is read several times in a call):
+	// the entry points that run or reconfigure it take this lock, so two host threads on one cached plan queue up instead of interleaving
+	std::mutex call_mu;
 	int device = 0;
 	bool is_grid = false;
 	std::string geometry;
@@ -390,8 +394,9 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 	{	// scratch for the per-wave partial moments of the analysis: 16 GiB where the device has room (MI355X: 288 GB),
 		// never more than 1/8 of what is free now.  Measured at config 3: 4 GiB 448.8, 8 GiB 442.7, 16 GiB 438.0, 24 GiB 437.7 ms.
 		size_t fr = 0, tot = 0;
-		if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) p->wk.part_budget = std::min<size_t>(size_t(16) << 30, std::max<size_t>(fr/8, size_t(256) << 20));
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) p->wk.part_budget = std::min<size_t>(size_t(2) << 30, std::max<size_t>(fr/8, size_t(256) << 20));      // (ordered analysis only: <= 2 GB of partial moments, m in chunks)
 		const char* e = getenv("PXS_PART_GB"); if (e) p->wk.part_budget = (size_t)atol(e) << 30;
+		{ const char* d = getenv("PXS_DETERMINISTIC"); p->wk.deterministic = d && atoi(d) != 0; }      // default of pxs_plan_option("deterministic")
 	}
 	{ const char* e = getenv("PXS_RESAMPLE_MB"); if (e) p->resample_chunk_bytes = (size_t)atol(e) << 20; }
 	{ const char* e = getenv("PXS_ANALYSIS"); if (e) { const std::string v(e); p->ana_weights = v == "weights" ? 1 : (v == "ducc0" ? 2 : (v == "interpolant" ? 0 : p->ana_weights)); } }
@@ -935,9 +940,13 @@ void pxs_plan_destroy(pxs_plan* plan) { delete plan; }
 int pxs_plan_option(pxs_plan* p, const char* name, int64_t value) {
 	PXS_TRY
 	PXS_REQUIRE(p && name, "pxs_plan_option: null argument");
+	std::lock_guard<std::mutex> plan_lock(p->call_mu);
 	if (std::string(name) == "analysis") {
 		PXS_REQUIRE(value >= 0 && value <= 2, "pxs_plan_option: analysis takes 0 (interpolant), 1 (weights) or 2 (ducc0)");
 		p->ana_weights = (int)value;
+	} else if (std::string(name) == "deterministic") {      // analysis sums in a fixed order: bitwise repeatable results (default 0: atomic adds, repeatable to ~1e-14)
+		PXS_REQUIRE(value == 0 || value == 1, "pxs_plan_option: deterministic takes 0 or 1");
+		p->wk.deterministic = value != 0;
 	} else if (std::string(name) == "build_tables") {      // build the recurrence tables of spin `value` now rather than in the first transform (cold-start accounting of bench.py)
 		PXS_REQUIRE(value >= 0 && value <= p->lmax + 1, "pxs_plan_option: build_tables takes a spin");
 		PXS_HIP(hipSetDevice(p->device));
@@ -1236,6 +1245,7 @@ int pxs_synthesis(pxs_plan* p, int spin, int mode, int adjoint, int nbatch,
 {
 	PXS_TRY
 	PXS_REQUIRE(p && alm && map, "pxs_synthesis: null argument");
+	std::lock_guard<std::mutex> plan_lock(p->call_mu);
 	PXS_REQUIRE(spin >= 0 && spin <= p->lmax + 1, "pxs_synthesis: bad spin");
 	PXS_REQUIRE(mode == PXS_MODE_STANDARD || (mode == PXS_MODE_DERIV1 && spin == 1), "DERIV1 needs spin 1");
 	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
@@ -1358,6 +1368,7 @@ int pxs_analysis(pxs_plan* p, int spin, int adjoint, int nbatch,
 {
 	PXS_TRY
 	PXS_REQUIRE(p && alm && map, "pxs_analysis: null argument");
+	std::lock_guard<std::mutex> plan_lock(p->call_mu);
 	PXS_REQUIRE(p->is_grid, "pxs_analysis needs a grid2d plan");
 	PXS_REQUIRE(map_dtype == PX_F32 || map_dtype == PX_F64, "map must be float32 or float64");
 	PXS_REQUIRE(nbatch >= 1, "pxs_analysis: nbatch must be >= 1");

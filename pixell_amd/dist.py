@@ -56,8 +56,8 @@ class AlmGather:
 		self.pad = torch.zeros((self.rmax, self.nelem), dtype=local.dtype, device=device) if min(self.rows) < self.rmax else None
 	def run(self, local, stream=None):
 		import torch, torch.distributed as dist
-		src = local
-		if self.pad is not None:
+		src = local      # even shards, and the full-size shards of an uneven split, go out of the caller's buffer as they are
+		if self.pad is not None and local.shape[0] < self.rmax:
 			self.pad[:local.shape[0]] = local; src = self.pad
 		if self.backend == "nccl":
 			dist.all_gather_into_tensor(torch.view_as_real(self.buf).view(self.world, -1), torch.view_as_real(src.contiguous()).view(-1))

@@ -7,7 +7,7 @@ Extra keyword `flip=(flip_y, flip_x)` (ours): the map is given in its native pix
 flips of curvedsky.map2buffer/buffer2map (curvedsky.py:1384-1411) are folded into kernel
 addressing; phi0 is still that of the flipped map (analyse_geometry().phi0).
 """
-import ctypes, os, contextlib
+import ctypes, os, contextlib, threading
 import numpy as np
 from . import _lib
 
@@ -43,20 +43,22 @@ def current_stream():
 	if _lib.is_hostsim(): return None
 	return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
 
-# host-array route (pixell_amd/hostio.py): the Pipeline of the API call in progress, if any
-_pipe = None
+# host-array route (pixell_amd/hostio.py): the Pipeline of the API call in progress ON THIS THREAD, if any.  Per thread: a call on
+# another thread must neither see this one's pipeline (its write-backs would complete on a queue this call may already have closed)
+# nor be kept from opening its own.
+_tls = threading.local()
+def _pipe(): return getattr(_tls, "pipe", None)
 @contextlib.contextmanager
 def host_pipeline(inputs=(), outputs=()):
 	"""for the duration of one API call: numpy `inputs` are uploaded by a background thread, in order, starting now; numpy outputs
 	of the transforms issued inside are downloaded in the background; everything is complete when the block exits"""
-	global _pipe
 	from . import hostio
-	if _pipe is not None or _lib.is_hostsim() or not any(hostio.eligible(a) for a in list(inputs)+list(outputs)):
+	if _pipe() is not None or _lib.is_hostsim() or not any(hostio.eligible(a) for a in list(inputs)+list(outputs)):
 		yield; return
-	_pipe = hostio.Pipeline(); _pipe.prefetch(inputs)
+	_tls.pipe = hostio.Pipeline(); _tls.pipe.prefetch(inputs)
 	try: yield
 	finally:
-		p = _pipe; _pipe = None; p.close()
+		p = _tls.pipe; _tls.pipe = None; p.close()
 
 class _Buf:
 	"""device view of a numpy array or torch tensor (contiguous), with optional write-back.  overwrite: the call writes every
@@ -77,7 +79,7 @@ class _Buf:
 			else:
 				torch = _torch()
 				from . import hostio
-				got = _pipe.take(arr) if _pipe is not None else None
+				pipe = _pipe(); got = pipe.take(arr) if pipe is not None else None
 				self.slab = hostio.eligible(arr)
 				if got is not None:                      # uploaded in the background since the call began
 					self.tmp, ev = got; torch.cuda.current_stream().wait_event(ev)
@@ -93,13 +95,14 @@ class _Buf:
 		elif self.slab:
 			from . import hostio
 			ev = _torch().cuda.Event(); ev.record()
-			if _pipe is not None: _pipe.writeback(self.tmp, self.arr, ev)      # complete when the host_pipeline block exits
+			pipe = _pipe()
+			if pipe is not None: pipe.writeback(self.tmp, self.arr, ev)      # complete when the host_pipeline block (of this thread) exits
 			else: hostio.download(self.tmp, self.arr, after=ev)
 		else: self.arr[...] = self.tmp.cpu().numpy()
 
 class Plan:
 	"""RAII wrapper of pxs_plan"""
-	def __init__(self, handle): self.handle = handle
+	def __init__(self, handle): self.handle = handle; self.lock = threading.RLock()      # (option + call pairs on a shared cached plan are atomic per thread)
 	def __del__(self):
 		try:
 			if self.handle: _lib.load().pxs_plan_destroy(self.handle); self.handle = None
@@ -118,7 +121,8 @@ class Plan:
 		_lib.check(_lib.load().pxs_profile_flops(self.handle, f, int(bool(reset))))
 		return f[0], f[1]
 	def set_option(self, name, value):
-		"""pxs_plan_option: "analysis" = 2 (ducc0's route, the default) | 0 (full theta-interpolant) | 1 (ring weights + adjoint synthesis where ntheta >= 2 lmax + 2)"""
+		"""pxs_plan_option: "analysis" = 2 (ducc0's route, the default) | 0 (full theta-interpolant) | 1 (ring weights + adjoint synthesis where ntheta >= 2 lmax + 2);
+		"deterministic" = 0 | 1 (ordered, bitwise repeatable analysis sums; see set_deterministic)"""
 		_lib.check(_lib.load().pxs_plan_option(self.handle, name.encode(), int(value)))
 	def query(self, name):
 		"""pxs_plan_query: "analysis_form", "ncc_circle", "ducc_ncc_circle" """
@@ -150,6 +154,22 @@ class _PlanCache:
 _plans = _PlanCache()
 def clear_plans(): _plans.clear()
 
+_deterministic = None
+def set_deterministic(on=True):
+	"""Bitwise repeatable transforms (pxs_plan_option "deterministic", include/pxsht.h): by default the Legendre analysis adds the
+	contributions of the ring chunks of an m with atomic adds in arrival order, so map2alm / alm2map_adjoint repeat from run to run
+	to ~1e-14 only.  on=True applies the ordered sums to every plan used from now on (cached plans included); None restores the
+	default (PXS_DETERMINISTIC as the plan was made)."""
+	global _deterministic
+	_deterministic = None if on is None else bool(on)
+def _apply_mode(plan):
+	want = _deterministic
+	if want is None and getattr(plan, "_det", None) is not None:      # a cached plan that was switched: back to the default
+		plan.set_option("deterministic", int(os.environ.get("PXS_DETERMINISTIC", "0") not in ("", "0"))); plan._det = None
+	elif want is not None and getattr(plan, "_det", None) != want:
+		plan.set_option("deterministic", int(want)); plan._det = want
+	return plan
+
 def tri_mstart(lmax, mmax=None):
 	if mmax is None: mmax = lmax
 	m = np.arange(mmax+1, dtype=np.int64)
@@ -165,7 +185,7 @@ def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1)
 		_lib.check(_lib.load().pxs_plan_grid2d(ctypes.byref(h), geometry.encode(), int(ntheta), int(nphi), float(phi0),
 			int(bool(flip[0])), int(bool(flip[1])), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
 		p = Plan(h); _plans[key] = p
-	return p
+	return _apply_mode(p)
 
 def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
 	th = np.ascontiguousarray(theta, dtype=np.float64); nph = np.ascontiguousarray(nphi, dtype=np.uint64)
@@ -178,7 +198,7 @@ def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixst
 		_lib.check(_lib.load().pxs_plan_rings(ctypes.byref(h), len(th), th.ctypes.data, nph.ctypes.data, p0.ctypes.data, rs.ctypes.data,
 			int(pixstride), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
 		p = Plan(h); _plans[key] = p
-	return p
+	return _apply_mode(p)
 
 def _ncomp(spin, mode):
 	if mode == "DERIV1": return 1, 2
@@ -242,13 +262,14 @@ def analysis_form(geometry, ntheta, nphi, lmax, mmax=None, mstart=None, phi0=0.0
 	return dict(form={0: "interpolant", 1: "weights", 2: "ducc0"}[plan.query("analysis_form")], ncc_circle=plan.query("ncc_circle"), ducc_ncc_circle=plan.query("ducc_ncc_circle"))
 
 def _run_ana(plan, map, alm, spin, adjoint, analysis=None, alm_dense=False):
-	plan.set_option("analysis", _analysis_mode(analysis))      # (host-side path choice of the calls that follow; plans are cached and shared)
 	ad, md = _np_dtype(alm), _np_dtype(map)
 	batched = alm.ndim == 3
 	nb = alm.shape[0] if batched else 1
 	av = _View(alm, 1, batched, not adjoint, overwrite=alm_dense and not adjoint); mv = _View(map, map.ndim-(2 if batched else 1), batched, bool(adjoint), overwrite=bool(adjoint))      # (a grid plan writes every pixel)
-	_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), int(nb), mv.ptr, _DT[md], mv.cstride, mv.bstride,
-		av.ptr, _DT[ad], av.cstride, av.bstride, current_stream()))
+	with plan.lock:      # the option and the call it applies to, as one step: plans are cached and shared between threads
+		plan.set_option("analysis", _analysis_mode(analysis))
+		_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), int(nb), mv.ptr, _DT[md], mv.cstride, mv.bstride,
+			av.ptr, _DT[ad], av.cstride, av.bstride, current_stream()))
 	av.finish(); mv.finish()
 
 def _grid_args(alm, map, spin, lmax, mmax, mstart, geometry, phi0, lstride, mode, flip):

@@ -4,7 +4,7 @@ semantics), plus the golden alm2map vector.  Reference: tests/test_pixell.py:870
 import os
 import numpy as np
 import pytest
-from pixell_amd import curvedsky, enmap
+from pixell_amd import curvedsky, enmap, sht
 
 def roundtrip_body(lmax=30):
 	for use_oalm in [False, True]:
@@ -345,10 +345,10 @@ def test_repeatable_and_cyl_equals_2d_gpu(monkeypatch):
 			torch.cuda.synchronize()
 			res.append((m.tensor.cpu().numpy().copy(), back.cpu().numpy().copy(), at.cpu().numpy().copy(), mc.tensor.cpu().numpy().copy(), atc.cpu().numpy().copy()))
 		return res
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1")
+	monkeypatch.setattr(sht, "_deterministic", True)
 	res = run()
 	for a, b in zip(res[0], res[1]): assert np.array_equal(a, b)
-	monkeypatch.delenv("PXS_DETERMINISTIC")
+	monkeypatch.setattr(sht, "_deterministic", None)
 	res2 = run()
 	for a, b, c in zip(res2[0], res2[1], res[0]):
 		assert np.max(np.abs(a-b)) <= 1e-13*np.max(np.abs(a))
@@ -364,7 +364,7 @@ def test_host_array_route_gpu(monkeypatch):
 	import torch
 	from pixell_amd import hostio
 	monkeypatch.setattr(hostio, "SLAB_BYTES", 24 << 20); monkeypatch.setattr(hostio, "MIN_BYTES", 16 << 20)
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1")      # (the default analysis adds with atomics: equal to rounding, not bit for bit, even between two device-resident calls)
+	monkeypatch.setattr(sht, "_deterministic", True)      # (the default analysis adds with atomics: equal to rounding, not bit for bit, even between two device-resident calls)
 	lmax = 1500
 	shape, wcs = enmap.fullsky_geometry(shape=(2000, 4000))
 	ainfo = curvedsky.alm_info(lmax)

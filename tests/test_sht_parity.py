@@ -68,27 +68,32 @@ def test_grid_small_hostsim(geometry, nt, nph, lmax, spin):
 @pytest.mark.hostsim
 @pytest.mark.parametrize("spin", [0, 2])
 def test_deterministic_mode_hostsim(monkeypatch, spin):
-	"""PXS_DETERMINISTIC=1: per-wave partial moments + ordered sum instead of atomic adds into the moments (legendre.hip, leg_analysis)"""
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1")
-	check_grid("F1", 20, 41, 19, spin)
+	"""pxs_plan_option("deterministic", 1) (sht.set_deterministic): per-wave partial moments + ordered sum instead of atomic adds into the
+	moments (legendre.hip, leg_analysis)"""
+	sht.set_deterministic(True)
+	try: check_grid("F1", 20, 41, 19, spin)
+	finally: sht.set_deterministic(None)
 
 @pytest.mark.gpu
 def test_deterministic_mode_gpu(monkeypatch):
 	"""several waves per m: the ordered scheme against the oracle (the default one is what every other test runs), the two
 	schemes against each other at a size with 3-6 waves per m, and the ordered one repeats bit for bit"""
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1")
-	check_grid("CC", 514, 1200, 512, 2, random_map=False)
-	nt, nph, lmax = 1500, 3000, 1400
-	rng = np.random.default_rng(5); ms = so._tri_mstart(lmax, lmax)
-	for spin, nc in ((0, 1), (2, 2)):
-		pix = rng.standard_normal((nc, nt, nph))
-		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry="F1", phi0=0.1)
-		res = []
-		for det in ("1", "1", "0", "0"):
-			monkeypatch.setenv("PXS_DETERMINISTIC", det)
-			oa = np.zeros((nc, int(ms[-1])+lmax+1), complex); sht.analysis_2d(alm=oa, map=pix, **kw); res.append(oa)
-		assert np.array_equal(res[0], res[1])
-		assert relrms(res[2], res[0]) < 1e-14 and relrms(res[3], res[2]) < 1e-14
+	try:
+		sht.set_deterministic(True)      # the plan option, not an environment variable: a drop-in backend is configured through its API
+		check_grid("CC", 514, 1200, 512, 2, random_map=False)
+		nt, nph, lmax = 1500, 3000, 1400
+		rng = np.random.default_rng(5); ms = so._tri_mstart(lmax, lmax)
+		for spin, nc in ((0, 1), (2, 2)):
+			pix = rng.standard_normal((nc, nt, nph))
+			kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry="F1", phi0=0.1)
+			res = []
+			for det in (True, True, False, False):      # (the same cached plan, switched between the calls)
+				sht.set_deterministic(det)
+				oa = np.zeros((nc, int(ms[-1])+lmax+1), complex); plan = sht.analysis_2d(alm=oa, map=pix, return_plan=True, **kw); res.append(oa)
+			assert np.array_equal(res[0], res[1])
+			assert relrms(res[2], res[0]) < 1e-14 and relrms(res[3], res[2]) < 1e-14
+			assert plan.info()["scratch_bytes"] < 60e9
+	finally: sht.set_deterministic(None)
 
 @pytest.mark.hostsim
 def test_scaled_recurrence_hostsim():
@@ -300,11 +305,11 @@ def check_seeds(lmax, nt, nph, reps=3):
 
 @pytest.mark.hostsim
 def test_seeds_hostsim(monkeypatch):
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0")
+	monkeypatch.setattr(sht, "_deterministic", True); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0")
 	check_seeds(28, 30, 60, reps=2)
 @pytest.mark.gpu
 def test_seeds_gpu(monkeypatch):
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1")           # (bitwise comparison of the analysis needs the ordered accumulation)
+	monkeypatch.setattr(sht, "_deterministic", True)           # (bitwise comparison of the analysis needs the ordered accumulation)
 	monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0")
 	check_seeds(1500, 1600, 3100)
 
@@ -633,12 +638,12 @@ def test_mm_analysis_gpu():
 
 @pytest.mark.hostsim
 def test_batched_deterministic_and_seeded_hostsim(monkeypatch):
-	"""batched calls on the two paths that launch maps one at a time: the ordered (bitwise repeatable) analysis, PXS_DETERMINISTIC=1, and
+	"""batched calls on the two paths that launch maps one at a time: the ordered (bitwise repeatable) analysis (sht.set_deterministic), and
 	the launch that records the recurrence seeds (the first map alone), forced on at toy size with PXS_SEED_MIN_LMAX=0"""
 	small = dict(nb=2, nt=18, nph=36, lmax=14)
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(**small)
-	monkeypatch.delenv("PXS_DETERMINISTIC"); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0"); sht.clear_plans(); check_batched(**small)
-	monkeypatch.setenv("PXS_DETERMINISTIC", "1"); sht.clear_plans(); check_batched(**small)
+	monkeypatch.setattr(sht, "_deterministic", True); sht.clear_plans(); check_batched(**small)
+	monkeypatch.setattr(sht, "_deterministic", None); monkeypatch.setenv("PXS_SEED_MIN_LMAX", "0"); sht.clear_plans(); check_batched(**small)
+	monkeypatch.setattr(sht, "_deterministic", True); sht.clear_plans(); check_batched(**small)
 	sht.clear_plans()
 
 def check_baseline_analysis_forms():
