@@ -438,6 +438,18 @@ template<int K> __global__ __launch_bounds__(64, (K == 4 ? 7 : 1)) void leg_syn_
 		// phase C: fast loop, two steps per iteration (lam1/lam2 swap roles, no register moves),
 		// coefficients of the next iteration prefetched with scalar loads (tables are padded by 2 rows)
 		double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1), a0 = LDC(at, k), a1 = LDC(at, k+1);
+#ifndef PXS_NO_PHASEC_UNROLL
+		// two pairs per iteration on alternating row sets: the prefetched rows are consumed where they landed (the single-pair loop
+		// rotated them with 8-16 s_mov_b64 per pair; SALU was 27-45 % of the VALU count, profiles/r04_leg_sq_counters_c3.txt)
+		while (k + 3 < nk) {
+			double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3), m0 = LDC(at, k+2), m1 = LDC(at, k+3);
+			S0_SYN_PAIR(c0, c1, a0, a1)
+			k += 2;
+			c0 = LDC(coef, k+2); c1 = LDC(coef, k+3); a0 = LDC(at, k+2); a1 = LDC(at, k+3);
+			S0_SYN_PAIR(n0, n1, m0, m1)
+			k += 2;
+		}
+#endif
 		for (; k + 1 < nk; k += 2) {
 			const double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3), m0 = LDC(at, k+2), m1 = LDC(at, k+3);
 			S0_SYN_PAIR(c0, c1, a0, a1)
@@ -654,6 +666,16 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
 	}
 	// phase C: every lane at scale 0 (or without data): next coefficients prefetched with scalar loads
 	double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1);
+#ifndef PXS_NO_PHASEC_UNROLL
+	while (k + 3 < nk) {      // (two pairs per iteration on alternating row sets, see leg_syn_s0)
+		double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3);
+		S0_ANA_PAIR(c0, c1)
+		k += 2;
+		c0 = LDC(coef, k+2); c1 = LDC(coef, k+3);
+		S0_ANA_PAIR(n0, n1)
+		k += 2;
+	}
+#endif
 	for (; k + 1 < nk; k += 2) {
 		const double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3);
 		S0_ANA_PAIR(c0, c1)
@@ -733,6 +755,9 @@ __device__ unsigned long long mm_prof[16];
 #define MM_TICK(i)
 #define MM_TDUMP
 #endif
+// step coefficient a x^2 + b' with both a and b' wave-uniform: gfx950 takes one scalar source per VALU op, so b' is copied to a VGPR
+// right at its use (left to the compiler, the copies of all 16 steps of a tile were made early and lived in 64 VGPRs: spills)
+__device__ __forceinline__ double mm_coef(double ca, double x2, double cb) { PXS_VCOPY(vb_, cb); return fma(ca, x2, vb_); }
 // LDS: [W][16][MM_PSTRIDE] P tiles + [2][4 NG][64] reduction tiles (the staging area of the prologue, 64 W entries of MM_ESTRIDE doubles, lies over both)
 __host__ __device__ constexpr int mm_lds_doubles(int NG, int W) { return W*16*MM_PSTRIDE + 2*NG*4*64 > 64*W*MM_ESTRIDE ? W*16*MM_PSTRIDE + 2*NG*4*64 : 64*W*MM_ESTRIDE; }
 static inline size_t mm_ana_lds(int NG, int W) { return sizeof(double)*(size_t)mm_lds_doubles(NG, W) + 16; }
@@ -868,10 +893,10 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_s0_mm
 				const int kq = k0 + 4*q4;
 				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
 				if (kq >= kw && kq < nk) {
-					p0 = lam2[0]; lam1[0] = fma(fma(cf[8*q4 + 0], csq[0], cf[8*q4 + 1]), lam2[0], lam1[0]);
-					p1 = lam1[0]; lam2[0] = fma(fma(cf[8*q4 + 2], csq[0], cf[8*q4 + 3]), lam1[0], lam2[0]);
-					p2 = lam2[0]; lam1[0] = fma(fma(cf[8*q4 + 4], csq[0], cf[8*q4 + 5]), lam2[0], lam1[0]);
-					p3 = lam1[0]; lam2[0] = fma(fma(cf[8*q4 + 6], csq[0], cf[8*q4 + 7]), lam1[0], lam2[0]);
+					p0 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 0], csq[0], cf[8*q4 + 1]), lam2[0], lam1[0]);
+					p1 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 2], csq[0], cf[8*q4 + 3]), lam1[0], lam2[0]);
+					p2 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 4], csq[0], cf[8*q4 + 5]), lam2[0], lam1[0]);
+					p3 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 6], csq[0], cf[8*q4 + 7]), lam1[0], lam2[0]);
 					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
 						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
 						pend = __any(sc[0] < 0);
@@ -919,6 +944,160 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_s0_mm
 	if (tlast >= 0) mm_flush(tlast);
 	MM_TDUMP
 	PXS_COUNT(1, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
+}
+
+
+// ---- batched spin-0 synthesis as an FP64-MFMA GEMM (round 5) ----------------------------------------------------------------------
+// The transpose of leg_ana_s0_mm: leg[ring][map, c] = sum_k p_k(ring) almt[k][map, c], c = the four real columns of alm_pre_s0 (even
+// part re / im, odd part re / im).  M = 16 ring pairs, N = 16 = 4 maps x 4 columns, K = recurrence steps: the accumulators
+// (64 ring pairs x 16 columns per group of 4 maps = 4 x 8 VGPRs) stay in registers for the whole l loop, one wave per workgroup
+// and NO cross-wave step at all (every wave owns its rings).  A operands: lane (i, kk) of MFMA (rb, q) takes step q + 4 kk of ring
+// pair 16 rb + i from the wave's [16][68] P tile (the same tile and recurrence as the analysis; rows of 68 doubles: the four steps of
+// an MFMA lie 4 rows = 32 banks apart); B operands: the pre-scaled alm rows of the tile, one double per lane and MFMA step-quad,
+// loaded a tile ahead (the 32 bytes per step and map the VALU kernel takes through the scalar cache).  At the end a lane holds one
+// column of one ring pair: the quad (even re, even im, odd re, odd im) is combined across lanes into the north and south ring values.
+#define MMS_PSTRIDE 68
+static inline size_t mm_syn_lds() { return sizeof(double)*16*MMS_PSTRIDE; }
+#ifdef PXS_HOST_SIM
+#define MMS_XOR2(v) __shfl_xor((v), 2)
+#else
+__device__ __forceinline__ double mms_xor2(double v) {      // value of lane ^ 2 (quad permute [2, 3, 0, 1])
+	const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4e, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4e, 0xf, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+#define MMS_XOR2(v) mms_xor2(v)
+#endif
+
+template<int NG> __global__ __launch_bounds__(64, 4) void leg_syn_s0_mm(const LegK a)
+{
+	PXS_SHARED(double, pmine);      // [16][MMS_PSTRIDE]
+	constexpr int K = 1;
+	const int lane = threadIdx.x;
+	int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
+	const int nk = (a.lmax - m)/2 + 1;
+	const double4_t* __restrict__ coef = a.coef + row0;
+	const int pbase = wv*64;
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64, a.npairs) - 1]; return c*c > 0.5; }();
+	double csq[K], lam1[K], lam2[K]; int sc[K];
+	bool alive;
+	{
+		const int p = pbase + lane;
+		const bool valid = p < a.npairs;
+		const double x = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0;
+		csq[0] = polar ? -sth*sth : x*x;
+		alive = valid && ((double)m <= a.lmax*sth + a.ofs);
+		lam1[0] = 0; lam2[0] = 0; sc[0] = 0;
+		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[0], sc[0]); }
+	}
+	mm_acc acc[NG][4];
+#pragma unroll
+	for (int g = 0; g < NG; g++)
+#pragma unroll
+		for (int rb = 0; rb < 4; rb++) { acc[g][rb][0] = 0; acc[g][rb][1] = 0; acc[g][rb][2] = 0; acc[g][rb][3] = 0; }
+	long ntile = 0;
+	// phase A: recurrence only until the first lane of the wave is at scale 0 (a wave without a live ring skips the loop below)
+	int k = 0;
+	const bool wave_alive = __any(alive);
+	if (wave_alive) { S0_PHASE_A }
+	const int kw = PXS_UNIFORM_INT(wave_alive ? k : nk + 16);      // (explicitly wave-uniform: left as a select, the loop below was compiled as divergent and the prefetched coefficient rows went to VGPRs)
+	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	{
+		const double* __restrict__ tab = reinterpret_cast<const double*>(polar ? a.coef2p : a.coef2) + 2*row0;      // (a, b') of step k at tab[2 k]
+		// B operand of MFMA step-quad q: lane (j, kk) holds column j & 3 of map 4 (bb NG + g) + (j >> 2) at step q + 4 kk of the tile
+		const int jcol = lane & 15, kk4 = lane >> 4;
+		const double* bsrc[NG]; bool bok[NG];
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const int map = (bb*NG + g)*4 + (jcol >> 2);
+			bok[g] = map < a.nmaps;
+			bsrc[g] = a.almt + (long)(bok[g] ? map : 0)*a.almt_bs + 4*row0 + (jcol & 3) + 16*kk4;
+		}
+		auto load_b = [&](int k0, double (*b)[4]) {
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int q = 0; q < 4; q++) b[g][q] = (bok[g] && k0 + q + 4*kk4 < nk) ? bsrc[g][4L*(k0 + q)] : 0.0;
+		};
+		bool pend = __any(sc[0] < 0);
+		const double* __restrict__ pread = pmine + 4*(lane >> 4)*MMS_PSTRIDE + (lane & 15);
+		double cf[32];      // coefficients of the 16 steps of the tile, requested a tile ahead (every tile from the wave's first one on is run)
+		double bcur[NG][4], bnxt[NG][4];
+		load_b(16*(kw >> 4), bcur);
+		if (kw < nk) {
+#pragma unroll
+			for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 32L*(kw >> 4) + i);
+		}
+		for (int t = kw >> 4; 16*t < nk; t++) {
+			const int k0 = 16*t;
+			ntile++;
+#pragma unroll
+			for (int q4 = 0; q4 < 4; q4++) {
+				const int kq = k0 + 4*q4;
+				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+				if (kq >= kw && kq < nk) {
+					p0 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 0], csq[0], cf[8*q4 + 1]), lam2[0], lam1[0]);
+					p1 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 2], csq[0], cf[8*q4 + 3]), lam1[0], lam2[0]);
+					p2 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 4], csq[0], cf[8*q4 + 5]), lam2[0], lam1[0]);
+					p3 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 6], csq[0], cf[8*q4 + 7]), lam1[0], lam2[0]);
+					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
+						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
+						pend = __any(sc[0] < 0);
+					}
+					if (kq + 1 >= nk) p1 = 0.0;
+					if (kq + 2 >= nk) p2 = 0.0;
+					if (kq + 3 >= nk) p3 = 0.0;
+				}
+				pmine[(4*q4 + 0)*MMS_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MMS_PSTRIDE + lane] = p1;
+				pmine[(4*q4 + 2)*MMS_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MMS_PSTRIDE + lane] = p3;
+			}
+			MM_WAVE_SYNC();
+			double av[4];
+#pragma unroll
+			for (int rb = 0; rb < 4; rb++) av[rb] = pread[16*rb];
+			MM_WAVE_SYNC();
+			if (k0 + 16 < nk) {      // the rows of the next tile (coefficients and pre-scaled alm), on their way during the MFMAs
+#pragma unroll
+				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
+				load_b(k0 + 16, bnxt);
+			}
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+#pragma unroll
+				for (int rb = 0; rb < 4; rb++) {
+					const double aq = q == 0 ? av[rb] : pread[q*MMS_PSTRIDE + 16*rb];
+#pragma unroll
+					for (int g = 0; g < NG; g++) acc[g][rb] = mm_mfma(aq, bcur[g][q], acc[g][rb]);
+				}
+			MM_WAVE_SYNC();      // the A operands are out of the tile before the next one is written
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int q = 0; q < 4; q++) bcur[g][q] = bnxt[g][q];
+		}
+	}
+	// register r of acc[g][rb] at lane (i4 = lane / 16, j = lane % 16): ring pair 16 rb + 4 r + i4, column j = 4 (map in the group) + c
+	const int c = lane & 3;
+#pragma unroll
+	for (int g = 0; g < NG; g++) {
+		const int map = (bb*NG + g)*4 + ((lane & 15) >> 2);
+		double* __restrict__ out = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + (long)m*a.ld) + (c & 1);
+#pragma unroll
+		for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int p = pbase + 16*rb + 4*r + (lane >> 4);
+				const bool valid = p < a.npairs && map < a.nmaps;
+				const double v = acc[g][rb][r], o = MMS_XOR2(v);
+				const double x = valid ? a.cth[p] : 0.0;
+				// c = 0, 1: north ring, even + x odd; c = 2, 3: south ring, even - x odd (this lane holds the odd part)
+				const double val = c < 2 ? fma(x, o, v) : fma(-x, v, o);
+				const int ring = valid ? (c < 2 ? a.ring_n[p] : a.ring_s[p]) : -1;
+				if (ring >= 0) out[2*ring] = val;
+			}
+	}
+	PXS_COUNT(0, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
 }
 
 // ---------------------------------------------------------------------------------
@@ -1076,6 +1255,16 @@ template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
 			}
 		// phase C: fast loop, next coefficients prefetched
 		double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1), a0 = LDC(at, j), a1 = LDC(at, j+1);
+#ifndef PXS_NO_PHASEC_UNROLL
+		while (j + 3 < nl) {      // (two pairs per iteration on alternating row sets, see leg_syn_s0)
+			double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3), m0 = LDC(at, j+2), m1 = LDC(at, j+3);
+			SPIN_SYN_PAIR(f0, f1, a0, a1)
+			j += 2;
+			f0 = LDC(coef, j+2); f1 = LDC(coef, j+3); a0 = LDC(at, j+2); a1 = LDC(at, j+3);
+			SPIN_SYN_PAIR(n0, n1, m0, m1)
+			j += 2;
+		}
+#endif
 		for (; j + 1 < nl; j += 2) {
 			const double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3), m0 = LDC(at, j+2), m1 = LDC(at, j+3);
 			SPIN_SYN_PAIR(f0, f1, a0, a1)
@@ -1206,6 +1395,16 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	}
 	// phase C: next coefficients prefetched
 	double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1);
+#ifndef PXS_NO_PHASEC_UNROLL
+	while (j + 3 < nl) {      // (two pairs per iteration on alternating row sets, see leg_syn_s0)
+		double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3);
+		SPIN_ANA_PAIR(f0, f1)
+		j += 2;
+		f0 = LDC(coef, j+2); f1 = LDC(coef, j+3);
+		SPIN_ANA_PAIR(n0, n1)
+		j += 2;
+	}
+#endif
 	for (; j + 1 < nl; j += 2) {
 		const double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3);
 		SPIN_ANA_PAIR(f0, f1)
@@ -1446,6 +1645,7 @@ static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dty
 	return k;
 }
 
+static int syn_mm_min() { static int v = [] { const char* e = getenv("PXS_SYN_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                    double2* leg, int deriv1, LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
@@ -1476,6 +1676,29 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		seeds_written(sb, st);
 	};
 	int b0 = 0;
+	// spin 0, 4 or more maps (PXS_SYN_MM_MIN): the FP64-MFMA form (leg_syn_s0_mm), 8 maps per wave; a remainder of <= 4 maps in 4-map waves,
+	// a single left-over map through the VALU kernel.  Each map's result equals its single-map call to rounding, not bit for bit.
+	if (tb.spin == 0 && nb >= syn_mm_min()) {
+		int nmm = nb; if (nb % 8 == 1) nmm = nb - 1;
+		if (!tb.d_coef2.p) {      // compact step table, built by the first batched transform on the plan
+			tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
+			hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
+		}
+		auto launch_mm = [&](int m0, int nmaps, int ng) {
+			const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
+			LegK a = make_legk(rs, tb, wk, leg + (size_t)m0*leg_bstride, ld, 1, ngroups, leg_bstride);
+			a.almt += (size_t)m0*a.almt_bs; a.nmaps = nmaps; a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
+			if (prof) prof->begin(st, 0);
+			if (ng == 2) hipLaunchKernelGGL(leg_syn_s0_mm<2>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
+			else         hipLaunchKernelGGL(leg_syn_s0_mm<1>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
+			if (prof) prof->end(st, 0);
+		};
+		static const int ngmax = env_k("PXS_SYN_MM_NG", 2, 1, 2);      // groups of 4 maps per wave (tuning)
+		const int mper = 4*ngmax, gmax = std::max(1, leg_max_batch(rs, tb, 1)), r = nmm % mper, n8 = nmm - r;
+		for (int m0 = 0; m0 < n8; m0 += mper*gmax) launch_mm(m0, std::min(mper*gmax, n8 - m0), ngmax);
+		if (r > 4) launch_mm(n8, r, 2); else if (r > 0) launch_mm(n8, r, 1);
+		b0 = nmm;
+	}
 	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
 	if (nb - b0 > 1 && seeds_pending(wk, rs, tb, 0, K)) { launch(b0, 1); b0 += 1; }
 	for (const int nmax = leg_max_batch(rs, tb, K); b0 < nb; b0 += nmax) launch(b0, std::min(nmax, nb - b0));
