@@ -123,7 +123,7 @@ def measured_traffic(config, dom):
 	profiles/r02_traffic_<config>.json; FETCH_SIZE corrected per access pattern -- x2 for 16-byte-per-lane row reads as the gfx950 note
 	of MI355X_MICROARCH.md prescribes, x1 where the known array sizes of the chain kernels show full counting -- WRITE_SIZE as reported).
 	Counters cannot be read from inside this process: null when no profile of this config is committed."""
-	for tag in ("r04b", "r04", "r03", "r02", "r01"):
+	for tag in ("r05", "r04b", "r04", "r03", "r02", "r01"):
 		path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config))
 		if os.path.exists(path): break
 	else: return dict(traffic=None)
@@ -297,11 +297,11 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 		t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 	stage_ms = {k: 0.0 for k in stages}
-	for r in range(len(evs)//8):
-		e = evs[8*r:8*r+8]
+	for r in range(len(evs)//7):      # per batch: six marks (before rand_alm, after rand_alm, after alm2map, after the FFT / spectrum loop twice, after map2alm ... ) + the inner FFT events
+		e = evs[7*r:7*r+7]
 		stage_ms["rand_alm"] += e[0].elapsed_time(e[1]); stage_ms["alm2map"] += e[1].elapsed_time(e[2])
-		stage_ms["map2alm"] += e[4].elapsed_time(e[5]); stage_ms["alm2cl"] += e[5].elapsed_time(e[6])
-		for e0, e1, e2 in e[7]: stage_ms["enmap_fft"] += e0.elapsed_time(e1); stage_ms["ps2d_lbin"] += e1.elapsed_time(e2)
+		stage_ms["map2alm"] += e[3].elapsed_time(e[4]); stage_ms["alm2cl"] += e[4].elapsed_time(e[5])
+		for e0, e1, e2 in e[6]: stage_ms["enmap_fft"] += e0.elapsed_time(e1); stage_ms["ps2d_lbin"] += e1.elapsed_time(e2)
 	nre = max(1, args.steps*nloc)
 	stage_ms = {k: round(v/nre, 3) for k, v in stage_ms.items()}
 	ms_step = dt/args.steps*1e3

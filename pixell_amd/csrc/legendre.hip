@@ -1488,7 +1488,7 @@ void RingSet::upload_all() {
 	d_sh2 = upload(sh2); d_ch2 = upload(ch2);
 }
 
-void LegTables::build(int lmax_, int mmax_, int spin_) {
+void LegTables::build_host(int lmax_, int mmax_, int spin_) {
 	lmax = lmax_; mmax = mmax_; spin = spin_;
 	row.assign(mmax+2, 0);
 	for (int m = 0; m <= mmax; m++) {
@@ -1568,6 +1568,146 @@ void LegTables::build(int lmax_, int mmax_, int spin_) {
 	d_alpha.alloc(sizeof(double)*(size_t)(nrows + 4)); PXS_HIP(hipMemcpy(d_alpha.p, alpha, d_alpha.bytes, hipMemcpyHostToDevice));
 }
 
+
+// ---- recurrence tables on the GPU in double-double arithmetic (round 5) --------------------------------------------------------------
+// The tables were built on host threads in long double (75 million rows of 4-6 square roots at lmax 10^4: 0.85 s of a 1.25 s cold
+// call, followed by a 3 GB pageable upload).  The rows of one m are a serial recurrence, the m are independent: one GPU thread per m in
+// double-double (106-bit) arithmetic builds the same rows in place in device memory in ~10 ms; the O(mmax) sectoral start values come from
+// the host in long double as (hi, lo) pairs.  build_host (PXS_TABLES_HOST=1) remains as the reference the tests compare against.
+// (error-free transforms: the compiler must not contract a product into a neighbouring add -- hipcc's default -ffp-contract=fast turned
+// a - x*x into fma(-x, x, a) inside these and the device tables came out with 4-7e-15 errors instead of 2e-16, tools/tables_probe.hip)
+#if defined(__clang__)
+#define PXS_FP_STRICT _Pragma("clang fp contract(off)")
+#else
+#define PXS_FP_STRICT
+#endif
+struct dd { double h, l; };
+__host__ __device__ __forceinline__ dd dd_norm(double a, double b) {
+	PXS_FP_STRICT const double s = a + b; return dd{s, b - (s - a)}; }
+__host__ __device__ __forceinline__ dd dd_of(double a) {
+	PXS_FP_STRICT return dd{a, 0.0}; }
+__host__ __device__ __forceinline__ dd dd_add(dd a, dd b) {
+	PXS_FP_STRICT
+	const double s = a.h + b.h, v = s - a.h, e = (a.h - (s - v)) + (b.h - v);
+	return dd_norm(s, e + (a.l + b.l));
+}
+__host__ __device__ __forceinline__ dd dd_neg(dd a) {
+	PXS_FP_STRICT return dd{-a.h, -a.l}; }
+__host__ __device__ __forceinline__ dd dd_mul(dd a, dd b) {
+	PXS_FP_STRICT
+	const double p = a.h*b.h, e = fma(a.h, b.h, -p);
+	return dd_norm(p, e + (a.h*b.l + a.l*b.h));
+}
+__host__ __device__ __forceinline__ dd dd_div(dd a, dd b) {
+	PXS_FP_STRICT
+	const double q1 = a.h/b.h;
+	dd r = dd_add(a, dd_neg(dd_mul(dd_of(q1), b)));
+	const double q2 = r.h/b.h;
+	r = dd_add(r, dd_neg(dd_mul(dd_of(q2), b)));
+	const double q3 = r.h/b.h;
+	return dd_add(dd_norm(q1, q2), dd_of(q3));
+}
+__host__ __device__ __forceinline__ dd dd_sqrt(dd a) {
+	PXS_FP_STRICT
+	if (a.h <= 0.0) return dd{0.0, 0.0};
+	const double x = sqrt(a.h);
+	// one Newton step in double-double: x + (a - x^2) / (2 x)
+	const double p = x*x, e = fma(x, x, -p);
+	const dd r = dd_add(a, dd{-p, -e});
+	return dd_norm(x, r.h/(2.0*x));
+}
+__host__ __device__ __forceinline__ double dd_val(dd a) {
+	PXS_FP_STRICT return a.h + a.l; }
+
+// spin 0: q(l) = eps_l^2 = (l^2 - m^2) / (4 l^2 - 1) (0 for l <= m); rows as in build_host
+__global__ __launch_bounds__(64) void leg_tables_s0(int lmax, int mmax, const long* __restrict__ row, const dd* __restrict__ cms, double4_t* __restrict__ coef, double* __restrict__ alpha) {
+	const int m = blockIdx.x*blockDim.x + threadIdx.x;
+	if (m > mmax) return;
+	auto q = [&](int l) -> dd { if (l <= m) return dd{0.0, 0.0}; const double L = l, M = m; return dd_div(dd_of(L*L - M*M), dd_of(4.0*L*L - 1.0)); };
+	const int nk = (lmax - m)/2 + 1;
+	dd a_prev = dd{0.0, 0.0}, a_cur = dd_mul(dd_sqrt(dd_of(2.0*m + 3.0)), cms[m]);
+	// sliding window of q(lp - 1) ... q(lp + 2), lp = m + 2 k + 1
+	dd qm1 = q(m), q0 = q(m + 1), qp1 = q(m + 2), qp2 = q(m + 3);
+	const long r0 = row[m];
+	for (int k = 0; k < nk; k++) {
+		const dd e2 = dd_add(qp1, q0), f = dd_sqrt(dd_mul(q0, qm1)), d = dd_sqrt(dd_mul(qp1, qp2));
+		const dd a_next = (k == 0) ? dd_div(a_cur, d) : dd_neg(dd_div(dd_mul(f, a_prev), d));
+		const dd ak = dd_div(a_cur, dd_mul(a_next, d));
+		const dd ake = dd_mul(ak, e2);
+		coef[r0 + k] = double4_t{dd_val(ak), -dd_val(ake), dd_val(dd_add(ak, dd_neg(ake))), 0.0};
+		alpha[r0 + k] = dd_val(a_cur);
+		a_prev = a_cur; a_cur = a_next;
+		const int lp = m + 2*k + 3;      // next step
+		qm1 = qp1; q0 = qp2; qp1 = q(lp + 1); qp2 = q(lp + 2);
+	}
+}
+// spin s: rows l = max(m, s) .. lmax as in build_host
+__global__ __launch_bounds__(64) void leg_tables_spin(int lmax, int mmax, int s, const long* __restrict__ row, const dd* __restrict__ nrm, double4_t* __restrict__ coef, double* __restrict__ alpha) {
+	const int m = blockIdx.x*blockDim.x + threadIdx.x;
+	if (m > mmax) return;
+	const int l0 = max(m, s), nl = lmax - l0 + 1;
+	if (nl <= 0) return;
+	auto Sf = [&](int l) -> dd { const double L = l, M = m, Sp = s; return dd_sqrt(dd_mul(dd_of(L*L - M*M), dd_of(L*L - Sp*Sp))); };
+	dd b_prev = dd{0.0, 0.0}, b_cur = (m & 1) ? dd_neg(nrm[m]) : nrm[m];
+	const long r0 = row[m];
+	dd sf = Sf(l0);
+	for (int l = l0; l <= lmax; l++) {
+		const double L = l;
+		const dd sf1 = Sf(l + 1);
+		const dd qq = dd_mul(dd_sqrt(dd_div(dd_of(2*L + 3), dd_of(2*L + 1))), dd_of(2*L + 1));
+		const dd A = dd_div(dd_mul(qq, dd_of(L + 1)), sf1);
+		const dd B = dd_div(dd_mul(qq, dd_of((double)m*(double)s)), dd_mul(dd_of(L), sf1));
+		dd b_next;
+		if (l == l0) b_next = dd_mul(A, b_cur);
+		else {
+			const dd C = dd_div(dd_mul(dd_mul(dd_sqrt(dd_div(dd_of(2*L + 3), dd_of(2*L - 1))), dd_of(L + 1)), sf), dd_mul(dd_of(L), sf1));
+			b_next = dd_mul(C, b_prev);
+		}
+		const dd ca = dd_div(dd_mul(A, b_cur), b_next), cb = dd_div(dd_mul(B, b_cur), b_next);
+		coef[r0 + (l - l0)] = double4_t{dd_val(ca), dd_val(cb), dd_val(dd_add(ca, cb)), dd_val(dd_add(ca, dd_neg(cb)))};
+		alpha[r0 + (l - l0)] = dd_val(b_cur);
+		b_prev = b_cur; b_cur = b_next; sf = sf1;
+	}
+}
+
+void LegTables::build(int lmax_, int mmax_, int spin_) {
+	{ const char* e = getenv("PXS_TABLES_HOST"); if (e && atoi(e) != 0) { build_host(lmax_, mmax_, spin_); return; } }
+	lmax = lmax_; mmax = mmax_; spin = spin_;
+	row.assign(mmax+2, 0);
+	for (int m = 0; m <= mmax; m++) {
+		long n = spin == 0 ? (lmax - m)/2 + 1 : std::max(0, lmax - std::max(m, spin) + 1);
+		row[m+1] = row[m] + n;
+	}
+	nrows = row[mmax+1];
+	typedef long double LDb;
+	const LDb PIl = 3.141592653589793238462643383279502884L;
+	// sectoral start values (a serial product over m): host, long double, handed over as (hi, lo)
+	std::vector<dd> start(mmax+1);
+	auto put = [&](int m, LDb v) { const double h = (double)v; start[m] = dd{h, (double)(v - (LDb)h)}; };
+	if (spin == 0) {
+		LDb cm = 1/sqrtl(4*PIl);
+		for (int m = 0; m <= mmax; m++) { if (m > 0) cm = -cm*sqrtl((LDb)(2*m+1)/(LDb)(2*m)); put(m, cm); }
+	} else {
+		const int s = spin;
+		LDb h = 2*s+1; for (int i = 1; i <= s; i++) h = h*(LDb)(s+i)/(LDb)i;
+		for (int m = 0; m < std::min(s, mmax+1); m++) { if (m > 0) h = h*(LDb)(s-m+1)/(LDb)(s+m); put(m, sqrtl(h/(4*PIl))); }
+		if (s <= mmax) {
+			LDb c2 = (LDb)(2*s+1)/(4*PIl*powl(4.0L, s));
+			put(s, sqrtl(c2));
+			for (int m = s+1; m <= mmax; m++) { c2 = c2*(LDb)(2*m+1)*(LDb)(2*m)/(4*(LDb)(m+s)*(LDb)(m-s)); put(m, sqrtl(c2)); }
+		}
+	}
+	d_row = upload(row);
+	DevBuf d_start = upload(start);
+	d_coef.alloc(sizeof(double4_t)*(size_t)(nrows + 4)); d_alpha.alloc(sizeof(double)*(size_t)(nrows + 4));
+	// (+4 rows: the fast loops prefetch up to 3 rows ahead)
+	PXS_HIP(hipMemset((char*)d_coef.p + sizeof(double4_t)*(size_t)nrows, 0, sizeof(double4_t)*4)); PXS_HIP(hipMemset((char*)d_alpha.p + sizeof(double)*(size_t)nrows, 0, sizeof(double)*4));
+	const dim3 grid((unsigned)((mmax + 1 + 63)/64));
+	if (spin == 0) hipLaunchKernelGGL(leg_tables_s0, grid, dim3(64), 0, (hipStream_t)0, lmax, mmax, d_row.as<long>(), d_start.as<dd>(), d_coef.as<double4_t>(), d_alpha.as<double>());
+	else           hipLaunchKernelGGL(leg_tables_spin, grid, dim3(64), 0, (hipStream_t)0, lmax, mmax, spin, d_row.as<long>(), d_start.as<dd>(), d_coef.as<double4_t>(), d_alpha.as<double>());
+	PXS_HIP(hipGetLastError());
+	PXS_HIP(hipDeviceSynchronize());      // (d_start goes out of scope; the tables are plan state, built once)
+}
 
 // doubles per map of the pre-scaled alm / the moments of a batched call
 static long leg_almt_stride(const LegTables& tb) { return 4*(tb.nrows + 4); }

@@ -24,7 +24,8 @@ struct LegTables {
 	long nrows = 0;
 	DevBuf d_row, d_coef, d_alpha;   // coef[row] = (a,b); alpha[row] = scaling folded into the alm
 	mutable DevBuf d_coef2, d_coef2p; // spin 0, batched analysis (leg_ana_s0_mm): compact rows (a, b) / (a, a + b), built on first use
-	void build(int lmax, int mmax, int spin);
+	void build(int lmax, int mmax, int spin);        // on the GPU, double-double (legendre.hip)
+	void build_host(int lmax, int mmax, int spin);   // host threads, long double: the reference (PXS_TABLES_HOST=1, tests)
 };
 
 // optional per-stage device timers (hipEvents on the launch stream); stage ids: see pxsht.h PXS_STAGE_*

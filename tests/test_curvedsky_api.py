@@ -383,7 +383,7 @@ def test_host_array_route_gpu(monkeypatch):
 	h_back = np.full_like(alm, np.nan); curvedsky.map2alm(h_map, alm=h_back, spin=[0, 2], ainfo=ainfo)
 	assert np.array_equal(h_back, d_back.cpu().numpy())
 	# the ducc-shaped route (one call per spin group, no pipeline) through the same slabs
-	from pixell_amd import sht
+
 	mi = curvedsky.analyse_geometry(h_map.shape, wcs)
 	kw = dict(lmax=lmax, mstart=ainfo.mstart, geometry=mi.ducc_geo.name, phi0=mi.phi0, flip=tuple(bool(f) for f in mi.flip))
 	m2 = np.full((2,)+shape, np.nan); sht.synthesis_2d(alm=alm[1:], map=m2, spin=2, **kw)

@@ -95,6 +95,30 @@ def test_deterministic_mode_gpu(monkeypatch):
 			assert plan.info()["scratch_bytes"] < 60e9
 	finally: sht.set_deterministic(None)
 
+def check_device_tables(lmax, nt, nph, monkeypatch):
+	"""recurrence tables built on the GPU in double-double (LegTables::build) against the host long-double builder (build_host,
+	PXS_TABLES_HOST=1; the rows agree to 2e-16 relative, tools/tables_probe.hip): transforms through either agree to the transform's own error level"""
+	ms = so._tri_mstart(lmax, lmax); rng = np.random.default_rng(3)
+	for spin, nc in ((0, 1), (2, 2), (1, 2)):
+		alm = so.rand_alm_simple(lmax, nc, 8, spin=(spin,)); pix = rng.standard_normal((nc, nt, nph))
+		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry="F1", phi0=0.1)
+		res = []
+		for host in ("1", "0"):
+			monkeypatch.setenv("PXS_TABLES_HOST", host); sht.clear_plans()
+			m = np.zeros((nc, nt, nph)); sht.synthesis_2d(alm=alm, map=m, **kw)
+			a = np.zeros_like(alm); sht.adjoint_synthesis_2d(alm=a, map=pix, **kw)
+			res.append((m, a))
+		sht.clear_plans()
+		# (the rows agree to an ulp; an ulp in a coefficient moves a recurrence of lmax steps by ~lmax ulp: the algorithm's own error level)
+		tol = 2e-14 if lmax < 100 else 2e-12
+		assert np.abs(res[0][0]-res[1][0]).max() < tol*np.abs(res[0][0]).max()
+		assert np.abs(res[0][1]-res[1][1]).max() < tol*np.abs(res[0][1]).max()
+
+@pytest.mark.hostsim
+def test_device_tables_hostsim(monkeypatch): check_device_tables(40, 42, 84, monkeypatch)
+@pytest.mark.gpu
+def test_device_tables_gpu(monkeypatch): check_device_tables(1500, 1600, 3200, monkeypatch); check_device_tables(4000, 4100, 8200, monkeypatch)
+
 @pytest.mark.hostsim
 def test_scaled_recurrence_hostsim():
 	"""large enough that sin^m(theta) needs the extended exponent near the poles (spin 0 and 2)"""

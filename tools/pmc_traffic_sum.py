@@ -33,5 +33,5 @@ for k in sorted(set(f) | set(w)):
 	res[k] = {"launches": nf, "launches_per_round_trip": nf/ROUND_TRIPS, "ms_total_under_pmc": round(msf, 3), "fetch_MB_per_launch_raw": round(kbf/1024/max(nf, 1), 3),
 		"fetch_MB_per_launch_x2": round(2*kbf/1024/max(nf, 1), 3), "fetch_factor_calibrated": fetch_factor(k),
 		"fetch_MB_per_launch_calibrated": round(fetch_factor(k)*kbf/1024/max(nf, 1), 3), "write_MB_per_launch": round(kbw/1024/max(nw, 1), 3)}
-json.dump({"config": cfg, "round_trips_in_trace": ROUND_TRIPS, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB counters / 1024); x2 = gfx950 wide-read correction of MI355X_MICROARCH.md; calibrated = per-kernel factor from the known array sizes of the FFT-chain kernels (see tools/pmc_traffic_sum.py)", "kernels": res}, open(f"profiles/{tag}_traffic_{cfg}.json", "w"), indent=1)
+json.dump({"config": cfg, "round_trips_in_trace": ROUND_TRIPS, "units": "the *_MB_per_launch fields are MiB (2^20 bytes: rocprofv3 reports KiB, divided by 1024 here); bench.py converts them to bytes with 2^20", "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB counters / 1024); x2 = gfx950 wide-read correction of MI355X_MICROARCH.md; calibrated = per-kernel factor from the known array sizes of the FFT-chain kernels (see tools/pmc_traffic_sum.py)", "kernels": res}, open(f"profiles/{tag}_traffic_{cfg}.json", "w"), indent=1)
 for k, v in res.items(): print(f"{k:62s} n={v['launches']:4d} ms={v['ms_total_under_pmc']:9.2f} fetch={v['fetch_MB_per_launch_raw']:10.2f} (x2 {v['fetch_MB_per_launch_x2']:10.2f}) write={v['write_MB_per_launch']:10.2f} MB/launch")
