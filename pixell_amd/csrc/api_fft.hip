@@ -140,7 +140,7 @@ static void fft_axis(FftContext& fc, hipStream_t st, long n, bool forward, std::
 	if (!FftContext::supported(n)) { bluestein_axis(fc, g_fft_device, st, n, forward, dims, is_e, os_e, ld, stf); return; }
 	{	// the generic radix pass costs n*p for a prime factor p: beyond ~128 two chirp FFTs of a smooth length are cheaper
 		// (healpix ring lengths 4k: alm2map_healpix at nside 2048, lmax 4096, 3 components 270 -> 94 ms)
-		static const long pmin = [] { const char* e = getenv("PXS_BLUESTEIN_MINPRIME"); return e ? atol(e) : 128L; }();
+		static const long pmin = [] { const char* e = lab_getenv("PXS_BLUESTEIN_MINPRIME"); return e ? atol(e) : 128L; }();
 		const bool plain = (ld.mode == LD_PLAIN || (ld.mode == LD_HERM && !ld.herm_fold)) && !ld.mul && !stf.mul && ld.shift == 0 && stf.shift == 0 && !stf.conj_out
 			&& stf.two_sided_k < 0 && !stf.real_pair;
 		long m = n, big = 1;

@@ -55,4 +55,13 @@ inline FastDiv make_fastdiv(uint32_t d) {
 
 enum DType : int { PX_F32 = 0, PX_F64 = 1, PX_C64 = 2, PX_C128 = 3 };
 
+// Tuning and experiment switches (tile shapes, ring pairs per lane, planner overrides, alternative paths kept for A/B runs) are read
+// from the environment in LAB builds only (-DPXS_LAB, tools/build_variants.sh); the product build compiles their defaults in.  What
+// the product reads from the environment is listed in DESIGN.md ("Environment switches").
+#ifdef PXS_LAB
+inline const char* lab_getenv(const char* name) { return getenv(name); }
+#else
+inline const char* lab_getenv(const char*) { return nullptr; }
+#endif
+
 } // namespace pxs

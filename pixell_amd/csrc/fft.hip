@@ -352,7 +352,7 @@ template<int LM> static void launch_tiles_m(const KArgs& k, long nblk, size_t sh
 	// 512 threads per workgroup: LDS allows 4 workgroups of 2048 points per CU, and at < 64 VGPRs twice the waves fit
 	// tiles of more than 2048 points (lines of 1025..2048 points: 64 KiB of LDS, 2 workgroups per CU) get 512 threads:
 	// measured 1.39 -> 1.86 TB/s at n = 2048; for the 32 KiB tiles 512 threads were 3-8 % slower
-	static const int nt_env = [] { const char* e = getenv("PXS_FFT_NT"); return e ? atoi(e) : 0; }();
+	static const int nt_env = [] { const char* e = lab_getenv("PXS_FFT_NT"); return e ? atoi(e) : 0; }();
 	const int nt = nt_override ? nt_override : nt_env ? nt_env : ((long)k.T*k.n >= 2048 ? 512 : 256);
 	static const bool once = [] {
 		(void)hipFuncSetAttribute((const void*)fft_lds_kernel<LM, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
@@ -396,7 +396,7 @@ static std::vector<int> factorize(long n) {
 	// Odd radices first: in the first pass (L = 1) lane b touches points b*R + i, a stride of R points of 16 bytes:
 	// conflict-free over the 64 LDS banks for R = 3, 5 but 4-way for R = 4.  The last radix sets the stride n/R of the
 	// digit-reversed scatter on load; 4 keeps it the least harmful for lengths that are multiples of 8.
-	static const int oddfirst = [] { const char* e = getenv("PXS_FFT_ODDFIRST"); return e ? atoi(e) : 1; }();
+	static const int oddfirst = [] { const char* e = lab_getenv("PXS_FFT_ODDFIRST"); return e ? atoi(e) : 1; }();
 	if (oddfirst) {
 		while (n % 3 == 0) { f.push_back(3); n /= 3; }
 		while (n % 5 == 0) { f.push_back(5); n /= 5; }
@@ -442,7 +442,7 @@ static bool split_two(long n, long& n1, long& n2) {
 		if (a % 8 == 0 && b % 8 == 0 && 4*a >= b) best8 = a;
 	}
 	if (best < 0) return false;
-	static const int align8 = [] { const char* e = getenv("PXS_FFT_ALIGN8"); return e ? atoi(e) : 1; }();
+	static const int align8 = [] { const char* e = lab_getenv("PXS_FFT_ALIGN8"); return e ? atoi(e) : 1; }();
 	if (best8 > 0 && align8) best = best8;
 	n1 = best; n2 = n/best;
 	return n1 <= FFT_NLOC_MAX && n2 <= FFT_NLOC_MAX;
@@ -476,7 +476,7 @@ long FftContext::good_size(long n) {
 // for an even R puts them on few LDS banks.
 static std::vector<int> factorize_comp(long n, int maxr) {
 	static const std::vector<int> allowed = [] {
-		std::vector<int> a; const char* e = getenv("PXS_FFT_RADICES");
+		std::vector<int> a; const char* e = lab_getenv("PXS_FFT_RADICES");
 		std::string s = e ? e : "16,15,12,10,9,8,7,6,5,4,3,2";
 		size_t pos = 0;
 		while (pos < s.size()) { size_t c = s.find(',', pos); if (c == std::string::npos) c = s.size(); int v = atoi(s.substr(pos, c-pos).c_str()); if (v >= 2 && (v <= 5 || v <= PXS_COMP_MAXR)) a.push_back(v); pos = c+1; }
@@ -495,7 +495,7 @@ static std::vector<int> factorize_comp(long n, int maxr) {
 
 std::shared_ptr<FftSub> FftContext::sub(long n, bool comp, int maxr) {
 	std::lock_guard<std::mutex> g(mu_);
-	static const bool comp_on = [] { const char* e = getenv("PXS_FFT_COMP"); return e ? atoi(e) != 0 : true; }();
+	static const bool comp_on = [] { const char* e = lab_getenv("PXS_FFT_COMP"); return e ? atoi(e) != 0 : true; }();
 	comp = comp && comp_on;
 	maxr = std::min(maxr, PXS_COMP_MAXR);
 	const long key = comp ? -(n + ((long)maxr << 40)) : n;
@@ -553,7 +553,7 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	k.pass = s.d_pass.as<PassDesc>();
 	k.perm = s.perm.as<int>(); k.tw = s.tw.as<double2>();
 	int bufs = s.generic ? 2 : 1;
-	static const long env_pts = [] { const char* e = getenv("PXS_FFT_PTS"); return e ? atol(e) : 0L; }();
+	static const long env_pts = [] { const char* e = lab_getenv("PXS_FFT_PTS"); return e ? atol(e) : 0L; }();
 	long pts = s.n <= 1024 ? FFT_LDS_PTS/2 : FFT_LDS_PTS;    // 32 KiB tiles for short lines: 4-5 workgroups per CU
 	if (env_pts > 0 && s.n <= env_pts/2) pts = env_pts;
 	long T = (pts - s.n)/((long)bufs*s.n);
@@ -562,7 +562,7 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	// Tiles that run along the contiguous memory direction (four-step column passes, adjacent lines) move T*16-byte
 	// runs: keep them whole 128-byte lines.  Neighbouring tiles are handled by workgroups on different XCDs, so a
 	// line shared by two tiles is fetched from HBM twice (FETCH_SIZE of this kernel was 1.6x its WRITE_SIZE).
-	static const int align8 = [] { const char* e = getenv("PXS_FFT_ALIGN8"); return e ? atoi(e) : 1; }();
+	static const int align8 = [] { const char* e = lab_getenv("PXS_FFT_ALIGN8"); return e ? atoi(e) : 1; }();
 	if (align8) {
 		if (T >= 8) T -= T % 8;
 		else if (T >= 5 && (long)bufs*8*s.n + s.n <= FFT_LDS_PTS) T = 8;
@@ -574,7 +574,7 @@ static void fill_sub(KArgs& k, const FftSub& s, long maxlines) {
 	// contiguous memory direction.  With 16-byte points a stride that is a multiple of 8 points (which the 128-byte
 	// alignment rule above makes the normal case: 200, 216, 320) puts 16 lanes on 1-2 bank groups: 8-16-way LDS bank
 	// conflicts (SQ_LDS_BANK_CONFLICT was 1.9x SQ_ACTIVE_INST_LDS).  An odd stride spreads them over all banks.
-	static const int lpad = [] { const char* e = getenv("PXS_FFT_LINEPAD"); return e ? atoi(e) : 1; }();
+	static const int lpad = [] { const char* e = lab_getenv("PXS_FFT_LINEPAD"); return e ? atoi(e) : 1; }();
 	k.ns = lpad ? (s.n | 1) : s.n;
 }
 

@@ -618,7 +618,7 @@ static LdsFft mk(FftContext* fc, long n, int maxr = 9) {
 #else
 	constexpr int nofft = 0;
 #endif
-	static const int nspad = [] { const char* e = getenv("PXS_CH_NS_PAD"); return e ? atoi(e) : 0; }();     // experiments: line stride (n | 1) + pad
+	static const int nspad = [] { const char* e = lab_getenv("PXS_CH_NS_PAD"); return e ? atoi(e) : 0; }();     // experiments: line stride (n | 1) + pad
 	f.n = v.n; f.nfac = nofft ? 0 : v.nfac; f.ns = v.ns + nspad; f.generic = v.generic; f.pass = (const PassDesc*)v.pass; f.perm = v.perm; f.tw = v.tw; f.dn = make_fastdiv((uint32_t)n);
 	return f;
 }
@@ -653,7 +653,7 @@ static int tile_lines(long n_a, long n_b, long nlines, int mult, long tab_pts = 
 	if (T < 1) T = 1;
 	const long cap = ((nlines + mult - 1)/mult)*mult;
 	if (T > cap) T = cap;
-	static const long limit = [] { const char* e = getenv("PXS_RING_TILE_KB"); return e ? (long)(atof(e)*1024) : 0L; }();
+	static const long limit = [] { const char* e = lab_getenv("PXS_RING_TILE_KB"); return e ? (long)(atof(e)*1024) : 0L; }();
 	if (tab_pts >= 0 && limit > 0)
 		while (T > mult && (long)sizeof(double2)*(tab_pts + T*(n | 1) + 2) > limit) T -= mult;
 	return (int)T;
@@ -669,7 +669,7 @@ template<class S> void FftChain::set_tiles(S& s, int T, long nlines, long X) {
 // blocked; C4 26.6 / 26.6 -- the 128-byte runs of the intermediates are not what holds the chain kernels at ~3 TB/s (a bare
 // load-tile / LDS / store-tile kernel on contiguous 40 KB tiles reaches 5.3 TB/s with 2, 3 or 4 workgroups per CU, and an LDS-DMA
 // double-buffered persistent variant of it only 4.6: tools/dma_skel.hip).  PXS_CH_BLOCKED=1 turns the layout on for experiments.
-static bool blocked_on() { static const bool on = [] { const char* e = getenv("PXS_CH_BLOCKED"); return e ? atoi(e) != 0 : false; }(); return on; }
+static bool blocked_on() { static const bool on = [] { const char* e = lab_getenv("PXS_CH_BLOCKED"); return e ? atoi(e) != 0 : false; }(); return on; }
 // reader side of a blocked intermediate: the writer made chunks of Tw lines out of na, the reader's tile has T rows
 static BlkIn mk_blk(int Tw, long na, int T) {
 	BlkIn b; memset(&b, 0, sizeof(b));
@@ -689,10 +689,10 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	PXS_REQUIRE((long)s.T*std::max(s.fa.n, s.fb.n) <= S::PTS, "internal: chain tile too large");
 	PXS_REQUIRE(nblk < (1L << 31), "internal: chain grid too large");
 	size_t sh = sizeof(double2)*((size_t)s.fa.n + (S::TWO && s.fb.n == s.fa.n ? 0 : s.fb.n) + (S::HAS_TW ? std::max(s.fa.n, s.fb.n) : 0) + (size_t)s.T*std::max(s.fa.ns, s.fb.ns) + 2);
-	{ static const size_t pad = [] { const char* e = getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
+	{ static const size_t pad = [] { const char* e = lab_getenv("PXS_CH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); sh += pad; }   // occupancy experiments
 	{ static const int pf = [] {      // PXS_CH_PF: every stage; PXS_CH_PF_SID<k>: the stage with S::SID = k
 		const std::string name = "PXS_CH_PF_SID" + std::to_string(S::SID);
-		const char* e1 = getenv(name.c_str()); const char* e = getenv("PXS_CH_PF");
+		const char* e1 = lab_getenv(name.c_str()); const char* e = lab_getenv("PXS_CH_PF");
 		return e1 ? atoi(e1) : (e ? atoi(e) : S::PF); }(); const_cast<S&>(s).pf = pf; }
 	if (getenv("PXS_CHAIN_VERBOSE")) {
 		static std::mutex mu; static std::set<std::tuple<int, int, int, int>> seen; std::lock_guard<std::mutex> g(mu);
@@ -701,7 +701,7 @@ template<class S> static void launch_stage(const S& s, long nblk, hipStream_t st
 	}
 #ifndef PXS_HOST_SIM
 #ifdef PXS_CH_NT2      /* experiment builds: stages whose bit SID is set in PXS_CH_NT2_MASK run with PXS_CH_NT2 threads per workgroup */
-	static const long mask2 = [] { const char* e = getenv("PXS_CH_NT2_MASK"); return e ? strtol(e, nullptr, 0) : 0L; }();
+	static const long mask2 = [] { const char* e = lab_getenv("PXS_CH_NT2_MASK"); return e ? strtol(e, nullptr, 0) : 0L; }();
 	if ((mask2 >> S::SID) & 1) {
 		constexpr int NT2 = PXS_CH_NT2, MAXE2 = (S::PTS + NT2 - 1)/NT2;
 		static const bool once2 = [] { (void)hipFuncSetAttribute((const void*)chain_kernel<S, NT2, MAXE2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }();
@@ -757,7 +757,7 @@ bool FftChain::plan_rings(long nphi) {
 	for (long a = 320; a >= 16; a -= 16) if (nphi % a == 0 && nphi/a <= 160 && nphi/a >= 2 && sub_ok(a) && sub_ok(nphi/a)) { rs_.a = a; rs_.b = nphi/a; break; }
 	for (long b = 256; b >= 16; b -= 16) if (nphi % b == 0 && nphi/b >= 2 && nphi/b <= 320 && sub_ok(b) && sub_ok(nphi/b)) { ra_.b = b; ra_.a = nphi/b; break; }
 	{	// experiments: force the first factor of the analysis / synthesis split
-		const char* ea = getenv("PXS_RING_A_ANA"); const char* es = getenv("PXS_RING_A_SYN");
+		const char* ea = lab_getenv("PXS_RING_A_ANA"); const char* es = lab_getenv("PXS_RING_A_SYN");
 		if (ea && atol(ea) > 1 && nphi % atol(ea) == 0 && sub_ok(atol(ea)) && sub_ok(nphi/atol(ea))) { ra_.a = atol(ea); ra_.b = nphi/ra_.a; }
 		if (es && atol(es) > 1 && nphi % atol(es) == 0 && sub_ok(atol(es)) && sub_ok(nphi/atol(es))) { rs_.a = atol(es); rs_.b = nphi/rs_.a; }
 	}
@@ -790,8 +790,8 @@ static double tile_fill(long n) {
 static double modulus_pref(long g) { return 1.0 + 0.02*std::max(0.0, std::log2((double)g/160.0)) + 0.04*std::max(0.0, std::log2(64.0/(double)g)); }
 ThetaPlan FftChain::plan_theta(long N, int lmax) {
 	ThetaPlan best; double bestc = 1e300;
-	static const long gforce = [] { const char* e = getenv("PXS_THETA_G"); return e ? atol(e) : 0L; }();     // experiments: force the shared modulus
-	static const bool ducc_size = [] { const char* e = getenv("PXS_THETA_DUCC_NCC"); return e ? atoi(e) != 0 : true; }();     // 0: the planner's own N_cc only (rounds 1-3)
+	static const long gforce = [] { const char* e = lab_getenv("PXS_THETA_G"); return e ? atol(e) : 0L; }();     // experiments: force the shared modulus
+	static const bool ducc_size = [] { const char* e = lab_getenv("PXS_THETA_DUCC_NCC"); return e ? atoi(e) != 0 : true; }();     // 0: the planner's own N_cc only (rounds 1-3)
 	const long Nd = ducc_ncc(lmax);
 	auto consider = [&](long g, long ac) {
 		ThetaPlan t; t.N = N; t.g = g; t.bN = N/g; t.ac = ac; t.Ncc = g*ac;
@@ -799,7 +799,7 @@ ThetaPlan FftChain::plan_theta(long N, int lmax) {
 		if ((t.Ncc & 1) || !sub_ok(t.g2) || !sub_ok7(t.ac)) return;
 		// synthesis split: gs divides both Ncc and N; RS1 and RS3 run gs-point lines, RS2 lines of max(bs, aNs) points
 		long gs_best = 0; double gsc = 1e300;
-		static const long gsforce = [] { const char* e = getenv("PXS_THETA_GS"); return e ? atol(e) : 0L; }();     // experiments: force the modulus of the synthesis chain
+		static const long gsforce = [] { const char* e = lab_getenv("PXS_THETA_GS"); return e ? atol(e) : 0L; }();     // experiments: force the modulus of the synthesis chain
 		for (long gs = 2; gs <= 1024; gs++) if (t.Ncc % gs == 0 && N % gs == 0 && sub_ok7(gs) && sub_ok7(t.Ncc/gs) && sub_ok7(N/gs) && (!gsforce || gs == gsforce)) {
 			const double c = ((2.0*t.Ncc + 1.5*N)/tile_fill(gs) + (double)(t.Ncc + N)/tile_fill(std::max(t.Ncc/gs, N/gs)))*modulus_pref(gs);
 			if (c < gsc) { gsc = c; gs_best = gs; }

@@ -38,11 +38,15 @@ static int env_k(const char* name, int def, int lo, int hi) {
 	const char* v = getenv(name); if (!v) return def;
 	int k = atoi(v); return (k >= lo && k <= hi) ? k : def;
 }
-static int k_syn0() { static int k = env_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
-static int k_ana0() { static int k0 = env_k("PXS_K_ANA0", 8, 4, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : 4); return k; }
-static int k_syns() { static int k = env_k("PXS_K_SYNS", 3, 2, 4); return k; }
-static int k_anas() { static int k = env_k("PXS_K_ANAS", 4, 2, 6); return k; }   // 4: 149 VGPRs = 3 waves per SIMD (6: 227 = 2 waves; measured 146.9 vs 150.5 ms at config 3)
-static int xcd_map() { static int k = env_k("PXS_XCD_MAP", 1, 0, 1); return k; }
+static int lab_k(const char* name, int def, int lo, int hi) {
+	const char* v = lab_getenv(name); if (!v) return def;
+	int k = atoi(v); return (k >= lo && k <= hi) ? k : def;
+}
+static int k_syn0() { static int k = lab_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
+static int k_ana0() { static int k0 = lab_k("PXS_K_ANA0", 8, 4, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : 4); return k; }
+static int k_syns() { static int k = lab_k("PXS_K_SYNS", 3, 2, 4); return k; }
+static int k_anas() { static int k = lab_k("PXS_K_ANAS", 4, 2, 6); return k; }   // 4: 149 VGPRs = 3 waves per SIMD (6: 227 = 2 waves; measured 146.9 vs 150.5 ms at config 3)
+static int xcd_map() { static int k = lab_k("PXS_XCD_MAP", 1, 0, 1); return k; }
 
 struct double4_t { double a, b, c, d; };
 // Wave-uniform table rows are fetched through the constant address space: that makes them scalar loads (s_load_dwordx8)
@@ -1833,7 +1837,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 			else         hipLaunchKernelGGL(leg_syn_s0_mm<1>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
 			if (prof) prof->end(st, 0);
 		};
-		static const int ngmax = env_k("PXS_SYN_MM_NG", 2, 1, 2);      // groups of 4 maps per wave (tuning)
+		static const int ngmax = lab_k("PXS_SYN_MM_NG", 2, 1, 2);      // groups of 4 maps per wave (tuning)
 		const int mper = 4*ngmax, gmax = std::max(1, leg_max_batch(rs, tb, 1)), r = nmm % mper, n8 = nmm - r;
 		for (int m0 = 0; m0 < n8; m0 += mper*gmax) launch_mm(m0, std::min(mper*gmax, n8 - m0), ngmax);
 		if (r > 4) launch_mm(n8, r, 2); else if (r > 0) launch_mm(n8, r, 1);
@@ -1866,7 +1870,7 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
-	static const int W = [] { const int v = env_k("PXS_ANA_MM_W", MM_WAVES, 2, 16); return v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : 2)); }();      // waves per workgroup (tuning: 2 | 4 | 8 | 16)
+	static const int W = [] { const int v = lab_k("PXS_ANA_MM_W", MM_WAVES, 2, 16); return v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : 2)); }();      // waves per workgroup: 8 (lab builds: 2 | 4 | 8 | 16)
 	const int nm = tb.mmax+1;
 	const long n4 = leg_mom_stride(tb);
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
@@ -1885,14 +1889,17 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 		a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 		if (prof) prof->begin(st, 1);
 		const dim3 grid = leg_grid(a);
+#ifdef PXS_LAB      /* (lab builds: other workgroup sizes, PXS_ANA_MM_W; measured at C4: 2 waves 95 ms, 4: 78, 8: 77, 16: 82 per 64 maps) */
 		if (W == 16)     mm_launch<16>(ng, grid, st, a);
-		else if (W == 8) mm_launch<8>(ng, grid, st, a);
 		else if (W == 4) mm_launch<4>(ng, grid, st, a);
-		else             mm_launch<2>(ng, grid, st, a);
+		else if (W == 2) mm_launch<2>(ng, grid, st, a);
+		else
+#endif
+		mm_launch<8>(ng, grid, st, a);
 		if (prof) prof->end(st, 1);
 	};
 	const int gmax = std::max(1, leg_max_batch(rs, tb, W));      // groups one launch can take (grid limit)
-	static const int ngmax = env_k("PXS_ANA_MM_NG", 2, 1, 2);      // groups of 4 maps per workgroup (tuning)
+	static const int ngmax = lab_k("PXS_ANA_MM_NG", 2, 1, 2);      // groups of 4 maps per workgroup (tuning)
 	const int mper = 4*ngmax, r = nmm % mper, n8 = nmm - r;
 	for (int b0 = 0; b0 < n8; b0 += mper*gmax) launch(b0, std::min(mper*gmax, n8 - b0), ngmax);
 	if (r > 4) launch(n8, r, 2); else if (r > 0) launch(n8, r, 1);

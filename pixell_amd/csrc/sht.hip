@@ -390,7 +390,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 	p->d_mstart = upload(ms);
 	p->fc = &fft_context(device);
 	{ const char* e = getenv("PXS_FFT_TEMP_MB"); if (e) p->fc->temp_budget = (size_t)atol(e) << 20; }
-	{ const char* e = getenv("PXS_RING_PAIRS"); if (e) p->ring_pairs = atoi(e) != 0; }
+	{ const char* e = lab_getenv("PXS_RING_PAIRS"); if (e) p->ring_pairs = atoi(e) != 0; }
 	{	// scratch for the per-wave partial moments of the analysis: 16 GiB where the device has room (MI355X: 288 GB),
 		// never more than 1/8 of what is free now.  Measured at config 3: 4 GiB 448.8, 8 GiB 442.7, 16 GiB 438.0, 24 GiB 437.7 ms.
 		size_t fr = 0, tot = 0;
@@ -407,7 +407,7 @@ void plan_common(pxs_plan* p, int lmax, int mmax, const uint64_t* mstart, int64_
 	std::vector<double2> ph(mmax+1);
 	for (int m = 0; m <= mmax; m++) { LDb a = (LDb)m*(LDb)p->phi0; ph[m] = make_double2((double)cosl(a), (double)(-sinl(a))); }
 	p->phase = upload(ph);
-	{	static const bool use = [] { const char* e = getenv("PXS_CHAIN"); return e ? atoi(e) != 0 : true; }();
+	{	static const bool use = [] { const char* e = lab_getenv("PXS_CHAIN"); return e ? atoi(e) != 0 : true; }();
 		p->chain.reset(new FftChain(p->fc));
 		p->chain_rings = use && p->ring_pairs && 2L*mmax < p->nphi && p->chain->plan_rings(p->nphi);
 		if (getenv("PXS_CHAIN_VERBOSE")) fprintf(stderr, "[pxsht] ring chain nphi=%d mmax=%d: %s\n", p->nphi, mmax, p->chain_rings ? p->chain->describe().c_str() : "off");
@@ -423,12 +423,12 @@ void setup_resampling(pxs_plan* p) {
 	if (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
 	while (p->Ncc & 1) p->Ncc = FftContext::good_size(p->Ncc + 1);
 	{	// ducc0's own N_cc = 2 good_size_complex(lmax + 1) where the FFT engine takes it and twice it (the fused chains decide for themselves below)
-		static const bool ducc_size = [] { const char* e = getenv("PXS_THETA_DUCC_NCC"); return e ? atoi(e) != 0 : true; }();
+		static const bool ducc_size = [] { const char* e = lab_getenv("PXS_THETA_DUCC_NCC"); return e ? atoi(e) != 0 : true; }();
 		const long nd = FftChain::ducc_ncc(lmax);
 		if (ducc_size && nd >= 4 && FftContext::supported(nd) && FftContext::supported(2*nd)) p->Ncc = nd;
 	}
 	p->M = FftContext::good_size(p->N + 2L*lmax + 2);
-	{ const char* e = getenv("PXS_M_FINE"); if (e && atol(e) >= p->M && FftContext::supported(atol(e))) p->M = atol(e); }   // experiments: a larger fine grid with friendlier factors
+	{ const char* e = lab_getenv("PXS_M_FINE"); if (e && atol(e) >= p->M && FftContext::supported(atol(e))) p->M = atol(e); }   // experiments: a larger fine grid with friendlier factors
 	if (p->chain_rings) {	// the fused theta chains need N, M and Ncc to share a modulus: let their planner pick M and Ncc
 		p->tp = FftChain::plan_theta(p->N, lmax);
 		if (p->tp.ok) { p->Ncc = p->tp.Ncc; p->M = p->tp.M; }
@@ -452,7 +452,7 @@ void setup_resampling(pxs_plan* p) {
 	// synthesis: Legendre on the minimal CC grid + exact Fourier upsampling in theta pays once the map has clearly more rings
 	// (measured: at nring / ncc = 1.33 -- C2, C4 -- the detour pays for spin 2 and costs 11 ms per 64 scalar maps at C4)
 	// (a band: what counts is the ring-pair slots of its own rings, unpaired rings take a whole slot)
-	{ const char* e = getenv("PXS_SYN_VIA_CC"); const long rings = p->band ? 2L*p->rs_map.npairs : p->nring;
+	{ const char* e = lab_getenv("PXS_SYN_VIA_CC"); const long rings = p->band ? 2L*p->rs_map.npairs : p->nring;
 	  p->syn_via_cc = e ? atoi(e) != 0 : (rings > p->ncc + p->ncc/4);
 	  p->syn_via_cc0 = e ? atoi(e) != 0 : (rings > p->ncc + p->ncc/2); }
 	// sigma_i = sum_{|q|<=Ks} s_q e^{i q theta_i} on the M grid, via one device FFT
@@ -521,7 +521,7 @@ void setup_general(pxs_plan* p, int nring, const uint64_t* nphi, const double* p
 	p->g_blk_ring = upload(blk_ring); p->g_blk_k0 = upload(blk_k0); p->g_nphi = upload(np); p->g_zoff = upload(zoff);
 	p->g_rstart = upload(rstart); p->g_phi0 = upload(ph);
 	if (p->groups.size() >= 8) {
-		static const int ns = [] { const char* e = getenv("PXS_GEN_STREAMS"); return e ? std::max(0, atoi(e)) : 16; }();
+		static const int ns = [] { const char* e = lab_getenv("PXS_GEN_STREAMS"); return e ? std::max(0, atoi(e)) : 16; }();
 		p->gstreams.resize(ns); p->gjoin.resize(ns);
 		for (int i = 0; i < ns; i++) { PXS_HIP(hipStreamCreateWithFlags(&p->gstreams[i], hipStreamNonBlocking)); PXS_HIP(hipEventCreateWithFlags(&p->gjoin[i], hipEventDisableTiming)); }
 		PXS_HIP(hipEventCreateWithFlags(&p->gfork, hipEventDisableTiming));
@@ -917,7 +917,7 @@ int pxs_plan_rings(pxs_plan** plan, int nring, const double* theta, const uint64
 	// Rows of a Fejer-1 grid (a declination band of a CAR map, curvedsky.py:843-873): theta_r = (row0 + r + 1/2) pi / n.  Synthesis
 	// and its adjoint can then run their Legendre stage on the ~lmax+2 CC rings of that grid instead of the band's own ring-pair
 	// slots (an unpaired ring costs a whole slot); PXS_BAND_VIA_CC=0 turns it off.
-	{	static const bool on = [] { const char* e = getenv("PXS_BAND_VIA_CC"); return e ? atoi(e) != 0 : true; }();
+	{	static const bool on = [] { const char* e = lab_getenv("PXS_BAND_VIA_CC"); return e ? atoi(e) != 0 : true; }();
 		if (on && !p->general && p->chain_rings && nring >= 2) {
 			const LDb d = th[1] - th[0];
 			const long n = d > 0 ? (long)llroundl(PIl/d) : 0;
@@ -1147,7 +1147,7 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 				leg2map(p, st, nullptr, nr, map, map_dtype, map_cstride, nct, true, map_bstride, ncb);
 			} else {
 				PXS_REQUIRE(nb == 1, "internal: batched call on an unfused path");
-				static const bool fuse = [] { const char* e = getenv("PXS_FUSE_SPLIT"); return e ? atoi(e) != 0 : true; }();
+				static const bool fuse = [] { const char* e = lab_getenv("PXS_FUSE_SPLIT"); return e ? atoi(e) != 0 : true; }();
 				const bool via_h = fuse && !p->chain_rings;     // (the unfused transposing split writes dense h rows)
 				if (via_h) p->hbuf.ensure(sizeof(double2)*(size_t)ncm*nr*nm);
 				resample_from_cc(p, st, p->leg2.as<double2>(), p->leg.as<double2>(), ncm, spin, via_h ? p->hbuf.as<double2>() : nullptr);
@@ -1162,7 +1162,7 @@ static void synthesis_core(pxs_plan* p, int spin, int mode, int adjoint, int nb,
 		// the transpose of the synthesis through the CC grid, where that is the cheaper synthesis: grids (self-mirrored rings of
 		// CC / MW / MWflip count double in the reflection that stands for the zero extension, unit_weights_ext) and bands of F1 grids
 		// (rows outside the band are zero)
-		static const bool adj_cc = [] { const char* e = getenv("PXS_ADJ_VIA_CC"); return e ? atoi(e) != 0 : true; }();
+		static const bool adj_cc = [] { const char* e = lab_getenv("PXS_ADJ_VIA_CC"); return e ? atoi(e) != 0 : true; }();
 		const bool via = adj_cc && (p->is_grid || p->band) && th && (p->is_grid || p->geometry == "F1") && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
 		if (via && p->band) {
 			const long ldf = FftChain::pad8(p->nfull);

@@ -1,4 +1,5 @@
 # sweeps of the planner's choices with tools/chain_lab.py: shared modulus of the theta chains (PXS_THETA_G), first factor of the ring FFT splits
+# (the switches this script sets are read by LAB builds only: tools/build_variants.sh lab "-DPXS_LAB" <all stems>, then PIXELL_AMD_LIB=variants/libpxsht_lab.so)
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${1:-sweep}; mkdir -p $O; CFG=${2:-c3}
 for g in ${GS:-0 96 120 144 160 180 192 240 288 320 480}; do
   echo "== $CFG PXS_THETA_G=$g" | tee -a $O/sweep.txt
