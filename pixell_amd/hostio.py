@@ -109,6 +109,8 @@ def download(src, arr, after=None):
 			pb, po, pm = pend; S.free[pb].synchronize(); _par_copy(dstb[po:po+pm], S.pinned_np[pb][:pm])
 	return arr
 
+PREFETCH_DEPTH = 2      # inputs uploaded ahead of their transform
+
 def _key(arr):
 	return (arr.__array_interface__["data"][0], arr.shape, arr.strides, arr.dtype.str)
 
@@ -117,6 +119,9 @@ class Pipeline:
 	order; take(arr) -> (device tensor, event) or None; writeback(tensor, arr, event): download in the background; close(): wait."""
 	def __init__(self):
 		self.up = {}; self.jobs = queue.Queue(); self.err = None; self.device = _torch().cuda.current_device()
+		# at most PREFETCH_DEPTH uploaded inputs wait on the device for their transform (a call with many spin groups would otherwise hold all
+		# its inputs AND outputs at once); an upload that does not fit is left to the caller's synchronous path
+		self.slots = threading.Semaphore(PREFETCH_DEPTH)
 		self.thread = threading.Thread(target=self._run, daemon=True); self.thread.start()
 	def _run(self):
 		_torch().cuda.set_device(self.device)      # (the current device is per thread)
@@ -125,7 +130,11 @@ class Pipeline:
 			if job is None: return
 			kind, a, b, c, done = job
 			try:
-				if kind == "up": done.result = upload(a)
+				if kind == "up":
+					self.slots.acquire()
+					try: done.result = upload(a)
+					except _torch().cuda.OutOfMemoryError:      # no room to run ahead: take() returns None and the caller uploads when it gets there
+						done.result = None; self.slots.release(); _torch().cuda.empty_cache()
 				else: download(a, b, after=c)
 			except BaseException as e:      # noqa: surfaced by close() / take()
 				self.err = e
@@ -140,6 +149,7 @@ class Pipeline:
 		if done is None: return None
 		done.wait()
 		if self.err is not None: raise self.err
+		if done.result is not None: self.slots.release()
 		return done.result
 	def writeback(self, tensor, arr, event):
 		done = threading.Event(); self.jobs.put(("down", tensor, arr, event, done)); return done

@@ -83,6 +83,7 @@ class _Buf:
 				self.slab = hostio.eligible(arr)
 				if got is not None:                      # uploaded in the background since the call began
 					self.tmp, ev = got; torch.cuda.current_stream().wait_event(ev)
+					self.tmp.record_stream(torch.cuda.current_stream())      # (allocated by the background thread: tell the allocator which stream consumes it)
 				elif self.slab and writeback and overwrite:
 					self.tmp = torch.empty(arr.shape, dtype=getattr(torch, arr.dtype.name), device="cuda")
 				elif self.slab:
