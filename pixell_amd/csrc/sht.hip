@@ -1229,7 +1229,15 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 static int batch_chunk(const pxs_plan* p, int nbatch, int ncm) {
 	if (nbatch <= 1 || !p->chain_rings) return 1;           // the unfused paths take one map at a time
 	const size_t per_map = sizeof(double2)*(size_t)ncm*((size_t)(p->mmax+1)*(p->nring + (p->ncc > 0 ? p->ncc : 0))*2 + (size_t)p->nring*p->nphi);
-	static const size_t budget = [] { const char* e = getenv("PXS_BATCH_GB"); return (size_t)(e ? atol(e) : 32) << 30; }();
+	// scratch budget of one pass: PXS_BATCH_GB, default 64 GB (MI355X: 288 GB; 8 maps of config 5 = 56 GB, so that the batched Legendre kernels get
+	// their 8-map groups there; it was 32 in rounds 2-4), never more than 40 % of what is free on the device now beyond what the plan holds already
+	static const size_t budget_env = [] { const char* e = getenv("PXS_BATCH_GB"); return (size_t)(e ? atol(e) : 0) << 30; }();
+	size_t budget = budget_env ? budget_env : (size_t)64 << 30;
+	if (!budget_env) {
+		size_t fr = 0, tot = 0;
+		const size_t held = p->leg.bytes + p->leg2.bytes + p->hbuf.bytes + (p->chain ? p->chain->scratch_bytes() : 0);
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) budget = std::min(budget, std::max<size_t>((size_t)4 << 30, held + (size_t)(0.4*(double)fr)));
+	}
 	const int cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)nbatch, budget/std::max<size_t>(per_map, 1)));
 	if (ncm == 1 && cap >= 8 && nbatch > cap) {      // scalar maps: the batched Legendre analysis works on groups of 8 maps (leg_ana_s0_mm)
 		const int cap8 = cap & ~7, npass = (nbatch + cap8 - 1)/cap8;

@@ -276,7 +276,7 @@ def test_config4_shape_gpu():
 @pytest.mark.gpu
 def test_config4_full_batch_gpu():
 	"""BASELINE config 4 at its FULL batch on one GPU: 64 independent scalar maps 5400x10800, lmax 4000, one call per direction (the
-	library splits it into passes of PXS_BATCH_GB of scratch: 15 + 15 + 15 + 15 + 4 maps).  Maps from the first, a middle and the last
+	library splits it into passes of PXS_BATCH_GB of scratch, multiples of 8 maps: 24 + 24 + 16).  Maps from the first, a middle and the last
 	pass equal their single-map transforms; round trip over all 64."""
 	from pixell_amd import curvedsky, enmap
 	torch = _torch(); dev = torch.device("cuda")
