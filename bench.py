@@ -628,7 +628,8 @@ def main():
 		res = run_c5(args, torch, dist, rank, world, local, device, backend) if args.config == "c5" else run_sht(args, ctx)
 		# the other BASELINE configurations, after the headline loop: only beside the default headline (c3), so that `--config X` stays a
 		# short single-configuration run for profiling
-		if args.config == "c3" and res["config"]["lmax"] == CONFIGS["c3"]["lmax"] and not args.no_legs and not os.environ.get("PXS_BENCH_NO_LEGS"):
+		# (PXS_BENCH_REHEARSE_LEGS=1: the legs behind another headline configuration -- two-rank rehearsals of the N > 1 path on a one-GPU box)
+		if ((args.config == "c3" and res["config"]["lmax"] == CONFIGS["c3"]["lmax"]) or os.environ.get("PXS_BENCH_REHEARSE_LEGS") == "1") and not args.no_legs and not os.environ.get("PXS_BENCH_NO_LEGS"):
 			res["configs"] = secondary_legs(args, ctx)
 			res["configs_note"] = "secondary configurations run after the timed loop of the headline configuration, each on freshly built plans; never part of `value`"
 		res["bench_wall_s"] = round(time.time()-t_all, 1)

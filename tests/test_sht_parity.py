@@ -664,6 +664,37 @@ def check_mm_analysis(nbs=(4, 9, 12, 13), lmax=40, grid=None):
 				one = np.zeros_like(alm[i]); sht.analysis_2d(alm=one, map=maps[i], **kw)
 				assert relrms(back[i], one) < 1e-13 and np.abs(back[i]-one).max() < 1e-11*np.sqrt(np.mean(np.abs(one)**2))
 
+def check_mm_layouts(nb=5, nt=26, nph=48, lmax=20, mmax=13):
+	"""the batched FP64-MFMA kernels behind the other alm layouts of the boundary: mmax < lmax, single precision (complex64 alm, float32 maps),
+	an alm array with room to spare between the m blocks (mstart with gaps)"""
+	ms = so._tri_mstart(lmax, mmax)+3*np.arange(mmax+1, dtype=np.uint64)      # three unused slots after every m
+	nel = int(ms[-1])+lmax+1+3
+	rng = np.random.default_rng(21)
+	alm = np.zeros((nb, 1, nel), complex)
+	for b in range(nb):
+		for m in range(mmax+1):
+			v = rng.standard_normal(lmax+1-m)+1j*rng.standard_normal(lmax+1-m)
+			if m == 0: v = v.real+0j
+			alm[b, 0, int(ms[m])+m:int(ms[m])+lmax+1] = v
+	kw = dict(spin=0, lmax=lmax, mmax=mmax, mstart=ms, geometry="F1", phi0=0.1)
+	maps = np.zeros((nb, 1, nt, nph)); sht.synthesis_2d(alm=alm, map=maps, **kw)
+	for i in (0, nb-1):
+		one = np.zeros((1, nt, nph)); sht.synthesis_2d(alm=alm[i], map=one, **kw)
+		assert np.abs(one-maps[i]).max() < 1e-13*np.abs(one).max()
+		ref = np.zeros((1, nt, nph)); so.synthesis_2d(alm=alm[i], map=ref, **kw)
+		assert rel(maps[i], ref) < TOL
+	back = np.zeros_like(alm); sht.analysis_2d(alm=back, map=maps, **kw)
+	assert relrms(back, alm) < TOL
+	a32 = alm.astype(np.complex64); m32 = np.zeros((nb, 1, nt, nph), np.float32); sht.synthesis_2d(alm=a32, map=m32, **kw)
+	assert np.abs(m32-maps).max() < 2e-6*np.abs(maps).max()
+	b32 = np.zeros_like(a32); sht.analysis_2d(alm=b32, map=m32, **kw)
+	assert relrms(b32, alm) < 5e-6
+
+@pytest.mark.hostsim
+def test_mm_layouts_hostsim(): check_mm_layouts()
+@pytest.mark.gpu
+def test_mm_layouts_gpu(): check_mm_layouts(); check_mm_layouts(nb=9, nt=700, nph=1400, lmax=600, mmax=411)
+
 @pytest.mark.hostsim
 def test_mm_analysis_hostsim(): check_mm_analysis()
 @pytest.mark.gpu
