@@ -33,6 +33,7 @@ CONFIGS = {
 	"c3":  dict(ncomp=3, shape=(21600, 43200), lmax=10000, spin=[0, 2], name="C3 3x(21600x43200) T/Q/U lmax=10000 spin0/2"),
 	"c4":  dict(ncomp=1, shape=(5400, 10800),  lmax=4000,  spin=[0],    name="C4 64x[1x(5400x10800)] independent maps, lmax=4000 spin0", nbatch_total=64),
 	"c5":  dict(ncomp=1, shape=(10800, 21600), lmax=6000,  spin=[0],    name="C5 100x[rand_alm -> alm2map -> enmap.fft -> ps2d -> lbin | map2alm -> alm2cl], 1x(10800x21600), lmax=6000", nreal_total=100),
+	"tqu": dict(ncomp=3, shape=(5400, 10800),  lmax=4000,  spin=[0, 2], name="16x[3x(5400x10800)] T/Q/U maps in one call, lmax=4000 spin0/2 (batched polarisation sims; not a BASELINE configuration)", nbatch_total=16),
 	"ref": dict(ncomp=1, shape=(900, 1800),    lmax=750,   spin=[0],    name="reference benchmark shape 1x(900x1800) lmax=750"),
 }
 FRAC_DEFINITION = "frac: SURVEY 8(d) F_alg = (4 n0 + 12 n2) R nalm flop per direction over the kernel family's time / 78.6 TFLOP/s; frac_hw: the FP64 flops the kernels executed (recurrence + accumulation FMAs / MFMAs of the steps the waves ran, counted in the kernels) over the same time"
@@ -340,7 +341,7 @@ def run_sht(args, ctx):
 	ntot = int(os.environ.get("PXS_BENCH_NBATCH", cfg.get("nbatch_total", 0))) if batched else 0     # (smaller batches for rehearsals)
 	# memory check: fall back to the largest configuration that fits
 	free, total = torch.cuda.mem_get_info()
-	need = {"c3": 130e9, "c4": 1.5e9*max(1, ntot//world)+12e9, "c2": 12e9, "c1": 1e9, "ref": 1e9, "c5": 40e9}[args.config]
+	need = {"c3": 130e9, "c4": 1.5e9*max(1, ntot//world)+12e9, "tqu": 4.5e9*max(1, ntot//world)+40e9, "c2": 12e9, "c1": 1e9, "ref": 1e9, "c5": 40e9}[args.config]
 	if free < need:
 		log("config %s needs ~%.0f GB, only %.0f GB free: falling back to c2" % (args.config, need/1e9, free/1e9))
 		cfg = CONFIGS["c2"]; args.config = "c2"; batched = False
@@ -355,6 +356,9 @@ def run_sht(args, ctx):
 	ncomp_all = ncomp*nmaps
 	alm_in = torch.cat([make_alm(cfg, 1000+lo+i, device) for i in range(nmaps)], 0) if batched else make_alm(cfg, 1000+rank, device)
 	dmap = enmap.dmap(torch.zeros((ncomp_all, ny, nx), dtype=torch.float64, device=device), wcs)
+	if batched and ncomp > 1:      # a stack of T/Q/U maps: [map][component][...], one call per spin group over all maps
+		if world > 1: raise SystemExit("bench.py: --config %s is a single-GPU configuration" % args.config)
+		alm_in = alm_in.view(nmaps, ncomp, -1); dmap = enmap.dmap(dmap.tensor.view(nmaps, ncomp, ny, nx), wcs)
 	alm_out = torch.zeros_like(alm_in)
 	torch.cuda.synchronize()
 	# ---- the cold call, piece by piece (a script that transforms once on a geometry pays all of it; the timed steps below pay none):
@@ -450,7 +454,7 @@ def run_sht(args, ctx):
 	achieved = flops_dir/(dom_ms_per_step*1e-3)/1e12 if dom_ms_per_step > 0 else 0.0
 	exe = (fl_ana if dom == "leg_ana" else fl_syn)/max(args.steps, 1)        # flops the kernels of that family executed per step (counted in the kernels)
 	# batched scalar maps: the analysis of 4 or more maps per call is the FP64-MFMA kernel (leg_ana_s0_mm); everything else is plain v_fma_f64
-	mm = batched and nmaps >= 4 and dom == "leg_ana"
+	mm = batched and nmaps >= 4      # (analysis and synthesis, scalar maps and Q/U pairs alike)
 	roof = dict(bound="mfma" if mm else "fp64_valu",
 		pipe=("FP64 MFMA (v_mfma_f64_16x16x4_f64): the maps of a batch share one recurrence per ring pair, rings are the K dimension, 16 columns = 4 maps x 4 real right-hand sides; its dense peak equals the vector peak on MI355X"
 			if mm else "FP64 vector FMA (v_fma_f64): the contraction is 4 right-hand sides wide per map, too narrow for the 16x16x4 f64 MFMA, whose dense peak equals the vector peak; no MFMA instruction is issued"),
@@ -575,7 +579,7 @@ def main():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+	ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))      # (tqu: 16 T/Q/U maps in one call -- the batched spin-2 Legendre kernels; not a BASELINE configuration)
 	ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / fft / h2d legs")
 	ap.add_argument("--no-legs", action="store_true", help="skip the secondary configurations (`configs` block) after the headline loop")
 	ap.add_argument("--no-gather", action="store_true", help="skip the alm all-gather (N>1)")

@@ -1430,6 +1430,291 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 	if (kk > 0) leg_flush(red, pout + 4*jbase, lane, kk, a.atomic);
 }
 
+
+// ---- batched spin-s analysis as an FP64-MFMA GEMM (round 5) -----------------------------------------------------------------------
+// Stacks of T/Q/U maps (Monte-Carlo polarisation sims): the Q/U pairs of 4 or more maps in one call.  Per m
+//   mu+[l][map] = sum_ring G+_l(ring) T+_N + sgn_l G-_l(ring) T+_S,   mu-[l][map] = sum_ring G-_l(ring) T-_N + sgn_l G+_l(ring) T-_S,   sgn_l = (-1)^(l + m)
+// (leg_ana_spin), i.e. two GEMMs over the rings with the SAME G+ / G- for every map: A = 16 steps of G+ resp. G-, B = 16 columns = 4 maps x
+// (T+_N re, T+_N im, T-_S re, T-_S im) resp. (T+_S re, T+_S im, T-_N re, T-_N im); the sign, a function of the row only, is applied when the two
+// 16 x 16 accumulators of a tile are combined at the flush.  Structure as leg_ana_s0_mm (two P tiles per wave, W = 4 waves per workgroup over
+// 256 consecutive ring pairs, ring data through the LDS, one barrier per tile); both chains of a lane must be at scale 0 before it contributes.
+#define MMA_ESTRIDE 33
+__host__ __device__ constexpr int mm_spin_lds_doubles(int W) { return W*2*16*MM_PSTRIDE + 2*2*4*64 > 64*W*MMA_ESTRIDE ? W*2*16*MM_PSTRIDE + 2*2*4*64 : 64*W*MMA_ESTRIDE; }
+static inline size_t mm_spin_ana_lds(int W) { return sizeof(double)*(size_t)mm_spin_lds_doubles(W) + 16; }
+
+template<int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_mm(const LegK a)
+{
+	PXS_SHARED(double, sh);
+	constexpr int K = 1;
+	double* __restrict__ ptile = sh;                              // [W][2][16][MM_PSTRIDE]: G+ and G- of 16 steps
+	double* __restrict__ red = sh + W*2*16*MM_PSTRIDE;            // [2][2][4][64]: the two accumulators of a tile summed over the waves
+	int* __restrict__ s_kmin = reinterpret_cast<int*>(sh + mm_spin_lds_doubles(W));
+	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6);
+	int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
+	const int l0 = max(m, a.spin);
+	const int nl = a.lmax - l0 + 1;
+	if (nl <= 0) return;
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
+	const double4_t* __restrict__ coef = a.coef + row0;
+	const int pbase = wv*64*W;
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64*W, a.npairs) - 1]; return c*c > 0.5; }();
+	SpinState<K> S; int rn1[K], rs1[K];
+	// (spin_init addresses pair (wv K + s) 64 + lane: with K = 1 and the wave index wv W + w that is this lane's pair pbase + tid)
+	const bool alive = spin_init<K>(a, wv*W + w, lane, m, S, rn1, rs1, polar);
+	for (int i = tid; i < 2*2*4*64; i += 64*W) red[i] = 0.0;
+	if (tid == 0) *s_kmin = nl;
+	__syncthreads();
+	int j = 0;
+	const bool wave_alive = __any(alive);
+	if (wave_alive) { SPIN_PHASE_A }
+	const int kw = PXS_UNIFORM_INT(wave_alive ? j : nl + 16);
+	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	if (lane == 0) atomicMin(s_kmin, kw);
+	__syncthreads();
+	const int kmin = PXS_UNIFORM_INT(*s_kmin);
+	if (kmin >= nl) return;      // (workgroup-uniform) no ring of this chunk carries signal at this m
+	__syncthreads();             // (the reduction tiles were zeroed above; the staging area below lies over them)
+	// B operands through the LDS: thread = ring pair, entry = 4 maps x (T+_N re, im, T-_S re, im | T+_S re, im, T-_N re, im)
+	double bp[16], bm[16];
+	{
+		const int rn = rn1[0], rs = rs1[0];
+		double* __restrict__ ent = sh + tid*MMA_ESTRIDE;
+#pragma unroll
+		for (int mm = 0; mm < 4; mm++) {
+			const int map = bb*4 + mm;
+			const double2* __restrict__ inq = a.leg + (long)map*a.leg_bs + (long)m*a.ld;
+			const double2* __restrict__ inu = a.leg + (long)map*a.leg_bs + ((long)a.nm + m)*a.ld;
+			const bool okm = map < a.nmaps;
+			const double2 qn = (okm && rn >= 0) ? inq[rn] : make_double2(0, 0), un = (okm && rn >= 0) ? inu[rn] : make_double2(0, 0);
+			const double2 qs = (okm && rs >= 0) ? inq[rs] : make_double2(0, 0), us = (okm && rs >= 0) ? inu[rs] : make_double2(0, 0);
+			ent[8*mm + 0] = qn.x - un.y; ent[8*mm + 1] = qn.y + un.x;      // T+_N
+			ent[8*mm + 2] = qs.x + us.y; ent[8*mm + 3] = qs.y - us.x;      // T-_S
+			ent[8*mm + 4] = qs.x - us.y; ent[8*mm + 5] = qs.y + us.x;      // T+_S
+			ent[8*mm + 6] = qn.x + un.y; ent[8*mm + 7] = qn.y - un.x;      // T-_N
+		}
+		__syncthreads();
+		const double* __restrict__ rd = sh + (64*w + 16*(lane >> 4))*MMA_ESTRIDE + 8*((lane & 15) >> 2) + (lane & 3);
+#pragma unroll
+		for (int q = 0; q < 16; q++) { bp[q] = rd[q*MMA_ESTRIDE]; bm[q] = rd[q*MMA_ESTRIDE + 4]; }
+		__syncthreads();
+		for (int i = tid; i < 2*2*4*64; i += 64*W) red[i] = 0.0;
+		__syncthreads();
+	}
+	bool pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
+	double* __restrict__ pp = ptile + (w*2 + 0)*16*MM_PSTRIDE;
+	double* __restrict__ pm = ptile + (w*2 + 1)*16*MM_PSTRIDE;
+	const int rdo = (lane & 15)*MM_PSTRIDE + 16*(lane >> 4);
+	long ntile = 0;
+	int tlast = -1;
+	auto mm_flush = [&](int tf) {      // rows 4 r + lane / 16 of tile tf, column lane % 16 = 4 (map) + c: c < 2: mu+ = P + sgn M, else mu- = M + sgn P
+		double* __restrict__ redf = red + (tf & 1)*2*4*64;
+		for (int r = w; r < 4; r += W) {
+			double* rp = redf + r*64 + lane; double* rm = redf + (4 + r)*64 + lane;
+			const double vp = *rp, vm = *rm; *rp = 0.0; *rm = 0.0;
+			const int krow = 16*tf + 4*r + (lane >> 4), map = bb*4 + ((lane & 15) >> 2), c = lane & 3;
+			if (krow < nl && map < a.nmaps) {
+				const double sg = ((l0 + krow + m) & 1) ? -1.0 : 1.0;
+				const double v = c < 2 ? fma(sg, vm, vp) : fma(sg, vp, vm);
+				double* dst = a.mom + (long)map*a.mom_bs + 4*(row0 + krow) + c;
+#ifdef PXS_HOST_SIM
+				atomicAdd(dst, v);
+#else
+				unsafeAtomicAdd(dst, v);
+#endif
+			}
+		}
+	};
+	for (int t = kmin >> 4; 16*t < nl; t++) {
+		const int k0 = 16*t;
+		double* __restrict__ redt = red + (t & 1)*2*4*64;
+		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
+			ntile++;
+#pragma unroll
+			for (int q4 = 0; q4 < 4; q4++) {
+				const int kq = k0 + 4*q4;
+				double p0 = 0, p1 = 0, p2 = 0, p3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+				if (kq >= kw && kq < nl) {
+					const double4_t f0 = LDC(coef, kq), f1 = LDC(coef, kq+1), f2 = LDC(coef, kq+2), f3 = LDC(coef, kq+3);
+					double ax;
+					p0 = S.gp2[0]; m0 = S.gm2[0];
+					ax = f0.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f0.c : f0.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f0.d : -f0.b), S.gm2[0], -S.gm1[0]);
+					p1 = S.gp1[0]; m1 = S.gm1[0];
+					ax = f1.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f1.c : f1.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f1.d : -f1.b), S.gm1[0], -S.gm2[0]);
+					p2 = S.gp2[0]; m2 = S.gm2[0];
+					ax = f2.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f2.c : f2.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f2.d : -f2.b), S.gm2[0], -S.gm1[0]);
+					p3 = S.gp1[0]; m3 = S.gm1[0];
+					ax = f3.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f3.c : f3.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f3.d : -f3.b), S.gm1[0], -S.gm2[0]);
+					if (pend) {      // phase B: a lane contributes once BOTH chains are at scale 0; chains below it are rescaled every 4 steps
+						if (S.scp[0] < 0 || S.scm[0] < 0) { p0 = p1 = p2 = p3 = 0.0; m0 = m1 = m2 = m3 = 0.0; }
+						if (S.scp[0] < 0 && fabs(S.gp2[0]) > SC_BIG) { S.gp1[0] *= SC_SMALL; S.gp2[0] *= SC_SMALL; S.scp[0]++; }
+						if (S.scm[0] < 0 && fabs(S.gm2[0]) > SC_BIG) { S.gm1[0] *= SC_SMALL; S.gm2[0] *= SC_SMALL; S.scm[0]++; }
+						pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
+					}
+					if (kq + 1 >= nl) { p1 = 0.0; m1 = 0.0; }
+					if (kq + 2 >= nl) { p2 = 0.0; m2 = 0.0; }
+					if (kq + 3 >= nl) { p3 = 0.0; m3 = 0.0; }
+				}
+				pp[(4*q4 + 0)*MM_PSTRIDE + lane] = p0; pp[(4*q4 + 1)*MM_PSTRIDE + lane] = p1; pp[(4*q4 + 2)*MM_PSTRIDE + lane] = p2; pp[(4*q4 + 3)*MM_PSTRIDE + lane] = p3;
+				pm[(4*q4 + 0)*MM_PSTRIDE + lane] = m0; pm[(4*q4 + 1)*MM_PSTRIDE + lane] = m1; pm[(4*q4 + 2)*MM_PSTRIDE + lane] = m2; pm[(4*q4 + 3)*MM_PSTRIDE + lane] = m3;
+			}
+			MM_WAVE_SYNC();
+			mm_acc accp, accm;
+			accp[0] = accp[1] = accp[2] = accp[3] = 0; accm[0] = accm[1] = accm[2] = accm[3] = 0;
+#pragma unroll
+			for (int q = 0; q < 16; q++) {
+				accp = mm_mfma(pp[rdo + q], bp[q], accp);
+				accm = mm_mfma(pm[rdo + q], bm[q], accm);
+			}
+			if (tlast >= 0) { mm_flush(tlast); tlast = -1; }
+#pragma unroll
+			for (int r = 0; r < 4; r++) { mm_lds_add(redt + r*64 + lane, accp[r]); mm_lds_add(redt + (4 + r)*64 + lane, accm[r]); }
+		}
+		if (tlast >= 0) mm_flush(tlast);
+		tlast = t;
+		__syncthreads();
+	}
+	if (tlast >= 0) mm_flush(tlast);
+	PXS_COUNT(1, ntile*(2*256L + 64L) + (wave_alive ? (long)kw*4 : 0L));
+}
+
+
+// ---- batched spin-s synthesis as an FP64-MFMA GEMM (round 5) ----------------------------------------------------------------------
+// The transpose of leg_ana_spin_mm (cf. leg_syn_spin): north  P = sum_l G+ a+, M = sum_l G- a-;  south  P' = sum_l sgn_l G- a+, M' = sum_l sgn_l G+ a-.
+// Two GEMMs over the steps with A = G+ resp. G- (two [16][68] P tiles per wave) and B = the pre-scaled alm rows of the tile with the sign folded
+// into the columns that take it: B1 = (a+, sgn a-) for G+ gives (P, M'), B2 = (sgn a+, a-) for G- gives (P', M).  Accumulators: 64 ring pairs x
+// 16 columns x 2 per group of 4 maps, in registers for the whole l loop; one wave per workgroup (two waves per SIMD by the LDS: NG = 2 groups per wave).
+static inline size_t mm_spin_syn_lds() { return sizeof(double)*2*16*MMS_PSTRIDE; }
+template<int NG> __global__ __launch_bounds__(64, 2) void leg_syn_spin_mm(const LegK a)
+{
+	PXS_SHARED(double, ptile);      // [2][16][MMS_PSTRIDE]
+	constexpr int K = 1;
+	const int lane = threadIdx.x;
+	int wv, m, bb;
+	if (!leg_block(a, wv, m, bb)) return;
+	const int l0 = max(m, a.spin);
+	const int nl = a.lmax - l0 + 1;
+	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
+	const double4_t* __restrict__ coef = a.coef + row0;
+	const int pbase = wv*64;
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64, a.npairs) - 1]; return c*c > 0.5; }();
+	SpinState<K> S; int rn1[K], rs1[K];
+	const bool alive = spin_init<K>(a, wv, lane, m, S, rn1, rs1, polar);
+	mm_acc accp[NG][4], accm[NG][4];
+#pragma unroll
+	for (int g = 0; g < NG; g++)
+#pragma unroll
+		for (int rb = 0; rb < 4; rb++) { accp[g][rb][0] = accp[g][rb][1] = accp[g][rb][2] = accp[g][rb][3] = 0; accm[g][rb][0] = accm[g][rb][1] = accm[g][rb][2] = accm[g][rb][3] = 0; }
+	long ntile = 0;
+	int j = 0;
+	const bool wave_alive = nl > 0 && __any(alive);
+	if (wave_alive) { SPIN_PHASE_A }
+	const int kw = PXS_UNIFORM_INT(wave_alive ? j : max(nl, 0) + 16);
+	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	{
+		double* __restrict__ pp = ptile; double* __restrict__ pm = ptile + 16*MMS_PSTRIDE;
+		// B operands of MFMA step-quad q: lane (jc, kk) holds column jc & 3 of map 4 (bb NG + g) + (jc >> 2) at step q + 4 kk of the tile
+		const int jcol = lane & 15, kk4 = lane >> 4, cc = jcol & 3;
+		const double* bsrc[NG]; bool bok[NG];
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const int map = (bb*NG + g)*4 + (jcol >> 2);
+			bok[g] = map < a.nmaps;
+			bsrc[g] = a.almt + (long)(bok[g] ? map : 0)*a.almt_bs + 4*row0 + cc + 16*kk4;
+		}
+		// b1 = (a+, sgn a-), b2 = (sgn a+, a-), sgn = (-1)^(l + m) of the row
+		auto load_b = [&](int k0, double (*b1)[4], double (*b2)[4]) {
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int row = k0 + q + 4*kk4;
+					const double v = (bok[g] && row < nl) ? bsrc[g][4L*(k0 + q)] : 0.0;
+					const double sv = ((l0 + row + m) & 1) ? -v : v;
+					b1[g][q] = cc < 2 ? v : sv; b2[g][q] = cc < 2 ? sv : v;
+				}
+		};
+		bool pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
+		const int rdo = 4*(lane >> 4)*MMS_PSTRIDE + (lane & 15);
+		double b1c[NG][4], b2c[NG][4], b1n[NG][4], b2n[NG][4];
+		load_b(16*(kw >> 4), b1c, b2c);
+		for (int t = kw >> 4; 16*t < nl; t++) {
+			const int k0 = 16*t;
+			ntile++;
+#pragma unroll
+			for (int q4 = 0; q4 < 4; q4++) {
+				const int kq = k0 + 4*q4;
+				double p0 = 0, p1 = 0, p2 = 0, p3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+				if (kq >= kw && kq < nl) {
+					const double4_t f0 = LDC(coef, kq), f1 = LDC(coef, kq+1), f2 = LDC(coef, kq+2), f3 = LDC(coef, kq+3);
+					double ax;
+					p0 = S.gp2[0]; m0 = S.gm2[0];
+					ax = f0.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f0.c : f0.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f0.d : -f0.b), S.gm2[0], -S.gm1[0]);
+					p1 = S.gp1[0]; m1 = S.gm1[0];
+					ax = f1.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f1.c : f1.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f1.d : -f1.b), S.gm1[0], -S.gm2[0]);
+					p2 = S.gp2[0]; m2 = S.gm2[0];
+					ax = f2.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f2.c : f2.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f2.d : -f2.b), S.gm2[0], -S.gm1[0]);
+					p3 = S.gp1[0]; m3 = S.gm1[0];
+					ax = f3.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f3.c : f3.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f3.d : -f3.b), S.gm1[0], -S.gm2[0]);
+					if (pend) {
+						if (S.scp[0] < 0 || S.scm[0] < 0) { p0 = p1 = p2 = p3 = 0.0; m0 = m1 = m2 = m3 = 0.0; }
+						if (S.scp[0] < 0 && fabs(S.gp2[0]) > SC_BIG) { S.gp1[0] *= SC_SMALL; S.gp2[0] *= SC_SMALL; S.scp[0]++; }
+						if (S.scm[0] < 0 && fabs(S.gm2[0]) > SC_BIG) { S.gm1[0] *= SC_SMALL; S.gm2[0] *= SC_SMALL; S.scm[0]++; }
+						pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
+					}
+					if (kq + 1 >= nl) { p1 = 0.0; m1 = 0.0; }
+					if (kq + 2 >= nl) { p2 = 0.0; m2 = 0.0; }
+					if (kq + 3 >= nl) { p3 = 0.0; m3 = 0.0; }
+				}
+				pp[(4*q4 + 0)*MMS_PSTRIDE + lane] = p0; pp[(4*q4 + 1)*MMS_PSTRIDE + lane] = p1; pp[(4*q4 + 2)*MMS_PSTRIDE + lane] = p2; pp[(4*q4 + 3)*MMS_PSTRIDE + lane] = p3;
+				pm[(4*q4 + 0)*MMS_PSTRIDE + lane] = m0; pm[(4*q4 + 1)*MMS_PSTRIDE + lane] = m1; pm[(4*q4 + 2)*MMS_PSTRIDE + lane] = m2; pm[(4*q4 + 3)*MMS_PSTRIDE + lane] = m3;
+			}
+			MM_WAVE_SYNC();
+			if (k0 + 16 < nl) load_b(k0 + 16, b1n, b2n);      // the alm rows of the next tile, on their way during the MFMAs
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+#pragma unroll
+				for (int rb = 0; rb < 4; rb++) {
+					const double ap = pp[rdo + q*MMS_PSTRIDE + 16*rb], am = pm[rdo + q*MMS_PSTRIDE + 16*rb];
+#pragma unroll
+					for (int g = 0; g < NG; g++) { accp[g][rb] = mm_mfma(ap, b1c[g][q], accp[g][rb]); accm[g][rb] = mm_mfma(am, b2c[g][q], accm[g][rb]); }
+				}
+			MM_WAVE_SYNC();      // the A operands are out of the tiles before the next ones are written
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int q = 0; q < 4; q++) { b1c[g][q] = b1n[g][q]; b2c[g][q] = b2n[g][q]; }
+		}
+	}
+	// register r of acc[g][rb] at lane (i4 = lane / 16, jc = lane % 16): ring pair 16 rb + 4 r + i4, column 4 (map in the group) + c.
+	// accp: c = 0, 1: P re / im (north); 2, 3: M' re / im (south).  accm: c = 0, 1: P' re / im (south); 2, 3: M re / im (north).
+	// Q = (P + M) / 2, U = -i (P - M) / 2: lanes c < 2 write the north ring, lanes c >= 2 the south ring; even c the real part of Q and the imaginary
+	// part of U, odd c the other two.
+	const int c = lane & 3;
+#pragma unroll
+	for (int g = 0; g < NG; g++) {
+		const int map = (bb*NG + g)*4 + ((lane & 15) >> 2);
+		double* __restrict__ outq = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + (long)m*a.ld);
+		double* __restrict__ outu = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + ((long)a.nm + m)*a.ld);
+#pragma unroll
+		for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int p = pbase + 16*rb + 4*r + (lane >> 4);
+				const bool valid = p < a.npairs && map < a.nmaps;
+				const double own = accp[g][rb][r], oth = MMS_XOR2(accm[g][rb][r]);
+				const double P = c < 2 ? own : oth, M = c < 2 ? oth : own;
+				const double sum = 0.5*(P + M), dif = 0.5*(P - M);
+				const int ring = valid ? (c < 2 ? a.ring_n[p] : a.ring_s[p]) : -1;
+				if (ring >= 0) {
+					if (c & 1) { outq[2*ring + 1] = sum; outu[2*ring] = dif; }
+					else       { outq[2*ring] = sum; outu[2*ring + 1] = -dif; }
+				}
+			}
+	}
+	PXS_COUNT(0, ntile*(NG*512L + 64L) + (wave_alive ? (long)kw*4 : 0L));
+}
+
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
@@ -1843,6 +2128,21 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		if (r > 4) launch_mm(n8, r, 2); else if (r > 0) launch_mm(n8, r, 1);
 		b0 = nmm;
 	}
+	// spin s, 8 or more maps (Q/U pairs of a stack of maps): leg_syn_spin_mm, 8 maps per wave; what is left over (or a batch below 8: measured at
+	// 4 maps 31.6 against 29.5 ms, at 8 maps 48.1 against 58.7, 16 maps 95.7 against 116.4 per T/Q/U batch of 5400x10800 maps) takes the VALU kernel
+	if (tb.spin > 0 && nb >= std::max(8, syn_mm_min())) {
+		const int r = nb % 8, nmm = r > 4 ? nb : nb - r;
+		const int gmax = std::max(1, leg_max_batch(rs, tb, 1));
+		for (int m0 = 0; m0 < nmm; m0 += 8*gmax) {
+			const int nmaps = std::min(8*gmax, nmm - m0), ngroups = (nmaps + 7)/8;
+			LegK a = make_legk(rs, tb, wk, leg + (size_t)m0*leg_bstride, ld, 1, ngroups, leg_bstride);
+			a.almt += (size_t)m0*a.almt_bs; a.nmaps = nmaps;
+			if (prof) prof->begin(st, 0);
+			hipLaunchKernelGGL(leg_syn_spin_mm<2>, leg_grid(a), dim3(64), mm_spin_syn_lds(), st, a);
+			if (prof) prof->end(st, 0);
+		}
+		b0 = nmm;
+	}
 	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
 	if (nb - b0 > 1 && seeds_pending(wk, rs, tb, 0, K)) { launch(b0, 1); b0 += 1; }
 	for (const int nmax = leg_max_batch(rs, tb, K); b0 < nb; b0 += nmax) launch(b0, std::min(nmax, nb - b0));
@@ -1910,12 +2210,42 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 		leg_analysis(st, rs, tb, wk, leg + (size_t)nmm*leg_bstride, (char*)alm + aesz*(size_t)nmm*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, 0, prof, ld, 1, 0, 0);
 }
 
+// spin-s analysis of nb >= PXS_ANA_MM_MIN (4) maps: leg_ana_spin_mm, 4 maps (Q/U pairs) per workgroup; 1 - 3 left-over maps through the VALU kernel
+static void leg_analysis_spin_mm(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
+                  const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
+                  LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
+{
+	constexpr int W = 4;
+	const int nm = tb.mmax+1;
+	const long n4 = leg_mom_stride(tb);
+	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
+	const int nmm = nb - (nb % 4 == 1 ? 1 : 0);      // (a lone left-over map costs more in a 4-map workgroup than in the VALU kernel)
+	wk.mom.ensure(sizeof(double)*(size_t)n4*nmm);
+	PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nmm, st));
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_spin_mm<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
+	const int gmax = std::max(1, leg_max_batch(rs, tb, W));
+	for (int b0 = 0; b0 < nmm; b0 += 4*gmax) {
+		const int nmaps = std::min(4*gmax, nmm - b0), ngroups = (nmaps + 3)/4;
+		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg) + (size_t)b0*leg_bstride, ld, W, ngroups, leg_bstride);
+		a.mom = wk.mom.as<double>() + (size_t)b0*a.mom_bs; a.part = a.mom; a.atomic = 1; a.nmaps = nmaps;
+		if (prof) prof->begin(st, 1);
+		hipLaunchKernelGGL((leg_ana_spin_mm<W>), leg_grid(a), dim3(64*W), mm_spin_ana_lds(W), st, a);
+		if (prof) prof->end(st, 1);
+	}
+	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, 0, alm_bstride);
+	hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm, nmm), dim3(256), 0, st, ak);
+	PXS_HIP(hipGetLastError());
+	if (nmm < nb)
+		leg_analysis(st, rs, tb, wk, leg + (size_t)nmm*leg_bstride, (char*)alm + aesz*(size_t)nmm*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, 0, prof, ld, 1, 0, 0);
+}
+
 void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   int deriv1, LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
 	PXS_REQUIRE(alm_dtype == PX_C64 || alm_dtype == PX_C128, "alm must be complex64 or complex128");
 	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
+	if (tb.spin > 0 && !deriv1 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_spin_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	if (tb.spin == 0 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	const int K = tb.spin == 0 ? k_ana0() : k_anas();
 	const int nm = tb.mmax+1;

@@ -451,7 +451,7 @@ def check_batched(nb=3, geometry="F1", nt=24, nph=48, lmax=20):
 		alm = np.stack([so.rand_alm_simple(lmax, nc, 20+i, spin=(spin,)) for i in range(nb)])
 		kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.2)
 		out = np.zeros((nb, nc, nt, nph)); sht.synthesis_2d(alm=alm, map=out, **kw)
-		mm = spin == 0 and nb >= 4      # the FP64-MFMA Legendre kernels of batched scalar maps sum in another order than the single-map kernels: rounding, not bits
+		mm = nb >= 4      # the FP64-MFMA Legendre kernels of 4 or more maps per call sum in another order than the single-map kernels: rounding, not bits
 		for i in range(nb):
 			one = np.zeros((nc, nt, nph)); sht.synthesis_2d(alm=alm[i], map=one, **kw)
 			if mm: assert np.abs(one-out[i]).max() < 1e-13*np.abs(one).max()
@@ -464,7 +464,7 @@ def check_batched(nb=3, geometry="F1", nt=24, nph=48, lmax=20):
 		one = np.zeros_like(alm[0]); sht.adjoint_synthesis_2d(alm=one, map=out[1], **kw)
 		# spin 0, 4 or more maps: the Legendre analysis of the batch is the FP64-MFMA kernel (leg_ana_s0_mm), whose sum over the rings
 		# runs in another order than the single-map kernel's -- equal to rounding, not bit for bit
-		if spin == 0 and nb >= 4: assert relrms(adj[1], one) < 1e-13 and np.abs(adj[1]-one).max() < 1e-12*np.abs(one).max()
+		if mm: assert relrms(adj[1], one) < 1e-13 and np.abs(adj[1]-one).max() < 1e-12*np.abs(one).max()
 		else: assert np.array_equal(one, adj[1])
 		aa = np.zeros((nb, nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm, map=aa, **kw)
 		one = np.zeros((nc, nt, nph)); sht.adjoint_analysis_2d(alm=alm[nb-1], map=one, **kw)
@@ -626,43 +626,48 @@ def test_batched_shared_recurrence_hostsim():
 	with three columns groups masked), the synthesis map by map"""
 	check_batched(nb=5, nt=20, nph=40, lmax=16)
 
-def check_mm_analysis(nbs=(4, 9, 12, 13), lmax=40, grid=None):
-	"""Batched spin-0 Legendre analysis and synthesis as FP64-MFMA GEMMs (leg_ana_s0_mm: rings = K dimension, one recurrence per ring pair shared
-	by the maps, 8 maps per workgroup, a remainder of <= 4 in 4-map workgroups, a lone left-over map through the VALU kernel).  The
-	batch equals its single-map calls (the VALU kernel, pinned to the oracle elsewhere) to rounding -- NOT bit for bit: the sum over
-	the rings runs in another order -- and the oracle.  Rings from 1e-5 rad of the poles to the equator: lanes of one wave reach
-	scale 0 at very different l (masked P rows in phase B).  grid=(geometry, nt, nph): analysis_2d of a full grid (several ring chunks)."""
+def check_mm_analysis(nbs=(4, 9, 12, 13), lmax=40, grid=None, spins=(0, 2)):
+	"""Batched Legendre analysis and synthesis as FP64-MFMA GEMMs (leg_ana_s0_mm / leg_syn_s0_mm: one recurrence per ring pair shared by the maps, 8
+	scalar maps per workgroup, a remainder of <= 4 in 4-map workgroups, a lone left-over map through the VALU kernel; leg_ana_spin_mm / leg_syn_spin_mm:
+	the Q/U pairs of 4 maps per workgroup, two recurrences).  The batch equals its single-map calls (the VALU kernels, pinned to the oracle
+	elsewhere) to rounding -- NOT bit for bit: the sums run in another order -- and the oracle.  Rings from 1e-5 rad of the poles to the equator:
+	lanes of one wave reach scale 0 at very different l (masked P rows in phase B).  grid=(geometry, nt, nph): analysis_2d of a full grid
+	(several ring chunks)."""
 	rng = np.random.default_rng(11)
-	if grid is None:
-		th = np.array([1e-5, 3e-4, 0.004, 0.02, 0.3, 1.1, np.pi/2, np.pi-3e-4, np.pi-0.3, np.pi-1.1, 2.5]); nr = len(th); nph = 8
-		kw = dict(theta=th, nphi=np.full(nr, nph, np.uint64), phi0=np.full(nr, 0.1), ringstart=np.arange(nr, dtype=np.uint64)*nph,
-			lmax=lmax, mstart=so._tri_mstart(lmax, lmax), spin=0)
-		for nb in nbs:
-			pix = rng.standard_normal((nb, 1, nr*nph))
-			out = sht.adjoint_synthesis(map=pix, alm=np.zeros((nb, 1, so.nalm(lmax)), complex), **kw)
-			for i in sorted(set([0, 3, nb-1, nb//2])):
-				one = sht.adjoint_synthesis(map=pix[i], **kw)
-				assert relrms(out[i], one) < 1e-13 and np.abs(out[i]-one).max() < 1e-12*np.abs(one).max()
-			ref = so.adjoint_synthesis(map=pix[nb-1], **kw); ref[:, :lmax+1] = ref[:, :lmax+1].real
-			assert relrms(out[nb-1], ref) < TOL
-			# the synthesis of the batch (leg_syn_s0_mm: accumulators for 64 ring pairs x 8 maps in registers, steps = K dimension)
-			alm = np.stack([so.rand_alm_simple(lmax, 1, 50+i, spin=(0,)) for i in range(nb)])
-			maps = sht.synthesis(alm=alm, map=np.zeros((nb, 1, nr*nph)), **kw)
-			for i in sorted(set([0, 3, nb-1, nb//2])):
-				one = sht.synthesis(alm=alm[i], **kw)
-				assert np.abs(maps[i]-one).max() < 1e-12*np.abs(one).max()
-			assert rel(maps[nb-1], so.synthesis(alm=alm[nb-1], **kw)) < TOL
-	else:
-		geometry, nt, nph = grid
-		ms = so._tri_mstart(lmax, lmax); kw = dict(spin=0, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.3)
-		for nb in nbs:
-			alm = np.stack([so.rand_alm_simple(lmax, 1, 70+i, spin=(0,)) for i in range(nb)])
-			maps = np.zeros((nb, 1, nt, nph)); sht.synthesis_2d(alm=alm, map=maps, **kw)
-			maps += 0.1*rng.standard_normal(maps.shape)            # not band-limited: every l of every m carries something
-			back = np.zeros_like(alm); sht.analysis_2d(alm=back, map=maps, **kw)
-			for i in sorted(set([0, nb-1, nb//2])):
-				one = np.zeros_like(alm[i]); sht.analysis_2d(alm=one, map=maps[i], **kw)
-				assert relrms(back[i], one) < 1e-13 and np.abs(back[i]-one).max() < 1e-11*np.sqrt(np.mean(np.abs(one)**2))
+	for spin in spins:
+		nc = 1 if spin == 0 else 2
+		if grid is None:
+			th = np.array([1e-5, 3e-4, 0.004, 0.02, 0.3, 1.1, np.pi/2, np.pi-3e-4, np.pi-0.3, np.pi-1.1, 2.5]); nr = len(th); nph = 8
+			kw = dict(theta=th, nphi=np.full(nr, nph, np.uint64), phi0=np.full(nr, 0.1), ringstart=np.arange(nr, dtype=np.uint64)*nph,
+				lmax=lmax, mstart=so._tri_mstart(lmax, lmax), spin=spin)
+			for nb in nbs:
+				pix = rng.standard_normal((nb, nc, nr*nph))
+				out = sht.adjoint_synthesis(map=pix, alm=np.zeros((nb, nc, so.nalm(lmax)), complex), **kw)
+				for i in sorted(set([0, 3, nb-1, nb//2])):
+					one = sht.adjoint_synthesis(map=pix[i], **kw)
+					assert relrms(out[i], one) < 1e-13 and np.abs(out[i]-one).max() < 1e-12*np.abs(one).max()
+				ref = so.adjoint_synthesis(map=pix[nb-1], **kw); ref[:, :lmax+1] = ref[:, :lmax+1].real
+				assert relrms(out[nb-1], ref) < TOL
+				# the synthesis of the batch (accumulators for 64 ring pairs x the maps of a group in registers, steps = K dimension)
+				alm = np.stack([so.rand_alm_simple(lmax, nc, 50+i, spin=(spin,)) for i in range(nb)])
+				maps = sht.synthesis(alm=alm, map=np.zeros((nb, nc, nr*nph)), **kw)
+				for i in sorted(set([0, 3, nb-1, nb//2])):
+					one = sht.synthesis(alm=alm[i], **kw)
+					assert np.abs(maps[i]-one).max() < 1e-12*np.abs(one).max()
+				assert rel(maps[nb-1], so.synthesis(alm=alm[nb-1], **kw)) < TOL
+		else:
+			geometry, nt, nph = grid
+			ms = so._tri_mstart(lmax, lmax); kw = dict(spin=spin, lmax=lmax, mstart=ms, geometry=geometry, phi0=0.3)
+			for nb in nbs:
+				alm = np.stack([so.rand_alm_simple(lmax, nc, 70+i, spin=(spin,)) for i in range(nb)])
+				maps = np.zeros((nb, nc, nt, nph)); sht.synthesis_2d(alm=alm, map=maps, **kw)
+				one = np.zeros((nc, nt, nph)); sht.synthesis_2d(alm=alm[nb-1], map=one, **kw)
+				assert np.abs(maps[nb-1]-one).max() < 1e-12*np.abs(one).max()
+				maps += 0.1*rng.standard_normal(maps.shape)            # not band-limited: every l of every m carries something
+				back = np.zeros_like(alm); sht.analysis_2d(alm=back, map=maps, **kw)
+				for i in sorted(set([0, nb-1, nb//2])):
+					one = np.zeros_like(alm[i]); sht.analysis_2d(alm=one, map=maps[i], **kw)
+					assert relrms(back[i], one) < 1e-13 and np.abs(back[i]-one).max() < 1e-11*np.sqrt(np.mean(np.abs(one)**2))
 
 def check_mm_layouts(nb=5, nt=26, nph=48, lmax=20, mmax=13):
 	"""the batched FP64-MFMA kernels behind the other alm layouts of the boundary: mmax < lmax, single precision (complex64 alm, float32 maps),
@@ -696,7 +701,7 @@ def test_mm_layouts_hostsim(): check_mm_layouts()
 def test_mm_layouts_gpu(): check_mm_layouts(); check_mm_layouts(nb=9, nt=700, nph=1400, lmax=600, mmax=411)
 
 @pytest.mark.hostsim
-def test_mm_analysis_hostsim(): check_mm_analysis()
+def test_mm_analysis_hostsim(): check_mm_analysis(nbs=(4, 9, 13))
 @pytest.mark.gpu
 def test_mm_analysis_gpu():
 	check_mm_analysis(lmax=700); check_mm_analysis(nbs=(5, 16), lmax=1500, grid=("CC", 1502, 3008)); check_mm_analysis(nbs=(8,), lmax=2100, grid=("F1", 2800, 5600))
