@@ -79,8 +79,10 @@ int pxs_analysis(pxs_plan* plan, int spin, int adjoint, int nbatch,
 
 /* Plan options.  "analysis": how pxs_analysis integrates over theta on grid2d plans (CC, F1, MW, MWflip; DH and F2 always take ring
  * weights) -- all forms give the same alm for band-limited maps and differ at the 1e-3 level on maps that are not --
- *   2 (default) "ducc0": the route of ducc0's analysis_2d as published (ducc0 >= 0.36, src/ducc0/sht/sht.cc: analysis_2d ->
- *     resample_to_prepared_CC; the reference calls it at curvedsky.py:1032-1046).  The theta-interpolant of the rings -- low-passed to
+ *   2 (default) "ducc0": the route of ducc0's analysis_2d (ducc0 >= 0.36, src/ducc0/sht/sht.cc: analysis_2d -> resample_to_prepared_CC; the
+ *     reference calls it at curvedsky.py:1032-1046) as restated WITHOUT access to the package or its source in the build environment: all
+ *     forms agree on band-limited maps (pinned by tests); agreement with ducc0's numerics on maps that are not band-limited -- e.g. its
+ *     treatment of the Nyquist bin when the spectrum is resized -- is UNPINNED until checked against an installed ducc0.  The theta-interpolant of the rings -- low-passed to
  *     |k| < N_cc where the grid's circle has at least 2 N_cc samples -- is evaluated on the Clenshaw-Curtis grid of N_cc + 1 rings,
  *     multiplied by that grid's quadrature weights and carried to the N_cc/2 + 1 rings of the Legendre stage by the transposed
  *     band-limited upsampling; N_cc = 2 good_size_complex(lmax + 1) (ducc0's) whenever the grid's circle shares a usable factor with
