@@ -1433,89 +1433,132 @@ template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
 
 // ---- batched spin-s analysis as an FP64-MFMA GEMM (round 5) -----------------------------------------------------------------------
 // Stacks of T/Q/U maps (Monte-Carlo polarisation sims): the Q/U pairs of 4 or more maps in one call.  Per m
-//   mu+[l][map] = sum_ring G+_l(ring) T+_N + sgn_l G-_l(ring) T+_S,   mu-[l][map] = sum_ring G-_l(ring) T-_N + sgn_l G+_l(ring) T-_S,   sgn_l = (-1)^(l + m)
-// (leg_ana_spin), i.e. two GEMMs over the rings with the SAME G+ / G- for every map: A = 16 steps of G+ resp. G-, B = 16 columns = 4 maps x
-// (T+_N re, T+_N im, T-_S re, T-_S im) resp. (T+_S re, T+_S im, T-_N re, T-_N im); the sign, a function of the row only, is applied when the two
-// 16 x 16 accumulators of a tile are combined at the flush.  Structure as leg_ana_s0_mm (two P tiles per wave, W = 4 waves per workgroup over
-// 256 consecutive ring pairs, ring data through the LDS, one barrier per tile); both chains of a lane must be at scale 0 before it contributes.
-#define MMA_ESTRIDE 33
-__host__ __device__ constexpr int mm_spin_lds_doubles(int W) { return W*2*16*MM_PSTRIDE + 2*2*4*64 > 64*W*MMA_ESTRIDE ? W*2*16*MM_PSTRIDE + 2*2*4*64 : 64*W*MMA_ESTRIDE; }
-static inline size_t mm_spin_ana_lds(int W) { return sizeof(double)*(size_t)mm_spin_lds_doubles(W) + 16; }
+//   mu+[l][map] = sum_ring G+_l T+_N + sgn_l G-_l T+_S,   mu-[l][map] = sum_ring G-_l T-_N + sgn_l G+_l T-_S,   sgn_l = (-1)^(l + m)
+// (leg_ana_spin) with the SAME G+ / G- for every map.  One chain per HALF-WAVE: lanes 0-31 of a wave run G+ of 32 ring pairs, lanes 32-63 G- of the
+// same pairs, and the G- lanes park sgn_l G-.  With B = (T+_N re, im, T-_S re, im) on the G+ slots and (T+_S re, im, T-_N re, im) on the G- slots ONE
+// GEMM over the 64 slots gives (mu+, sgn_l mu-): the sign of the last two columns is a function of the row and is applied at the flush.  That makes the
+// kernel the shape of leg_ana_s0_mm -- one P tile per wave, 8 waves over 256 ring pairs, 8 maps per workgroup, four waves per SIMD.  (First form: both
+// chains in every lane, two P tiles per wave, two accumulators: the LDS held two waves per SIMD and the f64 MFMA, which needs several issuing waves for
+// its rate, ran the Q/U analysis of 16 maps in 111 ms against the VALU kernel's 123.)
+// one chain of leg_ana_spin's pair of recurrences: G_{l+1} = (a x + c) G_l - G_{l-1}, c = +-b (polar waves: a +- b with x = -2 sin^2(theta / 2))
+struct SpinChain { double x, g1, g2, sgl, pa; int sc; };
+__device__ __forceinline__ bool spin_chain_init(const LegK& a, int p, int m, int half, bool polar, SpinChain& C) {
+	const int s_ = a.spin;
+	const bool valid = p < a.npairs;
+	const double cth = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0, shh = valid ? a.sh2[p] : 0.0;
+	C.x = polar ? -2.0*shh*shh : cth; C.sgl = half ? -1.0 : 1.0; C.pa = polar ? 1.0 : 0.0;
+	const double t1 = a.lmax*sth + a.ofs, b = -2.0*s_*fabs(cth), c = (double)s_*s_ - t1*t1, discr = b*b - 4*c;      // (libsharp's m-limit generalised to spin, as spin_init)
+	const double mlim = discr <= 0 ? a.lmax : fmin((double)a.lmax, 0.5*(-b + sqrt(discr)));
+	const bool alive = valid && ((double)m <= mlim + 0.5);
+	C.g1 = 0; C.g2 = 0; C.sc = 0;
+	if (alive) {
+		const double sh = shh, ch = a.ch2[p];
+		double m1, m2; int e1, e2;
+		// exponents of sin(theta/2), cos(theta/2) of the start value: G+ (m + s, m - s) / G- (m - s, m + s) for m >= s, (s + m, s - m) / (s - m, s + m) below
+		const int es = m >= s_ ? (half ? m - s_ : m + s_) : (half ? s_ - m : s_ + m), ec = m >= s_ ? (half ? m + s_ : m - s_) : (half ? s_ + m : s_ - m);
+		pow_scaled(sh, es, m1, e1); pow_scaled(ch, ec, m2, e2);
+		double mt = m1*m2; int e = e1 + e2 + (m >= s_ ? m : 0); frexp_norm(mt, e); to_scaled(mt, e, C.g2, C.sc);
+		if (m < s_ && half && ((s_ - m) & 1)) C.g2 = -C.g2;
+	}
+	return alive;
+}
+// coefficient of a step from the row (a, b): a x + (polar ? a : 0) +- b
+__device__ __forceinline__ double spin_chain_coef(const SpinChain& C, double ca, double cb) { return fma(ca, C.x, fma(C.sgl, cb, C.pa*ca)); }
 
-template<int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_mm(const LegK a)
+template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_mm(const LegK a)
 {
 	PXS_SHARED(double, sh);
-	constexpr int K = 1;
-	double* __restrict__ ptile = sh;                              // [W][2][16][MM_PSTRIDE]: G+ and G- of 16 steps
-	double* __restrict__ red = sh + W*2*16*MM_PSTRIDE;            // [2][2][4][64]: the two accumulators of a tile summed over the waves
-	int* __restrict__ s_kmin = reinterpret_cast<int*>(sh + mm_spin_lds_doubles(W));
-	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6);
+	double* __restrict__ ptile = sh;                              // [W][16][MM_PSTRIDE]
+	double* __restrict__ red = sh + W*16*MM_PSTRIDE;              // [2][4 NG][64]
+	int* __restrict__ s_kmin = reinterpret_cast<int*>(sh + mm_lds_doubles(NG, W));
+	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6), half = lane >> 5;
 	int wv, m, bb;
 	if (!leg_block(a, wv, m, bb)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	if (nl <= 0) return;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const double4_t* __restrict__ coef = a.coef + row0;
-	const int pbase = wv*64*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64*W, a.npairs) - 1]; return c*c > 0.5; }();
-	SpinState<K> S; int rn1[K], rs1[K];
-	// (spin_init addresses pair (wv K + s) 64 + lane: with K = 1 and the wave index wv W + w that is this lane's pair pbase + tid)
-	const bool alive = spin_init<K>(a, wv*W + w, lane, m, S, rn1, rs1, polar);
-	for (int i = tid; i < 2*2*4*64; i += 64*W) red[i] = 0.0;
+	const int pbase = wv*32*W;
+	const bool polar = [&] { const double c = a.cth[min(pbase + 32*W, a.npairs) - 1]; return c*c > 0.5; }();
+	const int pmine_ = pbase + 32*w + (lane & 31);       // ring pair of this lane's chain
+	SpinChain C;
+	const bool alive = spin_chain_init(a, pmine_, m, half, polar, C);
+	const double* __restrict__ tab = reinterpret_cast<const double*>(a.coef2) + 2*row0;      // (a, b) of step k at tab[2 k]
 	if (tid == 0) *s_kmin = nl;
 	__syncthreads();
-	int j = 0;
+	// phase A, per wave: recurrence only until the first lane of the wave is at scale 0
+	int k = 0;
 	const bool wave_alive = __any(alive);
-	if (wave_alive) { SPIN_PHASE_A }
-	const int kw = PXS_UNIFORM_INT(wave_alive ? j : nl + 16);
-	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	if (wave_alive) {
+		while (k + 4 <= nl) {
+			if (__any(C.sc == 0 && C.g2 != 0.0)) break;
+			double cq[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) cq[i] = LDCD(tab, 2L*k + i);
+			C.g1 = fma(spin_chain_coef(C, cq[0], cq[1]), C.g2, -C.g1);
+			C.g2 = fma(spin_chain_coef(C, cq[2], cq[3]), C.g1, -C.g2);
+			C.g1 = fma(spin_chain_coef(C, cq[4], cq[5]), C.g2, -C.g1);
+			C.g2 = fma(spin_chain_coef(C, cq[6], cq[7]), C.g1, -C.g2);
+			if (C.sc < 0 && fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; }
+			k += 4;
+		}
+	}
+	const int kw = PXS_UNIFORM_INT(wave_alive ? k : nl + 16);
 	if (lane == 0) atomicMin(s_kmin, kw);
 	__syncthreads();
 	const int kmin = PXS_UNIFORM_INT(*s_kmin);
 	if (kmin >= nl) return;      // (workgroup-uniform) no ring of this chunk carries signal at this m
-	__syncthreads();             // (the reduction tiles were zeroed above; the staging area below lies over them)
-	// B operands through the LDS: thread = ring pair, entry = 4 maps x (T+_N re, im, T-_S re, im | T+_S re, im, T-_N re, im)
-	double bp[16], bm[16];
+	// B operands through the LDS: thread = slot (chain of a ring pair), 4 maps per round: G+ slots (T+_N re, im, T-_S re, im), G- slots (T+_S re, im, T-_N re, im)
+	double breg[NG][16];
 	{
-		const int rn = rn1[0], rs = rs1[0];
-		double* __restrict__ ent = sh + tid*MMA_ESTRIDE;
+		const bool ok = pmine_ < a.npairs;
+		const int rn = ok ? a.ring_n[pmine_] : -1, rs = ok ? a.ring_s[pmine_] : -1;
+		double* __restrict__ ent = sh + tid*MM_ESTRIDE;
+		const double* __restrict__ rd = sh + (64*w + 16*(lane >> 4))*MM_ESTRIDE + (lane & 15);
 #pragma unroll
-		for (int mm = 0; mm < 4; mm++) {
-			const int map = bb*4 + mm;
-			const double2* __restrict__ inq = a.leg + (long)map*a.leg_bs + (long)m*a.ld;
-			const double2* __restrict__ inu = a.leg + (long)map*a.leg_bs + ((long)a.nm + m)*a.ld;
-			const bool okm = map < a.nmaps;
-			const double2 qn = (okm && rn >= 0) ? inq[rn] : make_double2(0, 0), un = (okm && rn >= 0) ? inu[rn] : make_double2(0, 0);
-			const double2 qs = (okm && rs >= 0) ? inq[rs] : make_double2(0, 0), us = (okm && rs >= 0) ? inu[rs] : make_double2(0, 0);
-			ent[8*mm + 0] = qn.x - un.y; ent[8*mm + 1] = qn.y + un.x;      // T+_N
-			ent[8*mm + 2] = qs.x + us.y; ent[8*mm + 3] = qs.y - us.x;      // T-_S
-			ent[8*mm + 4] = qs.x - us.y; ent[8*mm + 5] = qs.y + us.x;      // T+_S
-			ent[8*mm + 6] = qn.x + un.y; ent[8*mm + 7] = qn.y - un.x;      // T-_N
+		for (int g = 0; g < NG; g++) {
+			double2 qn[4], un[4], qs[4], us[4];
+#pragma unroll
+			for (int mm = 0; mm < 4; mm++) {
+				const int map = (bb*NG + g)*4 + mm;
+				const double2* __restrict__ inq = a.leg + (long)map*a.leg_bs + (long)m*a.ld;
+				const double2* __restrict__ inu = a.leg + (long)map*a.leg_bs + ((long)a.nm + m)*a.ld;
+				const bool okm = map < a.nmaps;
+				qn[mm] = (okm && rn >= 0) ? inq[rn] : make_double2(0, 0); un[mm] = (okm && rn >= 0) ? inu[rn] : make_double2(0, 0);
+				qs[mm] = (okm && rs >= 0) ? inq[rs] : make_double2(0, 0); us[mm] = (okm && rs >= 0) ? inu[rs] : make_double2(0, 0);
+			}
+			if (g > 0) __syncthreads();      // the reads of the previous round
+#pragma unroll
+			for (int mm = 0; mm < 4; mm++) {
+				// T+ = Q + iU, T- = Q - iU
+				const double tpn_r = qn[mm].x - un[mm].y, tpn_i = qn[mm].y + un[mm].x, tmn_r = qn[mm].x + un[mm].y, tmn_i = qn[mm].y - un[mm].x;
+				const double tps_r = qs[mm].x - us[mm].y, tps_i = qs[mm].y + us[mm].x, tms_r = qs[mm].x + us[mm].y, tms_i = qs[mm].y - us[mm].x;
+				ent[4*mm + 0] = half ? tps_r : tpn_r; ent[4*mm + 1] = half ? tps_i : tpn_i;
+				ent[4*mm + 2] = half ? tmn_r : tms_r; ent[4*mm + 3] = half ? tmn_i : tms_i;
+			}
+			__syncthreads();
+#pragma unroll
+			for (int q = 0; q < 16; q++) breg[g][q] = rd[q*MM_ESTRIDE];
 		}
 		__syncthreads();
-		const double* __restrict__ rd = sh + (64*w + 16*(lane >> 4))*MMA_ESTRIDE + 8*((lane & 15) >> 2) + (lane & 3);
-#pragma unroll
-		for (int q = 0; q < 16; q++) { bp[q] = rd[q*MMA_ESTRIDE]; bm[q] = rd[q*MMA_ESTRIDE + 4]; }
-		__syncthreads();
-		for (int i = tid; i < 2*2*4*64; i += 64*W) red[i] = 0.0;
+		for (int i = tid; i < 2*NG*4*64; i += 64*W) red[i] = 0.0;
 		__syncthreads();
 	}
-	bool pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
-	double* __restrict__ pp = ptile + (w*2 + 0)*16*MM_PSTRIDE;
-	double* __restrict__ pm = ptile + (w*2 + 1)*16*MM_PSTRIDE;
-	const int rdo = (lane & 15)*MM_PSTRIDE + 16*(lane >> 4);
+	bool pend = __any(C.sc < 0);
+	double* __restrict__ pmine = ptile + w*16*MM_PSTRIDE;
+	const double* __restrict__ pread = pmine + (lane & 15)*MM_PSTRIDE + 16*(lane >> 4);
+	double cf[32];      // (a, b) of the 16 steps of a tile, requested a tile ahead
+	int cf_tile = -1;
 	long ntile = 0;
-	int tlast = -1;
-	auto mm_flush = [&](int tf) {      // rows 4 r + lane / 16 of tile tf, column lane % 16 = 4 (map) + c: c < 2: mu+ = P + sgn M, else mu- = M + sgn P
-		double* __restrict__ redf = red + (tf & 1)*2*4*64;
-		for (int r = w; r < 4; r += W) {
-			double* rp = redf + r*64 + lane; double* rm = redf + (4 + r)*64 + lane;
-			const double vp = *rp, vm = *rm; *rp = 0.0; *rm = 0.0;
-			const int krow = 16*tf + 4*r + (lane >> 4), map = bb*4 + ((lane & 15) >> 2), c = lane & 3;
+	auto mm_flush = [&](int tf) {      // rows 4 r + lane / 16 of tile tf, column lane % 16 = 4 (map in the group) + c; c >= 2 (mu-): x sgn of the row
+		double* __restrict__ redf = red + (tf & 1)*NG*4*64;
+		for (int cidx = w; cidx < 4*NG; cidx += W) {
+			const int g = cidx >> 2, r = cidx & 3;
+			double* rp = redf + cidx*64 + lane;
+			double v = *rp; *rp = 0.0;
+			const int krow = 16*tf + 4*r + (lane >> 4), map = (bb*NG + g)*4 + ((lane & 15) >> 2), c = lane & 3;
 			if (krow < nl && map < a.nmaps) {
-				const double sg = ((l0 + krow + m) & 1) ? -1.0 : 1.0;
-				const double v = c < 2 ? fma(sg, vm, vp) : fma(sg, vp, vm);
+				if (c >= 2 && ((l0 + krow + m) & 1)) v = -v;
 				double* dst = a.mom + (long)map*a.mom_bs + 4*(row0 + krow) + c;
 #ifdef PXS_HOST_SIM
 				atomicAdd(dst, v);
@@ -1525,59 +1568,71 @@ template<int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_mm(const
 			}
 		}
 	};
+	int tlast = -1;
 	for (int t = kmin >> 4; 16*t < nl; t++) {
 		const int k0 = 16*t;
-		double* __restrict__ redt = red + (t & 1)*2*4*64;
+		double* __restrict__ redt = red + (t & 1)*NG*4*64;
 		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
 			ntile++;
+			if (cf_tile != t) {
+#pragma unroll
+				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*k0 + i);
+			}
 #pragma unroll
 			for (int q4 = 0; q4 < 4; q4++) {
 				const int kq = k0 + 4*q4;
-				double p0 = 0, p1 = 0, p2 = 0, p3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
 				if (kq >= kw && kq < nl) {
-					const double4_t f0 = LDC(coef, kq), f1 = LDC(coef, kq+1), f2 = LDC(coef, kq+2), f3 = LDC(coef, kq+3);
-					double ax;
-					p0 = S.gp2[0]; m0 = S.gm2[0];
-					ax = f0.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f0.c : f0.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f0.d : -f0.b), S.gm2[0], -S.gm1[0]);
-					p1 = S.gp1[0]; m1 = S.gm1[0];
-					ax = f1.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f1.c : f1.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f1.d : -f1.b), S.gm1[0], -S.gm2[0]);
-					p2 = S.gp2[0]; m2 = S.gm2[0];
-					ax = f2.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f2.c : f2.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f2.d : -f2.b), S.gm2[0], -S.gm1[0]);
-					p3 = S.gp1[0]; m3 = S.gm1[0];
-					ax = f3.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f3.c : f3.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f3.d : -f3.b), S.gm1[0], -S.gm2[0]);
-					if (pend) {      // phase B: a lane contributes once BOTH chains are at scale 0; chains below it are rescaled every 4 steps
-						if (S.scp[0] < 0 || S.scm[0] < 0) { p0 = p1 = p2 = p3 = 0.0; m0 = m1 = m2 = m3 = 0.0; }
-						if (S.scp[0] < 0 && fabs(S.gp2[0]) > SC_BIG) { S.gp1[0] *= SC_SMALL; S.gp2[0] *= SC_SMALL; S.scp[0]++; }
-						if (S.scm[0] < 0 && fabs(S.gm2[0]) > SC_BIG) { S.gm1[0] *= SC_SMALL; S.gm2[0] *= SC_SMALL; S.scm[0]++; }
-						pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
+					p0 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 0], cf[8*q4 + 1]), C.g2, -C.g1);
+					p1 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 2], cf[8*q4 + 3]), C.g1, -C.g2);
+					p2 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 4], cf[8*q4 + 5]), C.g2, -C.g1);
+					p3 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 6], cf[8*q4 + 7]), C.g1, -C.g2);
+					if (pend) {      // phase B: a chain below scale 0 contributes nothing yet; rescale it every 4 steps
+						if (C.sc < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; } }
+						pend = __any(C.sc < 0);
 					}
-					if (kq + 1 >= nl) { p1 = 0.0; m1 = 0.0; }
-					if (kq + 2 >= nl) { p2 = 0.0; m2 = 0.0; }
-					if (kq + 3 >= nl) { p3 = 0.0; m3 = 0.0; }
+					// the G- lanes park sgn_l G-: the sign of the first row of the group, alternating
+					const double se = (half && ((l0 + kq + m) & 1)) ? -1.0 : 1.0, so = half ? -se : 1.0;
+					p0 *= se; p1 *= so; p2 *= se; p3 *= so;
+					if (kq + 1 >= nl) p1 = 0.0;
+					if (kq + 2 >= nl) p2 = 0.0;
+					if (kq + 3 >= nl) p3 = 0.0;
 				}
-				pp[(4*q4 + 0)*MM_PSTRIDE + lane] = p0; pp[(4*q4 + 1)*MM_PSTRIDE + lane] = p1; pp[(4*q4 + 2)*MM_PSTRIDE + lane] = p2; pp[(4*q4 + 3)*MM_PSTRIDE + lane] = p3;
-				pm[(4*q4 + 0)*MM_PSTRIDE + lane] = m0; pm[(4*q4 + 1)*MM_PSTRIDE + lane] = m1; pm[(4*q4 + 2)*MM_PSTRIDE + lane] = m2; pm[(4*q4 + 3)*MM_PSTRIDE + lane] = m3;
+				pmine[(4*q4 + 0)*MM_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MM_PSTRIDE + lane] = p1;
+				pmine[(4*q4 + 2)*MM_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MM_PSTRIDE + lane] = p3;
 			}
 			MM_WAVE_SYNC();
-			mm_acc accp, accm;
-			accp[0] = accp[1] = accp[2] = accp[3] = 0; accm[0] = accm[1] = accm[2] = accm[3] = 0;
+			double av[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) av[q] = pread[q];
+			MM_WAVE_SYNC();
+			if (k0 + 16 < nl) {
+#pragma unroll
+				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
+				cf_tile = t + 1;
+			}
+			mm_acc acc[NG];
+#pragma unroll
+			for (int g = 0; g < NG; g++) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
 #pragma unroll
 			for (int q = 0; q < 16; q++) {
-				accp = mm_mfma(pp[rdo + q], bp[q], accp);
-				accm = mm_mfma(pm[rdo + q], bm[q], accm);
+				const double aq = q < 4 ? av[q] : pread[q];
+#pragma unroll
+				for (int g = 0; g < NG; g++) acc[g] = mm_mfma(aq, breg[g][q], acc[g]);
 			}
 			if (tlast >= 0) { mm_flush(tlast); tlast = -1; }
 #pragma unroll
-			for (int r = 0; r < 4; r++) { mm_lds_add(redt + r*64 + lane, accp[r]); mm_lds_add(redt + (4 + r)*64 + lane, accm[r]); }
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) mm_lds_add(redt + (g*4 + r)*64 + lane, acc[g][r]);
 		}
 		if (tlast >= 0) mm_flush(tlast);
 		tlast = t;
 		__syncthreads();
 	}
 	if (tlast >= 0) mm_flush(tlast);
-	PXS_COUNT(1, ntile*(2*256L + 64L) + (wave_alive ? (long)kw*4 : 0L));
+	PXS_COUNT(1, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
 }
-
 
 // ---- batched spin-s synthesis as an FP64-MFMA GEMM (round 5) ----------------------------------------------------------------------
 // The transpose of leg_ana_spin_mm (cf. leg_syn_spin): north  P = sum_l G+ a+, M = sum_l G- a-;  south  P' = sum_l sgn_l G- a+, M' = sum_l sgn_l G+ a-.
@@ -2210,28 +2265,42 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 		leg_analysis(st, rs, tb, wk, leg + (size_t)nmm*leg_bstride, (char*)alm + aesz*(size_t)nmm*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, 0, prof, ld, 1, 0, 0);
 }
 
-// spin-s analysis of nb >= PXS_ANA_MM_MIN (4) maps: leg_ana_spin_mm, 4 maps (Q/U pairs) per workgroup; 1 - 3 left-over maps through the VALU kernel
+// spin-s analysis of nb >= PXS_ANA_MM_MIN (4) maps: leg_ana_spin_mm, 8 maps (Q/U pairs) per workgroup, a remainder of <= 4 in 4-map workgroups, a lone
+// left-over map through the VALU kernel
+static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact step table (a, b) / (a, a + b), built by the first batched transform on the plan
+	if (tb.d_coef2.p) return;
+	tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
+	hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
+}
 static void leg_analysis_spin_mm(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
 {
-	constexpr int W = 4;
+	constexpr int W = MM_WAVES;
 	const int nm = tb.mmax+1;
 	const long n4 = leg_mom_stride(tb);
 	const size_t aesz = alm_dtype == PX_C64 ? 8 : 16;
-	const int nmm = nb - (nb % 4 == 1 ? 1 : 0);      // (a lone left-over map costs more in a 4-map workgroup than in the VALU kernel)
+	const int nmm = nb - (nb % 8 == 1 ? 1 : 0);      // (a lone left-over map costs more in a 4-map workgroup than in the VALU kernel)
 	wk.mom.ensure(sizeof(double)*(size_t)n4*nmm);
 	PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nmm, st));
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_spin_mm<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
-	const int gmax = std::max(1, leg_max_batch(rs, tb, W));
-	for (int b0 = 0; b0 < nmm; b0 += 4*gmax) {
-		const int nmaps = std::min(4*gmax, nmm - b0), ngroups = (nmaps + 3)/4;
-		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg) + (size_t)b0*leg_bstride, ld, W, ngroups, leg_bstride);
+	ensure_coef2(st, tb);
+	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_spin_mm<2, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+		(void)hipFuncSetAttribute((const void*)leg_ana_spin_mm<1, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
+	auto launch = [&](int b0, int nmaps, int ng) {
+		const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
+		// (a workgroup covers 32 W ring pairs: nwave of the block mapping counts those)
+		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg) + (size_t)b0*leg_bstride, ld, 1, ngroups, leg_bstride);
+		a.nwave = (rs.npairs + 32*W - 1)/(32*W);
 		a.mom = wk.mom.as<double>() + (size_t)b0*a.mom_bs; a.part = a.mom; a.atomic = 1; a.nmaps = nmaps;
+		a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 		if (prof) prof->begin(st, 1);
-		hipLaunchKernelGGL((leg_ana_spin_mm<W>), leg_grid(a), dim3(64*W), mm_spin_ana_lds(W), st, a);
+		if (ng == 2) hipLaunchKernelGGL((leg_ana_spin_mm<2, W>), leg_grid(a), dim3(64*W), mm_ana_lds(2, W), st, a);
+		else         hipLaunchKernelGGL((leg_ana_spin_mm<1, W>), leg_grid(a), dim3(64*W), mm_ana_lds(1, W), st, a);
 		if (prof) prof->end(st, 1);
-	}
+	};
+	const int gmax = std::max(1, leg_max_batch(rs, tb, 2)), r = nmm % 8, n8 = nmm - r;
+	for (int b0 = 0; b0 < n8; b0 += 8*gmax) launch(b0, std::min(8*gmax, n8 - b0), 2);
+	if (r > 4) launch(n8, r, 2); else if (r > 0) launch(n8, r, 1);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, 0, alm_bstride);
 	hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm, nmm), dim3(256), 0, st, ak);
 	PXS_HIP(hipGetLastError());
