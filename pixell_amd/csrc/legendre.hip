@@ -1636,39 +1636,49 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_
 
 // ---- batched spin-s synthesis as an FP64-MFMA GEMM (round 5) ----------------------------------------------------------------------
 // The transpose of leg_ana_spin_mm (cf. leg_syn_spin): north  P = sum_l G+ a+, M = sum_l G- a-;  south  P' = sum_l sgn_l G- a+, M' = sum_l sgn_l G+ a-.
-// Two GEMMs over the steps with A = G+ resp. G- (two [16][68] P tiles per wave) and B = the pre-scaled alm rows of the tile with the sign folded
-// into the columns that take it: B1 = (a+, sgn a-) for G+ gives (P, M'), B2 = (sgn a+, a-) for G- gives (P', M).  Accumulators: 64 ring pairs x
-// 16 columns x 2 per group of 4 maps, in registers for the whole l loop; one wave per workgroup (two waves per SIMD by the LDS: NG = 2 groups per wave).
-static inline size_t mm_spin_syn_lds() { return sizeof(double)*2*16*MMS_PSTRIDE; }
-template<int NG> __global__ __launch_bounds__(64, 2) void leg_syn_spin_mm(const LegK a)
+// One chain per half-wave as in the analysis: the 64 rows of a wave's accumulators are the G+ slots of 32 ring pairs (row blocks 0, 1) and their
+// G- slots (row blocks 2, 3); the G- lanes park sgn_l G-, and with B = (a+, sgn_l a-) -- ONE B for all rows -- the G+ rows come out as (P, M') and the G-
+// rows as (P', M).  The shape of leg_syn_s0_mm: one P tile, 4 x 8 accumulator VGPRs per group of 4 maps, one wave per workgroup, no cross-wave step.
+template<int NG> __global__ __launch_bounds__(64, 4) void leg_syn_spin_mm(const LegK a)
 {
-	PXS_SHARED(double, ptile);      // [2][16][MMS_PSTRIDE]
-	constexpr int K = 1;
-	const int lane = threadIdx.x;
+	PXS_SHARED(double, pmine);      // [16][MMS_PSTRIDE]
+	const int lane = threadIdx.x, half = lane >> 5;
 	int wv, m, bb;
 	if (!leg_block(a, wv, m, bb)) return;
 	const int l0 = max(m, a.spin);
 	const int nl = a.lmax - l0 + 1;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const double4_t* __restrict__ coef = a.coef + row0;
-	const int pbase = wv*64;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64, a.npairs) - 1]; return c*c > 0.5; }();
-	SpinState<K> S; int rn1[K], rs1[K];
-	const bool alive = spin_init<K>(a, wv, lane, m, S, rn1, rs1, polar);
-	mm_acc accp[NG][4], accm[NG][4];
+	const int pbase = wv*32;
+	const bool polar = [&] { const double c = a.cth[min(pbase + 32, a.npairs) - 1]; return c*c > 0.5; }();
+	SpinChain C;
+	const bool alive = spin_chain_init(a, pbase + (lane & 31), m, half, polar, C);
+	mm_acc acc[NG][4];
 #pragma unroll
 	for (int g = 0; g < NG; g++)
 #pragma unroll
-		for (int rb = 0; rb < 4; rb++) { accp[g][rb][0] = accp[g][rb][1] = accp[g][rb][2] = accp[g][rb][3] = 0; accm[g][rb][0] = accm[g][rb][1] = accm[g][rb][2] = accm[g][rb][3] = 0; }
+		for (int rb = 0; rb < 4; rb++) { acc[g][rb][0] = 0; acc[g][rb][1] = 0; acc[g][rb][2] = 0; acc[g][rb][3] = 0; }
 	long ntile = 0;
-	int j = 0;
+	const double* __restrict__ tab = reinterpret_cast<const double*>(a.coef2) + 2*row0;      // (a, b) of step k at tab[2 k]
+	// phase A: recurrence only until the first lane of the wave is at scale 0 (a wave without a live ring skips the loop below)
+	int k = 0;
 	const bool wave_alive = nl > 0 && __any(alive);
-	if (wave_alive) { SPIN_PHASE_A }
-	const int kw = PXS_UNIFORM_INT(wave_alive ? j : max(nl, 0) + 16);
-	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
+	if (wave_alive) {
+		while (k + 4 <= nl) {
+			if (__any(C.sc == 0 && C.g2 != 0.0)) break;
+			double cq[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) cq[i] = LDCD(tab, 2L*k + i);
+			C.g1 = fma(spin_chain_coef(C, cq[0], cq[1]), C.g2, -C.g1);
+			C.g2 = fma(spin_chain_coef(C, cq[2], cq[3]), C.g1, -C.g2);
+			C.g1 = fma(spin_chain_coef(C, cq[4], cq[5]), C.g2, -C.g1);
+			C.g2 = fma(spin_chain_coef(C, cq[6], cq[7]), C.g1, -C.g2);
+			if (C.sc < 0 && fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; }
+			k += 4;
+		}
+	}
+	const int kw = PXS_UNIFORM_INT(wave_alive ? k : max(nl, 0) + 16);
 	{
-		double* __restrict__ pp = ptile; double* __restrict__ pm = ptile + 16*MMS_PSTRIDE;
-		// B operands of MFMA step-quad q: lane (jc, kk) holds column jc & 3 of map 4 (bb NG + g) + (jc >> 2) at step q + 4 kk of the tile
+		// B operand of MFMA step-quad q: lane (j, kk) holds column j & 3 of map 4 (bb NG + g) + (j >> 2) at step q + 4 kk of the tile: (a+ re, a+ im, sgn a- re, sgn a- im)
 		const int jcol = lane & 15, kk4 = lane >> 4, cc = jcol & 3;
 		const double* bsrc[NG]; bool bok[NG];
 #pragma unroll
@@ -1677,74 +1687,79 @@ template<int NG> __global__ __launch_bounds__(64, 2) void leg_syn_spin_mm(const 
 			bok[g] = map < a.nmaps;
 			bsrc[g] = a.almt + (long)(bok[g] ? map : 0)*a.almt_bs + 4*row0 + cc + 16*kk4;
 		}
-		// b1 = (a+, sgn a-), b2 = (sgn a+, a-), sgn = (-1)^(l + m) of the row
-		auto load_b = [&](int k0, double (*b1)[4], double (*b2)[4]) {
+		auto load_b = [&](int k0, double (*b)[4]) {
 #pragma unroll
 			for (int g = 0; g < NG; g++)
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const int row = k0 + q + 4*kk4;
 					const double v = (bok[g] && row < nl) ? bsrc[g][4L*(k0 + q)] : 0.0;
-					const double sv = ((l0 + row + m) & 1) ? -v : v;
-					b1[g][q] = cc < 2 ? v : sv; b2[g][q] = cc < 2 ? sv : v;
+					b[g][q] = (cc >= 2 && ((l0 + row + m) & 1)) ? -v : v;
 				}
 		};
-		bool pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
-		const int rdo = 4*(lane >> 4)*MMS_PSTRIDE + (lane & 15);
-		double b1c[NG][4], b2c[NG][4], b1n[NG][4], b2n[NG][4];
-		load_b(16*(kw >> 4), b1c, b2c);
+		bool pend = __any(C.sc < 0);
+		const double* __restrict__ pread = pmine + 4*(lane >> 4)*MMS_PSTRIDE + (lane & 15);
+		double cf[32];      // (a, b) of the 16 steps of the tile, requested a tile ahead (every tile from the wave's first one on is run)
+		double bcur[NG][4], bnxt[NG][4];
+		load_b(16*(kw >> 4), bcur);
+		if (kw < nl) {
+#pragma unroll
+			for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 32L*(kw >> 4) + i);
+		}
 		for (int t = kw >> 4; 16*t < nl; t++) {
 			const int k0 = 16*t;
 			ntile++;
 #pragma unroll
 			for (int q4 = 0; q4 < 4; q4++) {
 				const int kq = k0 + 4*q4;
-				double p0 = 0, p1 = 0, p2 = 0, p3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
 				if (kq >= kw && kq < nl) {
-					const double4_t f0 = LDC(coef, kq), f1 = LDC(coef, kq+1), f2 = LDC(coef, kq+2), f3 = LDC(coef, kq+3);
-					double ax;
-					p0 = S.gp2[0]; m0 = S.gm2[0];
-					ax = f0.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f0.c : f0.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f0.d : -f0.b), S.gm2[0], -S.gm1[0]);
-					p1 = S.gp1[0]; m1 = S.gm1[0];
-					ax = f1.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f1.c : f1.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f1.d : -f1.b), S.gm1[0], -S.gm2[0]);
-					p2 = S.gp2[0]; m2 = S.gm2[0];
-					ax = f2.a*S.x[0]; S.gp1[0] = fma(ax + (polar ? f2.c : f2.b), S.gp2[0], -S.gp1[0]); S.gm1[0] = fma(ax + (polar ? f2.d : -f2.b), S.gm2[0], -S.gm1[0]);
-					p3 = S.gp1[0]; m3 = S.gm1[0];
-					ax = f3.a*S.x[0]; S.gp2[0] = fma(ax + (polar ? f3.c : f3.b), S.gp1[0], -S.gp2[0]); S.gm2[0] = fma(ax + (polar ? f3.d : -f3.b), S.gm1[0], -S.gm2[0]);
+					p0 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 0], cf[8*q4 + 1]), C.g2, -C.g1);
+					p1 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 2], cf[8*q4 + 3]), C.g1, -C.g2);
+					p2 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 4], cf[8*q4 + 5]), C.g2, -C.g1);
+					p3 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 6], cf[8*q4 + 7]), C.g1, -C.g2);
 					if (pend) {
-						if (S.scp[0] < 0 || S.scm[0] < 0) { p0 = p1 = p2 = p3 = 0.0; m0 = m1 = m2 = m3 = 0.0; }
-						if (S.scp[0] < 0 && fabs(S.gp2[0]) > SC_BIG) { S.gp1[0] *= SC_SMALL; S.gp2[0] *= SC_SMALL; S.scp[0]++; }
-						if (S.scm[0] < 0 && fabs(S.gm2[0]) > SC_BIG) { S.gm1[0] *= SC_SMALL; S.gm2[0] *= SC_SMALL; S.scm[0]++; }
-						pend = __any(S.scp[0] < 0 || S.scm[0] < 0);
+						if (C.sc < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; } }
+						pend = __any(C.sc < 0);
 					}
-					if (kq + 1 >= nl) { p1 = 0.0; m1 = 0.0; }
-					if (kq + 2 >= nl) { p2 = 0.0; m2 = 0.0; }
-					if (kq + 3 >= nl) { p3 = 0.0; m3 = 0.0; }
+					const double se = (half && ((l0 + kq + m) & 1)) ? -1.0 : 1.0, so = half ? -se : 1.0;      // the G- lanes park sgn_l G-
+					p0 *= se; p1 *= so; p2 *= se; p3 *= so;
+					if (kq + 1 >= nl) p1 = 0.0;
+					if (kq + 2 >= nl) p2 = 0.0;
+					if (kq + 3 >= nl) p3 = 0.0;
 				}
-				pp[(4*q4 + 0)*MMS_PSTRIDE + lane] = p0; pp[(4*q4 + 1)*MMS_PSTRIDE + lane] = p1; pp[(4*q4 + 2)*MMS_PSTRIDE + lane] = p2; pp[(4*q4 + 3)*MMS_PSTRIDE + lane] = p3;
-				pm[(4*q4 + 0)*MMS_PSTRIDE + lane] = m0; pm[(4*q4 + 1)*MMS_PSTRIDE + lane] = m1; pm[(4*q4 + 2)*MMS_PSTRIDE + lane] = m2; pm[(4*q4 + 3)*MMS_PSTRIDE + lane] = m3;
+				pmine[(4*q4 + 0)*MMS_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MMS_PSTRIDE + lane] = p1;
+				pmine[(4*q4 + 2)*MMS_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MMS_PSTRIDE + lane] = p3;
 			}
 			MM_WAVE_SYNC();
-			if (k0 + 16 < nl) load_b(k0 + 16, b1n, b2n);      // the alm rows of the next tile, on their way during the MFMAs
+			double av[4];
+#pragma unroll
+			for (int rb = 0; rb < 4; rb++) av[rb] = pread[16*rb];
+			MM_WAVE_SYNC();
+			if (k0 + 16 < nl) {      // the rows of the next tile (coefficients and pre-scaled alm), on their way during the MFMAs
+#pragma unroll
+				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
+				load_b(k0 + 16, bnxt);
+			}
 #pragma unroll
 			for (int q = 0; q < 4; q++)
 #pragma unroll
 				for (int rb = 0; rb < 4; rb++) {
-					const double ap = pp[rdo + q*MMS_PSTRIDE + 16*rb], am = pm[rdo + q*MMS_PSTRIDE + 16*rb];
+					const double aq = q == 0 ? av[rb] : pread[q*MMS_PSTRIDE + 16*rb];
 #pragma unroll
-					for (int g = 0; g < NG; g++) { accp[g][rb] = mm_mfma(ap, b1c[g][q], accp[g][rb]); accm[g][rb] = mm_mfma(am, b2c[g][q], accm[g][rb]); }
+					for (int g = 0; g < NG; g++) acc[g][rb] = mm_mfma(aq, bcur[g][q], acc[g][rb]);
 				}
-			MM_WAVE_SYNC();      // the A operands are out of the tiles before the next ones are written
+			MM_WAVE_SYNC();      // the A operands are out of the tile before the next one is written
 #pragma unroll
 			for (int g = 0; g < NG; g++)
 #pragma unroll
-				for (int q = 0; q < 4; q++) { b1c[g][q] = b1n[g][q]; b2c[g][q] = b2n[g][q]; }
+				for (int q = 0; q < 4; q++) bcur[g][q] = bnxt[g][q];
 		}
 	}
-	// register r of acc[g][rb] at lane (i4 = lane / 16, jc = lane % 16): ring pair 16 rb + 4 r + i4, column 4 (map in the group) + c.
-	// accp: c = 0, 1: P re / im (north); 2, 3: M' re / im (south).  accm: c = 0, 1: P' re / im (south); 2, 3: M re / im (north).
-	// Q = (P + M) / 2, U = -i (P - M) / 2: lanes c < 2 write the north ring, lanes c >= 2 the south ring; even c the real part of Q and the imaginary
-	// part of U, odd c the other two.
+	// register r of acc[g][rb] at lane (i4 = lane / 16, jc = lane % 16): slot 16 rb + 4 r + i4 (rb < 2: G+ of ring pair 16 rb + 4 r + i4, rb >= 2: G- of pair
+	// 16 (rb - 2) + 4 r + i4), column 4 (map in the group) + c.  G+ rows: c = 0, 1: P re / im (north); 2, 3: M' re / im (south).  G- rows: c = 0, 1: P' re / im
+	// (south); 2, 3: M re / im (north).  Q = (P + M) / 2, U = -i (P - M) / 2: lanes c < 2 write the north ring, lanes c >= 2 the south ring; even c the
+	// real part of Q and the imaginary part of U, odd c the other two.
 	const int c = lane & 3;
 #pragma unroll
 	for (int g = 0; g < NG; g++) {
@@ -1752,12 +1767,12 @@ template<int NG> __global__ __launch_bounds__(64, 2) void leg_syn_spin_mm(const 
 		double* __restrict__ outq = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + (long)m*a.ld);
 		double* __restrict__ outu = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + ((long)a.nm + m)*a.ld);
 #pragma unroll
-		for (int rb = 0; rb < 4; rb++)
+		for (int rb = 0; rb < 2; rb++)
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
 				const int p = pbase + 16*rb + 4*r + (lane >> 4);
 				const bool valid = p < a.npairs && map < a.nmaps;
-				const double own = accp[g][rb][r], oth = MMS_XOR2(accm[g][rb][r]);
+				const double own = acc[g][rb][r], oth = MMS_XOR2(acc[g][rb + 2][r]);
 				const double P = c < 2 ? own : oth, M = c < 2 ? oth : own;
 				const double sum = 0.5*(P + M), dif = 0.5*(P - M);
 				const int ring = valid ? (c < 2 ? a.ring_n[p] : a.ring_s[p]) : -1;
@@ -1767,7 +1782,7 @@ template<int NG> __global__ __launch_bounds__(64, 2) void leg_syn_spin_mm(const 
 				}
 			}
 	}
-	PXS_COUNT(0, ntile*(NG*512L + 64L) + (wave_alive ? (long)kw*4 : 0L));
+	PXS_COUNT(0, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
 }
 
 // ---------------------------------------------------------------------------------
@@ -2129,6 +2144,11 @@ static AlmK make_almk(const LegTables& tb, LegWork& wk, const void* alm, int dty
 	return k;
 }
 
+static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact step table (a, b) / (a, a + b), built by the first batched transform on the plan
+	if (tb.d_coef2.p) return;
+	tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
+	hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
+}
 static int syn_mm_min() { static int v = [] { const char* e = getenv("PXS_SYN_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
@@ -2164,10 +2184,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	// a single left-over map through the VALU kernel.  Each map's result equals its single-map call to rounding, not bit for bit.
 	if (tb.spin == 0 && nb >= syn_mm_min()) {
 		int nmm = nb; if (nb % 8 == 1) nmm = nb - 1;
-		if (!tb.d_coef2.p) {      // compact step table, built by the first batched transform on the plan
-			tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
-			hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
-		}
+		ensure_coef2(st, tb);
 		auto launch_mm = [&](int m0, int nmaps, int ng) {
 			const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
 			LegK a = make_legk(rs, tb, wk, leg + (size_t)m0*leg_bstride, ld, 1, ngroups, leg_bstride);
@@ -2183,19 +2200,25 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		if (r > 4) launch_mm(n8, r, 2); else if (r > 0) launch_mm(n8, r, 1);
 		b0 = nmm;
 	}
-	// spin s, 8 or more maps (Q/U pairs of a stack of maps): leg_syn_spin_mm, 8 maps per wave; what is left over (or a batch below 8: measured at
-	// 4 maps 31.6 against 29.5 ms, at 8 maps 48.1 against 58.7, 16 maps 95.7 against 116.4 per T/Q/U batch of 5400x10800 maps) takes the VALU kernel
-	if (tb.spin > 0 && nb >= std::max(8, syn_mm_min())) {
-		const int r = nb % 8, nmm = r > 4 ? nb : nb - r;
-		const int gmax = std::max(1, leg_max_batch(rs, tb, 1));
-		for (int m0 = 0; m0 < nmm; m0 += 8*gmax) {
-			const int nmaps = std::min(8*gmax, nmm - m0), ngroups = (nmaps + 7)/8;
+	// spin s, 4 or more maps (Q/U pairs of a stack of maps): leg_syn_spin_mm, 8 maps per wave, a remainder of <= 4 in 4-map waves, a lone left-over map
+	// through the VALU kernel
+	if (tb.spin > 0 && nb >= syn_mm_min()) {
+		const int nmm = nb - (nb % 8 == 1 ? 1 : 0);
+		ensure_coef2(st, tb);
+		auto launch_mm = [&](int m0, int nmaps, int ng) {
+			const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
 			LegK a = make_legk(rs, tb, wk, leg + (size_t)m0*leg_bstride, ld, 1, ngroups, leg_bstride);
-			a.almt += (size_t)m0*a.almt_bs; a.nmaps = nmaps;
+			a.nwave = (rs.npairs + 31)/32;      // (a wave covers 32 ring pairs: one chain per half-wave)
+			a.almt += (size_t)m0*a.almt_bs; a.nmaps = nmaps; a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
+			PXS_REQUIRE((long)8*((a.nm + 7)/8)*a.nwave*ngroups < (1L << 31), "internal: Legendre grid too large for one launch");
 			if (prof) prof->begin(st, 0);
-			hipLaunchKernelGGL(leg_syn_spin_mm<2>, leg_grid(a), dim3(64), mm_spin_syn_lds(), st, a);
+			if (ng == 2) hipLaunchKernelGGL(leg_syn_spin_mm<2>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
+			else         hipLaunchKernelGGL(leg_syn_spin_mm<1>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
 			if (prof) prof->end(st, 0);
-		}
+		};
+		const int gmax = std::max(1, leg_max_batch(rs, tb, 1)/2), r = nmm % 8, n8 = nmm - r;
+		for (int m0 = 0; m0 < n8; m0 += 8*gmax) launch_mm(m0, std::min(8*gmax, n8 - m0), 2);
+		if (r > 4) launch_mm(n8, r, 2); else if (r > 0) launch_mm(n8, r, 1);
 		b0 = nmm;
 	}
 	// (the launch that records the recurrence seeds takes one map, so that only one wave writes each seed)
@@ -2233,10 +2256,7 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 	if (nb % 8 == 1) nmm = nb - 1;      // (a lone map in a 4-map workgroup costs more than the VALU kernel)
 	wk.mom.ensure(sizeof(double)*(size_t)n4*nmm);
 	PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nmm, st));
-	if (!tb.d_coef2.p) {      // compact step table, built by the first batched analysis on the plan
-		tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
-		hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
-	}
+	ensure_coef2(st, tb);
 	auto launch = [&](int b0, int nmaps, int ng) {      // maps [b0, b0 + nmaps) in groups of 4 ng
 		const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
 		LegK a = make_legk(rs, tb, wk, const_cast<double2*>(leg) + (size_t)b0*leg_bstride, ld, W, ngroups, leg_bstride);
@@ -2267,11 +2287,6 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 
 // spin-s analysis of nb >= PXS_ANA_MM_MIN (4) maps: leg_ana_spin_mm, 8 maps (Q/U pairs) per workgroup, a remainder of <= 4 in 4-map workgroups, a lone
 // left-over map through the VALU kernel
-static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact step table (a, b) / (a, a + b), built by the first batched transform on the plan
-	if (tb.d_coef2.p) return;
-	tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
-	hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
-}
 static void leg_analysis_spin_mm(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
