@@ -38,6 +38,14 @@ CONFIGS = {
 }
 FRAC_DEFINITION = "frac: SURVEY 8(d) F_alg = (4 n0 + 12 n2) R nalm flop per direction over the kernel family's time / 78.6 TFLOP/s; frac_hw: the FP64 flops the kernels executed (recurrence + accumulation FMAs / MFMAs of the steps the waves ran, counted in the kernels) over the same time"
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
+# what a kernel of nothing but independent v_fma_f64 with three VGPR operands (the form of the analysis accumulation and of every recurrence step) sustains
+# on the gpurun boxes: 54-65 TFLOP/s by hipEvent time at ANY occupancy from 1 to 8 waves per SIMD -- one wave alone issues one every 4.4 s_memtime counts, and
+# the counts per ms fall from 1.85e6 to 1.1e6 as waves are added (tools/dp_rate.hip, profiles/r05_dp_rate_and_k_waves.txt); with one scalar operand (the synthesis accumulation) 74.6-76.1
+# (tools/fma_peak.hip, round 3); a v_mfma_f64_16x16x4_f64 stream 65.7 (profiles/r05_mfma_f64_rate.txt).  Context for frac_hw; `peak` stays the nominal figure.
+FP64_SUSTAINED_TFLOPS = 64.9
+def sustained_note(frac_hw_both):
+	return dict(fp64_fma_stream_TFLOPs=FP64_SUSTAINED_TFLOPS, source="tools/dp_rate.hip: v_fma_f64 with three VGPR operands only, best of 1-8 waves per SIMD (profiles/r05_dp_rate_and_k_waves.txt); 74.6-76.1 with one scalar operand (tools/fma_peak.hip); 78.6 nominal",
+		frac_hw_of_stream={k: round(v*FP64_PEAK_TFLOPS/FP64_SUSTAINED_TFLOPS, 4) for k, v in frac_hw_both.items()})
 HBM_PEAK_GBS = 8000.0
 
 def log(*a):
@@ -321,7 +329,8 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 		roofline=dict(bound="mfma" if (dom == "leg_ana" and nbc >= 4) else "fp64_valu", kernel="leg_ana_* (Legendre analysis of a batch)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis of a batch)",
 			achieved=round(F_dir/(leg[dom]*1e-3)/1e12, 3) if leg[dom] > 0 else 0.0, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
 			frac=round(F_dir/(leg[dom]*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if leg[dom] > 0 else 0.0, frac_hw=frac_hw[dom], frac_hw_both=frac_hw, frac_definition=FRAC_DEFINITION, traffic=None,
-			kernel_ms_per_realisation={k: round(v, 3) for k, v in leg.items()}, algorithmic_flops_per_realisation_direction=F_dir, executed_flops_per_realisation=exe),
+			kernel_ms_per_realisation={k: round(v, 3) for k, v in leg.items()}, algorithmic_flops_per_realisation_direction=F_dir, executed_flops_per_realisation=exe,
+			sustained=sustained_note(frac_hw)),
 		fft=dict(bound="hbm", kernel="enmap.fft real -> complex, 10800x21600", ms=stage_ms["enmap_fft"], achieved=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9, 1) if stage_ms["enmap_fft"] > 0 else 0.0,
 			peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9/HBM_PEAK_GBS, 4) if stage_ms["enmap_fft"] > 0 else 0.0),
 		checks=dict(roundtrip_rms_error=rt_err, alm2cl_invariance=cl_err, binned_ps2d_over_cl_median=flat_ratio), ducc0=probe_ducc0())
@@ -466,6 +475,7 @@ def run_sht(args, ctx):
 		frac_hw_both={k: (round(v/max(args.steps, 1)/(prof[k][0]/args.steps*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if prof[k][0] > 0 else 0.0) for k, v in (("leg_syn", fl_syn), ("leg_ana", fl_ana))},
 		kernel_ms_per_step=round(dom_ms_per_step, 3),
 		launches_per_step=prof[dom][1]//max(args.steps, 1), R_algorithmic=R_alg, R_actual_syn=R_syn, R_actual_ana=R_ana)
+	roof["sustained"] = sustained_note(roof["frac_hw_both"])
 	roof.update(measured_traffic(args.config, [dom]))
 	# ---- the HBM-bound family: ring FFTs + theta resampling (fused chains, csrc/fftchain.hip) ----
 	chain_ms = (prof["ring_fft"][0]+prof["resample"][0])/args.steps
@@ -538,7 +548,7 @@ def compact_leg(res):
 	out["workload"] = res["config"]["workload"]
 	if "ms_per_realisation" in res: out.update(ms_per_realisation=res["ms_per_realisation"], stage_ms_per_realisation=res["stage_ms_per_realisation"], roundtrip_rms_error=res["checks"]["roundtrip_rms_error"], realisations_per_call=res["config"]["realisations_per_call"])
 	r = res["roofline"]
-	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_hw", "frac_hw_both", "frac_definition", "kernel_ms_per_step", "kernel_ms_per_realisation") if k in r}
+	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_hw", "frac_hw_both", "frac_definition", "sustained", "kernel_ms_per_step", "kernel_ms_per_realisation") if k in r}
 	if "fft_chain" in res: out["fft_chain"] = {k: res["fft_chain"][k] for k in ("bound", "achieved", "unit", "frac", "kernel_ms_per_step")}
 	if "fft" in res and res["fft"] and "frac" in res["fft"]: out["fft"] = res["fft"]
 	return out
