@@ -701,7 +701,9 @@ def test_mm_layouts_hostsim(): check_mm_layouts()
 def test_mm_layouts_gpu(): check_mm_layouts(); check_mm_layouts(nb=9, nt=700, nph=1400, lmax=600, mmax=411)
 
 @pytest.mark.hostsim
-def test_mm_analysis_hostsim(): check_mm_analysis(nbs=(4, 9, 13)); check_mm_analysis(nbs=(5,), lmax=24, spins=(1, 3))
+def test_mm_analysis_hostsim():
+	# (the host simulation of the MFMA kernels is slow: the GPU test runs the full matrix of batch sizes and spins)
+	check_mm_analysis(nbs=(4, 9), lmax=32, spins=(0,)); check_mm_analysis(nbs=(13,), lmax=32, spins=(2,)); check_mm_analysis(nbs=(5,), lmax=24, spins=(3,))
 @pytest.mark.gpu
 def test_mm_analysis_gpu():
 	check_mm_analysis(lmax=700); check_mm_analysis(nbs=(5, 16), lmax=1500, grid=("CC", 1502, 3008)); check_mm_analysis(nbs=(8,), lmax=2100, grid=("F1", 2800, 5600))
