@@ -247,13 +247,29 @@ def _to_host(m):
 def _ptr(x):
 	x = _data(x)
 	return x.data_ptr() if hasattr(x, "data_ptr") else x.ctypes.data
+def _geo_key(shape, wcs):
+	"""what the l axes of a map depend on: its pixel shape and the WCS numbers (None: no usable key, do not cache)"""
+	try: return (tuple(int(v) for v in shape[-2:]), tuple(np.asarray(wcs.wcs.cdelt, float)), tuple(np.asarray(wcs.wcs.crval, float)), tuple(np.asarray(wcs.wcs.crpix, float)), tuple(wcs.wcs.ctype))
+	except Exception: return None
+_axes_cache = {}
 def _dev_axes(shape, wcs, like):
-	"""ly, lx as device f64 arrays living next to `like`"""
+	"""ly, lx as device f64 arrays living next to `like` (kept per geometry and device: a Monte-Carlo loop calls lbin / map2harm on the
+	same geometry every realisation, and the upload from pageable memory is a host synchronisation each time)"""
 	from . import sht
-	ly, lx = laxes(shape, wcs)
-	if sht._lib.is_hostsim(): return np.ascontiguousarray(ly), np.ascontiguousarray(lx)
-	torch = _torch()
-	return torch.from_numpy(np.ascontiguousarray(ly)).to(like.device), torch.from_numpy(np.ascontiguousarray(lx)).to(like.device)
+	if sht._lib.is_hostsim():
+		ly, lx = laxes(shape, wcs)
+		return np.ascontiguousarray(ly), np.ascontiguousarray(lx)
+	key = _geo_key(shape, wcs)
+	if key is not None: key = key+(str(like.device),)
+	hit = _axes_cache.get(key) if key is not None else None
+	if hit is None:
+		torch = _torch()
+		ly, lx = laxes(shape, wcs)
+		hit = (torch.from_numpy(np.ascontiguousarray(ly)).to(like.device), torch.from_numpy(np.ascontiguousarray(lx)).to(like.device))
+		if key is not None:
+			if len(_axes_cache) >= 8: _axes_cache.pop(next(iter(_axes_cache)))
+			_axes_cache[key] = hit
+	return hit
 
 def _rotate_pairs(hmap, spin, iau, inverse):
 	"""rotate every spin-s pair of a contiguous complex harmonic map [...,ncomp,ny,nx] in place"""
@@ -330,15 +346,23 @@ def calc_ps2d(harm, harm2=None):
 	res = _wrap(out, h1)
 	return _to_host(res) if host1 else res
 
+_lbin_cache = {}
 def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=None):
 	"""radial binning of a real fourier-space map in |l| (enmap.lbin / _bin_helper, enmap.py:2526-2556): returns b(l), l"""
 	from . import sht
 	if lop is not None: raise NotImplementedError("lbin: lop is not supported by the accelerated path")
-	ly, lx = laxes(map.shape, map.wcs)
-	if bsize is None: bsize = min(abs(lx[1]), abs(ly[1]))
-	bsize = float(bsize*brel)
-	lmax = float(np.sqrt(np.max(ly**2)+np.max(lx**2)))
-	n = int(lmax/bsize)
+	gkey = _geo_key(map.shape, map.wcs)
+	geo = _lbin_cache.get((gkey, bsize, brel)) if gkey is not None else None
+	if geo is None:
+		ly, lx = laxes(map.shape, map.wcs)
+		bs = min(abs(lx[1]), abs(ly[1])) if bsize is None else bsize
+		bs = float(bs*brel)
+		lmax = float(np.sqrt(np.max(ly**2)+np.max(lx**2)))
+		geo = dict(bsize=bs, n=int(lmax/bs), lsum=None, nhit=None)
+		if gkey is not None:
+			if len(_lbin_cache) >= 8: _lbin_cache.pop(next(iter(_lbin_cache)))
+			_lbin_cache[(gkey, bsize, brel)] = geo
+	bsize, n = geo["bsize"], geo["n"]
 	dev_map, was_host = _to_device(map)
 	d = _data(dev_map)
 	if sht._np_dtype(d) not in (np.dtype(np.float32), np.dtype(np.float64)): raise ValueError("lbin needs a real map")
@@ -351,15 +375,19 @@ def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=No
 	else: acc = np.zeros((npre+2, max(n, 1)))
 	lib = sht._lib.load(); dev = sht.device_index(); st = sht.current_stream()
 	esz = sht._np_dtype(d).itemsize
+	# the sums of |l| and the pixel counts per bin depend on the geometry alone: taken with the first map of the first call on a geometry
+	# and kept (two of the kernel's three atomic adds per pixel)
 	for i in range(npre):
-		first = i == 0
+		first = i == 0 and geo["nhit"] is None
 		sht._lib.check(lib.pxm_lbin(ny, nx, _ptr(dly), _ptr(dlx), bsize, n, _ptr(d)+i*ny*nx*esz, sht._DT[sht._np_dtype(d)],
 			_ptr(acc)+i*max(n, 1)*8, (_ptr(acc)+npre*max(n, 1)*8) if first else None, (_ptr(acc)+(npre+1)*max(n, 1)*8) if first else None, dev, st))
 	acc = acc.cpu().numpy() if hasattr(acc, "data_ptr") else acc
-	nhit = acc[npre+1, :n]
+	if geo["nhit"] is None and npre > 0: geo["lsum"], geo["nhit"] = acc[npre, :n].copy(), acc[npre+1, :n].copy()
+	nhit = geo["nhit"] if geo["nhit"] is not None else acc[npre+1, :n]
+	lsum = geo["lsum"] if geo["lsum"] is not None else acc[npre, :n]
 	with np.errstate(invalid="ignore", divide="ignore"):
 		mout = (acc[:npre, :n]/nhit).reshape(tuple(d.shape[:-2])+(n,))
-		orads = acc[npre, :n]/nhit
+		orads = lsum/nhit
 	if return_bins:
 		edges = np.arange(len(orads)+1)*bsize
 		orads = np.array([orads, edges[:-1], edges[1:]])

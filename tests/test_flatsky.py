@@ -55,6 +55,9 @@ def ps_body(golden_dir):
 	ok = d["lbin_nhit"] > 0                                              # empty bins are nan on both sides
 	np.testing.assert_allclose(b[ok], d["lbin_b"][ok], rtol=1e-12); np.testing.assert_allclose(l[ok], d["lbin_l"][ok], rtol=1e-12)
 	assert np.all(np.isnan(b[~ok])) and np.all(np.isnan(d["lbin_b"][~ok]))
+	# a second call on the geometry takes the |l| sums and pixel counts of the bins from the first (they depend on the geometry alone)
+	b2, l2, nhit2 = enmap.lbin(enmap.ndmap(d["ps2d"][0, 0]*2, wcs), return_nhit=True)
+	assert np.array_equal(nhit2, nhit) and np.array_equal(l2[ok], l[ok]); np.testing.assert_allclose(b2[ok], 2*b[ok], rtol=1e-14)
 	b3, l3 = enmap.lbin(enmap.ndmap(d["ps2d"][:, 0], wcs), brel=2.5, return_bins=True)
 	assert b3.shape == d["lbin3_b"].shape and l3.shape == d["lbin3_l"].shape
 	np.testing.assert_allclose(b3, d["lbin3_b"], rtol=1e-12, equal_nan=True); np.testing.assert_allclose(l3, d["lbin3_l"], rtol=1e-12, equal_nan=True)
