@@ -132,7 +132,7 @@ def measured_traffic(config, dom):
 	profiles/r02_traffic_<config>.json; FETCH_SIZE corrected per access pattern -- x2 for 16-byte-per-lane row reads as the gfx950 note
 	of MI355X_MICROARCH.md prescribes, x1 where the known array sizes of the chain kernels show full counting -- WRITE_SIZE as reported).
 	Counters cannot be read from inside this process: null when no profile of this config is committed."""
-	for tag in ("r05", "r04b", "r04", "r03", "r02", "r01"):
+	for tag in ("r05b", "r05", "r04b", "r04", "r03", "r02", "r01"):
 		path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config))
 		if os.path.exists(path): break
 	else: return dict(traffic=None)
@@ -254,13 +254,14 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 		mark()
 		for j in range(n): alm_in[j] = curvedsky.rand_alm(cl_in, ainfo=ainfo, seed=200+i0+j, rng="device")
 		mark(); curvedsky.alm2map(alm_in[:n], enmap.dmap(m.tensor[:n], wcs), spin=[0], ainfo=ainfo)
+		mark()
 		bs = []; t_fft = []
 		for j in range(n):
 			e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
 			e0.record(); f = enmap.fft(enmap.dmap(m.tensor[j:j+1], wcs), omap=fbuf, normalize="phys")
 			e1.record(); ps = enmap.calc_ps2d(f); b, l = enmap.lbin(ps); e2.record()
 			bs.append(b); t_fft.append((e0, e1, e2))
-		mark(); mark()      # (the FFT / spectrum stages of the n maps alternate: their split comes from the inner events)
+		mark()      # (the FFT / spectrum stages of the n maps alternate: their split comes from the inner events)
 		curvedsky.map2alm(enmap.dmap(m.tensor[:n], wcs), alm=alm_out[:n], spin=[0], ainfo=ainfo)
 		mark(); cl = torch.stack([curvedsky.alm2cl(alm_out[j], ainfo=ainfo) for j in range(n)])
 		mark()
@@ -306,7 +307,7 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 		t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 	stage_ms = {k: 0.0 for k in stages}
-	for r in range(len(evs)//7):      # per batch: six marks (before rand_alm, after rand_alm, after alm2map, after the FFT / spectrum loop twice, after map2alm ... ) + the inner FFT events
+	for r in range(len(evs)//7):      # per batch: six marks (before rand_alm, after rand_alm, after alm2map, after the FFT / spectrum loop, after map2alm, after alm2cl) + the inner FFT events
 		e = evs[7*r:7*r+7]
 		stage_ms["rand_alm"] += e[0].elapsed_time(e[1]); stage_ms["alm2map"] += e[1].elapsed_time(e[2])
 		stage_ms["map2alm"] += e[3].elapsed_time(e[4]); stage_ms["alm2cl"] += e[4].elapsed_time(e[5])
