@@ -182,79 +182,131 @@ struct AlmK {
 };
 __device__ __forceinline__ void* alm_of_batch(const AlmK& a) { return (char*)a.alm + (size_t)(a.dtype == PX_C64 ? 8 : 16)*(size_t)blockIdx.z*(size_t)a.alm_bs; }
 
+// Each thread takes ALM_U rows 256 apart and issues all their loads before the first store: with one row per thread a wave had 1 KB of
+// loads in flight behind a chain of dependent scalar loads (alm_pre_spin 1.15 TB/s at config 3).
+#define ALM_U 4
+static inline dim3 alm_grid(int nrows, int nm, int nb) { return dim3((unsigned)((nrows + 256*ALM_U - 1)/(256*ALM_U)), (unsigned)nm, (unsigned)nb); }
 // spin 0: almt[row(m)+k] = alpha_k * ( eps_{l+1} a_l + eps_{l+2} a_{l+2},  a_{l+1} ),  l = m+2k
 __global__ __launch_bounds__(256) void alm_pre_s0(AlmK a) {
 	const int m = blockIdx.y;
 	const int nk = (a.lmax - m)/2 + 1;
-	const int k = blockIdx.x*blockDim.x + threadIdx.x;
-	if (k >= nk) return;
-	const int l = m + 2*k;
+	const int kb = blockIdx.x*(256*ALM_U) + threadIdx.x;
+	if (kb >= nk) return;
 	const long base = (long)a.mstart[m];
+	const long row = a.row[m];
 	const void* alm = alm_of_batch(a);
-	double2 a0 = ld_alm(alm, a.dtype, base + (long)l*a.lstride);
-	double2 a1 = (l+1 <= a.lmax) ? ld_alm(alm, a.dtype, base + (long)(l+1)*a.lstride) : make_double2(0, 0);
-	double2 a2 = (l+2 <= a.lmax) ? ld_alm(alm, a.dtype, base + (long)(l+2)*a.lstride) : make_double2(0, 0);
-	const double al = a.alpha[a.row[m] + k];
-	const double e1 = eps_lm(l+1, m), e2 = eps_lm(l+2, m);
-	double* o = a.almt + (long)blockIdx.z*a.almt_bs + 4*(a.row[m] + k);
-	o[0] = al*(e1*a0.x + e2*a2.x); o[1] = al*(e1*a0.y + e2*a2.y);
-	o[2] = al*a1.x;                o[3] = al*a1.y;
+	double2 a0[ALM_U], a1[ALM_U], a2[ALM_U]; double al[ALM_U];
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int k = kb + 256*u, l = m + 2*k;
+		const bool ok = k < nk;
+		a0[u] = ok ? ld_alm(alm, a.dtype, base + (long)l*a.lstride) : make_double2(0, 0);
+		a1[u] = (ok && l+1 <= a.lmax) ? ld_alm(alm, a.dtype, base + (long)(l+1)*a.lstride) : make_double2(0, 0);
+		a2[u] = (ok && l+2 <= a.lmax) ? ld_alm(alm, a.dtype, base + (long)(l+2)*a.lstride) : make_double2(0, 0);
+		al[u] = ok ? a.alpha[row + k] : 0.0;
+	}
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int k = kb + 256*u, l = m + 2*k;
+		if (k >= nk) break;
+		const double e1 = eps_lm(l+1, m), e2 = eps_lm(l+2, m);
+		double* o = a.almt + (long)blockIdx.z*a.almt_bs + 4*(row + k);
+		o[0] = al[u]*(e1*a0[u].x + e2*a2[u].x); o[1] = al[u]*(e1*a0[u].y + e2*a2[u].y);
+		o[2] = al[u]*a1[u].x;                   o[3] = al[u]*a1[u].y;
+	}
 }
 // a_{m+2k} = eps_{l+1} alpha_k M1_k + eps_l alpha_{k-1} M1_{k-1};  a_{m+2k+1} = alpha_k M2_k
 __global__ __launch_bounds__(256) void alm_post_s0(AlmK a) {
 	const int m = blockIdx.y;
 	const int nk = (a.lmax - m)/2 + 1;
-	const int k = blockIdx.x*blockDim.x + threadIdx.x;
-	if (k >= nk) return;
-	const int l = m + 2*k;
-	const long r = a.row[m] + k;
-	const double* M = a.mom + (long)blockIdx.z*a.mom_bs + 4*r;
-	const double al = a.alpha[r];
-	const double e1 = eps_lm(l+1, m), e0 = eps_lm(l, m);
-	double2 v = make_double2(e1*al*M[0], e1*al*M[1]);
-	if (k > 0) { const double alp = a.alpha[r-1]; v.x += e0*alp*M[-4]; v.y += e0*alp*M[-3]; }
+	const int kb = blockIdx.x*(256*ALM_U) + threadIdx.x;
+	if (kb >= nk) return;
+	const long row = a.row[m];
 	const long base = (long)a.mstart[m];
 	void* alm = alm_of_batch(a);
-	st_alm(alm, a.dtype, base + (long)l*a.lstride, v);
-	if (l+1 <= a.lmax) st_alm(alm, a.dtype, base + (long)(l+1)*a.lstride, make_double2(al*M[2], al*M[3]));
+	double M0[ALM_U], M1[ALM_U], M2[ALM_U], M3[ALM_U], P0[ALM_U], P1[ALM_U], al[ALM_U], alp[ALM_U];
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int k = kb + 256*u;
+		const bool ok = k < nk;
+		const long r = row + k;
+		const double* M = a.mom + (long)blockIdx.z*a.mom_bs + 4*r;
+		M0[u] = ok ? M[0] : 0.0; M1[u] = ok ? M[1] : 0.0; M2[u] = ok ? M[2] : 0.0; M3[u] = ok ? M[3] : 0.0;
+		al[u] = ok ? a.alpha[r] : 0.0;
+		const bool prev = ok && k > 0;
+		P0[u] = prev ? M[-4] : 0.0; P1[u] = prev ? M[-3] : 0.0; alp[u] = prev ? a.alpha[r-1] : 0.0;
+	}
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int k = kb + 256*u, l = m + 2*k;
+		if (k >= nk) break;
+		const double e1 = eps_lm(l+1, m), e0 = eps_lm(l, m);
+		double2 v = make_double2(e1*al[u]*M0[u], e1*al[u]*M1[u]);
+		if (k > 0) { v.x += e0*alp[u]*P0[u]; v.y += e0*alp[u]*P1[u]; }
+		st_alm(alm, a.dtype, base + (long)l*a.lstride, v);
+		if (l+1 <= a.lmax) st_alm(alm, a.dtype, base + (long)(l+1)*a.lstride, make_double2(al[u]*M2[u], al[u]*M3[u]));
+	}
 }
 // spin s: rows l = l0..lmax; almt = beta_l * ( a+ = -(E+iB),  a- = -(-1)^s (E-iB) )
 __global__ __launch_bounds__(256) void alm_pre_spin(AlmK a) {
 	const int m = blockIdx.y;
 	const int l0 = max(m, a.spin);
-	const int l = l0 + blockIdx.x*blockDim.x + threadIdx.x;
-	if (l > a.lmax) return;
-	const long idx = (long)a.mstart[m] + (long)l*a.lstride;
+	const int lb = l0 + blockIdx.x*(256*ALM_U) + threadIdx.x;
+	if (lb > a.lmax) return;
+	const long base = (long)a.mstart[m], row = a.row[m];
 	const void* alm = alm_of_batch(a);
-	double2 E = ld_alm(alm, a.dtype, idx), B;
-	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); E.x *= f; E.y *= f; B = make_double2(0, 0); }
-	else B = ld_alm(alm, a.dtype, idx + a.cstride);
-	const long r = a.row[m] + (l - l0);
-	const double be = a.alpha[r];
+	double2 E[ALM_U], B[ALM_U]; double be[ALM_U];
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int l = lb + 256*u;
+		const bool ok = l <= a.lmax;
+		const long idx = base + (long)l*a.lstride;
+		E[u] = ok ? ld_alm(alm, a.dtype, idx) : make_double2(0, 0);
+		B[u] = (ok && !a.deriv1) ? ld_alm(alm, a.dtype, idx + a.cstride) : make_double2(0, 0);
+		be[u] = ok ? a.alpha[row + (l - l0)] : 0.0;
+	}
 	const double sg = (a.spin & 1) ? -1.0 : 1.0;
-	double* o = a.almt + (long)blockIdx.z*a.almt_bs + 4*r;
-	o[0] = -be*(E.x - B.y); o[1] = -be*(E.y + B.x);
-	o[2] = -sg*be*(E.x + B.y); o[3] = -sg*be*(E.y - B.x);
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int l = lb + 256*u;
+		if (l > a.lmax) break;
+		double2 e = E[u]; const double2 b = B[u];
+		if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); e.x *= f; e.y *= f; }
+		double* o = a.almt + (long)blockIdx.z*a.almt_bs + 4*(row + (l - l0));
+		o[0] = -be[u]*(e.x - b.y); o[1] = -be[u]*(e.y + b.x);
+		o[2] = -sg*be[u]*(e.x + b.y); o[3] = -sg*be[u]*(e.y - b.x);
+	}
 }
 // E = -1/2 beta (mu+ + sg mu-),  B = i/2 beta (mu+ - sg mu-)
 __global__ __launch_bounds__(256) void alm_post_spin(AlmK a) {
 	const int m = blockIdx.y;
 	const int l0 = max(m, a.spin);
-	const int l = blockIdx.x*blockDim.x + threadIdx.x + min(m, l0);   // also zero-fill m <= l < l0
-	if (l > a.lmax) return;
-	const long idx = (long)a.mstart[m] + (long)l*a.lstride;
-	double2 E = make_double2(0, 0), B = make_double2(0, 0);
-	if (l >= l0) {
-		const long r = a.row[m] + (l - l0);
-		const double* M = a.mom + (long)blockIdx.z*a.mom_bs + 4*r;
-		const double be = a.alpha[r];
-		const double sg = (a.spin & 1) ? -1.0 : 1.0;
-		E = make_double2(-0.5*be*(M[0] + sg*M[2]), -0.5*be*(M[1] + sg*M[3]));
-		B = make_double2(-0.5*be*(M[1] - sg*M[3]),  0.5*be*(M[0] - sg*M[2]));
-	}
+	const int lb = blockIdx.x*(256*ALM_U) + threadIdx.x + min(m, l0);   // also zero-fill m <= l < l0
+	if (lb > a.lmax) return;
+	const long base = (long)a.mstart[m], row = a.row[m];
 	void* alm = alm_of_batch(a);
-	if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); st_alm(alm, a.dtype, idx, make_double2(f*E.x, f*E.y)); }
-	else { st_alm(alm, a.dtype, idx, E); st_alm(alm, a.dtype, idx + a.cstride, B); }
+	double M0[ALM_U], M1[ALM_U], M2[ALM_U], M3[ALM_U], be[ALM_U];
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int l = lb + 256*u;
+		const bool ok = l <= a.lmax && l >= l0;
+		const long r = row + (l - l0);
+		const double* M = a.mom + (long)blockIdx.z*a.mom_bs + 4*r;
+		M0[u] = ok ? M[0] : 0.0; M1[u] = ok ? M[1] : 0.0; M2[u] = ok ? M[2] : 0.0; M3[u] = ok ? M[3] : 0.0;
+		be[u] = ok ? a.alpha[r] : 0.0;
+	}
+	const double sg = (a.spin & 1) ? -1.0 : 1.0;
+#pragma unroll
+	for (int u = 0; u < ALM_U; u++) {
+		const int l = lb + 256*u;
+		if (l > a.lmax) break;
+		const long idx = base + (long)l*a.lstride;
+		// (rows m <= l < l0: be = 0 and the moments read as 0: E = B = 0)
+		const double2 E = make_double2(-0.5*be[u]*(M0[u] + sg*M2[u]), -0.5*be[u]*(M1[u] + sg*M3[u]));
+		const double2 B = make_double2(-0.5*be[u]*(M1[u] - sg*M3[u]),  0.5*be[u]*(M0[u] - sg*M2[u]));
+		if (a.deriv1) { const double f = sqrt((double)l*(l+1.0)); st_alm(alm, a.dtype, idx, make_double2(f*E.x, f*E.y)); }
+		else { st_alm(alm, a.dtype, idx, E); st_alm(alm, a.dtype, idx + a.cstride, B); }
+	}
 }
 
 // mom[row] = sum over the waves that wrote that row.  A wave writes rows from the end of its phase A on and nothing at all
@@ -2160,8 +2212,8 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
 	const int nm = tb.mmax+1;
 	const int K = tb.spin == 0 ? k_syn0() : k_syns();
-	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, dim3((tb.lmax/2 + 1 + 255)/256, nm, nb), dim3(256), 0, st, ak);
-	else              hipLaunchKernelGGL(alm_pre_spin, dim3((tb.lmax + 1 + 255)/256, nm, nb), dim3(256), 0, st, ak);
+	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, alm_grid(tb.lmax/2 + 1, nm, nb), dim3(256), 0, st, ak);
+	else              hipLaunchKernelGGL(alm_pre_spin, alm_grid(tb.lmax + 1, nm, nb), dim3(256), 0, st, ak);
 	// maps [b0, b0 + n) in one launch
 	auto launch = [&](int b0, int n) {
 		LegK a = make_legk(rs, tb, wk, leg + (size_t)b0*leg_bstride, ld, K, n, leg_bstride);
@@ -2279,7 +2331,7 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 	for (int b0 = 0; b0 < n8; b0 += mper*gmax) launch(b0, std::min(mper*gmax, n8 - b0), ngmax);
 	if (r > 4) launch(n8, r, 2); else if (r > 0) launch(n8, r, 1);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, 0, alm_bstride);
-	hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm, nmm), dim3(256), 0, st, ak);
+	hipLaunchKernelGGL(alm_post_s0, alm_grid(tb.lmax/2 + 1, nm, nmm), dim3(256), 0, st, ak);
 	PXS_HIP(hipGetLastError());
 	if (nmm < nb)
 		leg_analysis(st, rs, tb, wk, leg + (size_t)nmm*leg_bstride, (char*)alm + aesz*(size_t)nmm*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, 0, prof, ld, 1, 0, 0);
@@ -2317,7 +2369,7 @@ static void leg_analysis_spin_mm(hipStream_t st, const RingSet& rs, const LegTab
 	for (int b0 = 0; b0 < n8; b0 += 8*gmax) launch(b0, std::min(8*gmax, n8 - b0), 2);
 	if (r > 4) launch(n8, r, 2); else if (r > 0) launch(n8, r, 1);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, 0, alm_bstride);
-	hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm, nmm), dim3(256), 0, st, ak);
+	hipLaunchKernelGGL(alm_post_spin, alm_grid(tb.lmax + 1, nm, nmm), dim3(256), 0, st, ak);
 	PXS_HIP(hipGetLastError());
 	if (nmm < nb)
 		leg_analysis(st, rs, tb, wk, leg + (size_t)nmm*leg_bstride, (char*)alm + aesz*(size_t)nmm*alm_bstride, alm_dtype, alm_cstride, d_mstart, lstride, 0, prof, ld, 1, 0, 0);
@@ -2415,8 +2467,8 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	}
 	seeds_written(seeds, st);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
-	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, dim3((tb.lmax/2+1+255)/256, nm, nb), dim3(256), 0, st, ak);
-	else              hipLaunchKernelGGL(alm_post_spin, dim3((tb.lmax+1+255)/256, nm, nb), dim3(256), 0, st, ak);
+	if (tb.spin == 0) hipLaunchKernelGGL(alm_post_s0, alm_grid(tb.lmax/2 + 1, nm, nb), dim3(256), 0, st, ak);
+	else              hipLaunchKernelGGL(alm_post_spin, alm_grid(tb.lmax + 1, nm, nb), dim3(256), 0, st, ak);
 	PXS_HIP(hipGetLastError());
 }
 
