@@ -71,6 +71,33 @@ def test_harm_gpu(golden_dir): harm_body(golden_dir)
 @pytest.mark.gpu
 def test_ps_gpu(golden_dir): ps_body(golden_dir)
 
+def lbin_edges_body(shape2):
+	"""Pixels ON bin edges: on a full-sky CAR map the default bin width is the l step of the x axis, so the whole ly = 0 row sits on edges
+	(and the lx = 0 column for brel = ly step / lx step): the bin of each pixel is floor(|l| / bsize) as numpy's float64 expression gives it
+	(enmap._bin_helper, enmap.py:2533-2556) -- the kernel takes a fast square root / reciprocal and must fall back to the exact expression there."""
+	shape, wcs = enmap.fullsky_geometry(shape=shape2)
+	ly, lx = enmap.laxes(shape, wcs)
+	rng = np.random.default_rng(5)
+	m = rng.standard_normal(shape)
+	for brel in (1.0, abs(ly[1])/abs(lx[1]), 0.37):
+		bsize = min(abs(lx[1]), abs(ly[1]))*brel
+		l = np.sqrt(ly[:, None]**2+lx[None, :]**2)
+		n = int(float(np.sqrt(np.max(ly**2)+np.max(lx**2)))/bsize)
+		ib = np.floor(l/bsize).astype(np.int64).ravel()
+		keep = ib < n
+		hit_ref = np.bincount(ib[keep], minlength=n)[:n]
+		sum_ref = np.bincount(ib[keep], weights=m.ravel()[keep], minlength=n)[:n]
+		b, lc, nhit = enmap.lbin(enmap.ndmap(m, wcs), brel=brel, return_nhit=True)
+		assert len(nhit) == n and np.array_equal(nhit, hit_ref), "pixels in the wrong bin (brel %.3f): %d bins differ" % (brel, int(np.sum(nhit != hit_ref)))
+		ok = hit_ref > 0
+		np.testing.assert_allclose(b[ok]*hit_ref[ok], sum_ref[ok], rtol=1e-10, atol=1e-10)
+		b2, _ = enmap.lbin(enmap.ndmap(m, wcs), brel=brel)      # (second call: counts from the cache, one atomic add per pixel)
+		np.testing.assert_allclose(b2[ok], b[ok], rtol=1e-12, atol=1e-13)
+@pytest.mark.hostsim
+def test_lbin_edges_hostsim(): lbin_edges_body((90, 180))
+@pytest.mark.gpu
+def test_lbin_edges_gpu(): lbin_edges_body((90, 180)); lbin_edges_body((1080, 2160)); lbin_edges_body((1350, 2048))
+
 @pytest.mark.gpu
 def test_flatsky_device_resident(golden_dir):
 	"""dmap in -> dmap out: the whole map -> T,E,B harmonics -> 2-D spectra -> binned spectrum chain stays in HBM"""
