@@ -4,6 +4,7 @@ plus enmap.fft / enmap.ifft running on the HIP FFT engine.
 Mirrors: ndmap (enmap.py:33-163), fullsky_geometry (enmap.py:1713-1740), spin_helper
 (enmap.py:3378-3388), area_cyl / pixsize (enmap.py:1032-1036, 1097-1099), fft / ifft
 (enmap.py:1307-1337)."""
+import threading
 import numpy as np
 from . import wcs as wcsutils, fft as enfft
 from .wcs import CarWCS
@@ -252,6 +253,7 @@ def _geo_key(shape, wcs):
 	try: return (tuple(int(v) for v in shape[-2:]), tuple(np.asarray(wcs.wcs.cdelt, float)), tuple(np.asarray(wcs.wcs.crval, float)), tuple(np.asarray(wcs.wcs.crpix, float)), tuple(wcs.wcs.ctype))
 	except Exception: return None
 _axes_cache = {}
+_cache_lock = threading.Lock()      # (the geometry caches below are shared between threads)
 def _dev_axes(shape, wcs, like):
 	"""ly, lx as device f64 arrays living next to `like` (kept per geometry and device: a Monte-Carlo loop calls lbin / map2harm on the
 	same geometry every realisation, and the upload from pageable memory is a host synchronisation each time)"""
@@ -267,8 +269,9 @@ def _dev_axes(shape, wcs, like):
 		ly, lx = laxes(shape, wcs)
 		hit = (torch.from_numpy(np.ascontiguousarray(ly)).to(like.device), torch.from_numpy(np.ascontiguousarray(lx)).to(like.device))
 		if key is not None:
-			if len(_axes_cache) >= 8: _axes_cache.pop(next(iter(_axes_cache)))
-			_axes_cache[key] = hit
+			with _cache_lock:
+				if len(_axes_cache) >= 8: _axes_cache.pop(next(iter(_axes_cache)))
+				_axes_cache[key] = hit
 	return hit
 
 def _rotate_pairs(hmap, spin, iau, inverse):
@@ -360,8 +363,9 @@ def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=No
 		lmax = float(np.sqrt(np.max(ly**2)+np.max(lx**2)))
 		geo = dict(bsize=bs, n=int(lmax/bs), lsum=None, nhit=None)
 		if gkey is not None:
-			if len(_lbin_cache) >= 8: _lbin_cache.pop(next(iter(_lbin_cache)))
-			_lbin_cache[(gkey, bsize, brel)] = geo
+			with _cache_lock:
+				if len(_lbin_cache) >= 8: _lbin_cache.pop(next(iter(_lbin_cache)))
+				_lbin_cache[(gkey, bsize, brel)] = geo
 	bsize, n = geo["bsize"], geo["n"]
 	dev_map, was_host = _to_device(map)
 	d = _data(dev_map)
