@@ -60,6 +60,18 @@ def run_mm_fuzz(ncases, seed, lmax_hi, oracle_lmax=0, nb_hi=22):
 			d = float(np.abs(one-back[i]).max()/np.sqrt(np.mean(np.abs(one)**2)))
 			if f64: worst["ana"] = max(worst["ana"], d)
 			assert d < (1e-11 if f64 else 3e-4), ("analysis: batch against single", what, i, d)
+		# the adjoints take the same kernels the other way round: adjoint_synthesis_2d = Legendre analysis without the quadrature, adjoint_analysis_2d = synthesis
+		if case % 2 == 0:
+			at = np.zeros_like(alm); sht.adjoint_synthesis_2d(alm=at, map=noisy, **kw)
+			mt = np.zeros_like(maps); sht.adjoint_analysis_2d(alm=alm, map=mt, **kw)
+			i = picks[-1]
+			one = np.zeros_like(alm[i]); sht.adjoint_synthesis_2d(alm=one, map=noisy[i], **kw)
+			# (unweighted sums over the rings: the low-m entries, fed by the polar rings, are ~100 x the rms: measured against the largest entry)
+			d = float(np.abs(one-at[i]).max()/np.abs(one).max())
+			assert d < (2e-12 if f64 else 3e-5), ("adjoint synthesis: batch against single", what, i, d)
+			onem = np.zeros((nc, nt, nph), rdt); sht.adjoint_analysis_2d(alm=alm[i], map=onem, **kw)
+			d = float(np.abs(onem-mt[i]).max()/np.abs(onem).max())
+			assert d < (2e-12 if f64 else 3e-5), ("adjoint analysis: batch against single", what, i, d)
 		if f64 and lmax <= oracle_lmax:
 			i = picks[-1]
 			ref = np.zeros((nc, nt, nph)); so.synthesis_2d(alm=alm[i].astype(complex), map=ref, **kw)
