@@ -49,7 +49,9 @@ def symmetric_subset(nring, idx):
 	return np.unique(np.concatenate([idx, nring-1-idx]))
 
 def synth_rings(alm, spin, lmax, theta_sub, mchunk=512, mstart=None):
-	"""leg[nm, nc, nsub] on the rings theta_sub (an ascending, mirror-symmetric list) for m = 0..lmax"""
+	"""leg[nm, nc, nsub] on the rings theta_sub (an ascending, mirror-symmetric list) for m = 0..lmax.
+	(A list that is NOT closed under theta -> pi - theta is accepted, but a lone ring next to the south pole is then good to ~1e-11 of the map rms only:
+	the port works from cos(theta).  tests/test_grid_fuzz.py::synth_rings_any evaluates the mirror-symmetric closure instead.)"""
 	alm = np.atleast_2d(alm); nc = alm.shape[0]
 	out = np.zeros((lmax+1, nc, len(theta_sub)), np.complex128)
 	for m0 in range(0, lmax+1, mchunk):
