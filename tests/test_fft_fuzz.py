@@ -55,10 +55,40 @@ def run_fft_fuzz(ncases, seed, big=True):
 		assert d < tol, ("fft engine against numpy", what, d)
 	return worst
 
+def run_enmap_fft_fuzz(ncases, seed, nmax):
+	"""enmap.fft / ifft (enmap.py:1307-1337): 2-D transform over the last two axes, unitary with normalize=True; real and complex maps, leading
+	axes, float32 / float64, shapes with even, odd and prime sides (real maps of 2-3-5-smooth shape take the fused chain stages of the hot path)"""
+	from pixell_amd import enmap
+	rng = np.random.default_rng(seed)
+	worst = 0.0
+	for case in range(ncases):
+		ny, nx = int(rng.integers(2, nmax)), int(rng.integers(2, nmax))
+		if rng.random() < 0.5: ny, nx = int(rng.choice([24, 45, 60, 96, 100, 135, 150, 240])), int(rng.choice([32, 48, 54, 90, 128, 160, 250, 270]))
+		pre = tuple(int(v) for v in rng.integers(1, 4, int(rng.integers(0, 3))))
+		f64 = rng.random() < 0.75; real = rng.random() < 0.6
+		rdt, cdt = (np.float64, np.complex128) if f64 else (np.float32, np.complex64)
+		x = rng.standard_normal(pre+(ny, nx))
+		if not real: x = x+1j*rng.standard_normal(pre+(ny, nx))
+		x = x.astype(rdt if real else cdt)
+		_, wcs = enmap.fullsky_geometry(shape=(max(ny, 2), max(nx, 2)))
+		normalize = bool(rng.random() < 0.7)
+		what = (case, pre, ny, nx, "real" if real else "complex", rdt.__name__, normalize)
+		f = enmap.fft(enmap.ndmap(x, wcs), normalize=normalize)
+		ref = np.fft.fftn(x.astype(np.complex128), axes=(-2, -1))/(np.sqrt(ny*nx) if normalize else 1.0)
+		tol = 2e-13 if f64 else 2e-5
+		d = float(np.max(np.abs(np.asarray(f)-ref))/np.max(np.abs(ref))); worst = max(worst, d if f64 else 0.0)
+		assert np.asarray(f).shape == ref.shape and d < tol, ("enmap.fft against numpy", what, d)
+		b = enmap.ifft(f, normalize=normalize)
+		refb = x.astype(np.complex128)*(1.0 if normalize else ny*nx)
+		d = float(np.max(np.abs(np.asarray(b)-refb))/np.max(np.abs(refb))); worst = max(worst, d if f64 else 0.0)
+		assert d < tol, ("enmap.ifft(enmap.fft(x)) against x", what, d)
+	return worst
+
 @pytest.mark.hostsim
-def test_fft_fuzz_hostsim(): run_fft_fuzz(25, 3, big=False)
+def test_fft_fuzz_hostsim(): run_fft_fuzz(25, 3, big=False); run_enmap_fft_fuzz(8, 5, 40)
 
 @pytest.mark.gpu
 def test_fft_fuzz_gpu():
 	w = run_fft_fuzz(150, 4)
-	print("\n[fft fuzz] 150 random transforms against numpy.fft: worst relative error (f64) %.2e" % w)
+	w2 = run_enmap_fft_fuzz(60, 6, 700)
+	print("\n[fft fuzz] 150 random transforms against numpy.fft: worst relative error (f64) %.2e; 60 random enmap.fft / ifft pairs: %.2e" % (w, w2))
