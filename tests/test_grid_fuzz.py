@@ -60,6 +60,45 @@ def run_grid_fuzz(ncases, seed, lmax_hi, npts=10):
 		sht.clear_plans()
 	return worst
 
+def run_band_fuzz(ncases, seed, lmax_hi):
+	"""declination bands as explicit rings (the cyl path, curvedsky.py:843-873, 928-962): rows r0 .. r0 + nr of a Fejer-1 or Clenshaw-Curtis grid of n rings,
+	stored plain or flipped in both directions; synthesis, its DERIV1 mode and the adjoint against the oracle"""
+	rng = np.random.default_rng(seed)
+	worst = 0.0
+	for case in range(ncases):
+		lmax = int(rng.integers(6, lmax_hi))
+		kind = str(rng.choice(["F1", "CC"]))
+		n = smooth(rng, 2*lmax+4, 6*lmax+60, even=True)//2+(1 if kind == "CC" else 0)
+		r0 = int(rng.integers(0, max(1, n//3))); nr = int(rng.integers(max(2, n//5), n-r0+1))
+		nph = smooth(rng, 2*lmax+2, 5*lmax+40, even=True)
+		th = (r0+np.arange(nr)+0.5)*np.pi/n if kind == "F1" else (r0+np.arange(nr))*np.pi/(n-1)
+		ms = tri(lmax, lmax)
+		spin, mode = [(0, "STANDARD"), (2, "STANDARD"), (1, "DERIV1"), (1, "STANDARD"), (3, "STANDARD")][int(rng.integers(0, 5))]
+		nca = 1 if (spin == 0 or mode == "DERIV1") else 2
+		alm = so.rand_alm_simple(lmax, nca, 100+case, spin=(spin if mode != "DERIV1" else 0,))
+		flip = rng.random() < 0.5
+		rs = (np.arange(nr)[::-1]*nph+nph-1).astype(np.uint64) if flip else np.arange(nr, dtype=np.uint64)*nph
+		kw = dict(theta=th, nphi=np.full(nr, nph, np.uint64), phi0=np.full(nr, float(rng.uniform(-3, 3))), ringstart=rs, lmax=lmax, mstart=ms, pixstride=-1 if flip else 1)
+		what = (case, kind, n, r0, nr, nph, lmax, spin, mode, flip)
+		ref = so.synthesis(alm=alm, spin=spin, mode=mode, **kw); out = sht.synthesis(alm=alm, spin=spin, mode=mode, **kw)
+		d = float(np.max(np.abs(out-ref))/np.max(np.abs(ref))); worst = max(worst, d)
+		assert d < 1e-11, ("band synthesis against the oracle", what, d)
+		pix = rng.standard_normal(ref.shape)
+		ra = so.adjoint_synthesis(map=pix, spin=spin, mode=mode, **kw); oa = sht.adjoint_synthesis(map=pix, spin=spin, mode=mode, **kw)
+		ra[:, :lmax+1] = ra[:, :lmax+1].real
+		d = float(np.sqrt(np.mean(np.abs(oa-ra)**2))/np.sqrt(np.mean(np.abs(ra)**2))); worst = max(worst, d)
+		assert d < 1e-11, ("band adjoint synthesis against the oracle", what, d)
+		sht.clear_plans()
+	return worst
+
+@pytest.mark.hostsim
+def test_band_fuzz_hostsim(): run_band_fuzz(4, 2, lmax_hi=16)
+
+@pytest.mark.gpu
+def test_band_fuzz_gpu():
+	w = run_band_fuzz(24, 9, lmax_hi=90)
+	print("\n[band fuzz] 24 random declination bands: worst error against the oracle %.2e" % w)
+
 @pytest.mark.hostsim
 def test_grid_fuzz_hostsim():
 	run_grid_fuzz(4, 3, lmax_hi=20, npts=4)
