@@ -86,7 +86,7 @@ def run_mm_fuzz(ncases, seed, lmax_hi, oracle_lmax=0, nb_hi=22):
 
 @pytest.mark.hostsim
 def test_mm_fuzz_hostsim():
-	run_mm_fuzz(3, 7, lmax_hi=22, oracle_lmax=22, nb_hi=10)
+	run_mm_fuzz(2, 7, lmax_hi=20, oracle_lmax=20, nb_hi=9)
 
 @pytest.mark.gpu
 def test_mm_fuzz_gpu():
@@ -95,3 +95,51 @@ def test_mm_fuzz_gpu():
 	w2 = run_mm_fuzz(12, 2, lmax_hi=60, oracle_lmax=60)
 	print("\n[mm fuzz] 52 cases in %.0f s; worst batch-vs-single difference: synthesis %.2e of the map maximum, analysis %.2e of the alm rms; against the oracle %.2e / %.2e"
 		% (time.time()-t0, max(w["syn"], w2["syn"]), max(w["ana"], w2["ana"]), w2["syn_oracle"], w2["ana_oracle"]))
+
+def run_api_fuzz(ncases, seed, lmax_hi):
+	"""curvedsky.alm2map / map2alm on maps with leading axes (curvedsky.py:763-765, 1038-1046 loop over them one ducc0 call at a time; here they go down
+	as batched library calls): full-sky and band CAR maps [pre..., ncomp, ny, nx], spin = [0, 2]; the whole-array call against the loop over the leading axes"""
+	from pixell_amd import curvedsky, enmap
+	rng = np.random.default_rng(seed)
+	for case in range(ncases):
+		lmax = int(rng.integers(8, lmax_hi))
+		ny = smooth(rng, 2*lmax+4, 4*lmax+40, even=True)//2; nx = smooth(rng, 2*lmax+2, 4*lmax+40, even=True)
+		variant = str(rng.choice(["fejer1", "cc"]))
+		if variant == "cc": ny += 1
+		shape, wcs = enmap.fullsky_geometry(shape=(ny, nx), variant=variant)
+		band = rng.random() < 0.35
+		if band:      # a declination band: rows [y0, y1) of the full-sky map (the cyl path)
+			y0 = int(rng.integers(0, ny//4)); y1 = int(rng.integers(3*ny//4, ny+1))
+			wcs = wcs.deepcopy(); wcs.wcs.crpix[1] -= y0; shape = (y1-y0, nx)        # (as enmap.band_geometry cuts it)
+		pre = [(), (2,), (5,), (2, 3), (7,), (9,)][int(rng.integers(0, 6))]
+		ncomp = int(rng.choice([1, 3]))
+		ainfo = curvedsky.alm_info(lmax)
+		nel = ainfo.nelem
+		l_of = np.concatenate([np.arange(m, lmax+1) for m in range(lmax+1)])
+		alm = (rng.standard_normal(pre+(ncomp, nel))+1j*rng.standard_normal(pre+(ncomp, nel)))/(l_of+1.0)
+		alm[..., :lmax+1] = alm[..., :lmax+1].real
+		if ncomp == 3: alm[..., 1:, l_of < 2] = 0
+		what = (case, variant, "band" if band else "full", tuple(shape), lmax, pre, ncomp)
+		m = enmap.ndmap(np.zeros(pre+(ncomp,)+tuple(shape[-2:])), wcs)
+		curvedsky.alm2map(alm, m, spin=[0, 2], ainfo=ainfo)
+		flat_a = alm.reshape((-1, ncomp, nel)); flat_m = np.asarray(m).reshape((-1, ncomp)+tuple(shape[-2:]))
+		for i in sorted(set([0, len(flat_a)-1, len(flat_a)//2])):
+			one = enmap.ndmap(np.zeros((ncomp,)+tuple(shape[-2:])), wcs); curvedsky.alm2map(flat_a[i], one, spin=[0, 2], ainfo=ainfo)
+			d = float(np.abs(np.asarray(one)-flat_m[i]).max()/np.abs(np.asarray(one)).max())
+			assert d < 2e-12, ("alm2map: whole array against the loop", what, i, d)
+		back = curvedsky.map2alm(m, lmax=lmax, spin=[0, 2], ainfo=ainfo)
+		flat_b = np.asarray(back).reshape((-1, ncomp, nel))
+		for i in sorted(set([0, len(flat_a)-1])):
+			one = curvedsky.map2alm(enmap.ndmap(flat_m[i].copy(), wcs), lmax=lmax, spin=[0, 2], ainfo=ainfo)
+			d = float(np.abs(np.asarray(one)-flat_b[i]).max()/np.abs(np.asarray(one)).max())
+			assert d < 2e-11, ("map2alm: whole array against the loop", what, i, d)
+		if not band:
+			d = float(np.sqrt(np.mean(np.abs(np.asarray(back)-alm)**2))/np.sqrt(np.mean(np.abs(alm)**2)))
+			assert d < 1e-11, ("round trip", what, d)
+		curvedsky.sht.clear_plans()
+
+@pytest.mark.hostsim
+def test_api_fuzz_hostsim(): run_api_fuzz(3, 4, 14)
+
+@pytest.mark.gpu
+def test_api_fuzz_gpu(): run_api_fuzz(24, 8, 260)
