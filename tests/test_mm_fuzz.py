@@ -86,7 +86,7 @@ def run_mm_fuzz(ncases, seed, lmax_hi, oracle_lmax=0, nb_hi=22):
 
 @pytest.mark.hostsim
 def test_mm_fuzz_hostsim():
-	run_mm_fuzz(2, 7, lmax_hi=20, oracle_lmax=20, nb_hi=9)
+	run_mm_fuzz(1, 7, lmax_hi=20, oracle_lmax=20, nb_hi=9)
 
 @pytest.mark.gpu
 def test_mm_fuzz_gpu():
