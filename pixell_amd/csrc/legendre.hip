@@ -329,14 +329,23 @@ __global__ __launch_bounds__(256) void reduce_partials(const double* __restrict_
 	mom[r0*4 + i] = s;
 }
 
-// A wave is 'polar' when all its rings have cos^2 > 1/2: it then runs the recurrences in the variable
+// A wave is 'polar' when all its rings have cos^2 > PXS_POLAR_COS2: it then runs the recurrences in the variable
 // -sin^2(theta) (spin 0) resp. -2 sin^2(theta/2) (spin s), with the constant term of the step
 // coefficient adjusted accordingly (table columns c,d).  This keeps full relative precision near the
-// poles, where x = cos(theta) rounds away the information about theta.
+// poles, where x = cos(theta) rounds away the information about theta: there the recurrence sits at its double root (step coefficient
+// 2 - (l theta)^2-ish) and an ABSOLUTE error eps in the coefficient grows like l^2 eps -- 4e-13 of the map rms on the rings next to the poles at
+// lmax 240, 3e-12 at lmax 600 (tests/test_grid_fuzz.py found it), against 1e-14 elsewhere.  The form is exact algebra for every ring but cancels
+// towards the equator (a (1 - sin^2) + b: the spin-0 equator ring of a wave forced into it went from 4e-14 to 7e-13 at lmax 240), so a wave takes it
+// only if its MOST EQUATORIAL ring still has cos^2 > 0.1 (theta < 71.5 deg: at most one digit of the coefficient).  Until round 5 the bound was 1/2:
+// a wave spans 256-512 ring pairs, so grids below 1024-2048 rings -- and the CC-grid detour of the synthesis up to lmax ~2000 -- never ran their
+// polar rings in this form; with 0.1 that shrinks to 644-1288 rings (below which l^2 eps stays under ~4e-12).
+#ifndef PXS_POLAR_COS2
+#define PXS_POLAR_COS2 0.1
+#endif
 __device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
-	const int last = min((wv+1)*K*64, a.npairs) - 1;   // most equatorial pair of the wave (wave-uniform)
+	const int last = min((wv+1)*K*64, a.npairs) - 1;   // most equatorial pair of the wave (wave-uniform; pairs are ordered pole first)
 	const double c = a.cth[last];
-	return c*c > 0.5;
+	return c*c > PXS_POLAR_COS2;
 }
 
 // make a VGPR copy of a wave-uniform value once, so that v_fma_f64 can take it as the addend next to
@@ -841,7 +850,7 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_s0_mm
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
 	const int pbase = wv*64*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64*W, a.npairs) - 1]; return c*c > 0.5; }();
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64*W, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
 	double csq[K], lam1[K], lam2[K]; int sc[K];
 	bool alive;
 	{
@@ -1035,7 +1044,7 @@ template<int NG> __global__ __launch_bounds__(64, 4) void leg_syn_s0_mm(const Le
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
 	const int pbase = wv*64;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64, a.npairs) - 1]; return c*c > 0.5; }();
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
 	double csq[K], lam1[K], lam2[K]; int sc[K];
 	bool alive;
 	{
@@ -1531,7 +1540,7 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_
 	if (nl <= 0) return;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int pbase = wv*32*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 32*W, a.npairs) - 1]; return c*c > 0.5; }();
+	const bool polar = [&] { const double c = a.cth[min(pbase + 32*W, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
 	const int pmine_ = pbase + 32*w + (lane & 31);       // ring pair of this lane's chain
 	SpinChain C;
 	const bool alive = spin_chain_init(a, pmine_, m, half, polar, C);
@@ -1701,7 +1710,7 @@ template<int NG> __global__ __launch_bounds__(64, 4) void leg_syn_spin_mm(const 
 	const int nl = a.lmax - l0 + 1;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int pbase = wv*32;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 32, a.npairs) - 1]; return c*c > 0.5; }();
+	const bool polar = [&] { const double c = a.cth[min(pbase + 32, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
 	SpinChain C;
 	const bool alive = spin_chain_init(a, pbase + (lane & 31), m, half, polar, C);
 	mm_acc acc[NG][4];
