@@ -850,7 +850,7 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_s0_mm
 	const int nk = (a.lmax - m)/2 + 1;
 	const double4_t* __restrict__ coef = a.coef + row0;
 	const int pbase = wv*64*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64*W, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
+	const bool polar = [&] { const double c = a.cth[min(pbase + 64*(w + 1), a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();      // (per wave: its own 64 pairs, its own coefficient stream)
 	double csq[K], lam1[K], lam2[K]; int sc[K];
 	bool alive;
 	{
@@ -1540,7 +1540,7 @@ template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_
 	if (nl <= 0) return;
 	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
 	const int pbase = wv*32*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 32*W, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
+	const bool polar = [&] { const double c = a.cth[min(pbase + 32*(w + 1), a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();      // (per wave)
 	const int pmine_ = pbase + 32*w + (lane & 31);       // ring pair of this lane's chain
 	SpinChain C;
 	const bool alive = spin_chain_init(a, pmine_, m, half, polar, C);
@@ -2210,6 +2210,15 @@ static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact 
 	tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
 	hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
 }
+// Rings per lane of a small ring set: a wave of 64 K ring pairs takes the polar form of the recurrences (leg_wave_polar) only if its most equatorial ring
+// stays within 71.5 degrees of the pole, so on a grid of a few hundred rings the default K leaves the rings next to the poles in the plain form (l^2 eps there).
+// Where a smaller compiled K makes the first wave eligible, take it (the work per ring pair grows by a few percent; these transforms take microseconds).
+static int k_small_grid(const RingSet& rs, int kdef, std::initializer_list<int> smaller) {
+	auto eligible = [&](int k) { const int last = std::min(64*k, rs.npairs) - 1; return last >= 0 && rs.cth[last]*rs.cth[last] > PXS_POLAR_COS2; };
+	if (rs.npairs <= 0 || eligible(kdef)) return kdef;
+	for (int k : smaller) if (k < kdef && eligible(k)) return k;
+	return kdef;
+}
 static int syn_mm_min() { static int v = [] { const char* e = getenv("PXS_SYN_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
 void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                    const void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
@@ -2220,7 +2229,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	wk.almt.ensure(sizeof(double)*(size_t)leg_almt_stride(tb)*nb);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
 	const int nm = tb.mmax+1;
-	const int K = tb.spin == 0 ? k_syn0() : k_syns();
+	const int K = tb.spin == 0 ? k_syn0() : k_small_grid(rs, k_syns(), {2});
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, alm_grid(tb.lmax/2 + 1, nm, nb), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_pre_spin, alm_grid(tb.lmax + 1, nm, nb), dim3(256), 0, st, ak);
 	// maps [b0, b0 + n) in one launch
@@ -2392,7 +2401,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
 	if (tb.spin > 0 && !deriv1 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_spin_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	if (tb.spin == 0 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
-	const int K = tb.spin == 0 ? k_ana0() : k_anas();
+	const int K = tb.spin == 0 ? k_small_grid(rs, k_ana0(), {4}) : k_small_grid(rs, k_anas(), {3, 2});
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = leg_mom_stride(tb);

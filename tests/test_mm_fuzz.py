@@ -59,6 +59,8 @@ def run_mm_fuzz(ncases, seed, lmax_hi, oracle_lmax=0, nb_hi=22):
 			one = np.zeros_like(alm[i]); sht.analysis_2d(alm=one, map=noisy[i], **kw)
 			d = float(np.abs(one-back[i]).max()/np.sqrt(np.mean(np.abs(one)**2)))
 			if f64: worst["ana"] = max(worst["ana"], d)
+			# (1e-12 is reached on grids of a few hundred rings: a wave of the single-map kernels spans 256-512 ring pairs there and leaves the rings next to
+			# the poles in the plain form of the recurrence (l^2 eps), the 64-pair waves of the batched kernels take the polar form; band-limited input: 2e-14 both)
 			assert d < (1e-11 if f64 else 3e-4), ("analysis: batch against single", what, i, d)
 		# the adjoints take the same kernels the other way round: adjoint_synthesis_2d = Legendre analysis without the quadrature, adjoint_analysis_2d = synthesis
 		if case % 2 == 0:
