@@ -42,8 +42,8 @@ static int lab_k(const char* name, int def, int lo, int hi) {
 	const char* v = lab_getenv(name); if (!v) return def;
 	int k = atoi(v); return (k >= lo && k <= hi) ? k : def;
 }
-static int k_syn0() { static int k = lab_k("PXS_K_SYN0", 4, 4, 8) >= 8 ? 8 : 4; return k; }
-static int k_ana0() { static int k0 = lab_k("PXS_K_ANA0", 8, 4, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : 4); return k; }
+static int k_syn0() { static int k0 = lab_k("PXS_K_SYN0", 4, 2, 8); static int k = k0 >= 8 ? 8 : (k0 >= 4 ? 4 : 2); return k; }
+static int k_ana0() { static int k0 = lab_k("PXS_K_ANA0", 8, 2, 12); static int k = k0 >= 12 ? 12 : (k0 >= 8 ? 8 : (k0 >= 4 ? 4 : 2)); return k; }
 static int k_syns() { static int k = lab_k("PXS_K_SYNS", 3, 2, 4); return k; }
 static int k_anas() { static int k = lab_k("PXS_K_ANAS", 4, 2, 6); return k; }   // 4: 149 VGPRs = 3 waves per SIMD (6: 227 = 2 waves; measured 146.9 vs 150.5 ms at config 3)
 static int xcd_map() { static int k = lab_k("PXS_XCD_MAP", 1, 0, 1); return k; }
@@ -2210,12 +2210,21 @@ static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact 
 	tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
 	hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
 }
-// Rings per lane of a small ring set: a wave of 64 K ring pairs takes the polar form of the recurrences (leg_wave_polar) only if its most equatorial ring
-// stays within 71.5 degrees of the pole, so on a grid of a few hundred rings the default K leaves the rings next to the poles in the plain form (l^2 eps there).
-// Where a smaller compiled K makes the first wave eligible, take it (the work per ring pair grows by a few percent; these transforms take microseconds).
+// Rings per lane of a small ring set.  (1) A wave of 64 K ring pairs takes the polar form of the recurrences (leg_wave_polar) only if its most equatorial ring
+// stays within 71.5 degrees of the pole, so on a grid of a few hundred rings the default K leaves the rings next to the poles in the plain form (l^2 eps there):
+// where a smaller compiled K makes the first wave eligible, take it.  (2) Up to 512 ring pairs (lmax ~1000) the launch is short of waves, not of work per wave
+// -- (mmax + 1) x ceil(npairs / 64 K) waves for 1024 SIMDs -- and the smallest K is the fastest (tools/ksmall_ab.sh, profiles/r05_k_small_grids.txt: the reference's
+// benchmark shape 900x1800, lmax 750: 0.365 -> 0.335 ms per round trip, its T/Q/U version 1.047 -> 0.938; at lmax 1500 the defaults are level, at 2500 ahead).
 static int k_small_grid(const RingSet& rs, int kdef, std::initializer_list<int> smaller) {
+#ifdef PXS_HOST_SIM
+	const bool off = [] { const char* e = getenv("PXS_K_SMALL_OFF"); return e && atoi(e) != 0; }();      // (the host simulation runs small grids only: its tests switch the rule off to reach the default kernels)
+#else
+	static const bool off = [] { const char* e = lab_getenv("PXS_K_SMALL_OFF"); return e && atoi(e) != 0; }();
+#endif
+	if (off || rs.npairs <= 0) return kdef;
+	if (rs.npairs <= 512) { int k = kdef; for (int c : smaller) k = std::min(k, c); return k; }
 	auto eligible = [&](int k) { const int last = std::min(64*k, rs.npairs) - 1; return last >= 0 && rs.cth[last]*rs.cth[last] > PXS_POLAR_COS2; };
-	if (rs.npairs <= 0 || eligible(kdef)) return kdef;
+	if (eligible(kdef)) return kdef;
 	for (int k : smaller) if (k < kdef && eligible(k)) return k;
 	return kdef;
 }
@@ -2229,7 +2238,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	wk.almt.ensure(sizeof(double)*(size_t)leg_almt_stride(tb)*nb);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
 	const int nm = tb.mmax+1;
-	const int K = tb.spin == 0 ? k_syn0() : k_small_grid(rs, k_syns(), {2});
+	const int K = tb.spin == 0 ? k_small_grid(rs, k_syn0(), {2}) : k_small_grid(rs, k_syns(), {2});
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, alm_grid(tb.lmax/2 + 1, nm, nb), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_pre_spin, alm_grid(tb.lmax + 1, nm, nb), dim3(256), 0, st, ak);
 	// maps [b0, b0 + n) in one launch
@@ -2239,8 +2248,9 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
 		if (prof) prof->begin(st, 0);
 		if (tb.spin == 0) {
-			if (K == 8) hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
-			else        hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
+			if (K == 8)      hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
+			else if (K == 2) hipLaunchKernelGGL(leg_syn_s0<2>, leg_grid(a), dim3(64), 0, st, a);
+			else             hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
 		} else {
 			if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
 			else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
@@ -2401,7 +2411,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
 	if (tb.spin > 0 && !deriv1 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_spin_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	if (tb.spin == 0 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
-	const int K = tb.spin == 0 ? k_small_grid(rs, k_ana0(), {4}) : k_small_grid(rs, k_anas(), {3, 2});
+	const int K = tb.spin == 0 ? k_small_grid(rs, k_ana0(), {4, 2}) : k_small_grid(rs, k_anas(), {3, 2});
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = leg_mom_stride(tb);
@@ -2469,6 +2479,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		if (tb.spin == 0) {
 			if (K == 12)     hipLaunchKernelGGL(leg_ana_s0<12>, grid, dim3(64), sh, st, a);
 			else if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
+			else if (K == 2) hipLaunchKernelGGL(leg_ana_s0<2>, grid, dim3(64), sh, st, a);
 			else             hipLaunchKernelGGL(leg_ana_s0<4>, grid, dim3(64), sh, st, a);
 		} else {
 			if (K >= 6)      hipLaunchKernelGGL(leg_ana_spin<6>, grid, dim3(64), sh, st, a);

@@ -66,6 +66,16 @@ def test_grid_small_hostsim(geometry, nt, nph, lmax, spin):
 	check_grid(geometry, nt, nph, lmax, spin)
 
 @pytest.mark.hostsim
+@pytest.mark.parametrize("geometry,nt,nph,lmax,spin", [("F1", 32, 64, 30, 0), ("CC", 41, 80, 30, 2), ("MW", 36, 72, 34, 1), ("F1", 140, 280, 64, 2)])
+def test_grid_default_k_hostsim(monkeypatch, geometry, nt, nph, lmax, spin):
+	"""Ring sets of up to 512 pairs run the smallest compiled K (k_small_grid, legendre.hip); the host simulation only sees such grids, so this case switches
+	the rule off (a switch of the simulation build alone) to walk the kernels of the large configurations -- leg_syn_s0<4>, leg_ana_s0<8>, leg_syn_spin<3>, leg_ana_spin<4>."""
+	monkeypatch.setenv("PXS_K_SMALL_OFF", "1")
+	sht.clear_plans()
+	check_grid(geometry, nt, nph, lmax, spin)
+	sht.clear_plans()
+
+@pytest.mark.hostsim
 @pytest.mark.parametrize("spin", [0, 2])
 def test_deterministic_mode_hostsim(monkeypatch, spin):
 	"""pxs_plan_option("deterministic", 1) (sht.set_deterministic): per-wave partial moments + ordered sum instead of atomic adds into the
