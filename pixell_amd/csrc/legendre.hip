@@ -2215,7 +2215,7 @@ static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact 
 // where a smaller compiled K makes the first wave eligible, take it.  (2) Up to 512 ring pairs (lmax ~1000) the launch is short of waves, not of work per wave
 // -- (mmax + 1) x ceil(npairs / 64 K) waves for 1024 SIMDs -- and the smallest K is the fastest (tools/ksmall_ab.sh, profiles/r05_k_small_grids.txt: the reference's
 // benchmark shape 900x1800, lmax 750: 0.365 -> 0.335 ms per round trip, its T/Q/U version 1.047 -> 0.938; at lmax 1500 the defaults are level, at 2500 ahead).
-static int k_small_grid(const RingSet& rs, int kdef, std::initializer_list<int> smaller) {
+static int k_small_grid(const RingSet& rs, int kdef, std::initializer_list<int> smaller, int kmid = 0) {
 #ifdef PXS_HOST_SIM
 	const bool off = [] { const char* e = getenv("PXS_K_SMALL_OFF"); return e && atoi(e) != 0; }();      // (the host simulation runs small grids only: its tests switch the rule off to reach the default kernels)
 #else
@@ -2223,6 +2223,9 @@ static int k_small_grid(const RingSet& rs, int kdef, std::initializer_list<int> 
 #endif
 	if (off || rs.npairs <= 0) return kdef;
 	if (rs.npairs <= 512) { int k = kdef; for (int c : smaller) k = std::min(k, c); return k; }
+	// (3) up to 1400 ring pairs (lmax ~2500: 2700 rings) the synthesis kernels are still 5-12 % faster with K = 2 and the scalar analysis 2-4 % with K = 4; at lmax 4000 the defaults
+	// are 20 % ahead (tools/kmid_ab.sh, tools/kbig_ab.sh, profiles/r05_k_mid_grids.txt)
+	if (kmid > 0 && rs.npairs <= 1400) return kmid;
 	auto eligible = [&](int k) { const int last = std::min(64*k, rs.npairs) - 1; return last >= 0 && rs.cth[last]*rs.cth[last] > PXS_POLAR_COS2; };
 	if (eligible(kdef)) return kdef;
 	for (int k : smaller) if (k < kdef && eligible(k)) return k;
@@ -2238,7 +2241,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 	wk.almt.ensure(sizeof(double)*(size_t)leg_almt_stride(tb)*nb);
 	AlmK ak = make_almk(tb, wk, alm, alm_dtype, alm_cstride, d_mstart, lstride, deriv1, alm_bstride);
 	const int nm = tb.mmax+1;
-	const int K = tb.spin == 0 ? k_small_grid(rs, k_syn0(), {2}) : k_small_grid(rs, k_syns(), {2});
+	const int K = tb.spin == 0 ? k_small_grid(rs, k_syn0(), {2}, 2) : k_small_grid(rs, k_syns(), {2}, 2);
 	if (tb.spin == 0) hipLaunchKernelGGL(alm_pre_s0, alm_grid(tb.lmax/2 + 1, nm, nb), dim3(256), 0, st, ak);
 	else              hipLaunchKernelGGL(alm_pre_spin, alm_grid(tb.lmax + 1, nm, nb), dim3(256), 0, st, ak);
 	// maps [b0, b0 + n) in one launch
@@ -2411,7 +2414,7 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 	PXS_REQUIRE(nb >= 1, "leg_analysis: nb must be >= 1");
 	if (tb.spin > 0 && !deriv1 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_spin_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
 	if (tb.spin == 0 && nb >= ana_mm_min() && !wk.deterministic) { leg_analysis_mm(st, rs, tb, wk, leg, alm, alm_dtype, alm_cstride, d_mstart, lstride, prof, ld, nb, alm_bstride, leg_bstride); return; }
-	const int K = tb.spin == 0 ? k_small_grid(rs, k_ana0(), {4, 2}) : k_small_grid(rs, k_anas(), {3, 2});
+	const int K = tb.spin == 0 ? k_small_grid(rs, k_ana0(), {4, 2}, 4) : k_small_grid(rs, k_anas(), {3, 2});
 	const int nm = tb.mmax+1;
 	const int nwave = (rs.npairs + 64*K - 1)/(64*K);
 	const long n4 = leg_mom_stride(tb);
