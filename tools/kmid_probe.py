@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, torch
 from pixell_amd import curvedsky, enmap, sht
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
-for (ny, nx), lmax in [((1100, 2200), 1050), ((1350, 2700), 1300), ((1600, 3200), 1500), ((2160, 4320), 2000), ((2700, 5400), 2500)]:
+sizes = [((1100, 2200), 1050), ((1350, 2700), 1300), ((1600, 3200), 1500), ((2160, 4320), 2000), ((2700, 5400), 2500)] if os.environ.get("KMID_SIZES", "") == "" else [((3000, 6000), 2900), ((3200, 6400), 3100), ((3600, 7200), 3500), ((4050, 8100), 3900)]
+for (ny, nx), lmax in sizes:
 	shape, wcs = enmap.fullsky_geometry(shape=(ny, nx)); ainfo = curvedsky.alm_info(lmax)
 	g = torch.Generator(device="cuda"); g.manual_seed(1)
 	alm = torch.randn((3, ainfo.nelem), dtype=torch.complex128, device="cuda", generator=g)
