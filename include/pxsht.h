@@ -101,7 +101,8 @@ int pxs_plan_option(pxs_plan* plan, const char* name, int64_t value);
 
 /* What a plan does: "analysis_form" = the form pxs_analysis runs now (0 interpolant, 1 ring weights, 2 fine-CC form of ducc0's
  * route), "ncc_circle" = N_cc, the circle of the CC grid of the Legendre stage (0: none), "ducc_ncc_circle" = ducc0's N_cc for
- * the plan's lmax. */
+ * the plan's lmax, "theta_line" = 1 if the theta resampling of pxs_analysis runs as one kernel with the line resident on a CU
+ * (the circle sizes compiled into thetaline.hip; PXS_THETA_LINE=0 switches it off), 0 if as the five-stage chain: same results. */
 int pxs_plan_query(const pxs_plan* plan, const char* name, int64_t* value);
 
 /* ducc0.sht.experimental.get_gridweights (curvedsky.py:501, 855): out[ntheta], sum = 4 pi. Host memory. */

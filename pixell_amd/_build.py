@@ -14,12 +14,19 @@ def needs_build(lib=LIB):
 	deps = sources()+glob.glob(os.path.join(CSRC, "*.hpp"))+[os.path.join(HERE, "..", "include", "pxsht.h")]
 	return any(os.path.getmtime(d) > t for d in deps)
 
+# per-file flags.  thetaline.hip: SimplifyCFG's sinking of common instructions merges the register-array accesses of the radix
+# switch into pointer phis before the array is split into scalars, and the whole line then lives in scratch memory (regfft_dev.hpp).
+FILE_FLAGS = {"thetaline.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+
+def flags_for(src):
+	return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]+FILE_FLAGS.get(os.path.basename(src), [])+os.environ.get("PXS_EXTRA_HIPCC_FLAGS", "").split()
+
 def hipcc_path():
 	return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 def compile_one(src, obj, verbose=False):
 	"""one translation unit -> gfx950 object (the build check of tests/test_capi.py compiles one with this, always for real)"""
-	cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]+os.environ.get("PXS_EXTRA_HIPCC_FLAGS", "").split()+["-c", src, "-o", obj]
+	cmd = [hipcc_path()]+flags_for(src)+["-c", src, "-o", obj]
 	if verbose: print(" ".join(cmd))
 	subprocess.check_call(cmd)
 	return obj
@@ -38,7 +45,7 @@ def build(force=False, verbose=False):
 		o = os.path.join(bdir, os.path.basename(s)+".o")
 		if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s),
 				max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.hpp")))):
-			cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]+os.environ.get("PXS_EXTRA_HIPCC_FLAGS", "").split()+["-c", s, "-o", o]
+			cmd = [hipcc]+flags_for(s)+["-c", s, "-o", o]
 			if verbose: print(" ".join(cmd))
 			procs.append((cmd, subprocess.Popen(cmd)))
 		objs.append(o)

@@ -21,6 +21,7 @@
 // Replaces ducc0's ring FFTs / resample_theta inside synthesis_2d / analysis_2d (pixell/curvedsky.py:907-924, 1032-1046).
 #include "fftchain.hpp"
 #include "fft_dev.hpp"
+#include "chain_dev.hpp"
 #include <algorithm>
 #include <set>
 #include <type_traits>
@@ -95,14 +96,6 @@ struct StageBase {
 	static constexpr int PFI = 0;
 	__device__ __forceinline__ const void* pfaddr(const TileC&, int) const { return nullptr; }
 };
-
-__device__ __forceinline__ double2 cscale(double2 a, double f) { return make_double2(a.x*f, a.y*f); }
-__device__ __forceinline__ double2 rd_real(const void* p, int dtype, long off) {
-	return dtype == PX_F32 ? make_double2((double)((const float*)p)[off], 0.0) : make_double2(((const double*)p)[off], 0.0);
-}
-__device__ __forceinline__ void wr_real(void* p, int dtype, long off, double v) {
-	if (dtype == PX_F32) ((float*)p)[off] = (float)v; else ((double*)p)[off] = v;
-}
 
 // (Tried: persistent workgroups that issue the global loads of their NEXT tile into registers before the LDS passes of the current
 // one.  The prefetch registers pushed the single-transform stages to 151-169 VGPRs and the two-transform stages to 256 (172 with
@@ -213,29 +206,6 @@ template<class S, int NT, int MAXE> __global__ PXS_CH_BOUNDS void chain_kernel(c
 // ---------------------------------------------------------------------------------------------------------------
 // theta chains
 // ---------------------------------------------------------------------------------------------------------------
-// value of circle sample j of the packed pair of columns (2p, 2p+1): even + odd extension (cf. LD_MIRROR_PAIR in fft.hip)
-struct PairSrc {
-	const double2* leg; long ld; int nr; int N; int mir_c; int a_odd; int ncol; long cstride;      // cstride: elements between the components of a launch
-	const double2* w;        // optional per-ring weight (.x), applied to a ring sample and to its mirror image
-	int plain, conj;         // plain: no packing, no extension: column p itself (the 2-D FFTs); conj: conjugated (backward transform as conj FFT conj)
-	__device__ __forceinline__ double2 get(int comp, int p, int j) const {
-		if (plain) { const double2 v = leg[(long)comp*cstride + (long)p*ld + j]; return conj ? cconj(v) : v; }
-		int src = j; bool mir = false;
-		if (j >= nr) { src = N - j - mir_c; if (src < 0) src += N; mir = true; }
-		const int tj = 2*j + mir_c;
-		const bool selfm = tj == 0 || tj == N || tj == 2*N;       // the sample is its own mirror image
-		const int ca = 2*p;
-		const double2* lc = leg + (long)comp*cstride;
-		double2 va = lc[(long)ca*ld + src];
-		double2 vb = (ca + 1 < ncol) ? lc[(long)(ca + 1)*ld + src] : make_double2(0, 0);
-		double2& vo = a_odd ? va : vb;
-		if (selfm) vo = make_double2(0, 0);
-		else if (mir) { vo.x = -vo.x; vo.y = -vo.y; }
-		const double2 sum = cadd(va, vb);
-		return w ? cscale(sum, w[src].x) : sum;
-	}
-};
-
 // pass 1 of the first transform of a chain: circle index j = b*j1 + j2, line = j2, a-point FFT over j1, four-step twiddle
 struct StFirst : StageBase {
 	static constexpr int SID = 0;
@@ -923,6 +893,7 @@ void FftChain::ring_scratch(long nring, int nc, bool analysis, size_t& b1) const
 void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
                      int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* wcc)
 {
+	if (line_analysis(st, tp, true, leg, ldleg, nr, mir_c, leg_cc, ldcc, ncc, nc, nm, spin, lmax, ph_shift, sigma, wcc, nullptr)) return;
 	const long npair = (nm + 1)/2;
 	const long g = tp.g, bN = tp.bN, g2 = tp.g2, ac = tp.ac;
 	const long ldY1 = pad8(bN), ldZ2 = pad8(g), ldV3 = pad8(g2), ldU4 = pad8(g);
@@ -989,6 +960,7 @@ void FftChain::to_cc(hipStream_t st, const ThetaPlan& tp, const double2* leg, lo
 void FftChain::from_cc_adjoint(hipStream_t st, const ThetaPlan& tp, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
                                int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* w, const double2* wring)
 {
+	if (line_analysis(st, tp, false, leg, ldleg, nr, mir_c, leg_cc, ldcc, ncc, nc, nm, spin, lmax, ph_shift, nullptr, w, wring)) return;
 	const long npair = (nm + 1)/2;
 	const long g = tp.g, bN = tp.bN, ac = tp.ac;
 	const long ldY1 = pad8(bN), ldU = pad8(g);

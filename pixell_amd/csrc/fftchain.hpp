@@ -6,6 +6,7 @@
 #include <tuple>
 #include <map>
 #include <mutex>
+#include <memory>
 
 namespace pxs {
 
@@ -60,6 +61,11 @@ public:
 	bool fft2_real(hipStream_t st, const void* in, int in_dtype, double2* out, long npre, long ny, long nx, bool forward, double scale);
 	// 2-D FFT of complex128 [npre][ny][nx] (in == out allowed); false if nx or ny has no usable factorisation
 	bool fft2_c2c(hipStream_t st, const double2* in, double2* out, long npre, long ny, long nx, bool forward, double scale);
+	// single-kernel form of to_cc (has_mid) / from_cc_adjoint for lines that fit a CU (thetaline.hip): one workgroup per pair of columns,
+	// no HBM intermediates.  false: not eligible (sizes, radices) or switched off (PXS_THETA_LINE=0) -- the caller runs the stage chain.
+	bool line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
+	                   int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* w, const double2* wring);
+	static bool line_takes(const ThetaPlan& tp, bool has_mid);      // ... would it (then the call needs no theta scratch)
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
 	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc, 3: to_cc_adjoint)
 	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);
@@ -76,6 +82,7 @@ private:
 	Split ra_, rs_;           // ring FFT splits: analysis, synthesis
 	long nphi_ = 0;
 	DevBuf s1_, s2_;          // ping-pong scratch
+	std::shared_ptr<struct ThetaLine> tl_;     // plans of the single-kernel theta engine
 };
 
 } // namespace pxs

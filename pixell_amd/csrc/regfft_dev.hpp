@@ -1,0 +1,197 @@
+// Register-resident line FFT for gfx950: one workgroup of NT threads holds a whole line of n complex128 points in its
+// registers (PMAX points per thread at most) and transforms it with Stockham decimation-in-frequency passes whose butterflies
+// (radix 2 ... 16) run entirely in registers.  Between two passes the line goes through the LDS ONE COMPONENT AT A TIME
+// (re, then im): the LDS holds n doubles, so a line of 16 128 points (258 KB) fits a CU -- 129 KB in the LDS during an exchange,
+// the other component in registers.  Used by the single-kernel theta resampling engine (thetaline.hip); host model of the same
+// index arithmetic: tools/regfft_model.py.
+//
+// Pass p (radix R, s = product of the earlier radices, nb = n / R butterflies, butterfly b = q + s*pp, q = b mod s):
+//   reads   a_k = x[b + nb*k]                            -- the same pattern for every pass: thread t holds butterflies t + NT*i
+//   writes  y[q + s*(R*pp + j)] = W_n^{(b - q) j} * sum_k a_k W_R^{jk}
+// After the last pass (s = nb) the outputs sit in natural order, output j of butterfly b being X[b + nb*j]: a transform that
+// follows with the same first radix can start from the registers without an exchange (the pointwise step of the theta chain).
+//
+// The radix sequence of a transform is a TEMPLATE parameter (RfSeq<16, 16, 9, 7>): lengths, strides, butterflies per thread and every
+// register index are compile-time constants and a transform is straight-line code.  What the compiler needs for the line to STAY in
+// registers was found the hard way (hipcc 7.2; each step measured in spill counts at the 128 registers of a 1024-thread workgroup):
+//  * a first form chose the radix of each pass at run time (a switch over 12 radices inside the pass loop): the register array
+//    stayed in scratch memory (SimplifyCFG merged the array accesses of the cases into pointer phis before SROA had split the array);
+//    with that pass disabled and every index a template constant (sfor, not `#pragma unroll`) the array was split, and the allocator
+//    spilled 1100-2700 times -- each further case of the switch added several hundred: C4's theta resampling 621 ms against the 86 of
+//    the stage chain;
+//  * no per-lane branch around the work of a register slot (lanes without work compute on what they hold and nothing reads it):
+//    with a branch per slot 2400 spills where the select form had 150;
+//  * the thread index passes through an opaque move at the start of every phase, or everything derived from it (the LDS addresses of
+//    every slot of every pass) is hoisted out of the line loop into registers that are then spilled.
+#pragma once
+#include "fft_dev.hpp"
+#include <type_traits>
+
+namespace pxs {
+
+static constexpr int RF_TWL = 128;         // two-level twiddles: W_n^e = lo[e mod 128] * hi[e / 128]
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = A ... B-1
+template<int A, int B, class F> __device__ __forceinline__ void sfor(F&& f) {
+	if constexpr (A < B) { f(std::integral_constant<int, A>()); sfor<A + 1, B>(static_cast<F&&>(f)); }
+}
+#define RF_INL __attribute__((always_inline))
+#define RF_IDX(C) decltype(C)::value
+
+#ifdef PXS_HOST_SIM
+#define RF_OPAQUE(x) do {} while (0)
+#define RF_PIN2(a) do {} while (0)
+#define RF_FENCE() do {} while (0)
+#else
+#define RF_OPAQUE(x) asm volatile("" : "+v"(x))
+#define RF_PIN2(a) asm volatile("" : "+v"((a).x), "+v"((a).y))
+#define RF_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+// a scheduling fence every PXS_RF_GROUP register slots: left alone the scheduler issues the reads of ALL slots of a phase before the
+// first use (up to 84 registers next to the 84 of the line); the other waves of the workgroup cover the latency of a group
+#ifndef PXS_RF_GROUP
+#define PXS_RF_GROUP 6
+#endif
+#define RF_FENCE_SLOT(c) do { if (((c) + 1) % PXS_RF_GROUP == 0) RF_FENCE(); } while (0)
+#define RF_BARRIER() PXS_LDS_BARRIER()      /* LDS traffic only: global stores of the previous line may still be in flight */
+
+// radix sequence of a transform of N = product points
+template<int... Rs> struct RfSeq {
+	static constexpr int NP = sizeof...(Rs);
+	static constexpr int N = (Rs * ... * 1);
+	static constexpr int rad(int p) { constexpr int r[NP] = {Rs...}; return r[p]; }
+	static constexpr int stride(int p) { int s = 1; for (int q = 0; q < p; q++) s *= rad(q); return s; }      // product of the earlier radices
+};
+// pass P of sequence S on NT threads
+template<class S, int P, int NT> struct RfPassT {
+	static constexpr int R = S::rad(P), s = S::stride(P), n = S::N, nb = n/R, K = (nb + NT - 1)/NT, slots = K*R;
+	static constexpr bool twiddled = s < nb;
+};
+
+// R-point butterfly on a local array; output j is left in position slot(j) (the composite radices of fft_dev.hpp permute)
+template<int R> struct RfB;
+#define PXS_RFB_PRIM(RR) template<> struct RfB<RR> { \
+	static __device__ __forceinline__ void run(double2* a) { butterfly<RR>(a); } \
+	static constexpr __host__ __device__ int slot(int j) { return j; } };
+#define PXS_RFB_COMP(AA, BB) template<> struct RfB<AA*BB> { \
+	static __device__ __forceinline__ void run(double2* a) { butterfly_comp<AA, BB>(a); } \
+	static constexpr __host__ __device__ int slot(int j) { return BB*(j % AA) + j/AA; } };
+PXS_RFB_PRIM(2) PXS_RFB_PRIM(3) PXS_RFB_PRIM(4) PXS_RFB_PRIM(5) PXS_RFB_PRIM(7)
+PXS_RFB_COMP(3, 2) PXS_RFB_COMP(4, 2) PXS_RFB_COMP(3, 3) PXS_RFB_COMP(5, 2) PXS_RFB_COMP(4, 3) PXS_RFB_COMP(5, 3) PXS_RFB_COMP(4, 4)
+
+template<int NT, int PMAX> struct RegFft {
+	using Regs = double2 (&)[PMAX];
+	// LDS word of line index i (one padding word per 16: the strided writes of the early passes spread over the banks)
+	static __device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
+
+	// read pattern of pass PS: slot c = i*R + k holds x[tid + NT*i + nb*k] (threads with tid + NT*i >= nb: no element; they get f(0)).
+	// Every slot of the pass is overwritten for every lane, so that the compiler sees the old contents die.
+	template<class PS, class F> static __device__ __forceinline__ void fill(Regs v, int tid, F&& f) {
+		static_assert(PS::slots <= PMAX, "pass needs more register slots than the kernel has");
+		RF_OPAQUE(tid);
+		sfor<0, PS::slots>([&](auto C) RF_INL {
+			constexpr int c = RF_IDX(C), i = c/PS::R, k = c % PS::R;
+			const bool ok = (i + 1)*NT <= PS::nb || tid < PS::nb - NT*i;
+			v[c] = f(ok ? tid + (NT*i + PS::nb*k) : 0);
+			RF_FENCE_SLOT(c);
+		});
+	}
+	template<class PS, int COMP> static __device__ __forceinline__ void read_comp(Regs v, int tid, const double* line) {
+		static_assert(PS::slots <= PMAX, "pass needs more register slots than the kernel has");
+		RF_OPAQUE(tid);
+		sfor<0, PS::slots>([&](auto C) RF_INL {
+			constexpr int c = RF_IDX(C), i = c/PS::R, k = c % PS::R;
+			const bool ok = (i + 1)*NT <= PS::nb || tid < PS::nb - NT*i;
+			const double x = line[pad(ok ? tid + (NT*i + PS::nb*k) : 0)];
+			if (COMP) v[c].y = x; else v[c].x = x;
+			RF_FENCE_SLOT(c);
+		});
+	}
+	// outputs of pass PS (output j of butterfly i in slot i*R + j) to their Stockham positions; COMP: 0 = re, 1 = im into a line of doubles
+	template<class PS, int COMP> static __device__ __forceinline__ void write_comp(Regs v, int tid, double* line) {
+		RF_OPAQUE(tid);
+		sfor<0, PS::K>([&](auto I) RF_INL {
+			constexpr int i = RF_IDX(I);
+			const int b = tid + NT*i;
+			if ((i + 1)*NT <= PS::nb || b < PS::nb) {
+				const int base = PS::R*b - (PS::R - 1)*(b % PS::s);
+				sfor<0, PS::R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); line[pad(base + PS::s*j)] = COMP ? v[i*PS::R + j].y : v[i*PS::R + j].x; });
+			}
+		});
+	}
+	// ... both components at once (the line area must hold n complex points)
+	template<class PS> static __device__ __forceinline__ void write_c128(Regs v, int tid, double2* line) {
+		RF_OPAQUE(tid);
+		sfor<0, PS::K>([&](auto I) RF_INL {
+			constexpr int i = RF_IDX(I);
+			const int b = tid + NT*i;
+			if ((i + 1)*NT <= PS::nb || b < PS::nb) {
+				const int base = PS::R*b - (PS::R - 1)*(b % PS::s);
+				sfor<0, PS::R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); line[pad(base + PS::s*j)] = v[i*PS::R + j]; });
+			}
+		});
+	}
+	// the butterflies of a pass and their Stockham twiddles (tw: this length's two-level table in the LDS)
+	template<class PS> static __device__ __forceinline__ void compute(Regs v, int tid, const double2* tw) {
+		constexpr int R = PS::R;
+		RF_OPAQUE(tid);
+		sfor<0, PS::K>([&](auto I) RF_INL {
+			constexpr int i = RF_IDX(I);
+			const int b = min(tid + NT*i, PS::nb - 1);      // (lanes past the last butterfly compute on what they hold; nothing reads it)
+			double2 a[R];
+			sfor<0, R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); a[j] = v[i*R + j]; });
+			RfB<R>::run(a);
+			if constexpr (PS::twiddled) {
+				const int e = b - b % PS::s;
+				const double2 w1 = cmul(tw[e & (RF_TWL - 1)], tw[RF_TWL + (e >> 7)]);
+				// W^j, j = 1 ... R-1, as two chains (odd and even powers) that advance by W^2
+				const double2 w2 = cmul(w1, w1);
+				double2 wo = w1, we = w2;
+#pragma unroll
+				for (int j = 1; j < R; j++) {
+					double2& x = a[RfB<R>::slot(j)];
+					if (j & 1) { x = cmul(x, wo); if (j + 2 < R) wo = cmul(wo, w2); }
+					else       { x = cmul(x, we); if (j + 2 < R) we = cmul(we, w2); }
+				}
+			}
+			sfor<0, R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); v[i*R + j] = a[RfB<R>::slot(j)]; RF_PIN2(v[i*R + j]); });
+			RF_FENCE();      // (the butterflies of a thread one after the other: interleaved they need their temporaries K times)
+		});
+	}
+	// pointwise step between a transform that ends with pass PS and one that starts with the same radix: output j of butterfly (tid, i)
+	// becomes input j of the same butterfly; f(value, line index)
+	template<class PS, class F> static __device__ __forceinline__ void pointwise(Regs v, int tid, F&& f) {
+		RF_OPAQUE(tid);
+		sfor<0, PS::slots>([&](auto C) RF_INL {
+			constexpr int c = RF_IDX(C), i = c/PS::R, j = c % PS::R;
+			const int b = min(tid + NT*i, PS::nb - 1);
+			v[c] = f(v[c], b + PS::nb*j);
+			RF_FENCE_SLOT(c);
+		});
+	}
+
+	// the registers hold the outputs of pass PP; they take the read pattern of pass PN (of the same or of another transform of the same length)
+	template<class PP, class PN> static __device__ __forceinline__ void exchange(Regs v, int tid, double* line) {
+		RF_BARRIER();
+		write_comp<PP, 0>(v, tid, line);
+		RF_BARRIER();
+		read_comp<PN, 0>(v, tid, line);
+		RF_BARRIER();
+		write_comp<PP, 1>(v, tid, line);
+		RF_BARRIER();
+		read_comp<PN, 1>(v, tid, line);
+	}
+
+	// forward transform of sequence S.  In: the registers hold the line in the read pattern of pass 0.  Out: they hold the outputs of the
+	// last pass.  tw: this length's twiddle table in the LDS.
+	template<class S> static __device__ __forceinline__ void run(Regs v, int tid, double* line, const double2* tw) {
+		sfor<0, S::NP>([&](auto P) RF_INL {
+			constexpr int p = RF_IDX(P);
+			using PS = RfPassT<S, p, NT>;
+			compute<PS>(v, tid, tw);
+			if constexpr (p + 1 < S::NP) exchange<PS, RfPassT<S, p + 1, NT>>(v, tid, line);
+		});
+	}
+};
+
+} // namespace pxs

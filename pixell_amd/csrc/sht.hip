@@ -956,6 +956,7 @@ int pxs_plan_option(pxs_plan* p, const char* name, int64_t value) {
 }
 
 static int ana_form_now(const pxs_plan* p);
+static int theta_line_now(const pxs_plan* p);
 int pxs_plan_query(const pxs_plan* p, const char* name, int64_t* value) {
 	PXS_TRY
 	PXS_REQUIRE(p && name && value, "pxs_plan_query: null argument");
@@ -963,6 +964,7 @@ int pxs_plan_query(const pxs_plan* p, const char* name, int64_t* value) {
 	if (n == "analysis_form") *value = ana_form_now(p);
 	else if (n == "ncc_circle") *value = p->ncc > 0 ? p->Ncc : 0;
 	else if (n == "ducc_ncc_circle") *value = FftChain::ducc_ncc(p->lmax);
+	else if (n == "theta_line") *value = theta_line_now(p);
 	else throw Error(PXS_ERR_ARG, std::string("pxs_plan_query: unknown name '") + name + "'");
 	PXS_CATCH
 }
@@ -1073,6 +1075,14 @@ struct AnaSet { const ThetaPlan* tp; const double2* sigma; const double2* wcc; c
 static AnaSet ana_set(const pxs_plan* p) {
 	if (p->ana_weights != 0 && p->Mf > 0) return AnaSet{&p->tpf, p->sigma_f.as<double2>(), p->wcc_f.as<double2>(), p->whalf_f.as<double2>(), p->Mf, true};
 	return AnaSet{&p->tp, p->sigma.as<double2>(), p->wcc.as<double2>(), p->whalf.as<double2>(), p->M, false};
+}
+// 1: the theta resampling of pxs_analysis (the plan's current form) runs as ONE kernel per call (thetaline.hip), 0: as the stage chain
+static int theta_line_now(const pxs_plan* p) {
+	if (!p->chain_theta()) return 0;
+	const AnaPath path = ana_path(p, 0);
+	if (path == ANA_CHAIN) return FftChain::line_takes(*ana_set(p).tp, true) ? 1 : 0;
+	if (path == ANA_CC_WEIGHTS) return FftChain::line_takes(p->tp, false) ? 1 : 0;
+	return 0;
 }
 static int ana_form_now(const pxs_plan* p) {
 	const AnaPath path = ana_path(p, 0);
@@ -1199,7 +1209,11 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 	const bool via_cc = (p->is_grid || (p->band && th)) && (spin == 0 ? p->syn_via_cc0 : p->syn_via_cc) && p->ncc > 0;
 	LegTables& tb = p->table(spin);
 	size_t c1 = 0, c2 = 0, r1 = 0;
-	auto theta = [&](int kind) { if (th) FftChain::theta_scratch((kind == 0 || kind == 3) ? *ana_set(p).tp : p->tp, (int)nm, nct, kind, c1, c2); };
+	auto theta = [&](int kind) {
+		if (!th) return;
+		const ThetaPlan& tpk = (kind == 0 || kind == 3) ? *ana_set(p).tp : p->tp;
+		if (kind <= 1 && FftChain::line_takes(tpk, kind == 0)) return;      // the single-kernel engine (thetaline.hip) has no intermediates
+		FftChain::theta_scratch(tpk, (int)nm, nct, kind, c1, c2); };
 	if (synthesis && !adjoint) {                        // alm -> map
 		p->wk.almt.ensure(sizeof(double)*4*(tb.nrows + 4)*nb);
 		p->leg.ensure(c16*nct*nm*ldm);

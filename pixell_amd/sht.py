@@ -126,7 +126,7 @@ class Plan:
 		"deterministic" = 0 | 1 (ordered, bitwise repeatable analysis sums; see set_deterministic)"""
 		_lib.check(_lib.load().pxs_plan_option(self.handle, name.encode(), int(value)))
 	def query(self, name):
-		"""pxs_plan_query: "analysis_form", "ncc_circle", "ducc_ncc_circle" """
+		"""pxs_plan_query: "analysis_form", "ncc_circle", "ducc_ncc_circle", "theta_line" """
 		v = ctypes.c_int64()
 		_lib.check(_lib.load().pxs_plan_query(self.handle, name.encode(), ctypes.byref(v)))
 		return int(v.value)

@@ -1,0 +1,47 @@
+"""The single-kernel theta resampling engine (pixell_amd/csrc/thetaline.hip) against the five-stage chain it replaces
+(FftChain::to_cc / from_cc_adjoint): same plan, same input, PXS_THETA_LINE switched per call.  The chain is pinned to the oracle by
+tests/test_sht_parity.py; here the two device paths must agree to rounding.  In the GPU-less container the host simulator runs
+the configuration compiled for it (360 rings, lmax 250: every feature of the C2 / C4 configuration at a fifteenth of its size)."""
+import numpy as np, pytest
+from pixell_amd import sht, _lib
+
+def relrms(a, b): return float(np.sqrt(np.mean(np.abs(a - b)**2)/np.mean(np.abs(b)**2)))
+
+def run_pair(nt, nph, lmax, spin, nb, monkeypatch, seed=3):
+	nc = 1 if spin == 0 else 2
+	ms = sht.tri_mstart(lmax, lmax); nalm = int(ms[-1]) + lmax + 1
+	kw = dict(spin=spin, lmax=lmax, geometry="F1", phi0=0.1, mstart=ms)
+	rng = np.random.default_rng(seed)
+	shape = (nb, nc, nt, nph) if nb > 1 else (nc, nt, nph)
+	noise = rng.standard_normal(shape)
+	out = {}
+	for line in ("1", "0"):
+		monkeypatch.setenv("PXS_THETA_LINE", line)
+		plan = sht.grid_plan("F1", nt, nph, 0.1, (False, False), lmax, lmax, ms, 1)
+		assert plan.query("theta_line") == int(line)
+		alm = np.zeros(shape[:-2] + (nalm,), complex)
+		sht.analysis_2d(alm=alm, map=noise, **kw)                       # to_cc (the default, fine-CC form)
+		alm2 = np.zeros_like(alm)
+		sht.adjoint_synthesis_2d(alm=alm2, map=noise, **kw)             # from_cc_adjoint (grids with > 1.25 / 1.5 N_cc/2 rings)
+		out[line] = (alm, alm2)
+	assert relrms(out["1"][0], out["0"][0]) < 1e-13, relrms(out["1"][0], out["0"][0])
+	assert relrms(out["1"][1], out["0"][1]) < 1e-13, relrms(out["1"][1], out["0"][1])
+	assert np.abs(out["0"][0]).max() > 0 and np.abs(out["0"][1]).max() > 0
+
+@pytest.mark.hostsim
+@pytest.mark.parametrize("spin,nb", [(0, 1), (1, 1)])      # (251 columns: the last pair has one member; spin 1: the odd column first)
+def test_line_engine_hostsim(monkeypatch, spin, nb):
+	assert _lib.is_hostsim()
+	run_pair(360, 720, 250, spin, nb, monkeypatch)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spin,nb", [(0, 1), (2, 1), (0, 3)])
+def test_line_engine_c2_size_gpu(monkeypatch, spin, nb):
+	"""BASELINE C2 / C4 grid: 5400 x 10800, lmax 4000 (N = 10 800, N_cc = 8064, M = 16 128)"""
+	run_pair(5400, 10800, 4000, spin, nb, monkeypatch)
+
+@pytest.mark.gpu
+def test_other_sizes_keep_the_chain_gpu():
+	lmax = 300; ms = sht.tri_mstart(lmax, lmax)
+	plan = sht.grid_plan("F1", 512, 1024, 0.0, (False, False), lmax, lmax, ms, 1)
+	assert plan.query("theta_line") == 0
