@@ -81,8 +81,19 @@ PXS_RFB_COMP(3, 2) PXS_RFB_COMP(4, 2) PXS_RFB_COMP(3, 3) PXS_RFB_COMP(5, 2) PXS_
 
 template<int NT, int PMAX> struct RegFft {
 	using Regs = double2 (&)[PMAX];
-	// LDS word of line index i (one padding word per 16: the strided writes of the early passes spread over the banks)
+	// LDS word of line index i: the index itself.  Measured on the C4 configuration (tools/tl_lab.sh, shader clocks per line): no padding
+	// 265 000, one padding word per 16 -- the first form -- 296 000, the words of each block of 16 rotated by the block's number 292 000.
+	// A bank model (ds_write_b64: 16 lanes x 16 banks, ds_read_b64: 32 x 32) gives the plain layout 3x the conflict-free write cycles and
+	// the padded ones 1.25x, but with the plain layout every LDS address of a phase is one base register plus a compile-time offset
+	// (base + s*j for the writes of a butterfly, tid + constant for the reads), and the address arithmetic of the other two -- ten integer
+	// operations per point and exchange -- costs more than the conflicts.
+#if defined(PXS_LAB_TL_PAD16)      /* lab builds: the other two layouts (the line area is sized for n + 32 words: pad16 on small lines only) */
 	static __device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
+#elif defined(PXS_LAB_TL_ROT16)
+	static __device__ __forceinline__ int pad(int i) { return (i & ~15) | ((i + (i >> 4)) & 15); }
+#else
+	static __device__ __forceinline__ int pad(int i) { return i; }
+#endif
 
 	// read pattern of pass PS: slot c = i*R + k holds x[tid + NT*i + nb*k] (threads with tid + NT*i >= nb: no element; they get f(0)).
 	// Every slot of the pass is overwritten for every lane, so that the compiler sees the old contents die.
@@ -134,6 +145,9 @@ template<int NT, int PMAX> struct RegFft {
 	// the butterflies of a pass and their Stockham twiddles (tw: this length's two-level table in the LDS)
 	template<class PS> static __device__ __forceinline__ void compute(Regs v, int tid, const double2* tw) {
 		constexpr int R = PS::R;
+#ifdef PXS_LAB_TL_NOCOMP      /* lab builds: timing without the butterflies (wrong results) */
+		return;
+#endif
 		RF_OPAQUE(tid);
 		sfor<0, PS::K>([&](auto I) RF_INL {
 			constexpr int i = RF_IDX(I);
@@ -172,6 +186,9 @@ template<int NT, int PMAX> struct RegFft {
 
 	// the registers hold the outputs of pass PP; they take the read pattern of pass PN (of the same or of another transform of the same length)
 	template<class PP, class PN> static __device__ __forceinline__ void exchange(Regs v, int tid, double* line) {
+#ifdef PXS_LAB_TL_NOXCHG      /* lab builds: timing without the LDS exchanges between the passes (wrong results) */
+		return;
+#endif
 		RF_BARRIER();
 		write_comp<PP, 0>(v, tid, line);
 		RF_BARRIER();

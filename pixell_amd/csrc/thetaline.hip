@@ -25,9 +25,20 @@ struct LineArgs {
 	const double2* leg; long ldleg, cstride; int nr, mir_c; const double2* wring;
 	int lmax;
 	const double2* sigma;
+	const double* sig_half;    // sigma real and mirror-symmetric (the weights table of the default analysis): sigma[i].x, i <= M/2; else null
 	int nr_out, a_odd, ncol, npair, ntask; FastDiv dnp;
 	double2* out; long ld, ocstride; const double2* w; double scale;
+#ifdef PXS_LAB_TL_TIME      /* lab builds: shader-clock time per phase, summed over the lines of workgroup 0 (tools/tl_lab.sh) */
+	unsigned long long* prof;
+#endif
 };
+#ifdef PXS_LAB_TL_TIME
+#define TL_T(k) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = clock64(); a.prof[k] += t_ - t0_; t0_ = t_; } } while (0)
+#define TL_T0() unsigned long long t0_ = clock64()
+#else
+#define TL_T(k) do {} while (0)
+#define TL_T0() do {} while (0)
+#endif
 
 // slot jp of a spectrum of X2 points <- bin of a spectrum of X1 points (StResize::mid of fftchain.hip, the non-transposed rule)
 struct ResizeRule {
@@ -56,11 +67,11 @@ template<int NT_, class SN_, class SMi_, class SMf_, class SC_> struct LineCfg {
 	static constexpr int PMAX = tl_max(tl_max(tl_slots<SN, NT>(), tl_slots<SC, NT>()), tl_max(tl_slots<SMi, NT>(), tl_slots<SMf, NT>()));
 	// the workgroup's twiddle table in the LDS: N, M, Ncc, then the shift phase W_2N^{c k}, k <= N/2
 	static constexpr int twN = 0, twM = twN + tl_twlen(N), twC = twM + (MID ? tl_twlen(M) : 0), twP = twC + tl_twlen(Ncc), ntw = twP + tl_twlen(N/2 + 1);
-	static constexpr int pad(int i) { return i + (i >> 4); }
-	static constexpr int words = tl_max(tl_max(pad(N), pad(M)), 2*pad(Ncc)) + 8;      // doubles of the line area
+	static constexpr int words = tl_max(tl_max(N, M), 2*Ncc) + 32;      // doubles of the line area (the swizzle of regfft_dev.hpp permutes within blocks of 16)
 	static constexpr size_t lds = sizeof(double2)*ntw + sizeof(double)*words + 16;
 	static_assert(!MID || SMi::N == SMf::N, "the two transforms on M differ in length");
 	static_assert(N/2 + 1 <= words/2, "a row of leg does not fit the line area");
+	static_assert(!MID || (M % 2 == 0 && M/2 <= words/2), "half of the pointwise table does not fit the line area");
 };
 
 template<class CFG> struct LineOps {
@@ -101,20 +112,28 @@ template<class CFG> struct LineOps {
 		});
 	}
 	// mirror-pair extension of columns (2 pr, 2 pr + 1) (PairSrc::get of the stage chain): each row goes through the LDS once -- coalesced
-	// loads, every element read from memory once -- and lands in the registers in the read pattern of pass PN
+	// loads, every element read from memory once -- and lands in the registers in the read pattern of pass PN.  The loads of BOTH rows are
+	// issued before the first wait (a loop over the row, one load per trip, paid the memory latency six times per row: 16 000 clocks).
 	template<class PN> static __device__ __forceinline__ void load_pair(Regs v, int tid, double2* line2, const LineArgs& a, int comp, int pr) {
 		static_assert(PN::slots <= PMAX, "pass needs more register slots than the kernel has");
-		constexpr int N = CFG::N;
+		constexpr int N = CFG::N, NL = (N/2 + 1 + NT - 1)/NT;      // row elements per thread
 		const int ca = 2*pr;
 		const double2* ra = a.leg + (long)comp*a.cstride + (long)ca*a.ldleg;
-		const int nrow = (ca + 1 < a.ncol) ? 2 : 1;
-#pragma unroll 1
-		for (int row = 0; row < 2; row++) {
-			const double2* r = ra + (long)row*a.ldleg;
+		const bool two = ca + 1 < a.ncol;      // (an odd number of columns: the last pair has one)
+		double2 raw[2][NL];
+		sfor<0, 2*NL>([&](auto Q) RF_INL {
+			constexpr int q = RF_IDX(Q), row = q/NL, u = q % NL;
+			const int i = tid + NT*u;
+			const bool ok = i < a.nr && (row == 0 || two);
+			double2 x = ra[(long)row*a.ldleg*(ok ? 1 : 0) + (ok ? i : 0)];
+			if (a.wring) x = cscale(x, a.wring[ok ? i : 0].x);
+			raw[row][u] = ok ? x : make_double2(0, 0);
+		});
+		sfor<0, 2>([&](auto RW) RF_INL {
+			constexpr int row = RF_IDX(RW);
 			const bool odd = row == 0 ? a.a_odd != 0 : a.a_odd == 0;      // this column is odd under the reflection
 			RF_BARRIER();
-			if (row < nrow) for (int i = tid; i < a.nr; i += NT) { double2 x = r[i]; if (a.wring) x = cscale(x, a.wring[i].x); line2[i] = x; }
-			else for (int i = tid; i < a.nr; i += NT) line2[i] = make_double2(0, 0);      // (an odd number of columns: the last pair has one)
+			sfor<0, NL>([&](auto U) RF_INL { constexpr int u = RF_IDX(U); const int i = tid + NT*u; if (i < a.nr) line2[i] = raw[row][u]; });
 			RF_BARRIER();
 			RF_OPAQUE(tid);
 			sfor<0, PN::slots>([&](auto C) RF_INL {
@@ -132,7 +151,7 @@ template<class CFG> struct LineOps {
 				v[c] = row == 0 ? x : cadd(v[c], x);
 				RF_FENCE_SLOT(c);
 			});
-		}
+		});
 	}
 };
 
@@ -154,31 +173,71 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 	const int tid = threadIdx.x;
 	for (int k = tid; k < CFG::ntw; k += NT) tws[k] = a.tw[k];
 	const double2* ph = a.has_ph ? tws + CFG::twP : nullptr;
+#if !defined(PXS_HOST_SIM) && !defined(PXS_LAB_TL_NOSTAGGER)
+	// Every line takes the same time, so workgroups that start together stay in step: all CUs then load their rows in the same
+	// microseconds (256 x 173 KB = 44 MB per burst, ~11 us of the memory system for what is 385 GB/s on average) and idle the memory
+	// for the rest of the line.  The start of workgroup w is delayed by w/256 of a line time (~130 us: s_sleep 127 = 8128 clocks).
+	for (int k = 0; k < (int)(blockIdx.x & 255)/8; k++) __builtin_amdgcn_s_sleep(127);
+#endif
 	for (int task = blockIdx.x; task < a.ntask; task += gridDim.x) {
 		const int comp = (int)fdiv((uint32_t)task, a.dnp), pr = task - comp*a.npair;
 		double2 v[PMAX];
+		TL_T0();
 		L::template load_pair<RfPassT<SN, 0, NT>>(v, tid, line2, a, comp, pr);
+		TL_T(0);
 		F::template run<SN>(v, tid, line, tws + CFG::twN);
+		TL_T(1);
 		using NL = RfPassT<SN, SN::NP - 1, NT>;
 		if constexpr (CFG::MID) {
 			constexpr int N = CFG::N, M = CFG::M;
 			ResizeRule r1; r1.X1 = N; r1.X2 = M; r1.kmax = M > N ? -1 : M/2 - 1; r1.nyq = M > N ? 1 : 0;
 			L::template resize<NL, RfPassT<SMi, 0, NT>>(v, tid, line, r1, ph);
+			TL_T(2);
 			F::template run<SMi>(v, tid, line, tws + CFG::twM);
+			TL_T(3);
 			{	// the pointwise table on the samples where they are; if the backward transform ends with the radix the forward one starts
 				// with, the registers are in place for it, else one exchange
 				using ML = RfPassT<SMi, SMi::NP - 1, NT>; using MF = RfPassT<SMf, 0, NT>;
-				const double2* sg = a.sigma;
-				F::template pointwise<ML>(v, tid, [&](double2 x, int idx) { return cmul(cconj(x), sg[idx]); });
+				// The table goes through the LDS (the line area is free between two exchanges): with one global load per register slot the
+				// compiler spilled the line around the loads and the step took 44 000 of the 296 000 clocks of a line.  A real, mirror-symmetric
+				// table (the quadrature weights of the default analysis) goes in at once as M/2 + 1 doubles; any other table half a circle
+				// at a time.
+				constexpr int M = CFG::M, H = M/2;
+				if (a.sig_half) {
+					constexpr int NH = (H + 1 + NT - 1)/NT;
+					double raw[NH];
+					sfor<0, NH>([&](auto U) RF_INL { constexpr int u = RF_IDX(U); const int i = tid + NT*u; raw[u] = a.sig_half[i <= H ? i : 0]; });
+					RF_BARRIER();
+					sfor<0, NH>([&](auto U) RF_INL { constexpr int u = RF_IDX(U); const int i = tid + NT*u; if (i <= H) line[i] = raw[u]; });
+					RF_BARRIER();
+					F::template pointwise<ML>(v, tid, [&](double2 x, int idx) { const double g = line[idx <= H ? idx : M - idx]; return make_double2(x.x*g, -x.y*g); });
+				} else {
+#pragma unroll 1
+					for (int half = 0; half < 2; half++) {
+						const double2* sg = a.sigma + half*H;
+						RF_BARRIER();
+						for (int i = tid; i < H; i += NT) line2[i] = sg[i];
+						RF_BARRIER();
+						const int lo = half*H;
+						F::template pointwise<ML>(v, tid, [&](double2 x, int idx) {
+							const bool in = (unsigned)(idx - lo) < (unsigned)H;
+							const double2 t = cmul(cconj(x), line2[in ? idx - lo : 0]);
+							return in ? t : x; });
+					}
+				}
 				if constexpr (ML::R != MF::R) F::template exchange<ML, MF>(v, tid, line); }
+			TL_T(4);
 			F::template run<SMf>(v, tid, line, tws + CFG::twM);
+			TL_T(5);
 			ResizeRule r2; r2.X1 = M; r2.X2 = CFG::Ncc; r2.kmax = a.lmax; r2.nyq = 0;
 			L::template resize<RfPassT<SMf, SMf::NP - 1, NT>, RfPassT<SC, 0, NT>>(v, tid, line, r2, nullptr);
+			TL_T(6);
 		} else {
 			ResizeRule r1; r1.X1 = CFG::N; r1.X2 = CFG::Ncc; r1.kmax = a.lmax; r1.nyq = 0;
 			L::template resize<NL, RfPassT<SC, 0, NT>>(v, tid, line, r1, ph);
 		}
 		F::template run<SC>(v, tid, line, tws + CFG::twC);
+		TL_T(7);
 		// the circle of Ncc points, both components (the line area is sized for it), then the separation of the pair by reflection
 		// symmetry (StSplit<0> of the stage chain)
 		RF_BARRIER();
@@ -202,6 +261,10 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 				if (ca + 1 < a.ncol) oc[(long)(ca + 1)*a.ld + t] = cscale(vb, f);
 			}
 		}
+		TL_T(8);
+#ifdef PXS_LAB_TL_TIME
+		if (blockIdx.x == 0 && tid == 0) a.prof[9] += 1;
+#endif
 	}
 }
 
@@ -234,16 +297,17 @@ using CfgSimA = LineCfg<64, RfSeq<12, 10, 6>, RfSeq<7, 9, 16>, RfSeq<16, 9, 7>, 
 using CfgSimB = LineCfg<64, RfSeq<12, 10, 6>, RfSeq<>, RfSeq<>, RfSeq<12, 7, 6>>;
 static const LineEntry LINE_CONFIGS[] = { entry_of<CfgSimA>(), entry_of<CfgSimB>() };
 #else
-// (radices up to 9 with two or three butterflies per thread: with radix 16 / 15 the compiler needs ~2x the registers of a butterfly --
-// inputs, outputs and the twiddle powers at once -- and spills 60-170 times per transform at the 128 registers of a 1024-thread
-// workgroup; these sequences spill 0-8 times.  A fifth pass per transform costs one more LDS exchange.)
-using CfgC4A = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<8, 8, 6, 6, 7>, RfSeq<8, 8, 6, 6, 7>, RfSeq<8, 8, 6, 3, 7>>;
-using CfgC4B = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<>, RfSeq<>, RfSeq<8, 8, 6, 3, 7>>;
+// (radices up to 12, two or three butterflies per thread: with radix 16 / 15 the compiler needs ~2x the registers of a butterfly --
+// inputs, outputs and the twiddle powers at once -- and spills 60-190 times per transform at the 128 registers of a 1024-thread
+// workgroup (C4 to_cc 13.7 ms per 8 maps against 7.8); these sequences spill 0-10 times.  A fifth pass costs one more LDS exchange.)
+using CfgC4A = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<8, 8, 6, 6, 7>, RfSeq<8, 8, 6, 6, 7>, RfSeq<12, 12, 8, 7>>;
+using CfgC4B = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<>, RfSeq<>, RfSeq<12, 12, 8, 7>>;
 static const LineEntry LINE_CONFIGS[] = { entry_of<CfgC4A>(), entry_of<CfgC4B>() };
 #endif
 
 struct ThetaLine {
 	std::map<std::tuple<long, long, long, int>, DevBuf> tw;      // twiddle tables per (configuration, shift)
+	std::map<std::pair<const void*, long>, DevBuf> sig;          // per pointwise table seen: its real half if it is real and mirror-symmetric (else empty)
 	int ncu = 0;
 };
 
@@ -263,7 +327,7 @@ bool FftChain::line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, 
 	const LineEntry* e = nullptr;
 	for (const LineEntry& c : LINE_CONFIGS) if (c.N == tp.N && c.Ncc == tp.Ncc && c.M == (has_mid ? tp.M : 0)) e = &c;
 	if (!e || nr > tp.N/2 + 1 || ncc != tp.Ncc/2 + 1) return false;
-	const double2* tw;
+	const double2* tw; const double* sig_half = nullptr;
 	{	std::lock_guard<std::mutex> g(mu_);
 		if (!tl_) tl_ = std::make_shared<ThetaLine>();
 		DevBuf& b = tl_->tw[std::make_tuple(e->N, e->M, e->Ncc, mir_c)];
@@ -279,6 +343,22 @@ bool FftChain::line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, 
 			b = upload(t);
 		}
 		tw = b.as<double2>();
+		if (has_mid) {	// the pointwise table: is it real and mirror-symmetric (the quadrature weights of the default analysis are)?  Looked at once
+			// per table -- a table belongs to its plan and is never rewritten -- with one copy to the host.
+			auto key = std::make_pair((const void*)sigma, (long)e->M);
+			auto it = tl_->sig.find(key);
+			if (it == tl_->sig.end()) {
+				std::vector<double2> hs((size_t)e->M);
+				PXS_HIP(hipStreamSynchronize(st));
+				PXS_HIP(hipMemcpy(hs.data(), sigma, sizeof(double2)*hs.size(), hipMemcpyDeviceToHost));
+				bool sym = true;
+				for (long i = 0; i < e->M && sym; i++) sym = hs[i].y == 0.0 && hs[i].x == hs[(e->M - i) % e->M].x;
+				DevBuf hb;
+				if (sym) { std::vector<double> half((size_t)e->M/2 + 1); for (size_t i = 0; i < half.size(); i++) half[i] = hs[i].x; hb = upload(half); }
+				it = tl_->sig.emplace(key, std::move(hb)).first;
+			}
+			sig_half = it->second.as<double>();
+		}
 		if (tl_->ncu == 0) {
 #ifdef PXS_HOST_SIM
 			tl_->ncu = 2;
@@ -293,7 +373,10 @@ bool FftChain::line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, 
 	LineArgs a; memset(&a, 0, sizeof(a));
 	a.tw = tw; a.ntw = e->ntw; a.has_ph = mir_c != 0 ? 1 : 0;
 	a.leg = leg; a.cstride = (long)nm*ldleg; a.ldleg = ldleg; a.nr = nr; a.mir_c = mir_c; a.wring = wring;
-	a.lmax = lmax; a.sigma = sigma;
+	a.lmax = lmax; a.sigma = sigma; a.sig_half = sig_half;
+#ifdef PXS_LAB_TL_NOSIGHALF
+	a.sig_half = nullptr;
+#endif
 	a.nr_out = ncc; a.a_odd = spin & 1; a.ncol = nm; a.npair = (int)npair; a.dnp = make_fastdiv((uint32_t)npair);
 	const long ntask = (long)nc*npair;
 	PXS_REQUIRE(ntask < (1L << 31), "internal: theta line grid too large");
@@ -301,8 +384,20 @@ bool FftChain::line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, 
 	a.out = leg_cc; a.ld = ldcc; a.ocstride = (long)nm*ldcc; a.w = w; a.scale = 1.0;
 	const long per_cu = std::max<long>(1, std::min<long>(2048/e->nt, (long)(160*1024)/(long)e->lds));
 	const long nwg = std::min<long>(ntask, (long)tl_->ncu*per_cu);
+#ifdef PXS_LAB_TL_TIME
+	static DevBuf prof(16*sizeof(unsigned long long));
+	PXS_HIP(hipMemsetAsync(prof.p, 0, prof.bytes, st)); a.prof = prof.as<unsigned long long>();
+#endif
 	e->launch(a, e->lds, nwg, st);
 	PXS_HIP(hipGetLastError());
+#ifdef PXS_LAB_TL_TIME
+	{	unsigned long long h[16]; PXS_HIP(hipStreamSynchronize(st)); PXS_HIP(hipMemcpy(h, prof.p, sizeof(h), hipMemcpyDeviceToHost));
+		static const char* nm[9] = {"load", "fftN", "resize1", "fftMi", "sigma", "fftMf", "resize2", "fftC", "split+store"};
+		double tot = 0; for (int k = 0; k < 9; k++) tot += (double)h[k];
+		fprintf(stderr, "[pxsht lab] theta line, workgroup 0, %llu lines, shader clocks (100 MHz) per line:", h[9]);
+		for (int k = 0; k < 9; k++) fprintf(stderr, " %s %.0f (%.0f%%)", nm[k], (double)h[k]/std::max<double>(1, (double)h[9]), 100.0*h[k]/std::max(tot, 1.0));
+		fprintf(stderr, "\n"); }
+#endif
 	return true;
 }
 

@@ -40,7 +40,7 @@ class Pass:
 				self.roff[c] = NT*i + self.nb*k
 				self.rlim[c] = self.nb - NT*i
 
-def pad(i): return i + (i >> 4)
+def pad(i): return i      # (the kernel's layout: regfft_dev.hpp)
 
 class Line:
 	"""the registers of a workgroup: v[t, c]"""
@@ -168,7 +168,7 @@ def to_cc_regs(a, b, N, M, Ncc, nr, mir_c, a_odd, lmax, ph, sigma, wcc, NT, PMAX
 	pMi = make_passes(M, NT, PMAX, rM[::-1])      # backward: ends with the radix the forward transform starts with
 	pMf = make_passes(M, NT, PMAX, rM)
 	pC = make_passes(Ncc, NT, PMAX, rC)
-	lds = np.zeros(pad(max(N, M, Ncc)) + 1, complex)
+	lds = np.zeros(max(N, M, Ncc) + 16, complex)
 	line = Line(NT, PMAX)
 	z = pair_src(a, b, N, nr, mir_c, a_odd)
 	line.fill(pN[0], lambda idx: z[idx])
@@ -214,7 +214,7 @@ if __name__ == "__main__":
 		if r is None: print(n, NT, PMAX, "no plan"); continue
 		ps = make_passes(n, NT, PMAX, r)
 		x = rng.standard_normal(n) + 1j*rng.standard_normal(n)
-		line = Line(NT, PMAX); lds = np.zeros(pad(n) + 1, complex)
+		line = Line(NT, PMAX); lds = np.zeros(n + 16, complex)
 		line.fill(ps[0], lambda idx: x[idx])
 		fft_line(line, ps, lds)
 		X = line.gather(Pass(n, NT, PMAX, r[-1], n//r[-1]))
