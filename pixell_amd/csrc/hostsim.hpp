@@ -105,6 +105,7 @@ template<class F> void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
 }
 static inline int lane_id() { return (t_threadIdx.x + t_threadIdx.y*t_blockDim.x) & 63; }
 static inline int wave_id() { return (t_threadIdx.x + t_threadIdx.y*t_blockDim.x) >> 6; }
+static inline void wave_sync() { BlockCtx* c = t_ctx; if (c->nthreads > 1) c->wbar[wave_id()]->wait(); }      // (lanes are OS threads here: what lockstep execution gives a wave for free)
 static inline uint64_t xchg(uint64_t v, int src_lane) {
 	BlockCtx* c = t_ctx; int w = wave_id(), l = lane_id();
 	uint64_t* s = c->wslot->data() + (size_t)w*128;

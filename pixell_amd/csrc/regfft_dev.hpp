@@ -54,6 +54,13 @@ template<int A, int B, class F> __device__ __forceinline__ void sfor(F&& f) {
 #endif
 #define RF_FENCE_SLOT(c) do { if (((c) + 1) % PXS_RF_GROUP == 0) RF_FENCE(); } while (0)
 #define RF_BARRIER() PXS_LDS_BARRIER()      /* LDS traffic only: global stores of the previous line may still be in flight */
+// between the LDS phases of ONE wave on its own stretch of the LDS: nothing on the GPU (the LDS runs a wave's operations in order);
+// the simulator's lanes are OS threads and meet here
+#ifdef PXS_HOST_SIM
+#define RF_WAVE_SYNC() pxsim::wave_sync()
+#else
+#define RF_WAVE_SYNC() do {} while (0)
+#endif
 
 // radix sequence of a transform of N = product points
 template<int... Rs> struct RfSeq {
@@ -78,6 +85,54 @@ template<int R> struct RfB;
 	static constexpr __host__ __device__ int slot(int j) { return BB*(j % AA) + j/AA; } };
 PXS_RFB_PRIM(2) PXS_RFB_PRIM(3) PXS_RFB_PRIM(4) PXS_RFB_PRIM(5) PXS_RFB_PRIM(7)
 PXS_RFB_COMP(3, 2) PXS_RFB_COMP(4, 2) PXS_RFB_COMP(3, 3) PXS_RFB_COMP(5, 2) PXS_RFB_COMP(4, 3) PXS_RFB_COMP(5, 3) PXS_RFB_COMP(4, 4)
+
+// 16-point butterfly + the Stockham twiddles W^j on output j (w1 = W, twid: multiply at all), written for REGISTERS: the generic
+// composite butterfly (butterfly_comp<4, 4>) plus the twiddle loop has its four independent radix-4 butterflies per stage and all 15
+// twiddle powers in flight at once under hipcc's scheduler -- 64 registers of data, ~70 more of temporaries, 70-90 spills per
+// transform at the 128 registers of a 1024-thread workgroup.  Here every radix-4 butterfly is tied to the next one's inputs by an empty
+// asm statement ("+v" operands: the values are redefined there, what depends on them cannot start earlier), and the twiddles advance
+// in steps of W^4 inside each output group.  Output j ends in a[4 (j mod 4) + j / 4], the layout of butterfly_comp<4, 4>.
+#ifdef PXS_HOST_SIM
+#define RF_TIE8(a0, a1, a2, a3, b0, b1, b2, b3) do {} while (0)
+#define RF_TIE2(a0, a1) do {} while (0)
+#else
+#define RF_TIE8(a0, a1, a2, a3, b0, b1, b2, b3) asm volatile("" : "+v"((a0).x), "+v"((a0).y), "+v"((a1).x), "+v"((a1).y), "+v"((a2).x), "+v"((a2).y), "+v"((a3).x), "+v"((a3).y), \
+	"+v"((b0).x), "+v"((b0).y), "+v"((b1).x), "+v"((b1).y), "+v"((b2).x), "+v"((b2).y), "+v"((b3).x), "+v"((b3).y))
+#define RF_TIE2(a0, a1) asm volatile("" : "+v"((a0).x), "+v"((a0).y), "+v"((a1).x), "+v"((a1).y))
+#endif
+template<bool TWID> __device__ __forceinline__ void rf_bfly16(double2 (&a)[16], const double2 w1) {
+	// stage 1: radix 4 over (n2, n2 + 4, n2 + 8, n2 + 12), then W_16^{n2 k1}
+	sfor<0, 4>([&](auto N2) RF_INL {
+		constexpr int n2 = RF_IDX(N2);
+		double2 t[4] = {a[n2], a[4 + n2], a[8 + n2], a[12 + n2]};
+		butterfly<4>(t);
+		a[n2] = t[0];
+		sfor<1, 4>([&](auto K1) RF_INL {
+			constexpr int k1 = RF_IDX(K1), m = n2*k1;
+			if constexpr (m == 0) a[4*k1 + n2] = t[k1];
+			else if constexpr (m == 4) a[4*k1 + n2] = mulmi(t[k1]);
+			else a[4*k1 + n2] = cmul(t[k1], RadixTw<16>::w(m));
+		});
+		if constexpr (n2 < 3) RF_TIE8(a[n2], a[4 + n2], a[8 + n2], a[12 + n2], a[n2 + 1], a[5 + n2], a[9 + n2], a[13 + n2]);
+	});
+	// stage 2: radix 4 over (4 k1 ... 4 k1 + 3): X[k1 + 4 k2] in a[4 k1 + k2]; twiddle W^{k1 + 4 k2}
+	double2 w2 = make_double2(0, 0), w4 = make_double2(0, 0);
+	if constexpr (TWID) { w2 = cmul(w1, w1); w4 = cmul(w2, w2); }
+	sfor<0, 4>([&](auto K1) RF_INL {
+		constexpr int k1 = RF_IDX(K1);
+		butterfly<4>(&a[4*k1]);
+		if constexpr (TWID) {
+			double2 t = k1 == 1 ? w1 : (k1 == 2 ? w2 : cmul(w2, w1));      // W^{k1} (k1 = 0: unused)
+			if constexpr (k1 > 0) a[4*k1] = cmul(a[4*k1], t);
+			sfor<1, 4>([&](auto K2) RF_INL {
+				constexpr int k2 = RF_IDX(K2);
+				if constexpr (k1 == 0 && k2 == 1) t = w4; else t = cmul(t, w4);
+				a[4*k1 + k2] = cmul(a[4*k1 + k2], t);
+			});
+		}
+		if constexpr (k1 < 3) { RF_TIE8(a[4*k1], a[4*k1 + 1], a[4*k1 + 2], a[4*k1 + 3], a[4*k1 + 4], a[4*k1 + 5], a[4*k1 + 6], a[4*k1 + 7]); if constexpr (TWID) RF_TIE2(w2, w4); }
+	});
+}
 
 template<int NT, int PMAX> struct RegFft {
 	using Regs = double2 (&)[PMAX];
@@ -154,6 +209,11 @@ template<int NT, int PMAX> struct RegFft {
 			const int b = min(tid + NT*i, PS::nb - 1);      // (lanes past the last butterfly compute on what they hold; nothing reads it)
 			double2 a[R];
 			sfor<0, R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); a[j] = v[i*R + j]; });
+			if constexpr (R == 16) {      // the register-lean form (above)
+				double2 w1 = make_double2(1, 0);
+				if constexpr (PS::twiddled) { const int e = b - b % PS::s; w1 = cmul(tw[e & (RF_TWL - 1)], tw[RF_TWL + (e >> 7)]); }
+				rf_bfly16<PS::twiddled>(a, w1);
+			} else {
 			RfB<R>::run(a);
 			if constexpr (PS::twiddled) {
 				const int e = b - b % PS::s;
@@ -167,6 +227,7 @@ template<int NT, int PMAX> struct RegFft {
 					if (j & 1) { x = cmul(x, wo); if (j + 2 < R) wo = cmul(wo, w2); }
 					else       { x = cmul(x, we); if (j + 2 < R) we = cmul(we, w2); }
 				}
+			}
 			}
 			sfor<0, R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); v[i*R + j] = a[RfB<R>::slot(j)]; RF_PIN2(v[i*R + j]); });
 			RF_FENCE();      // (the butterflies of a thread one after the other: interleaved they need their temporaries K times)
@@ -185,28 +246,34 @@ template<int NT, int PMAX> struct RegFft {
 	}
 
 	// the registers hold the outputs of pass PP; they take the read pattern of pass PN (of the same or of another transform of the same length)
-	template<class PP, class PN> static __device__ __forceinline__ void exchange(Regs v, int tid, double* line) {
+	// SYNC = false: the line belongs to ONE wave (NT = 64, `line` = the wave's own stretch of the LDS): the LDS executes a wave's
+	// operations in order and no barrier is needed.  (A four-step form built on this -- a radix-16 pass across the 16 waves, then every
+	// wave transforms its row of n / 16 points on its own, the waves drifting apart -- was measured and lost: wave 0 sees its private
+	// exchanges at 3 000 clocks, but the LAST wave finishes after 7 600 per pass, the price of a barrier-separated pass, and the index
+	// maps of the row layout cost the boundary steps more than the passes gained: 305 000 clocks per line against 272 000.
+	// tools/xchg_probe2.hip keeps the measurement.)
+	template<class PP, class PN, bool SYNC = true> static __device__ __forceinline__ void exchange(Regs v, int tid, double* line) {
 #ifdef PXS_LAB_TL_NOXCHG      /* lab builds: timing without the LDS exchanges between the passes (wrong results) */
 		return;
 #endif
-		RF_BARRIER();
+		if (SYNC) RF_BARRIER(); else RF_WAVE_SYNC();
 		write_comp<PP, 0>(v, tid, line);
-		RF_BARRIER();
+		if (SYNC) RF_BARRIER(); else RF_WAVE_SYNC();
 		read_comp<PN, 0>(v, tid, line);
-		RF_BARRIER();
+		if (SYNC) RF_BARRIER(); else RF_WAVE_SYNC();
 		write_comp<PP, 1>(v, tid, line);
-		RF_BARRIER();
+		if (SYNC) RF_BARRIER(); else RF_WAVE_SYNC();
 		read_comp<PN, 1>(v, tid, line);
 	}
 
 	// forward transform of sequence S.  In: the registers hold the line in the read pattern of pass 0.  Out: they hold the outputs of the
 	// last pass.  tw: this length's twiddle table in the LDS.
-	template<class S> static __device__ __forceinline__ void run(Regs v, int tid, double* line, const double2* tw) {
+	template<class S, bool SYNC = true> static __device__ __forceinline__ void run(Regs v, int tid, double* line, const double2* tw) {
 		sfor<0, S::NP>([&](auto P) RF_INL {
 			constexpr int p = RF_IDX(P);
 			using PS = RfPassT<S, p, NT>;
 			compute<PS>(v, tid, tw);
-			if constexpr (p + 1 < S::NP) exchange<PS, RfPassT<S, p + 1, NT>>(v, tid, line);
+			if constexpr (p + 1 < S::NP) exchange<PS, RfPassT<S, p + 1, NT>, SYNC>(v, tid, line);
 		});
 	}
 };

@@ -33,7 +33,7 @@ struct LineArgs {
 #endif
 };
 #ifdef PXS_LAB_TL_TIME
-#define TL_T(k) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = clock64(); a.prof[k] += t_ - t0_; t0_ = t_; } } while (0)
+#define TL_T(k) do { if (blockIdx.x == 0 && tid == CFG::NT - 64) { const unsigned long long t_ = clock64(); a.prof[k] += t_ - t0_; t0_ = t_; } } while (0)
 #define TL_T0() unsigned long long t0_ = clock64()
 #else
 #define TL_T(k) do {} while (0)
@@ -263,7 +263,7 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 		}
 		TL_T(8);
 #ifdef PXS_LAB_TL_TIME
-		if (blockIdx.x == 0 && tid == 0) a.prof[9] += 1;
+		if (blockIdx.x == 0 && tid == CFG::NT - 64) a.prof[9] += 1;
 #endif
 	}
 }
@@ -300,7 +300,7 @@ static const LineEntry LINE_CONFIGS[] = { entry_of<CfgSimA>(), entry_of<CfgSimB>
 // (radices up to 12, two or three butterflies per thread: with radix 16 / 15 the compiler needs ~2x the registers of a butterfly --
 // inputs, outputs and the twiddle powers at once -- and spills 60-190 times per transform at the 128 registers of a 1024-thread
 // workgroup (C4 to_cc 13.7 ms per 8 maps against 7.8); these sequences spill 0-10 times.  A fifth pass costs one more LDS exchange.)
-using CfgC4A = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<8, 8, 6, 6, 7>, RfSeq<8, 8, 6, 6, 7>, RfSeq<12, 12, 8, 7>>;
+using CfgC4A = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<7, 9, 16, 16>, RfSeq<16, 16, 9, 7>, RfSeq<12, 12, 8, 7>>;
 using CfgC4B = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<>, RfSeq<>, RfSeq<12, 12, 8, 7>>;
 static const LineEntry LINE_CONFIGS[] = { entry_of<CfgC4A>(), entry_of<CfgC4B>() };
 #endif
@@ -394,7 +394,7 @@ bool FftChain::line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, 
 	{	unsigned long long h[16]; PXS_HIP(hipStreamSynchronize(st)); PXS_HIP(hipMemcpy(h, prof.p, sizeof(h), hipMemcpyDeviceToHost));
 		static const char* nm[9] = {"load", "fftN", "resize1", "fftMi", "sigma", "fftMf", "resize2", "fftC", "split+store"};
 		double tot = 0; for (int k = 0; k < 9; k++) tot += (double)h[k];
-		fprintf(stderr, "[pxsht lab] theta line, workgroup 0, %llu lines, shader clocks (100 MHz) per line:", h[9]);
+		fprintf(stderr, "[pxsht lab] theta line, workgroup 0, last wave, %llu lines, shader clocks per line:", h[9]);
 		for (int k = 0; k < 9; k++) fprintf(stderr, " %s %.0f (%.0f%%)", nm[k], (double)h[k]/std::max<double>(1, (double)h[9]), 100.0*h[k]/std::max(tot, 1.0));
 		fprintf(stderr, "\n"); }
 #endif

@@ -7,17 +7,18 @@ from pixell_amd import sht, _lib
 
 def relrms(a, b): return float(np.sqrt(np.mean(np.abs(a - b)**2)/np.mean(np.abs(b)**2)))
 
-def run_pair(nt, nph, lmax, spin, nb, monkeypatch, seed=3):
+def run_pair(nt, nph, lmax, spin, nb, monkeypatch, seed=3, mmax=None):
 	nc = 1 if spin == 0 else 2
-	ms = sht.tri_mstart(lmax, lmax); nalm = int(ms[-1]) + lmax + 1
-	kw = dict(spin=spin, lmax=lmax, geometry="F1", phi0=0.1, mstart=ms)
+	if mmax is None: mmax = lmax
+	ms = sht.tri_mstart(lmax, mmax); nalm = int(ms[-1]) + lmax + 1
+	kw = dict(spin=spin, lmax=lmax, mmax=mmax, geometry="F1", phi0=0.1, mstart=ms)
 	rng = np.random.default_rng(seed)
 	shape = (nb, nc, nt, nph) if nb > 1 else (nc, nt, nph)
 	noise = rng.standard_normal(shape)
 	out = {}
 	for line in ("1", "0"):
 		monkeypatch.setenv("PXS_THETA_LINE", line)
-		plan = sht.grid_plan("F1", nt, nph, 0.1, (False, False), lmax, lmax, ms, 1)
+		plan = sht.grid_plan("F1", nt, nph, 0.1, (False, False), lmax, mmax, ms, 1)
 		assert plan.query("theta_line") == int(line)
 		alm = np.zeros(shape[:-2] + (nalm,), complex)
 		sht.analysis_2d(alm=alm, map=noise, **kw)                       # to_cc (the default, fine-CC form)
@@ -29,10 +30,10 @@ def run_pair(nt, nph, lmax, spin, nb, monkeypatch, seed=3):
 	assert np.abs(out["0"][0]).max() > 0 and np.abs(out["0"][1]).max() > 0
 
 @pytest.mark.hostsim
-@pytest.mark.parametrize("spin,nb", [(0, 1), (1, 1)])      # (251 columns: the last pair has one member; spin 1: the odd column first)
+@pytest.mark.parametrize("spin,nb", [(0, 1), (1, 1)])      # (mmax = 24: 25 columns, the last pair has one member; spin 1: the odd column first)
 def test_line_engine_hostsim(monkeypatch, spin, nb):
 	assert _lib.is_hostsim()
-	run_pair(360, 720, 250, spin, nb, monkeypatch)
+	run_pair(360, 720, 250, spin, nb, monkeypatch, mmax=24)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("spin,nb", [(0, 1), (2, 1), (0, 3)])
