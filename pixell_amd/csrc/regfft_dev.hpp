@@ -52,6 +52,9 @@ template<int A, int B, class F> __device__ __forceinline__ void sfor(F&& f) {
 #ifndef PXS_RF_GROUP
 #define PXS_RF_GROUP 6
 #endif
+#ifndef PXS_RF_LEAN_MIN
+#define PXS_RF_LEAN_MIN 6      /* composite radices from here on take rf_bfly_lean */
+#endif
 #define RF_FENCE_SLOT(c) do { if (((c) + 1) % PXS_RF_GROUP == 0) RF_FENCE(); } while (0)
 #define RF_BARRIER() PXS_LDS_BARRIER()      /* LDS traffic only: global stores of the previous line may still be in flight */
 // between the LDS phases of ONE wave on its own stretch of the LDS: nothing on the GPU (the LDS runs a wave's operations in order);
@@ -86,53 +89,59 @@ template<int R> struct RfB;
 PXS_RFB_PRIM(2) PXS_RFB_PRIM(3) PXS_RFB_PRIM(4) PXS_RFB_PRIM(5) PXS_RFB_PRIM(7)
 PXS_RFB_COMP(3, 2) PXS_RFB_COMP(4, 2) PXS_RFB_COMP(3, 3) PXS_RFB_COMP(5, 2) PXS_RFB_COMP(4, 3) PXS_RFB_COMP(5, 3) PXS_RFB_COMP(4, 4)
 
-// 16-point butterfly + the Stockham twiddles W^j on output j (w1 = W, twid: multiply at all), written for REGISTERS: the generic
-// composite butterfly (butterfly_comp<4, 4>) plus the twiddle loop has its four independent radix-4 butterflies per stage and all 15
-// twiddle powers in flight at once under hipcc's scheduler -- 64 registers of data, ~70 more of temporaries, 70-90 spills per
-// transform at the 128 registers of a 1024-thread workgroup.  Here every radix-4 butterfly is tied to the next one's inputs by an empty
-// asm statement ("+v" operands: the values are redefined there, what depends on them cannot start earlier), and the twiddles advance
-// in steps of W^4 inside each output group.  Output j ends in a[4 (j mod 4) + j / 4], the layout of butterfly_comp<4, 4>.
-#ifdef PXS_HOST_SIM
-#define RF_TIE8(a0, a1, a2, a3, b0, b1, b2, b3) do {} while (0)
-#define RF_TIE2(a0, a1) do {} while (0)
-#else
-#define RF_TIE8(a0, a1, a2, a3, b0, b1, b2, b3) asm volatile("" : "+v"((a0).x), "+v"((a0).y), "+v"((a1).x), "+v"((a1).y), "+v"((a2).x), "+v"((a2).y), "+v"((a3).x), "+v"((a3).y), \
-	"+v"((b0).x), "+v"((b0).y), "+v"((b1).x), "+v"((b1).y), "+v"((b2).x), "+v"((b2).y), "+v"((b3).x), "+v"((b3).y))
-#define RF_TIE2(a0, a1) asm volatile("" : "+v"((a0).x), "+v"((a0).y), "+v"((a1).x), "+v"((a1).y))
-#endif
-template<bool TWID> __device__ __forceinline__ void rf_bfly16(double2 (&a)[16], const double2 w1) {
-	// stage 1: radix 4 over (n2, n2 + 4, n2 + 8, n2 + 12), then W_16^{n2 k1}
-	sfor<0, 4>([&](auto N2) RF_INL {
+// Composite butterfly of A*B points + the Stockham twiddles W^j on output j (w1 = W; TWID: multiply at all), written for REGISTERS.
+// Under hipcc's scheduler the generic form (butterfly_comp<A, B> of fft_dev.hpp, then a loop over the outputs) has the independent
+// sub-butterflies of a stage and all twiddle powers in flight at once: for 16 points 64 registers of data and ~70 more of temporaries,
+// 70-190 spills per transform at the 128 registers of a 1024-thread workgroup.  Here the outputs of every sub-butterfly and the inputs
+// of the next one pass through empty asm statements ("+v" operands: the values are redefined there, so what depends on them cannot
+// start earlier, and volatile statements keep their order), and the twiddles advance in steps of W^A inside each output group with
+// only W, W^A, the group's first power and the running one alive.  Output j ends in a[B (j mod A) + j / A], the layout of
+// butterfly_comp<A, B>.  Spills of a transform of 16 128 points as 16 16 9 7: 147 -> 25.
+// RF_PIN2 on a[OFF + STRIDE i], i < CNT (a function, not a lambda: an asm operand may not name a variable captured by a nested lambda)
+template<int I, int CNT, int STRIDE, int OFF, int LEN> __device__ __forceinline__ void rf_pin_range(double2 (&a)[LEN]) {
+	if constexpr (I < CNT) { RF_PIN2(a[OFF + STRIDE*I]); rf_pin_range<I + 1, CNT, STRIDE, OFF, LEN>(a); }
+}
+__device__ __forceinline__ void rf_pin_two(double2& x, double2& y) { RF_PIN2(x); RF_PIN2(y); }
+template<int A, int B, bool TWID> __device__ __forceinline__ void rf_bfly_lean(double2 (&a)[A*B], const double2 w1) {
+	// stage 1: radix A over (n2, n2 + B, ...), then W_{AB}^{n2 k1}
+	sfor<0, B>([&](auto N2) RF_INL {
 		constexpr int n2 = RF_IDX(N2);
-		double2 t[4] = {a[n2], a[4 + n2], a[8 + n2], a[12 + n2]};
-		butterfly<4>(t);
-		a[n2] = t[0];
-		sfor<1, 4>([&](auto K1) RF_INL {
+		double2 t[A];
+		sfor<0, A>([&](auto N1) RF_INL { t[RF_IDX(N1)] = a[B*RF_IDX(N1) + n2]; });
+		butterfly<A>(t);
+		sfor<0, A>([&](auto K1) RF_INL {
 			constexpr int k1 = RF_IDX(K1), m = n2*k1;
-			if constexpr (m == 0) a[4*k1 + n2] = t[k1];
-			else if constexpr (m == 4) a[4*k1 + n2] = mulmi(t[k1]);
-			else a[4*k1 + n2] = cmul(t[k1], RadixTw<16>::w(m));
+			if constexpr (m == 0) a[B*k1 + n2] = t[k1];
+			else if constexpr (4*m == A*B) a[B*k1 + n2] = mulmi(t[k1]);      // W^{AB/4} = -i
+			else a[B*k1 + n2] = cmul(t[k1], RadixTw<A*B>::w(m));
 		});
-		if constexpr (n2 < 3) RF_TIE8(a[n2], a[4 + n2], a[8 + n2], a[12 + n2], a[n2 + 1], a[5 + n2], a[9 + n2], a[13 + n2]);
+		if constexpr (n2 + 1 < B) { rf_pin_range<0, A, B, n2, A*B>(a); rf_pin_range<0, A, B, n2 + 1, A*B>(a); }
 	});
-	// stage 2: radix 4 over (4 k1 ... 4 k1 + 3): X[k1 + 4 k2] in a[4 k1 + k2]; twiddle W^{k1 + 4 k2}
-	double2 w2 = make_double2(0, 0), w4 = make_double2(0, 0);
-	if constexpr (TWID) { w2 = cmul(w1, w1); w4 = cmul(w2, w2); }
-	sfor<0, 4>([&](auto K1) RF_INL {
+	// stage 2: radix B over (B k1 ... B k1 + B - 1): X[k1 + A k2] in a[B k1 + k2]; twiddle W^{k1 + A k2}
+	double2 wA = w1, start = make_double2(1, 0);      // W^A; W^{k1}, the first power of group k1
+	if constexpr (TWID) sfor<1, A>([&](auto) RF_INL { wA = cmul(wA, w1); });
+	sfor<0, A>([&](auto K1) RF_INL {
 		constexpr int k1 = RF_IDX(K1);
-		butterfly<4>(&a[4*k1]);
+		butterfly<B>(&a[B*k1]);
 		if constexpr (TWID) {
-			double2 t = k1 == 1 ? w1 : (k1 == 2 ? w2 : cmul(w2, w1));      // W^{k1} (k1 = 0: unused)
-			if constexpr (k1 > 0) a[4*k1] = cmul(a[4*k1], t);
-			sfor<1, 4>([&](auto K2) RF_INL {
+			if constexpr (k1 == 1) start = w1; else if constexpr (k1 > 1) start = cmul(start, w1);
+			double2 t = start;
+			if constexpr (k1 > 0) a[B*k1] = cmul(a[B*k1], t);
+			sfor<1, B>([&](auto K2) RF_INL {
 				constexpr int k2 = RF_IDX(K2);
-				if constexpr (k1 == 0 && k2 == 1) t = w4; else t = cmul(t, w4);
-				a[4*k1 + k2] = cmul(a[4*k1 + k2], t);
+				if constexpr (k1 == 0 && k2 == 1) t = wA; else t = cmul(t, wA);
+				a[B*k1 + k2] = cmul(a[B*k1 + k2], t);
 			});
 		}
-		if constexpr (k1 < 3) { RF_TIE8(a[4*k1], a[4*k1 + 1], a[4*k1 + 2], a[4*k1 + 3], a[4*k1 + 4], a[4*k1 + 5], a[4*k1 + 6], a[4*k1 + 7]); if constexpr (TWID) RF_TIE2(w2, w4); }
+		if constexpr (k1 + 1 < A) {
+			rf_pin_range<0, B, 1, B*k1, A*B>(a); rf_pin_range<0, B, 1, B*(k1 + 1), A*B>(a);
+			if constexpr (TWID) rf_pin_two(wA, start);
+		}
 	});
 }
+template<int R> struct RfLean { static constexpr bool has = false; static constexpr int A = 1, B = 1; };
+#define PXS_RFLEAN(AA, BB) template<> struct RfLean<AA*BB> { static constexpr bool has = true; static constexpr int A = AA, B = BB; };
+PXS_RFLEAN(3, 2) PXS_RFLEAN(4, 2) PXS_RFLEAN(3, 3) PXS_RFLEAN(5, 2) PXS_RFLEAN(4, 3) PXS_RFLEAN(5, 3) PXS_RFLEAN(4, 4)
 
 template<int NT, int PMAX> struct RegFft {
 	using Regs = double2 (&)[PMAX];
@@ -209,10 +218,10 @@ template<int NT, int PMAX> struct RegFft {
 			const int b = min(tid + NT*i, PS::nb - 1);      // (lanes past the last butterfly compute on what they hold; nothing reads it)
 			double2 a[R];
 			sfor<0, R>([&](auto J) RF_INL { constexpr int j = RF_IDX(J); a[j] = v[i*R + j]; });
-			if constexpr (R == 16) {      // the register-lean form (above)
+			if constexpr (RfLean<R>::has && R >= PXS_RF_LEAN_MIN) {      // the composite radices: the register-lean form (above)
 				double2 w1 = make_double2(1, 0);
 				if constexpr (PS::twiddled) { const int e = b - b % PS::s; w1 = cmul(tw[e & (RF_TWL - 1)], tw[RF_TWL + (e >> 7)]); }
-				rf_bfly16<PS::twiddled>(a, w1);
+				rf_bfly_lean<RfLean<R>::A, RfLean<R>::B, PS::twiddled>(a, w1);
 			} else {
 			RfB<R>::run(a);
 			if constexpr (PS::twiddled) {

@@ -297,11 +297,11 @@ using CfgSimA = LineCfg<64, RfSeq<12, 10, 6>, RfSeq<7, 9, 16>, RfSeq<16, 9, 7>, 
 using CfgSimB = LineCfg<64, RfSeq<12, 10, 6>, RfSeq<>, RfSeq<>, RfSeq<12, 7, 6>>;
 static const LineEntry LINE_CONFIGS[] = { entry_of<CfgSimA>(), entry_of<CfgSimB>() };
 #else
-// (radices up to 12, two or three butterflies per thread: with radix 16 / 15 the compiler needs ~2x the registers of a butterfly --
-// inputs, outputs and the twiddle powers at once -- and spills 60-190 times per transform at the 128 registers of a 1024-thread
-// workgroup (C4 to_cc 13.7 ms per 8 maps against 7.8); these sequences spill 0-10 times.  A fifth pass costs one more LDS exchange.)
-using CfgC4A = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<7, 9, 16, 16>, RfSeq<16, 16, 9, 7>, RfSeq<12, 12, 8, 7>>;
-using CfgC4B = LineCfg<1024, RfSeq<8, 6, 5, 5, 9>, RfSeq<>, RfSeq<>, RfSeq<12, 12, 8, 7>>;
+// (four passes per transform, radices up to 16: the composite radices run the register-lean butterfly of regfft_dev.hpp -- with the
+// generic one these sequences spilled 70-190 times per transform and C4's to_cc took 13.7 ms per 8 maps; five-pass sequences of
+// radices up to 9, which did not spill, 7.2 ms)
+using CfgC4A = LineCfg<1024, RfSeq<16, 15, 15, 3>, RfSeq<7, 9, 16, 16>, RfSeq<16, 16, 9, 7>, RfSeq<16, 8, 9, 7>>;
+using CfgC4B = LineCfg<1024, RfSeq<16, 15, 15, 3>, RfSeq<>, RfSeq<>, RfSeq<16, 8, 9, 7>>;
 static const LineEntry LINE_CONFIGS[] = { entry_of<CfgC4A>(), entry_of<CfgC4B>() };
 #endif
 
