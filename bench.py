@@ -36,13 +36,25 @@ CONFIGS = {
 	"tqu": dict(ncomp=3, shape=(5400, 10800),  lmax=4000,  spin=[0, 2], name="16x[3x(5400x10800)] T/Q/U maps in one call, lmax=4000 spin0/2 (batched polarisation sims; not a BASELINE configuration)", nbatch_total=16),
 	"ref": dict(ncomp=1, shape=(900, 1800),    lmax=750,   spin=[0],    name="reference benchmark shape 1x(900x1800) lmax=750"),
 }
-FRAC_DEFINITION = "frac: SURVEY 8(d) F_alg = (4 n0 + 12 n2) R nalm flop per direction over the kernel family's time / 78.6 TFLOP/s; frac_hw: the FP64 flops the kernels executed (recurrence + accumulation FMAs / MFMAs of the steps the waves ran, counted in the kernels) over the same time"
+FRAC_DEFINITION = "frac: credited flops of one direction over the kernel family's time / 78.6 TFLOP/s, never above 1 (frac_convention_exceeds_peak says if it was clipped) -- VALU kernels: SURVEY 8(d) F_alg = (4 n0 + 12 n2) R nalm; FP64-MFMA kernels (batched scalar maps): the GEMM, 2 flop per (l, m, ring, map) = F_alg / 2; frac_hw: the FP64 flops the kernels executed (recurrence + accumulation FMAs / MFMAs of the steps the waves ran, counted in the kernels) over the same time"
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 # what a kernel of nothing but independent v_fma_f64 with three VGPR operands (the form of the analysis accumulation and of every recurrence step) sustains
 # on the gpurun boxes: 54-65 TFLOP/s by hipEvent time at ANY occupancy from 1 to 8 waves per SIMD -- one wave alone issues one every 4.4 s_memtime counts, and
 # the counts per ms fall from 1.85e6 to 1.1e6 as waves are added (tools/dp_rate.hip, profiles/r05_dp_rate_and_k_waves.txt); with one scalar operand (the synthesis accumulation) 74.6-76.1
 # (tools/fma_peak.hip, round 3); a v_mfma_f64_16x16x4_f64 stream 65.7 (profiles/r05_mfma_f64_rate.txt).  Context for frac_hw; `peak` stays the nominal figure.
 FP64_SUSTAINED_TFLOPS = 64.9
+def credited_flops(F_survey, mm, n0_only=True):
+	"""flops one direction is credited with in `roofline.achieved / frac`.  VALU kernels: SURVEY 8(d)'s F_alg (4 flop per (l, m, ring) for spin 0,
+	12 for a Q/U pair).  FP64-MFMA kernels (batched scalar maps): the GEMM the algorithm needs, 2 flop per (l, m, ring, map) -- half of
+	SURVEY's scalar credit, which prices the two FMAs of a VALU accumulation and made `frac` exceed 1 for kernels that issue one MFMA
+	multiply-add per (l, m, ring, map, side).  The recurrence shared by the maps of a batch is not credited."""
+	return 0.5*F_survey if mm else F_survey
+
+def roof_frac(achieved_tflops):
+	"""(frac, flag): a fraction of peak is reported as one -- a convention that credits more than the pipe can do is clipped and flagged"""
+	f = achieved_tflops/FP64_PEAK_TFLOPS
+	return (round(min(f, 1.0), 4), f > 1.0)
+
 def sustained_note(frac_hw_both):
 	return dict(fp64_fma_stream_TFLOPs=FP64_SUSTAINED_TFLOPS, source="tools/dp_rate.hip: v_fma_f64 with three VGPR operands only, best of 1-8 waves per SIMD (profiles/r05_dp_rate_and_k_waves.txt); 74.6-76.1 with one scalar operand (tools/fma_peak.hip); 78.6 nominal",
 		frac_hw_of_stream={k: round(v*FP64_PEAK_TFLOPS/FP64_SUSTAINED_TFLOPS, 4) for k, v in frac_hw_both.items()})
@@ -98,6 +110,28 @@ def probe_ducc0():
 	except Exception as e:
 		return dict(available=False, reason="%s: %s" % (type(e).__name__, e))
 
+def ducc0_accuracy():
+	"""accuracy.vs_ducc0: the HIP path against ducc0 itself (when the box has it) on a C1-sized grid -- white noise through analysis_2d (where
+	the quadrature of the default form shows), a band-limited map through synthesis_2d; tests/test_ducc0_live.py is the full comparison"""
+	if not probe_ducc0()["available"]: return dict(available=False, note="ducc0 not importable on this box: the default analysis form stays pinned to the oracle's restatement only (tests/test_ducc0_live.py skips)")
+	import ducc0
+	from pixell_amd import sht
+	nt, nph, lmax = 1024, 2048, 512
+	ms = sht.tri_mstart(lmax, lmax); na = int(ms[-1])+lmax+1
+	rng = np.random.default_rng(5)
+	out = dict(available=True, version=getattr(ducc0, "__version__", "?"), grid="F1 %dx%d lmax %d" % (nt, nph, lmax))
+	rel = lambda a, b: float(np.sqrt(np.mean(np.abs(a-b)**2)/np.mean(np.abs(b)**2)))
+	for spin in (0, 2):
+		nc = 1 if spin == 0 else 2
+		kw = dict(spin=spin, lmax=lmax, mmax=lmax, geometry="F1", phi0=0.0, mstart=ms)
+		noise = rng.standard_normal((nc, nt, nph))
+		a_ref = np.zeros((nc, na), complex); ducc0.sht.experimental.analysis_2d(alm=a_ref, map=noise, nthreads=0, **kw)
+		a_got = np.zeros((nc, na), complex); sht.analysis_2d(alm=a_got, map=noise, **kw)
+		m_ref = np.zeros((nc, nt, nph)); ducc0.sht.experimental.synthesis_2d(alm=a_ref, map=m_ref, nthreads=0, **kw)
+		m_got = np.zeros((nc, nt, nph)); sht.synthesis_2d(alm=a_ref, map=m_got, **kw)
+		out["spin%d" % spin] = dict(analysis_2d_white_noise_rel_rms=rel(a_got, a_ref), synthesis_2d_rel_rms=rel(m_got, m_ref))
+	return out
+
 def ducc0_baseline(cfg, budget_s=30.0):
 	"""ducc0.sht.experimental.analysis_2d + synthesis_2d on all host cores (only when ducc0 imports and one round trip fits the budget)"""
 	import ducc0
@@ -126,6 +160,26 @@ def cpu_baseline(cfg, budget_s=20.0):
 		except Exception as e: log("ducc0 baseline failed: %r" % (e,))
 	from oracle import sht_port
 	return sht_port.time_sample(cfg, budget_s)
+
+def cpu_baseline_full(name, cfg, nmaps=1):
+	"""cpu_baseline of a secondary configuration: ONE FULL round trip of the CPU port on the host cores, nothing extrapolated
+	(oracle.sht_port.time_full), outside every timed region.  Batched configurations (independent maps): one map measured, times the maps.
+	The reference's benchmark shape also with one thread, as scripts/benchmark_pixell.py:17-21 sets OMP_NUM_THREADS=1."""
+	from oracle import sht_port
+	one = dict(cfg); one["ncomp"] = cfg["ncomp"]
+	try:
+		r = sht_port.time_full(one, None, max_seconds=45.0)
+		if r is None: return dict(kind="port", value=None, note="one full round trip of the CPU port would take more than 45 s on this host: not run (the headline's cpu_baseline is the sampled one)")
+		if nmaps > 1:
+			r = dict(r); r["seconds_per_round_trip_one_map"] = r["seconds_per_round_trip"]; r["maps"] = nmaps
+			r["seconds_per_round_trip"] = round(r["seconds_per_round_trip"]*nmaps, 4); r["value"] = round(1.0/r["seconds_per_round_trip"], 6)
+			r["unit"] = "round-trips/s of the whole batch"; r["sample"] += " One map measured in full; the batch is %d independent maps (x %d)." % (nmaps, nmaps)
+		if name == "ref":
+			r1 = sht_port.time_full(one, 1, max_seconds=45.0)
+			if r1: r["one_thread"] = {k: r1[k] for k in ("value", "unit", "cores", "seconds_per_round_trip", "legendre_s", "ring_fft_s", "theta_resampling_s")}
+		return r
+	except Exception as e:
+		return dict(kind="port", value=None, error=repr(e))
 
 def measured_traffic(config, dom):
 	"""HBM bytes of a kernel family per step from the committed PMC passes of this bench command (tools/pmc_traffic.sh ->
@@ -316,7 +370,7 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 	stage_ms = {k: round(v/nre, 3) for k, v in stage_ms.items()}
 	ms_step = dt/args.steps*1e3
 	# algorithmic bytes / flops per realisation: SHT round trip 2 F_alg, 2 (map + alm) bytes; the 2-D FFT reads the real map and writes the complex one
-	R_alg = min(ny, lmax+2); F_dir = 4*R_alg*nalm(lmax); B_fft = ny*nx*(8+16)
+	R_alg = min(ny, lmax+2); F_survey = 4*R_alg*nalm(lmax); F_dir = credited_flops(F_survey, nbc >= 4); B_fft = ny*nx*(8+16)
 	leg = {k: prof[k][0]/nre for k in ("leg_syn", "leg_ana")}      # Legendre kernel ms per realisation, hipEvents inside the library (pxs_profile)
 	dom = "leg_ana" if leg["leg_ana"] >= leg["leg_syn"] else "leg_syn"
 	exe = {"leg_syn": fl_syn/nre, "leg_ana": fl_ana/nre}
@@ -329,8 +383,9 @@ def run_c5(args, torch, dist, rank, world, local, device, backend):
 		ms_per_realisation=round(ms_step/max(nloc, 1), 3), stage_ms_per_realisation=stage_ms,
 		roofline=dict(bound="mfma" if (dom == "leg_ana" and nbc >= 4) else "fp64_valu", kernel="leg_ana_* (Legendre analysis of a batch)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis of a batch)",
 			achieved=round(F_dir/(leg[dom]*1e-3)/1e12, 3) if leg[dom] > 0 else 0.0, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-			frac=round(F_dir/(leg[dom]*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if leg[dom] > 0 else 0.0, frac_hw=frac_hw[dom], frac_hw_both=frac_hw, frac_definition=FRAC_DEFINITION, traffic=None,
-			kernel_ms_per_realisation={k: round(v, 3) for k, v in leg.items()}, algorithmic_flops_per_realisation_direction=F_dir, executed_flops_per_realisation=exe,
+			frac=roof_frac(F_dir/(leg[dom]*1e-3)/1e12)[0] if leg[dom] > 0 else 0.0, frac_convention_exceeds_peak=roof_frac(F_dir/(leg[dom]*1e-3)/1e12)[1] if leg[dom] > 0 else False,
+			frac_hw=frac_hw[dom], frac_hw_both=frac_hw, frac_definition=FRAC_DEFINITION, traffic=None,
+			kernel_ms_per_realisation={k: round(v, 3) for k, v in leg.items()}, algorithmic_flops_per_realisation_direction=F_dir, survey_flops_per_realisation_direction=F_survey, executed_flops_per_realisation=exe,
 			sustained=sustained_note(frac_hw)),
 		fft=dict(bound="hbm", kernel="enmap.fft real -> complex, 10800x21600", ms=stage_ms["enmap_fft"], achieved=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9, 1) if stage_ms["enmap_fft"] > 0 else 0.0,
 			peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B_fft/(stage_ms["enmap_fft"]*1e-3)/1e9/HBM_PEAK_GBS, 4) if stage_ms["enmap_fft"] > 0 else 0.0),
@@ -376,6 +431,7 @@ def run_sht(args, ctx):
 	# the first transform of each direction (scratch allocation, recurrence seeds recorded), the second round trip (seeds loaded)
 	def timed(fn):
 		torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return (time.perf_counter()-t)*1e3, r
+	mem0 = sht.memory()
 	minfo = curvedsky.analyse_geometry(dmap.shape, wcs)
 	t_plan, plan = timed(lambda: sht.grid_plan(minfo.ducc_geo.name, ny, nx, minfo.phi0, minfo.flip, lmax, lmax, ainfo.mstart, 1))
 	t_tab, _ = timed(lambda: [plan.set_option("build_tables", s) for s in sorted(set(cfg["spin"]))])
@@ -383,9 +439,13 @@ def run_sht(args, ctx):
 	t_ana1, _ = timed(lambda: curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo))
 	rt_err = float((alm_out-alm_in).abs().pow(2).mean().sqrt()/alm_in.abs().pow(2).mean().sqrt())
 	t_rt2, _ = timed(lambda: (curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo), curvedsky.alm2map(alm_out, dmap, spin=cfg["spin"], ainfo=ainfo)))
+	mem1 = sht.memory()
 	cold = dict(plan_build_ms=round(t_plan+t_tab, 1), plan_object_ms=round(t_plan, 1), recurrence_tables_ms=round(t_tab, 1),
+		hipMalloc_ms=round(mem1["malloc_ms"]-mem0["malloc_ms"], 1), hipMalloc_GB=round((mem1["malloc_bytes"]-mem0["malloc_bytes"])/1e9, 2), hipMalloc_calls=mem1["malloc_calls"]-mem0["malloc_calls"],
+		arena_hits=mem1["arena_hits"]-mem0["arena_hits"], arena_GB_kept=round(mem1["arena_bytes"]/1e9, 2),
 		first_alm2map_ms=round(t_syn1, 1), first_map2alm_ms=round(t_ana1, 1), first_roundtrip_ms=round(t_plan+t_tab+t_syn1+t_ana1, 1), second_roundtrip_ms=round(t_rt2, 1),
-		note="first_roundtrip_ms = plan_build_ms + the first transform of each direction on the fresh plan (scratch allocation, recurrence seeds recorded where the plan uses them); steady_ms is the timed step")
+		note="first_roundtrip_ms = plan_build_ms + the first transform of each direction on the fresh plan (scratch allocation, recurrence seeds recorded where the plan uses them); steady_ms is the timed step. "
+			"hipMalloc_ms is the part of it the library spent inside hipMalloc (pxs_memory): the device scratch of a plan is mapped at a box-dependent rate; scratch released by earlier plans of the process is reused (arena_hits) instead")
 	log("[rank %d] setup %.1fs; %d map(s); round-trip rms error %.2e; cold call: %s" % (rank, time.time()-t0, nmaps, rt_err, {k: v for k, v in cold.items() if k != "note"}))
 	# north_star: alm must come back to < 1e-8 relative rms.  A throughput number of a transform that does not is worthless.
 	if not (rt_err < 1e-8) and not os.environ.get("PXS_BENCH_NOCHECK"): raise SystemExit("bench.py: round-trip rms error %.3e exceeds 1e-8 -- refusing to time a wrong transform" % rt_err)
@@ -461,17 +521,19 @@ def run_sht(args, ctx):
 	dom = "leg_ana" if prof["leg_ana"][0] >= prof["leg_syn"][0] else "leg_syn"
 	flops_dir = alg_flops_direction(cfg, R_alg, nmaps)             # all spin groups / maps of one direction on this rank
 	dom_ms_per_step = prof[dom][0]/args.steps
-	achieved = flops_dir/(dom_ms_per_step*1e-3)/1e12 if dom_ms_per_step > 0 else 0.0
 	exe = (fl_ana if dom == "leg_ana" else fl_syn)/max(args.steps, 1)        # flops the kernels of that family executed per step (counted in the kernels)
 	# batched scalar maps: the analysis of 4 or more maps per call is the FP64-MFMA kernel (leg_ana_s0_mm); everything else is plain v_fma_f64
 	mm = batched and nmaps >= 4      # (analysis and synthesis, scalar maps and Q/U pairs alike)
+	flops_survey = flops_dir; flops_dir = credited_flops(flops_survey, mm)
+	achieved = flops_dir/(dom_ms_per_step*1e-3)/1e12 if dom_ms_per_step > 0 else 0.0
+	frac_, clipped_ = roof_frac(achieved)
 	roof = dict(bound="mfma" if mm else "fp64_valu",
 		pipe=("FP64 MFMA (v_mfma_f64_16x16x4_f64): the maps of a batch share one recurrence per ring pair, rings are the K dimension, 16 columns = 4 maps x 4 real right-hand sides; its dense peak equals the vector peak on MI355X"
 			if mm else "FP64 vector FMA (v_fma_f64): the contraction is 4 right-hand sides wide per map, too narrow for the 16x16x4 f64 MFMA, whose dense peak equals the vector peak; no MFMA instruction is issued"),
 		kernel="leg_ana_* (Legendre analysis, all launches of a step)" if dom == "leg_ana" else "leg_syn_* (Legendre synthesis, all launches of a step)",
-		achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved/FP64_PEAK_TFLOPS, 4),
+		achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_, frac_convention_exceeds_peak=clipped_,
 		frac_hw=round(exe/(dom_ms_per_step*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if dom_ms_per_step > 0 else 0.0, frac_definition=FRAC_DEFINITION, traffic=None,
-		algorithmic_flops_per_step_direction=flops_dir, executed_flops_per_step_direction=exe,
+		algorithmic_flops_per_step_direction=flops_dir, survey_flops_per_step_direction=flops_survey, executed_flops_per_step_direction=exe,
 		executed_flops_both={"leg_syn": fl_syn/max(args.steps, 1), "leg_ana": fl_ana/max(args.steps, 1)},
 		frac_hw_both={k: (round(v/max(args.steps, 1)/(prof[k][0]/args.steps*1e-3)/1e12/FP64_PEAK_TFLOPS, 4) if prof[k][0] > 0 else 0.0) for k, v in (("leg_syn", fl_syn), ("leg_ana", fl_ana))},
 		kernel_ms_per_step=round(dom_ms_per_step, 3),
@@ -532,6 +594,12 @@ def run_sht(args, ctx):
 				del alm_in; torch.cuda.empty_cache()
 				res["fft"] = fft_block(enmap.dmap(dmap.tensor[:1], wcs), enmap, torch)
 			except Exception as e: log("fft block failed: %r" % (e,)); res["fft"] = None
+			# (the driver's parsed line keeps `roofline` whole: the HBM-bound families' fractions ride inside it as well)
+			res["roofline"]["hbm_families"] = dict(
+				fft_chain=dict(frac=res["fft_chain"]["frac"], achieved_GBps=res["fft_chain"]["achieved"], kernel_ms_per_step=res["fft_chain"]["kernel_ms_per_step"], traffic=res["fft_chain"].get("traffic")),
+				enmap_fft=({k: res["fft"][k] for k in ("frac_of_8TBps", "frac_of_8TBps_complex_to_complex") if k in res["fft"]} if res.get("fft") else None))
+			try: res["accuracy"] = dict(vs_ducc0=ducc0_accuracy())
+			except Exception as e: res["accuracy"] = dict(vs_ducc0=dict(error=repr(e)))
 			try:
 				res["cpu_baseline"] = cpu_baseline(dict(cfg, ncomp=ncomp))
 			except Exception as e:   # the baseline must never take the GPU number down with it
@@ -549,7 +617,7 @@ def compact_leg(res):
 	out["workload"] = res["config"]["workload"]
 	if "ms_per_realisation" in res: out.update(ms_per_realisation=res["ms_per_realisation"], stage_ms_per_realisation=res["stage_ms_per_realisation"], roundtrip_rms_error=res["checks"]["roundtrip_rms_error"], realisations_per_call=res["config"]["realisations_per_call"])
 	r = res["roofline"]
-	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_hw", "frac_hw_both", "frac_definition", "sustained", "kernel_ms_per_step", "kernel_ms_per_realisation") if k in r}
+	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_convention_exceeds_peak", "frac_hw", "frac_hw_both", "frac_definition", "sustained", "kernel_ms_per_step", "kernel_ms_per_realisation") if k in r}
 	if "fft_chain" in res: out["fft_chain"] = {k: res["fft_chain"][k] for k in ("bound", "achieved", "unit", "frac", "kernel_ms_per_step")}
 	if "fft" in res and res["fft"] and "frac" in res["fft"]: out["fft"] = res["fft"]
 	return out
@@ -561,7 +629,8 @@ def secondary_legs(args, ctx):
 	torch = ctx.torch
 	from pixell_amd import sht
 	legs = {}
-	plan = [("c4", dict(config="c4", steps=2, warmup=1))] if ctx.world > 1 else [
+	plan = [("c4", dict(config="c4", steps=5, warmup=2))] if ctx.world > 1 else [
+		("c1", dict(config="c1", steps=20, warmup=2)),
 		("c2", dict(config="c2", steps=3, warmup=1)),
 		("c4_share", dict(config="c4", steps=3, warmup=1, nbatch=8)),
 		("c4", dict(config="c4", steps=2, warmup=1)),
@@ -576,6 +645,13 @@ def secondary_legs(args, ctx):
 			if "nreal" in kw: os.environ["PXS_BENCH_NREAL"] = str(kw["nreal"])
 			res = run_c5(leg, ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.local, ctx.device, ctx.backend) if kw["config"] == "c5" else run_sht(leg, ctx)
 			legs[name] = compact_leg(res); legs[name]["leg_wall_s"] = round(time.time()-t0, 1)
+			if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu:      # (after the leg's timed loop; rank 0 at N = 1 only, as the headline's)
+				t1 = time.time()
+				cfgl = CONFIGS[kw["config"]]
+				nm = int(kw.get("nbatch", cfgl.get("nbatch_total", 1))) if kw["config"] == "c4" else 1
+				legs[name]["cpu_baseline"] = cpu_baseline_full(name, cfgl, nm)
+				if kw["config"] == "c5": legs[name]["cpu_baseline"]["note_c5"] = "the map2alm + alm2map pair of one realisation only (the 2-D FFT / spectrum steps of the pipeline are not in it)"
+				legs[name]["cpu_baseline_wall_s"] = round(time.time()-t1, 1)
 			if name == "ref": legs[name]["note"] = "the reference's own benchmark shape (scripts/benchmark_pixell_runner.py:13-27: 900x1800, lmax 750, 40 iterations): wall time per round trip including the Python layer"
 		except Exception as e:
 			if ctx.world > 1: raise          # (a rank that skipped a leg's collectives would hang the others)

@@ -96,7 +96,11 @@ int pxs_analysis(pxs_plan* plan, int spin, int adjoint, int nbatch,
  * "deterministic" (0 | 1; default 0, or 1 when PXS_DETERMINISTIC=1 is set as the plan is made): the Legendre analysis (pxs_analysis,
  *   adjoint synthesis) sums the contributions of the ring chunks of an m with atomic adds in arrival order -- results repeat from
  *   run to run to ~1e-14 of their size, not bit for bit (ducc0 on the CPU is bitwise repeatable).  1 selects ordered sums through
- *   per-chunk partial moments (<= 2 GB of scratch, m in passes; batched calls one map at a time): bitwise repeatable, slower. */
+ *   per-chunk partial moments (<= 2 GB of scratch, m in passes; batched calls one map at a time): bitwise repeatable, slower.
+ *   The promise is run-to-run repeatability of the SAME call.  A map transformed inside a batch of 4 or more takes the FP64-MFMA
+ *   kernels (another summation order) and equals its single-map call to rounding (1e-13), not bit for bit, with or without this
+ *   option -- the reference loops over the maps and is identical per map; PXS_SYN_MM_MIN=0 / PXS_ANA_MM_MIN=0 keep batches on the
+ *   single-map kernels. */
 int pxs_plan_option(pxs_plan* plan, const char* name, int64_t value);
 
 /* What a plan does: "analysis_form" = the form pxs_analysis runs now (0 interpolant, 1 ring weights, 2 fine-CC form of ducc0's
@@ -177,6 +181,13 @@ int pxm_mul_axis(int64_t total, int64_t n, int64_t inner, void* data, int dtype,
 /* 1 if the engine can transform this length (2,3,5-smooth or prime factors small enough) */
 int pxf_fft_supported(int64_t n);
 int64_t pxf_fft_good_size(int64_t n);
+
+/* Device memory of the library.  Plans release their scratch into a per-process arena (blocks >= 32 MB, at most PXS_ARENA_GB = 48 GB
+ * kept) that the next plan draws from, so that dropping and rebuilding plans does not go through hipMalloc again.  release != 0: give
+ * the kept blocks back to the driver now.  stats (may be null): [0] ms spent in hipMalloc so far, [1] hipMalloc calls, [2] bytes they
+ * allocated, [3] requests served from the arena, [4] bytes kept in the arena now, [5] bytes in use by plans.  No reference counterpart
+ * (ducc0 allocates host memory per call). */
+int pxs_memory(int release, double* stats);
 
 const char* pxs_last_error(void);
 const char* pxs_version(void);

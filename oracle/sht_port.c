@@ -40,6 +40,16 @@ static void to_scaled(double mant, int e, double* v, int* scale) {
 }
 static long double epsl(int l, int m) { if (l <= m) return 0; long double L = l, M = m; return sqrtl((L*L-M*M)/(4*L*L-1)); }
 
+/* threads of the OpenMP loops (0: leave as is); returns the previous maximum */
+int sht_port_set_threads(int n) {
+#ifdef _OPENMP
+	const int old = omp_get_max_threads();
+	if (n > 0) omp_set_num_threads(n);
+	return old;
+#else
+	(void)n; return 1;
+#endif
+}
 int sht_port_threads(void) {
 #ifdef _OPENMP
 	return omp_get_max_threads();

@@ -156,6 +156,66 @@ def time_sample(cfg, budget_s=20.0):
 			"pocketfft via scipy, one block of columns per host thread) timed at two sample sizes, fixed + per-column cost extrapolated to %d columns, both directions. "
 			"A restatement of the same algorithm on the CPU, NOT ducc0." % (ncores, R, str(nsel_used), lmax+1, ncores, nr, cfg["ncomp"]*ny, cfg["ncomp"]*(lmax+1)))
 
+def time_full(cfg, nthreads=None, max_seconds=60.0):
+	"""One FULL round trip of `cfg` on the host, nothing extrapolated: every m of the Legendre stage (synthesis + adjoint on the CC grid
+	of lmax + 2 rings), every ring FFT, every column of the theta resampling in both directions -- the same three stages as time_sample,
+	for configurations small enough to run whole (the reference's benchmark shape, BASELINE C1 and C2).  nthreads: host threads (None:
+	all; 1 = the OMP_NUM_THREADS=1 setting of the reference's own benchmark script).  Returns None if a calibration step says the whole
+	would take longer than max_seconds.  A restatement of the same algorithm on the CPU, NOT ducc0."""
+	import scipy.fft as sfft
+	L = lib(); L.sht_port_set_threads.restype = ctypes.c_int
+	nthr = int(nthreads) if nthreads else L.sht_port_threads()
+	old = L.sht_port_set_threads(nthr)
+	try:
+		lmax = cfg["lmax"]; ny, nx = cfg["shape"]
+		R = min(ny, lmax+2)
+		theta = np.arange(R)*np.pi/(R-1)
+		rng = np.random.default_rng(0)
+		allm = np.arange(lmax+1)
+		# calibration on 2 % of the m values
+		msel = np.unique(np.linspace(0, lmax, max(8, (lmax+1)//50)).astype(int))
+		t0 = time.perf_counter()
+		for spin in cfg["spin"]:
+			nc = 1 if spin == 0 else 2
+			a = rng.standard_normal((len(msel), nc, lmax+1))+0j
+			leg(spin, lmax, msel, theta, leg=leg(spin, lmax, msel, theta, alm=a))
+		if (time.perf_counter()-t0)*(lmax+1)/len(msel) > max_seconds: return None      # (also the warm-up of the OpenMP threads)
+		t_leg = 0.0
+		for spin in cfg["spin"]:
+			nc = 1 if spin == 0 else 2
+			alm = rng.standard_normal((lmax+1, nc, lmax+1))+1j*rng.standard_normal((lmax+1, nc, lmax+1))
+			t0 = time.perf_counter()
+			lg = leg(spin, lmax, allm, theta, alm=alm)
+			leg(spin, lmax, allm, theta, leg=lg)
+			t_leg += time.perf_counter()-t0
+			del alm, lg
+		x = rng.standard_normal((cfg["ncomp"]*ny, nx))
+		t0 = time.perf_counter(); h = sfft.rfft(x, axis=1, workers=nthr); sfft.irfft(h, n=nx, axis=1, workers=nthr); t_fft = time.perf_counter()-t0
+		del x, h
+		t_res = 0.0
+		if ny > R:
+			from concurrent.futures import ThreadPoolExecutor
+			from . import sht_fast
+			sht_fast._resample_tables("F1", ny, lmax)
+			ncol = cfg["ncomp"]*(lmax+1)
+			with ThreadPoolExecutor(max_workers=nthr) as ex:      # warm-up: thread start, page faults of the tables
+				list(ex.map(lambda k: sht_fast.theta_resample(rng.standard_normal((2, ny))+0j, np.arange(2) % 2, "F1", ny, lmax, workers=1), range(nthr)))
+			t0 = time.perf_counter()
+			for c0 in range(0, ncol, 4096):      # (blocks: the temporaries of a column are ~8 padded complex lines)
+				n = min(4096, ncol-c0)
+				Lc = rng.standard_normal((n, ny))+1j*rng.standard_normal((n, ny))
+				blocks = [b for b in np.array_split(np.arange(n), nthr) if len(b)]
+				with ThreadPoolExecutor(max_workers=nthr) as ex:
+					list(ex.map(lambda idx: sht_fast.theta_resample(Lc[idx], idx % 2, "F1", ny, lmax, workers=1), blocks))
+			t_res = 2*(time.perf_counter()-t0)      # both directions (the transpose costs the same; the data generation above is inside: < 2 %)
+		total = t_leg+t_fft+t_res
+		return dict(value=round(1.0/total, 6), unit="round-trips/s", cores=nthr, kind="port", full=True, seconds_per_round_trip=round(total, 4),
+			legendre_s=round(t_leg, 4), ring_fft_s=round(t_fft, 4), theta_resampling_s=round(t_res, 4),
+			sample="oracle/sht_port.c (C, f64, OpenMP x%d) + scipy.fft: ONE FULL round trip, nothing extrapolated -- Legendre synthesis + adjoint for all %d m on the CC grid of %d rings, "
+				"rfft + irfft of all %d rings, theta resampling of all %d columns (timed one way, counted twice). A restatement of the same algorithm on the CPU, NOT ducc0." % (nthr, lmax+1, R, cfg["ncomp"]*ny, cfg["ncomp"]*(lmax+1) if ny > R else 0))
+	finally:
+		L.sht_port_set_threads(old)
+
 if __name__ == "__main__":
 	import json, sys
 	cfg = dict(shape=(5400, 10800), lmax=4000, spin=[0, 2], ncomp=3)

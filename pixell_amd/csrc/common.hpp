@@ -24,6 +24,13 @@ void set_last_error(const std::string& msg);
 	throw pxs::Error(pxs::PXS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define PXS_REQUIRE(cond, msg) do { if (!(cond)) throw pxs::Error(pxs::PXS_ERR_ARG, std::string(msg)); } while (0)
 
+// Device memory of the library goes through one per-process arena (arena.hip): blocks of 32 MB and more that a plan releases are
+// kept (up to PXS_ARENA_GB, default 48) and handed to the next plan that asks for a similar size instead of going back to the driver
+// -- the scratch of a plan is tens of GB, hipMalloc maps it at a box-dependent rate, and a program that drops its plans between
+// workloads (bench.py's legs, sht.clear_plans()) paid for it again each time.  pxs_memory() reports and releases.
+void* dev_alloc(size_t bytes);
+void dev_free(void* p, size_t bytes);
+
 // simple owning device buffer
 struct DevBuf {
 	void* p = nullptr; size_t bytes = 0;
@@ -33,9 +40,9 @@ struct DevBuf {
 	DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
 	DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; return *this; }
 	~DevBuf() { release(); }
-	void alloc(size_t n) { release(); if (n) { PXS_HIP(hipMalloc(&p, n)); bytes = n; } }
+	void alloc(size_t n) { release(); if (n) { p = dev_alloc(n); bytes = n; } }
 	void ensure(size_t n) { if (n > bytes) alloc(n); }
-	void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+	void release() { if (p) { dev_free(p, bytes); p = nullptr; bytes = 0; } }
 	template<class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 

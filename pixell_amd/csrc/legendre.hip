@@ -2209,6 +2209,9 @@ static void ensure_coef2(hipStream_t st, const LegTables& tb) {      // compact 
 	if (tb.d_coef2.p) return;
 	tb.d_coef2.alloc(sizeof(double2)*(size_t)(tb.nrows + 32)); tb.d_coef2p.alloc(sizeof(double2)*(size_t)(tb.nrows + 32));
 	hipLaunchKernelGGL(coef2_kernel, dim3((unsigned)((tb.nrows + 32 + 255)/256)), dim3(256), 0, st, tb.d_coef.as<double4_t>(), tb.nrows, tb.d_coef2.as<double2>(), tb.d_coef2p.as<double2>());
+	// the table is plan state that later calls read on THEIR streams with no dependency on this launch: it is complete before the pointer is
+	// handed out (once per plan and spin; the seeds order themselves with events, LegTables::build synchronises the device likewise)
+	PXS_HIP(hipStreamSynchronize(st));
 }
 // Rings per lane of a small ring set.  (1) A wave of 64 K ring pairs takes the polar form of the recurrences (leg_wave_polar) only if its most equatorial ring
 // stays within 71.5 degrees of the pole, so on a grid of a few hundred rings the default K leaves the rings next to the poles in the plain form (l^2 eps there):

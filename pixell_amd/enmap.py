@@ -263,13 +263,14 @@ def _dev_axes(shape, wcs, like):
 		return np.ascontiguousarray(ly), np.ascontiguousarray(lx)
 	key = _geo_key(shape, wcs)
 	if key is not None: key = key+(str(like.device),)
-	hit = _axes_cache.get(key) if key is not None else None
-	if hit is None:
-		torch = _torch()
-		ly, lx = laxes(shape, wcs)
-		hit = (torch.from_numpy(np.ascontiguousarray(ly)).to(like.device), torch.from_numpy(np.ascontiguousarray(lx)).to(like.device))
-		if key is not None:
-			with _cache_lock:
+	with _cache_lock:      # lookup, fill and eviction as one step; the cached tensors are shared and must not be modified by callers
+		hit = _axes_cache.get(key) if key is not None else None
+		if hit is None:
+			torch = _torch()
+			ly, lx = laxes(shape, wcs)
+			hit = (torch.from_numpy(np.ascontiguousarray(ly)).to(like.device), torch.from_numpy(np.ascontiguousarray(lx)).to(like.device))
+			torch.cuda.current_stream().synchronize()      # (complete before another thread's stream may read them)
+			if key is not None:
 				if len(_axes_cache) >= 8: _axes_cache.pop(next(iter(_axes_cache)))
 				_axes_cache[key] = hit
 	return hit
@@ -355,15 +356,15 @@ def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=No
 	from . import sht
 	if lop is not None: raise NotImplementedError("lbin: lop is not supported by the accelerated path")
 	gkey = _geo_key(map.shape, map.wcs)
-	geo = _lbin_cache.get((gkey, bsize, brel)) if gkey is not None else None
-	if geo is None:
-		ly, lx = laxes(map.shape, map.wcs)
-		bs = min(abs(lx[1]), abs(ly[1])) if bsize is None else bsize
-		bs = float(bs*brel)
-		lmax = float(np.sqrt(np.max(ly**2)+np.max(lx**2)))
-		geo = dict(bsize=bs, n=int(lmax/bs), lsum=None, nhit=None)
-		if gkey is not None:
-			with _cache_lock:
+	with _cache_lock:
+		geo = _lbin_cache.get((gkey, bsize, brel)) if gkey is not None else None
+		if geo is None:
+			ly, lx = laxes(map.shape, map.wcs)
+			bs = min(abs(lx[1]), abs(ly[1])) if bsize is None else bsize
+			bs = float(bs*brel)
+			lmax = float(np.sqrt(np.max(ly**2)+np.max(lx**2)))
+			geo = dict(bsize=bs, n=int(lmax/bs), lsum=None, nhit=None)
+			if gkey is not None:
 				if len(_lbin_cache) >= 8: _lbin_cache.pop(next(iter(_lbin_cache)))
 				_lbin_cache[(gkey, bsize, brel)] = geo
 	bsize, n = geo["bsize"], geo["n"]
@@ -386,7 +387,8 @@ def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=No
 		sht._lib.check(lib.pxm_lbin(ny, nx, _ptr(dly), _ptr(dlx), bsize, n, _ptr(d)+i*ny*nx*esz, sht._DT[sht._np_dtype(d)],
 			_ptr(acc)+i*max(n, 1)*8, (_ptr(acc)+npre*max(n, 1)*8) if first else None, (_ptr(acc)+(npre+1)*max(n, 1)*8) if first else None, dev, st))
 	acc = acc.cpu().numpy() if hasattr(acc, "data_ptr") else acc
-	if geo["nhit"] is None and npre > 0: geo["lsum"], geo["nhit"] = acc[npre, :n].copy(), acc[npre+1, :n].copy()
+	if geo["nhit"] is None and npre > 0:
+		with _cache_lock: geo["lsum"], geo["nhit"] = acc[npre, :n].copy(), acc[npre+1, :n].copy()      # (the geometry-only sums: set once, under the lock)
 	nhit = geo["nhit"] if geo["nhit"] is not None else acc[npre+1, :n]
 	lsum = geo["lsum"] if geo["lsum"] is not None else acc[npre, :n]
 	with np.errstate(invalid="ignore", divide="ignore"):

@@ -122,6 +122,7 @@ class Pipeline:
 		# at most PREFETCH_DEPTH uploaded inputs wait on the device for their transform (a call with many spin groups would otherwise hold all
 		# its inputs AND outputs at once); an upload that does not fit is left to the caller's synchronous path
 		self.slots = threading.Semaphore(PREFETCH_DEPTH)
+		self.closing = False      # set by close(): queued uploads nobody will take are dropped instead of waiting for a slot
 		self.thread = threading.Thread(target=self._run, daemon=True); self.thread.start()
 	def _run(self):
 		_torch().cuda.set_device(self.device)      # (the current device is per thread)
@@ -131,10 +132,16 @@ class Pipeline:
 			kind, a, b, c, done = job
 			try:
 				if kind == "up":
-					self.slots.acquire()
-					try: done.result = upload(a)
+					# wait for a slot, but never for ever: if the call ended (an exception between prefetch and take), nobody frees one
+					while not self.slots.acquire(timeout=0.05):
+						if self.closing: break
+					if self.closing: done.result = None; continue
+					ok = False
+					try: done.result = upload(a); ok = True
 					except _torch().cuda.OutOfMemoryError:      # no room to run ahead: take() returns None and the caller uploads when it gets there
-						done.result = None; self.slots.release(); _torch().cuda.empty_cache()
+						done.result = None; _torch().cuda.empty_cache()
+					finally:
+						if not ok: self.slots.release()      # (any failure gives the slot back, not only running out of memory)
 				else: download(a, b, after=c)
 			except BaseException as e:      # noqa: surfaced by close() / take()
 				self.err = e
@@ -154,5 +161,6 @@ class Pipeline:
 	def writeback(self, tensor, arr, event):
 		done = threading.Event(); self.jobs.put(("down", tensor, arr, event, done)); return done
 	def close(self):
+		self.closing = True
 		self.jobs.put(None); self.thread.join()
 		if self.err is not None: raise self.err

@@ -103,7 +103,9 @@ class _Buf:
 
 class Plan:
 	"""RAII wrapper of pxs_plan"""
-	def __init__(self, handle): self.handle = handle; self.lock = threading.RLock()      # (option + call pairs on a shared cached plan are atomic per thread)
+	def __init__(self, handle):
+		self.handle = handle; self.lock = threading.RLock()      # (option + call pairs on a shared cached plan are atomic per thread)
+		self._det_default = int(os.environ.get("PXS_DETERMINISTIC", "0") not in ("", "0"))      # what the library gave the plan when it was made
 	def __del__(self):
 		try:
 			if self.handle: _lib.load().pxs_plan_destroy(self.handle); self.handle = None
@@ -153,7 +155,17 @@ class _PlanCache:
 	def clear(self): self.d.clear()
 	def __len__(self): return len(self.d)
 _plans = _PlanCache()
-def clear_plans(): _plans.clear()
+def clear_plans(release=False):
+	"""drop the cached plans.  Their device scratch goes to the library's arena (pxs_memory) for the next plans; release=True returns it to the driver."""
+	_plans.clear()
+	if release: memory(release=True)
+
+def memory(release=False):
+	"""pxs_memory: dict(malloc_ms, malloc_calls, malloc_bytes, arena_hits, arena_bytes, live_bytes); release=True empties the arena first"""
+	import gc; gc.collect()      # (plans dropped a moment ago have released their buffers)
+	st = (ctypes.c_double*6)()
+	_lib.check(_lib.load().pxs_memory(int(bool(release)), st))
+	return dict(malloc_ms=st[0], malloc_calls=int(st[1]), malloc_bytes=int(st[2]), arena_hits=int(st[3]), arena_bytes=int(st[4]), live_bytes=int(st[5]))
 
 _deterministic = None
 def set_deterministic(on=True):
@@ -164,9 +176,11 @@ def set_deterministic(on=True):
 	global _deterministic
 	_deterministic = None if on is None else bool(on)
 def _apply_mode(plan):
+	"""the process-wide deterministic switch onto a (cached, shared) plan.  Called with plan.lock held, in the same critical section as the
+	transform it applies to (_run_syn / _run_ana): a toggle by another thread cannot land between an option and its call."""
 	want = _deterministic
-	if want is None and getattr(plan, "_det", None) is not None:      # a cached plan that was switched: back to the default
-		plan.set_option("deterministic", int(os.environ.get("PXS_DETERMINISTIC", "0") not in ("", "0"))); plan._det = None
+	if want is None and getattr(plan, "_det", None) is not None:      # a cached plan that was switched: back to the default it was made with
+		plan.set_option("deterministic", plan._det_default); plan._det = None
 	elif want is not None and getattr(plan, "_det", None) != want:
 		plan.set_option("deterministic", int(want)); plan._det = want
 	return plan
@@ -186,7 +200,7 @@ def grid_plan(geometry, ntheta, nphi, phi0, flip, lmax, mmax, mstart, lstride=1)
 		_lib.check(_lib.load().pxs_plan_grid2d(ctypes.byref(h), geometry.encode(), int(ntheta), int(nphi), float(phi0),
 			int(bool(flip[0])), int(bool(flip[1])), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
 		p = Plan(h); _plans[key] = p
-	return _apply_mode(p)
+	return p
 
 def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixstride=1):
 	th = np.ascontiguousarray(theta, dtype=np.float64); nph = np.ascontiguousarray(nphi, dtype=np.uint64)
@@ -199,7 +213,7 @@ def ring_plan(theta, nphi, phi0, ringstart, lmax, mmax, mstart, lstride=1, pixst
 		_lib.check(_lib.load().pxs_plan_rings(ctypes.byref(h), len(th), th.ctypes.data, nph.ctypes.data, p0.ctypes.data, rs.ctypes.data,
 			int(pixstride), int(lmax), int(mmax), ms.ctypes.data, int(lstride), device_index()))
 		p = Plan(h); _plans[key] = p
-	return _apply_mode(p)
+	return p
 
 def _ncomp(spin, mode):
 	if mode == "DERIV1": return 1, 2
@@ -242,8 +256,10 @@ def _run_syn(plan, alm, map, spin, mode, adjoint, map_overwrite=False):
 	batched = alm.ndim == 3
 	nb = alm.shape[0] if batched else 1
 	av = _View(alm, 1, batched, bool(adjoint)); mv = _View(map, map.ndim-(2 if batched else 1), batched, not adjoint, overwrite=map_overwrite and not adjoint)
-	_lib.check(_lib.load().pxs_synthesis(plan.handle, int(spin), 1 if mode == "DERIV1" else 0, int(bool(adjoint)), int(nb),
-		av.ptr, _DT[ad], av.cstride, av.bstride, mv.ptr, _DT[md], mv.cstride, mv.bstride, current_stream()))
+	with plan.lock:      # (the adjoint synthesis runs the Legendre analysis: the deterministic option and the call as one step)
+		_apply_mode(plan)
+		_lib.check(_lib.load().pxs_synthesis(plan.handle, int(spin), 1 if mode == "DERIV1" else 0, int(bool(adjoint)), int(nb),
+			av.ptr, _DT[ad], av.cstride, av.bstride, mv.ptr, _DT[md], mv.cstride, mv.bstride, current_stream()))
 	av.finish(); mv.finish()
 
 ANALYSIS_MODES = {"ducc0": 2, "interpolant": 0, "weights": 1}
@@ -267,7 +283,8 @@ def _run_ana(plan, map, alm, spin, adjoint, analysis=None, alm_dense=False):
 	batched = alm.ndim == 3
 	nb = alm.shape[0] if batched else 1
 	av = _View(alm, 1, batched, not adjoint, overwrite=alm_dense and not adjoint); mv = _View(map, map.ndim-(2 if batched else 1), batched, bool(adjoint), overwrite=bool(adjoint))      # (a grid plan writes every pixel)
-	with plan.lock:      # the option and the call it applies to, as one step: plans are cached and shared between threads
+	with plan.lock:      # the options and the call they apply to, as one step: plans are cached and shared between threads
+		_apply_mode(plan)
 		plan.set_option("analysis", _analysis_mode(analysis))
 		_lib.check(_lib.load().pxs_analysis(plan.handle, int(spin), int(bool(adjoint)), int(nb), mv.ptr, _DT[md], mv.cstride, mv.bstride,
 			av.ptr, _DT[ad], av.cstride, av.bstride, current_stream()))

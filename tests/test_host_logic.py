@@ -116,3 +116,32 @@ def test_plan_cache_is_bounded():
 	c = sht._PlanCache(); c.cap = 2
 	for k in "abc": c[k] = object()
 	assert len(c) == 2 and c.get("a") is None and c.get("c") is not None
+
+def test_prefetch_pipeline_close_does_not_hang(monkeypatch):
+	"""with more uploads queued than prefetch slots, a call that ends before taking them (an exception in a transform) must
+	still be able to close its pipeline -- the worker's wait for a slot is cancellable, and a failed upload gives its slot back."""
+	import threading, time, types
+	from pixell_amd import hostio
+	class OOM(Exception): pass
+	fake = types.SimpleNamespace(cuda=types.SimpleNamespace(current_device=lambda: 0, set_device=lambda d: None, OutOfMemoryError=OOM, empty_cache=lambda: None))
+	monkeypatch.setattr(hostio, "_torch", lambda: fake)
+	monkeypatch.setattr(hostio, "eligible", lambda a: True)
+	calls = []
+	def fake_upload(a):
+		calls.append(a.shape)
+		if a.shape[0] == 3: raise ValueError("upload failed")      # not an out-of-memory error: the slot must come back all the same
+		return (a, None)
+	monkeypatch.setattr(hostio, "upload", fake_upload)
+	p = hostio.Pipeline()
+	arrs = [np.zeros((k + 1, 4)) for k in range(5)]
+	p.prefetch(arrs)
+	assert p.take(arrs[0]) is not None      # frees one slot; the third upload fails, the rest wait for slots nobody will free
+	t0 = time.time()
+	closer = threading.Thread(target=lambda: [None for _ in [0] if not _close(p)], daemon=True)
+	def _close(pp):
+		try: pp.close()
+		except ValueError: pass
+		return True
+	closer.start(); closer.join(5.0)
+	assert not closer.is_alive(), "Pipeline.close() hangs on the prefetch semaphore"
+	assert time.time() - t0 < 5.0
