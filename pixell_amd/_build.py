@@ -14,9 +14,9 @@ def needs_build(lib=LIB):
 	deps = sources()+glob.glob(os.path.join(CSRC, "*.hpp"))+[os.path.join(HERE, "..", "include", "pxsht.h")]
 	return any(os.path.getmtime(d) > t for d in deps)
 
-# per-file flags.  thetaline.hip: SimplifyCFG's sinking of common instructions merges the register-array accesses of the radix
+# per-file flags.  thetaline.hip, ringline.hip (the register-resident line FFT): SimplifyCFG's sinking of common instructions merges the register-array accesses of the radix
 # switch into pointer phis before the array is split into scalars, and the whole line then lives in scratch memory (regfft_dev.hpp).
-FILE_FLAGS = {"thetaline.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+FILE_FLAGS = {"thetaline.hip": ["-mllvm", "-simplifycfg-sink-common=false"], "ringline.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 def flags_for(src):
 	return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]+FILE_FLAGS.get(os.path.basename(src), [])+os.environ.get("PXS_EXTRA_HIPCC_FLAGS", "").split()

@@ -401,7 +401,6 @@ template<int MODE> struct StSplit : StageBase {
 // ---------------------------------------------------------------------------------------------------------------
 // ring FFTs
 // ---------------------------------------------------------------------------------------------------------------
-struct MapAddr { void* ptr; int dtype; long cstride, bstride, off0, rstride, pstride; int nring, ncb; FastDiv dncb; };   // "component" index = b*ncb + c
 
 // MA1: two real rings as one complex line z = ring(2q) + i ring(2q+1); pixel x = b*j1 + j2, line = j2, a-point FFT over j1
 struct StRingA1 : StageBase {
@@ -794,11 +793,6 @@ ThetaPlan FftChain::plan_theta(long N, int lmax) {
 	return best;
 }
 
-static MapAddr map_addr(const FftChain::MapDesc& m) {
-	MapAddr a; a.ptr = const_cast<void*>(m.ptr); a.dtype = m.dtype; a.cstride = m.cstride; a.bstride = m.bstride; a.off0 = m.ring_off0; a.rstride = m.ring_stride; a.pstride = m.pix_stride; a.nring = m.nring;
-	a.ncb = m.ncb > 0 ? m.ncb : (1 << 30); a.dncb = make_fastdiv((uint32_t)a.ncb);
-	return a;
-}
 
 // ring pairs per pass of the ring-FFT stages: PXS_RING_CHUNK_MB > 0 bounds the intermediate of a pass (experiment: keeping it in
 // the 256 MB memory-side cache between the two kernels of a pass); 0 = all pairs at once.  Measured at C3 (ring FFT ms per round
@@ -842,6 +836,7 @@ void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, doubl
 
 void FftChain::h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax, long hcomp) {
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
+	if (line_h2map(st, h, ldh, m, nc, mmax, hcomp)) return;      // (ring lengths compiled into ringline.hip: one kernel, no intermediate)
 	const long npair_all = (m.nring + 1)/2, a = rs_.a, b = rs_.b, ldY = pad8(b);
 	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, 1);
 	const int T1 = tile_lines_for<StRingS1>(a, 0, b, 8, 2*a), T2 = tile_lines_for<StRingS2>(b, 0, a, 16, b);
@@ -883,7 +878,8 @@ void FftChain::theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size
 	const int cc = theta_comp_chunk(nc, n1, n2);
 	b1 = sizeof(double2)*n1*cc; b2 = sizeof(double2)*n2*cc;
 }
-void FftChain::ring_scratch(long nring, int nc, bool analysis, size_t& b1) const {
+void FftChain::ring_scratch(long nring, int nc, bool analysis, size_t& b1, int mmax) const {
+	if (!analysis && mmax >= 0 && line_h2map_takes(nphi_, mmax)) { b1 = 0; return; }
 	const long npair = (nring + 1)/2, a = analysis ? ra_.a : rs_.a, b = analysis ? ra_.b : rs_.b;
 	b1 = sizeof(double2)*(size_t)nc*npair*a*pad8(b);       // (ring_chunk only shrinks it)
 }

@@ -66,10 +66,13 @@ public:
 	bool line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, const double2* leg, long ldleg, int nr, int mir_c, double2* leg_cc, long ldcc, int ncc,
 	                   int nc, int nm, int spin, int lmax, const double2* ph_shift, const double2* sigma, const double2* w, const double2* wring);
 	static bool line_takes(const ThetaPlan& tp, bool has_mid);      // ... would it (then the call needs no theta scratch)
+	// single-kernel form of h2map for ring lengths compiled into ringline.hip: one workgroup per ring pair, no HBM intermediate
+	bool line_h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax, long hcomp);
+	static bool line_h2map_takes(long nphi, int mmax);
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
 	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc, 3: to_cc_adjoint)
 	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);
-	void ring_scratch(long nring, int nc, bool analysis, size_t& b1) const;
+	void ring_scratch(long nring, int nc, bool analysis, size_t& b1, int mmax = -1) const;      // (mmax given: 0 for a synthesis that ringline.hip takes)
 	void reserve(size_t b1, size_t b2) { s1_.ensure(b1); s2_.ensure(b2); }
 private:
 	const double2* small_tw(long X, int n, int T);
@@ -84,5 +87,13 @@ private:
 	DevBuf s1_, s2_;          // ping-pong scratch
 	std::shared_ptr<struct ThetaLine> tl_;     // plans of the single-kernel theta engine
 };
+
+// where the pixels of a map live, in the form the ring-FFT kernels take it (fftchain.hip, ringline.hip)
+struct MapAddr { void* ptr; int dtype; long cstride, bstride, off0, rstride, pstride; int nring, ncb; FastDiv dncb; };   // "component" index = b*ncb + c
+inline MapAddr map_addr(const FftChain::MapDesc& m) {
+	MapAddr a; a.ptr = const_cast<void*>(m.ptr); a.dtype = m.dtype; a.cstride = m.cstride; a.bstride = m.bstride; a.off0 = m.ring_off0; a.rstride = m.ring_stride; a.pstride = m.pix_stride; a.nring = m.nring;
+	a.ncb = m.ncb > 0 ? m.ncb : (1 << 30); a.dncb = make_fastdiv((uint32_t)a.ncb);
+	return a;
+}
 
 } // namespace pxs

@@ -1219,7 +1219,7 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 		p->leg.ensure(c16*nct*nm*ldm);
 		if (via_cc) { p->leg2.ensure(c16*nct*nm*ldc); if (th) { p->hbuf.ensure(c16*nct*(p->band ? (size_t)p->nfull : nr)*ldh); theta(2); } }
 		else p->hbuf.ensure(c16*nct*nr*ldh);
-		p->chain->ring_scratch(p->nring, nct, false, r1);
+		p->chain->ring_scratch(p->nring, nct, false, r1, p->mmax);
 	} else if (synthesis) {                             // map -> alm, transpose of the synthesis
 		p->wk.mom.ensure(sizeof(double)*4*std::max<long>(tb.nrows, 1)*nb);
 		const bool via = (p->is_grid || p->band) && th && (p->is_grid || p->geometry == "F1") && via_cc;
@@ -1234,7 +1234,7 @@ static void reserve_call(pxs_plan* p, int spin, int mode, bool synthesis, bool a
 		else if (path == ANA_CC_WEIGHTS) { p->leg2.ensure(c16*nct*nm*ldc); if (adjoint) { p->hbuf.ensure(c16*nct*nr*ldh); theta(2); } else { p->leg.ensure(c16*nct*nm*ldm); theta(1); } }
 		else if (!adjoint) { p->leg.ensure(c16*nct*nm*ldm); p->leg2.ensure(c16*nct*nm*ldc); theta(0); }      // analysis_2d
 		else { p->leg2.ensure(c16*nct*nm*ldc); p->hbuf.ensure(c16*nct*nr*ldh); theta(3); }                   // adjoint_analysis_2d (fused transposed chain)
-		p->chain->ring_scratch(p->nring, nct, !adjoint, r1);
+		p->chain->ring_scratch(p->nring, nct, !adjoint, r1, p->mmax);
 	}
 	p->chain->reserve(std::max(c1, r1), c2);
 }

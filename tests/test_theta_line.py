@@ -41,6 +41,37 @@ def test_line_engine_c2_size_gpu(monkeypatch, spin, nb):
 	"""BASELINE C2 / C4 grid: 5400 x 10800, lmax 4000 (N = 10 800, N_cc = 8064, M = 16 128)"""
 	run_pair(5400, 10800, 4000, spin, nb, monkeypatch)
 
+def run_ring_pair(nt, nph, lmax, spin, monkeypatch, dtype=np.float64, flip=(False, False), mmax=None):
+	"""synthesis_2d with the single-kernel ring FFT (ringline.hip) and with the two-stage chain: the same map"""
+	nc = 1 if spin == 0 else 2
+	if mmax is None: mmax = lmax
+	ms = sht.tri_mstart(lmax, mmax); nalm = int(ms[-1]) + lmax + 1
+	rng = np.random.default_rng(4)
+	alm = rng.standard_normal((nc, nalm)) + 1j*rng.standard_normal((nc, nalm))
+	for m0 in ms[:1]: alm[:, int(m0):int(m0) + lmax + 1] = alm[:, int(m0):int(m0) + lmax + 1].real
+	out = {}
+	for line in ("1", "0"):
+		monkeypatch.setenv("PXS_RING_LINE", line)
+		m = np.zeros((nc, nt, nph), dtype)
+		sht.synthesis_2d(alm=alm, map=m, spin=spin, lmax=lmax, mmax=mmax, geometry="F1", phi0=0.2, mstart=ms, flip=flip)
+		out[line] = m
+	scale = np.abs(out["0"]).max()
+	assert scale > 0 and np.abs(out["1"] - out["0"]).max() < (1e-13 if dtype == np.float64 else 1e-6)*scale
+
+@pytest.mark.hostsim
+def test_ring_line_hostsim(monkeypatch):
+	run_ring_pair(360, 720, 250, 0, monkeypatch, mmax=60)      # (odd ring-pair handling: 360 rings = 180 pairs; 720 pixels = the simulator's configuration)
+	run_ring_pair(181, 720, 200, 2, monkeypatch, mmax=40)      # an odd number of rings: the last pair has one ring
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spin,dtype,flip", [(0, np.float64, (False, False)), (2, np.float64, (True, True)), (0, np.float32, (False, True))])
+def test_ring_line_c2_size_gpu(monkeypatch, spin, dtype, flip):
+	run_ring_pair(5400, 10800, 4000, spin, monkeypatch, dtype=dtype, flip=flip)
+
+@pytest.mark.gpu
+def test_ring_line_odd_rings_gpu(monkeypatch):
+	run_ring_pair(2701, 10800, 2600, 0, monkeypatch)
+
 @pytest.mark.gpu
 def test_other_sizes_keep_the_chain_gpu():
 	lmax = 300; ms = sht.tri_mstart(lmax, lmax)
