@@ -227,6 +227,14 @@ template<int NT, int PMAX> struct RegFft {
 			if constexpr (PS::twiddled) {
 				const int e = b - b % PS::s;
 				const double2 w1 = cmul(tw[e & (RF_TWL - 1)], tw[RF_TWL + (e >> 7)]);
+				if constexpr (PS::slots > 16) {      // a full register file (three radix-7 butterflies per thread): ONE chain of powers, tied to the outputs
+					double2 wj = w1;
+					sfor<1, R>([&](auto J) RF_INL {
+						constexpr int j = RF_IDX(J);
+						a[RfB<R>::slot(j)] = cmul(a[RfB<R>::slot(j)], wj);
+						if constexpr (j + 1 < R) { wj = cmul(wj, w1); rf_pin_two(a[RfB<R>::slot(j)], wj); }
+					});
+				} else {
 				// W^j, j = 1 ... R-1, as two chains (odd and even powers) that advance by W^2
 				const double2 w2 = cmul(w1, w1);
 				double2 wo = w1, we = w2;
@@ -235,6 +243,7 @@ template<int NT, int PMAX> struct RegFft {
 					double2& x = a[RfB<R>::slot(j)];
 					if (j & 1) { x = cmul(x, wo); if (j + 2 < R) wo = cmul(wo, w2); }
 					else       { x = cmul(x, we); if (j + 2 < R) we = cmul(we, w2); }
+				}
 				}
 			}
 			}

@@ -33,7 +33,7 @@ struct LineArgs {
 #endif
 };
 #ifdef PXS_LAB_TL_TIME
-#define TL_T(k) do { if (blockIdx.x == 0 && tid == CFG::NT - 64) { const unsigned long long t_ = clock64(); a.prof[k] += t_ - t0_; t0_ = t_; } } while (0)
+#define TL_T(k) do { if (blockIdx.x == 0 && tid0 == CFG::NT - 64) { const unsigned long long t_ = clock64(); a.prof[k] += t_ - t0_; t0_ = t_; } } while (0)
 #define TL_T0() unsigned long long t0_ = clock64()
 #else
 #define TL_T(k) do {} while (0)
@@ -120,20 +120,26 @@ template<class CFG> struct LineOps {
 		const int ca = 2*pr;
 		const double2* ra = a.leg + (long)comp*a.cstride + (long)ca*a.ldleg;
 		const bool two = ca + 1 < a.ncol;      // (an odd number of columns: the last pair has one)
-		double2 raw[2][NL];
-		sfor<0, 2*NL>([&](auto Q) RF_INL {
-			constexpr int q = RF_IDX(Q), row = q/NL, u = q % NL;
-			const int i = tid + NT*u;
-			const bool ok = i < a.nr && (row == 0 || two);
-			double2 x = ra[(long)row*a.ldleg*(ok ? 1 : 0) + (ok ? i : 0)];
-			if (a.wring) x = cscale(x, a.wring[ok ? i : 0].x);
-			raw[row][u] = ok ? x : make_double2(0, 0);
-		});
+		// row 0 is loaded first; the loads of row 1 are issued while row 0 sits in the LDS, and wait in registers through its gather
+		// (both rows up front held 12 complex values per thread next to the line that is being filled: spills)
+		double2 raw[NL], raw1[NL];
+		auto load_row = [&](double2 (&dst)[NL], int row) RF_INL {
+			sfor<0, NL>([&](auto U) RF_INL {
+				constexpr int u = RF_IDX(U);
+				const int i = tid + NT*u;
+				const bool ok = i < a.nr && (row == 0 || two);
+				double2 x = ra[(ok ? (long)row*a.ldleg : 0) + (ok ? i : 0)];
+				if (a.wring) x = cscale(x, a.wring[ok ? i : 0].x);
+				dst[u] = ok ? x : make_double2(0, 0);
+			});
+		};
+		load_row(raw, 0);
 		sfor<0, 2>([&](auto RW) RF_INL {
 			constexpr int row = RF_IDX(RW);
 			const bool odd = row == 0 ? a.a_odd != 0 : a.a_odd == 0;      // this column is odd under the reflection
 			RF_BARRIER();
-			sfor<0, NL>([&](auto U) RF_INL { constexpr int u = RF_IDX(U); const int i = tid + NT*u; if (i < a.nr) line2[i] = raw[row][u]; });
+			sfor<0, NL>([&](auto U) RF_INL { constexpr int u = RF_IDX(U); const int i = tid + NT*u; if (i < a.nr) line2[i] = row == 0 ? raw[u] : raw1[u]; });
+			if constexpr (row == 0) load_row(raw1, 1);
 			RF_BARRIER();
 			RF_OPAQUE(tid);
 			sfor<0, PN::slots>([&](auto C) RF_INL {
@@ -170,8 +176,8 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 	double2* tws = lds;
 	double* line = reinterpret_cast<double*>(lds + CFG::ntw);
 	double2* line2 = lds + CFG::ntw;
-	const int tid = threadIdx.x;
-	for (int k = tid; k < CFG::ntw; k += NT) tws[k] = a.tw[k];
+	const int tid0 = threadIdx.x;
+	for (int k = tid0; k < CFG::ntw; k += NT) tws[k] = a.tw[k];
 	const double2* ph = a.has_ph ? tws + CFG::twP : nullptr;
 #if !defined(PXS_HOST_SIM) && !defined(PXS_LAB_TL_NOSTAGGER)
 	// Every line takes the same time, so workgroups that start together stay in step: all CUs then load their rows in the same
@@ -181,6 +187,9 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 #endif
 	for (int task = blockIdx.x; task < a.ntask; task += gridDim.x) {
 		const int comp = (int)fdiv((uint32_t)task, a.dnp), pr = task - comp*a.npair;
+		// (the thread index, opaque per line: the per-thread addresses of everything a line touches -- table entries, rows, outputs -- are loop
+		// invariants, and hoisted out of this loop they occupy registers that are spilled in the prologue and reloaded on every line)
+		int tid = tid0; RF_OPAQUE(tid);
 		double2 v[PMAX];
 		TL_T0();
 		L::template load_pair<RfPassT<SN, 0, NT>>(v, tid, line2, a, comp, pr);
@@ -203,6 +212,7 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 				// table (the quadrature weights of the default analysis) goes in at once as M/2 + 1 doubles; any other table half a circle
 				// at a time.
 				constexpr int M = CFG::M, H = M/2;
+				RF_OPAQUE(tid);
 				if (a.sig_half) {
 					constexpr int NH = (H + 1 + NT - 1)/NT;
 					double raw[NH];
@@ -243,6 +253,7 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 		RF_BARRIER();
 		F::template write_c128<RfPassT<SC, SC::NP - 1, NT>>(v, tid, line2);
 		RF_BARRIER();
+		RF_OPAQUE(tid);
 		{	constexpr int Ncc = CFG::Ncc;
 			const int ca = 2*pr;
 			double2* oc = a.out + (long)comp*a.ocstride;
@@ -263,7 +274,7 @@ template<class CFG> __global__ PXS_TL_BOUNDS void theta_line_kernel(const LineAr
 		}
 		TL_T(8);
 #ifdef PXS_LAB_TL_TIME
-		if (blockIdx.x == 0 && tid == CFG::NT - 64) a.prof[9] += 1;
+		if (blockIdx.x == 0 && tid0 == CFG::NT - 64) a.prof[9] += 1;
 #endif
 	}
 }
