@@ -807,7 +807,6 @@ static long ring_chunk(long npair, long bytes_per_pair, int mult) {
 
 void FftChain::map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale) {
 	PXS_REQUIRE(rings_ok() && m.nphi == nphi_, "internal: ring chain not planned");
-	if (line_map2leg(st, m, nc, mmax, leg, ldleg, tab, scale)) return;      // (ring lengths compiled into ringline.hip)
 	const long npair_all = (m.nring + 1)/2, a = ra_.a, b = ra_.b, ldY = pad8(b);
 	int T2 = tile_lines_for<StRingA2>(b, 0, 2*npair_all, 8, b); if (T2 < 2) T2 = 2; T2 -= T2 % 2;
 	const long qchunk = ring_chunk(npair_all, (long)sizeof(double2)*nc*a*ldY, T2/2);

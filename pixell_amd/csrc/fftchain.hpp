@@ -69,7 +69,6 @@ public:
 	// single-kernel form of h2map for ring lengths compiled into ringline.hip: one workgroup per ring pair, no HBM intermediate
 	bool line_h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax, long hcomp);
 	static bool line_h2map_takes(long nphi, int mmax);
-	bool line_map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale);      // ... of map2leg
 	size_t scratch_bytes() const { return s1_.bytes + s2_.bytes; }
 	// scratch a call needs, so that the plan can size it before the first launch of the call (kind 0: to_cc, 1: from_cc_adjoint, 2: from_cc, 3: to_cc_adjoint)
 	static void theta_scratch(const ThetaPlan& tp, int nm, int nc, int kind, size_t& b1, size_t& b2);

@@ -2254,12 +2254,17 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
 		if (prof) prof->begin(st, 0);
 		if (tb.spin == 0) {
-			if (K == 8)      hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a);
-			else if (K == 2) hipLaunchKernelGGL(leg_syn_s0<2>, leg_grid(a), dim3(64), 0, st, a);
+			// (ring pairs per lane the product's rules select: 4 and 2; lab builds -- PXS_K_* -- compile the others too)
+#ifdef PXS_LAB
+			if (K == 8)      hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a); else
+#endif
+			if (K == 2) hipLaunchKernelGGL(leg_syn_s0<2>, leg_grid(a), dim3(64), 0, st, a);
 			else             hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
 		} else {
-			if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a);
-			else if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
+#ifdef PXS_LAB
+			if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a); else
+#endif
+			if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
 			else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
 		}
 		if (prof) prof->end(st, 0);
@@ -2483,14 +2488,18 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		if (prof) prof->begin(st, 1);
 		const dim3 grid = leg_grid(a);
 		if (tb.spin == 0) {
-			if (K == 12)     hipLaunchKernelGGL(leg_ana_s0<12>, grid, dim3(64), sh, st, a);
-			else if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
+#ifdef PXS_LAB
+			if (K == 12)     hipLaunchKernelGGL(leg_ana_s0<12>, grid, dim3(64), sh, st, a); else
+#endif
+			if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
 			else if (K == 2) hipLaunchKernelGGL(leg_ana_s0<2>, grid, dim3(64), sh, st, a);
 			else             hipLaunchKernelGGL(leg_ana_s0<4>, grid, dim3(64), sh, st, a);
 		} else {
+#ifdef PXS_LAB
 			if (K >= 6)      hipLaunchKernelGGL(leg_ana_spin<6>, grid, dim3(64), sh, st, a);
-			else if (K == 5) hipLaunchKernelGGL(leg_ana_spin<5>, grid, dim3(64), sh, st, a);
-			else if (K == 4) hipLaunchKernelGGL(leg_ana_spin<4>, grid, dim3(64), sh, st, a);
+			else if (K == 5) hipLaunchKernelGGL(leg_ana_spin<5>, grid, dim3(64), sh, st, a); else
+#endif
+			if (K >= 4) hipLaunchKernelGGL(leg_ana_spin<4>, grid, dim3(64), sh, st, a);
 			else if (K == 3) hipLaunchKernelGGL(leg_ana_spin<3>, grid, dim3(64), sh, st, a);
 			else             hipLaunchKernelGGL(leg_ana_spin<2>, grid, dim3(64), sh, st, a);
 		}

@@ -4,9 +4,11 @@
 // (fftchain.hip, MS1 / MS2: a four-step transform through HBM) writes and reads an intermediate of 16 bytes per pixel pair.  HBM
 // traffic per pair: the two rows of h in, the two map rows out.  Same arithmetic statement as StRingS1::load / StRingS2::store; compiled
 // for an explicit list of ring lengths (RING_CONFIGS), everything else runs the stage chain.
-// The analysis direction (ring_line_ana_kernel: two map rows as one complex line, forward transform, the pair unpacked, leg[m][2q],
-// leg[m][2q + 1]) writes 32-byte pieces of 128-byte lines -- leg is ring-contiguous per m -- so the four workgroups that complete a
-// line are placed on the same XCD at the same time (block order below) and their pieces meet in that XCD's L2.
+// (The analysis direction was built the same way and measured: its output leg[m][ring] is ring-contiguous per m, so a workgroup that owns
+// two rings writes 32-byte pieces of 128-byte lines.  With the four workgroups that complete a line placed on one XCD in the same
+// iteration the pieces do merge in that XCD's L2 -- WRITE_SIZE 1.26x the bytes of leg, not 4x -- but a store instruction that touches 64
+// lines costs what the saved intermediate gains: 3.46 ms per 8 maps against 3.48 for the two-stage chain
+// (profiles/r06_ring_line_analysis_ab.txt; the kernel is in the history, commit "Analysis ring FFT as one kernel").  map2leg keeps MA1 / MA2.)
 // Replaces the ring FFTs inside ducc0's synthesis_2d / adjoint_analysis_2d (pixell/curvedsky.py:907-924).
 #include "fftchain.hpp"
 #include "chain_dev.hpp"
@@ -102,87 +104,10 @@ template<class CFG> __global__ PXS_RL_BOUNDS void ring_line_kernel(const RingArg
 	}
 }
 
-struct RingAnaArgs {
-	const double2* tw; int ntw;
-	MapAddr m; int mmax, npair, nring, ntask; FastDiv dnp;
-	double2* leg; long ldleg; int nm; const double2* tab; double scale;
-};
-
-// Task of (block, iteration): blocks go round-robin to the 8 XCDs; the 4 ring pairs whose outputs share every 128-byte line of leg
-// (pairs 4g ... 4g + 3 = rings 8g ... 8g + 7) go to 4 blocks of ONE XCD in the same iteration.
-__device__ __forceinline__ int ring_task(int bx, int nblk, int it) {
-	if ((nblk & 31) != 0) return bx + nblk*it;
-	const int xcd = bx & 7, slot = bx >> 3, per = nblk >> 3;      // per: blocks per XCD, a multiple of 4
-	return it*nblk + ((xcd*(per >> 2) + (slot >> 2)) << 2) + (slot & 3);
-}
-
-template<class CFG> __global__ PXS_RL_BOUNDS void ring_line_ana_kernel(const RingAnaArgs a)
-{
-	constexpr int NT = CFG::NT, PMAX = CFG::PMAX, X = CFG::X;
-	using F = RegFft<NT, PMAX>; using S = typename CFG::S;
-	using P0 = RfPassT<S, 0, NT>; using PL = RfPassT<S, S::NP - 1, NT>;
-	PXS_SHARED(double2, lds);
-	double2* tws = lds;
-	double* line = reinterpret_cast<double*>(lds + CFG::ntw);
-	double2* spec = lds + CFG::ntw;
-	const int tid0 = threadIdx.x;
-	for (int k = tid0; k < CFG::ntw; k += NT) tws[k] = a.tw[k];
-	const int mm = a.mmax;
-	for (int it = 0;; it++) {
-		const int task = ring_task((int)blockIdx.x, (int)gridDim.x, it);
-		if (it*(int)gridDim.x >= a.ntask) break;      // (every block leaves in the same iteration: the barriers below stay collective per workgroup anyway)
-		if (task >= a.ntask) continue;
-		int tid = tid0; RF_OPAQUE(tid);
-		const int comp = (int)fdiv((uint32_t)task, a.dnp), q = task - comp*a.npair;
-		const bool two = 2*q + 1 < a.nring;
-		const int bi = (int)fdiv((uint32_t)comp, a.m.dncb);
-		const long o0 = (long)bi*a.m.bstride + (long)(comp - bi*a.m.ncb)*a.m.cstride + a.m.off0 + (2L*q)*a.m.rstride;
-		// z = ring 2q + i ring 2q+1, straight from the map into the registers (pixel x = b + nb k: runs of consecutive pixels per slot)
-		double2 v[PMAX];
-		F::template fill<P0>(v, tid, [&](int x) {
-			const long o = o0 + (long)x*a.m.pstride;
-			const double re = rd_real(a.m.ptr, a.m.dtype, o).x, im = rd_real(a.m.ptr, a.m.dtype, two ? o + a.m.rstride : o).x;
-			return make_double2(re, two ? im : 0.0); });
-		RF_BARRIER();      // (first line: the twiddle table; later ones: the previous line's reads of the spectrum)
-		F::template run<S>(v, tid, line, tws);
-		// the bins the unpacking needs, both components: k <= mmax at k, k >= X - mmax at 2 mmax + 1 - (X - k)
-		RF_BARRIER();
-		RF_OPAQUE(tid);
-		sfor<0, PL::slots>([&](auto C) RF_INL {
-			constexpr int c = RF_IDX(C), i = c/PL::R, j = c % PL::R;
-			const int b = tid + NT*i, k = b + PL::nb*j;
-			if ((i + 1)*NT <= PL::nb || b < PL::nb) {
-				if (k <= mm) spec[k] = v[c];
-				else if (k >= X - mm) spec[2*mm + 1 - (X - k)] = v[c];
-			}
-		});
-		RF_BARRIER();
-		// X_a = (Z[k] + conj Z[X-k])/2, X_b = -i (Z[k] - conj Z[X-k])/2 (StRingA2::store of the stage chain)
-		for (int k = tid; k <= mm; k += NT) {
-			const double2 zp = spec[k];
-			const double2 zm = k == 0 ? zp : spec[2*mm + 1 - k];
-			double2 xa = make_double2(0.5*(zp.x + zm.x), 0.5*(zp.y - zm.y));
-			const double2 d = make_double2(zp.x - zm.x, zp.y + zm.y);
-			double2 xb = make_double2(0.5*d.y, -0.5*d.x);
-			const double2 t = a.tab ? a.tab[k] : make_double2(1, 0);
-			double2* o = a.leg + ((long)comp*a.nm + k)*a.ldleg + 2*q;
-			o[0] = cscale(cmul(xa, t), a.scale);
-			if (two) o[1] = cscale(cmul(xb, t), a.scale);
-		}
-	}
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct RingEntry { long X; int mcap, nt, ntw; size_t lds; void (*launch)(const RingArgs&, size_t, long, hipStream_t); void (*launch_ana)(const RingAnaArgs&, size_t, long, hipStream_t); };
-template<class CFG> static void launch_ring_ana(const RingAnaArgs& a, size_t lds, long nwg, hipStream_t st) {
-#ifndef PXS_HOST_SIM
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)ring_line_ana_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024); return true; }();
-	(void)once;
-#endif
-	hipLaunchKernelGGL((ring_line_ana_kernel<CFG>), dim3((unsigned)nwg), dim3(CFG::NT), lds, st, a);
-}
+struct RingEntry { long X; int mcap, nt, ntw; size_t lds; void (*launch)(const RingArgs&, size_t, long, hipStream_t); };
 template<class CFG> static void launch_ring(const RingArgs& a, size_t lds, long nwg, hipStream_t st) {
 #ifndef PXS_HOST_SIM
 	static const bool once = [] { (void)hipFuncSetAttribute((const void*)ring_line_kernel<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024); return true; }();
@@ -192,7 +117,7 @@ template<class CFG> static void launch_ring(const RingArgs& a, size_t lds, long 
 }
 template<class CFG> static RingEntry ring_entry() {
 	static_assert(CFG::lds <= 160*1024 - 256, "the ring pair does not fit the LDS");
-	return RingEntry{CFG::X, CFG::MCAP, CFG::NT, CFG::ntw, CFG::lds, &launch_ring<CFG>, &launch_ring_ana<CFG>};
+	return RingEntry{CFG::X, CFG::MCAP, CFG::NT, CFG::ntw, CFG::lds, &launch_ring<CFG>};
 }
 // Ring lengths compiled in (a plan takes the kernel when nphi matches and mmax is within the configuration's cap):
 //   10 800 pixels per ring (BASELINE C2 / C4, mmax <= 4000): 16 15 15 3 on 1024 threads, <= 16 points per thread
@@ -219,28 +144,6 @@ static const RingEntry* ring_find(long nphi, int mmax) {
 bool FftChain::line_h2map_takes(long nphi, int mmax) { return ring_find(nphi, mmax) != nullptr; }
 
 static void ring_tables(const RingEntry* e, const double2*& tw, int& ncu);
-
-// PXS_RING_LINE_ANA=0 keeps the stage chain for the analysis direction
-bool FftChain::line_map2leg(hipStream_t st, const MapDesc& m, int nc, int mmax, double2* leg, long ldleg, const double2* tab, double scale)
-{
-	{ const char* ev = getenv("PXS_RING_LINE_ANA"); if (ev && atoi(ev) == 0) return false; }
-	const RingEntry* e = ring_find(m.nphi, mmax);
-	if (!e) return false;
-	const double2* tw; int ncu; ring_tables(e, tw, ncu);
-	const long npair = (m.nring + 1)/2;
-	RingAnaArgs a; memset(&a, 0, sizeof(a));
-	a.tw = tw; a.ntw = e->ntw; a.m = map_addr(m); a.mmax = mmax; a.npair = (int)npair; a.nring = m.nring;
-	const long ntask = (long)nc*npair;
-	PXS_REQUIRE(ntask < (1L << 30), "internal: ring line grid too large");
-	a.ntask = (int)ntask; a.dnp = make_fastdiv((uint32_t)npair);
-	a.leg = leg; a.ldleg = ldleg; a.nm = mmax + 1; a.tab = tab; a.scale = scale;
-	const long per_cu = std::max<long>(1, std::min<long>(2048/e->nt, (long)(160*1024)/(long)e->lds));
-	long nwg = std::min<long>(ntask, (long)ncu*per_cu);
-	if (nwg >= 32) nwg -= nwg % 32;      // (whole groups of 4 blocks per XCD: ring_task)
-	e->launch_ana(a, e->lds, nwg, st);
-	PXS_HIP(hipGetLastError());
-	return true;
-}
 
 bool FftChain::line_h2map(hipStream_t st, const double2* h, long ldh, const MapDesc& m, int nc, int mmax, long hcomp)
 {

@@ -58,35 +58,6 @@ def run_ring_pair(nt, nph, lmax, spin, monkeypatch, dtype=np.float64, flip=(Fals
 	scale = np.abs(out["0"]).max()
 	assert scale > 0 and np.abs(out["1"] - out["0"]).max() < (1e-13 if dtype == np.float64 else 1e-6)*scale
 
-def run_ring_ana_pair(nt, nph, lmax, spin, monkeypatch, dtype=np.float64, flip=(False, False), mmax=None):
-	"""adjoint_synthesis_2d (ring FFT map -> leg, then the transposed Legendre stage) with the single-kernel analysis ring FFT and with
-	the two-stage chain: the same alm"""
-	nc = 1 if spin == 0 else 2
-	if mmax is None: mmax = lmax
-	ms = sht.tri_mstart(lmax, mmax); nalm = int(ms[-1]) + lmax + 1
-	m = np.random.default_rng(6).standard_normal((nc, nt, nph)).astype(dtype)
-	out = {}
-	for line in ("1", "0"):
-		monkeypatch.setenv("PXS_RING_LINE_ANA", line)
-		alm = np.zeros((nc, nalm), complex)
-		sht.adjoint_synthesis_2d(alm=alm, map=m, spin=spin, lmax=lmax, mmax=mmax, geometry="F1", phi0=0.2, mstart=ms, flip=flip)
-		out[line] = alm
-	assert np.abs(out["0"]).max() > 0 and relrms(out["1"], out["0"]) < (1e-13 if dtype == np.float64 else 1e-6)
-
-@pytest.mark.hostsim
-def test_ring_line_ana_hostsim(monkeypatch):
-	run_ring_ana_pair(360, 720, 250, 0, monkeypatch, mmax=60)
-	run_ring_ana_pair(181, 720, 200, 2, monkeypatch, mmax=40)      # an odd number of rings
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("spin,dtype,flip", [(0, np.float64, (False, False)), (2, np.float64, (True, True)), (0, np.float32, (False, True))])
-def test_ring_line_ana_c2_size_gpu(monkeypatch, spin, dtype, flip):
-	run_ring_ana_pair(5400, 10800, 4000, spin, monkeypatch, dtype=dtype, flip=flip)
-
-@pytest.mark.gpu
-def test_ring_line_ana_odd_rings_gpu(monkeypatch):
-	run_ring_ana_pair(2701, 10800, 2600, 0, monkeypatch)
-
 @pytest.mark.hostsim
 def test_ring_line_hostsim(monkeypatch):
 	run_ring_pair(360, 720, 250, 0, monkeypatch, mmax=60)      # (odd ring-pair handling: 360 rings = 180 pairs; 720 pixels = the simulator's configuration)

@@ -2,7 +2,7 @@
 # bench command (separate --pmc passes, kernel-trace only).  Everything guarded by timeouts; results under gpurun_out/<tag>/.
 TAG=${1:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+PXS_REQUIRE_FULL=1 timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; tail -1 $O/bench_c3.err
 timeout 600 python bench.py --config c2 --no-cpu --steps 10 --warmup 2 > $O/bench_c2.json 2> $O/bench_c2.err; tail -1 $O/bench_c2.err
 timeout 900 python bench.py --config c4 --no-cpu > $O/bench_c4.json 2> $O/bench_c4.err; tail -1 $O/bench_c4.err
