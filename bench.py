@@ -186,7 +186,7 @@ def measured_traffic(config, dom):
 	profiles/r02_traffic_<config>.json; FETCH_SIZE corrected per access pattern -- x2 for 16-byte-per-lane row reads as the gfx950 note
 	of MI355X_MICROARCH.md prescribes, x1 where the known array sizes of the chain kernels show full counting -- WRITE_SIZE as reported).
 	Counters cannot be read from inside this process: null when no profile of this config is committed."""
-	for tag in ("r05c", "r05b", "r05", "r04b", "r04", "r03", "r02", "r01"):
+	for tag in ("r06b", "r06", "r05c", "r05b", "r05", "r04b", "r04", "r03", "r02", "r01"):
 		path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (tag, config))
 		if os.path.exists(path): break
 	else: return dict(traffic=None)
@@ -543,11 +543,11 @@ def run_sht(args, ctx):
 	# ---- the HBM-bound family: ring FFTs + theta resampling (fused chains, csrc/fftchain.hip) ----
 	chain_ms = (prof["ring_fft"][0]+prof["resample"][0])/args.steps
 	chain_bytes = 2*chain_alg_bytes(cfg, R_ana, nmaps)           # both directions
-	chain = dict(bound="hbm", kernel="chain_kernel<*> (ring FFTs map<->leg and theta resampling leg<->leg_cc, both directions)",
+	chain = dict(bound="hbm", kernel="chain_kernel<*> + theta_line_kernel / ring_line_kernel where a line fits a CU (ring FFTs map<->leg and theta resampling leg<->leg_cc, both directions)",
 		achieved=round(chain_bytes/(chain_ms*1e-3)/1e9, 1) if chain_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
 		algorithmic_bytes_per_step=chain_bytes, kernel_ms_per_step=round(chain_ms, 3))
 	chain["frac"] = round(chain["achieved"]/HBM_PEAK_GBS, 4)
-	chain.update(measured_traffic(args.config, ["chain_kernel", "transpose", "fft_lds", "split_pair", "unpack", "fold"]))
+	chain.update(measured_traffic(args.config, ["chain_kernel", "theta_line_kernel", "ring_line_kernel", "transpose", "fft_lds", "split_pair", "unpack", "fold"]))
 	map_bytes = ncomp_all*ny*nx*8; alm_bytes = ncomp_all*nalm(lmax)*16
 	tot_bytes = (ntot*ncomp*(ny*nx*8+nalm(lmax)*16)) if batched else world*(map_bytes+alm_bytes)
 	hbm_gbs = 2*tot_bytes/(ms_step*1e-3)/1e9
