@@ -21,17 +21,14 @@
 //    v_permlane32_swap / v_permlane16_swap, one ds_write_b64 per step parks them in a tile of 16 steps; at a flush lane j owns
 //    output j, adds its 16 partial sums and the wave issues one contiguous 512-byte global_atomic_add_f64 into the moments
 //    (PXS_DETERMINISTIC=1: per-wave partial moments summed in wave order by reduce_partials instead).
-#include "legendre.hpp"
-#include <cmath>
-#include <algorithm>
+// Translation units: this file holds the host side (tables, seeds, dispatch), the alm pre / post kernels and the table kernels; leg_s0.hip and leg_spin.hip the
+// Legendre kernels themselves, legendre_dev.hpp what they share.
+#include "legendre_dev.hpp"
 #include <thread>
 #include <memory>
 
 namespace pxs {
 
-static constexpr double SC_BIG   = 0x1p+400;
-static constexpr double SC_SMALL = 0x1p-800;
-static constexpr int    SC_STEP  = 800;
 // ring pairs per lane (K): defaults chosen by measurement on MI355X; PXS_K_SYN0/PXS_K_ANA0 (4|8) and
 // PXS_K_SYNS/PXS_K_ANAS (2|3|4) override them for tuning runs
 static int env_k(const char* name, int def, int lo, int hi) {
@@ -47,114 +44,6 @@ static int k_ana0() { static int k0 = lab_k("PXS_K_ANA0", 8, 2, 12); static int 
 static int k_syns() { static int k = lab_k("PXS_K_SYNS", 3, 2, 4); return k; }
 static int k_anas() { static int k = lab_k("PXS_K_ANAS", 4, 2, 6); return k; }   // 4: 149 VGPRs = 3 waves per SIMD (6: 227 = 2 waves; measured 146.9 vs 150.5 ms at config 3)
 static int xcd_map() { static int k = lab_k("PXS_XCD_MAP", 1, 0, 1); return k; }
-
-struct double4_t { double a, b, c, d; };
-// Wave-uniform table rows are fetched through the constant address space: that makes them scalar loads (s_load_dwordx8)
-// even in kernels that also store to global memory inside their loops.  Without it the analysis kernels, whose flush
-// stores precede later row loads, got per-lane global_load broadcasts for every coefficient row (SQ_INSTS_SMEM 5.5e7
-// against SQ_INSTS_VMEM_RD 2.2e9 for leg_ana_spin<6> at config 3; the synthesis kernels had 4e9 scalar loads).
-#ifdef PXS_HOST_SIM
-#define LDC(p, i) ((p)[i])
-#else
-typedef double pxs_d4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double4_t ldc_row(const double4_t* p, long i) {
-	const __attribute__((address_space(4))) pxs_d4* c = (const __attribute__((address_space(4))) pxs_d4*)(unsigned long long)p;
-	const pxs_d4 v = c[i]; double4_t r; r.a = v.x; r.b = v.y; r.c = v.z; r.d = v.w; return r;
-}
-#define LDC(p, i) ldc_row((p), (i))
-#endif
-// one double of a wave-uniform table through the constant address space (s_load_dwordx2)
-#ifdef PXS_HOST_SIM
-#define LDCD(p, i) ((p)[i])
-#else
-__device__ __forceinline__ double ldc_double(const double* p, long i) {
-	const __attribute__((address_space(4))) double* c = (const __attribute__((address_space(4))) double*)(unsigned long long)p;
-	return c[i];
-}
-#define LDCD(p, i) ldc_double((p), (i))
-#endif
-
-struct LegK {
-	int lmax, mmax, spin, nm, npairs, nring, nwave;
-	long ld;                            // row stride of leg[m][ring] (>= nring; rows padded to whole 128-byte lines)
-	long nrows;
-	const long* row; const double4_t* coef; const double* alpha;
-	const int* ring_n; const int* ring_s; const double* cth; const double* sth; const double* sh2; const double* ch2;
-	double* almt; double* part; double* mom;
-	double2* leg;
-	double ofs;
-	int m0; long rowbase, rows_chunk;   // analysis processes m in chunks to bound the partial-moment scratch
-	int nmc, xcd;                       // m count of this launch; XCD-aware block order on/off
-	int* first;                         // analysis: see LegWork::first
-	int atomic;                         // analysis: waves add their sums into mom (part = mom) instead of writing per-wave partial moments
-	// recurrence seeds: the state of every chain at the end of phase A, per (m, wave): [nd][K][64] doubles, [ni][K][64] + 64 ints
-	// (the first of the last 64: the step reached).  mode 0: off, 1: run phase A and record, 2: load instead of running it
-	int seed_mode; double* seed_d; int* seed_i;
-	// executed-work counters (profiling on: pxs_profile; null otherwise): count[0] synthesis, count[1] analysis, in FMA instructions
-	// per lane: every wave adds (steps it ran) x K x (FMAs per ring pair and step: 6 per two degrees for spin 0, 12 per degree for
-	// spin s; 2 / 4 in the recurrence-only phase A).  x 64 lanes x 2 = the FP64 flops the hardware executed in the recurrences and
-	// accumulations (rings dropped as polar-dead and (wave, m) pairs skipped entirely are not in it, masked-off lanes are).
-	double* count;
-	// maps of a batched call in one launch: the waves of one m of ALL maps sit next to each other in an XCD's queue, so the maps
-	// share the coefficient rows in L2 and the scalar cache.  Strides in elements of leg (double2), almt and mom (double).
-	int nb; long leg_bs, almt_bs, mom_bs;
-	int nmaps;                          // MFMA kernels (leg_ana_s0_mm): nb counts GROUPS of maps there, nmaps the maps themselves
-	const double2* coef2; const double2* coef2p;      // compact step table (a, b) / (a, a + b) of the MFMA kernels (LegTables::coef2)
-};
-// (PXS_NCOUNT slots, one picked by the block index: 200 000 waves adding to ONE address cost ~10 ms per C3 step and 24 ms per C4 step)
-#define PXS_NCOUNT 1024
-#ifdef PXS_HOST_SIM
-#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) atomicAdd(a.count + 2*(blockIdx.x & (PXS_NCOUNT - 1)) + (dir), (double)(expr))
-#else
-#define PXS_COUNT(dir, expr) if (a.count != nullptr && lane == 0) unsafeAtomicAdd(a.count + 2*(blockIdx.x & (PXS_NCOUNT - 1)) + (dir), (double)(expr))
-#endif
-
-// Block -> (m, ring chunk).  Every wave of one m streams the same coefficient rows (32 B per l) through the
-// scalar cache; workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  With the plain
-// (chunk, m) grid the nwave readers of a stream were spread over all XCDs and drifted apart, and FETCH_SIZE
-// showed every one of them going to the fabric (49 GB per leg_syn_spin launch at config 3 = nwave x the
-// table).  This order gives all chunks of one m the same `block % 8`, back to back in that XCD's queue, so
-// one reader misses and the others hit in L2.
-// (Workgroups of 2-4 independent waves of the same m -- to share the rows in the CU's scalar cache -- were measured twice:
-// with __launch_bounds__(256) and the lane taken as threadIdx.x & 63 every kernel got slower even at one wave per workgroup
-// (config 3: leg_syn 106 -> 113 ms, leg_ana 144 -> 151 ms), 4 waves per workgroup 128 / 165 ms.  One wave per workgroup stays.)
-__device__ __forceinline__ bool leg_block(const LegK& a, int& wv, int& m, int& bb) {
-	if (!a.xcd) { wv = blockIdx.x; m = blockIdx.y + a.m0; bb = blockIdx.z; return true; }
-	const unsigned b = blockIdx.x, x = b & 7u, j = b >> 3;
-	const unsigned per_m = (unsigned)a.nwave*(unsigned)a.nb;
-	const unsigned ml = j / per_m, r = j - ml*per_m;
-	bb = (int)(r / (unsigned)a.nwave);
-	wv = (int)(r - (unsigned)bb*a.nwave);
-	const unsigned mi = ml*8u + x;
-	m = (int)mi + a.m0;
-	return mi < (unsigned)a.nmc;
-}
-static inline dim3 leg_grid(const LegK& a) { return a.xcd ? dim3((unsigned)(8*((a.nmc+7)/8)*a.nwave*a.nb)) : dim3(a.nwave, a.nmc, a.nb); }
-
-
-// ---------------------------------------------------------------------------------
-// scaled powers
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ void frexp_norm(double& m, int& e) { int d; m = frexp(m, &d); e += d; }
-
-// x^n as mant * 2^e, mant in [0.5,1) (or 0)
-__device__ __forceinline__ void pow_scaled(double x, int n, double& mant, int& e) {
-	double rm = 0.5; int re = 1;
-	int be = 0; double bm = frexp(x, &be);
-	while (n) {
-		if (n & 1) { rm *= bm; re += be; frexp_norm(rm, re); }
-		bm *= bm; be *= 2; frexp_norm(bm, be);
-		n >>= 1;
-	}
-	mant = rm; e = re;
-}
-// value = mant*2^e  ->  v*2^(800*scale), scale <= 0, |v| <= 2^400
-__device__ __forceinline__ void to_scaled(double mant, int e, double& v, int& scale) {
-	if (mant == 0.0) { v = 0.0; scale = 0; return; }
-	int s = (e >= 0) ? (e + SC_STEP/2)/SC_STEP : -((-e + SC_STEP/2)/SC_STEP);
-	if (s > 0) s = 0;
-	v = ldexp(mant, e - SC_STEP*s); scale = s;
-}
 
 // ---------------------------------------------------------------------------------
 // alm pre / post transforms
@@ -330,502 +219,7 @@ __global__ __launch_bounds__(256) void reduce_partials(const double* __restrict_
 }
 
 // A wave is 'polar' when all its rings have cos^2 > PXS_POLAR_COS2: it then runs the recurrences in the variable
-// -sin^2(theta) (spin 0) resp. -2 sin^2(theta/2) (spin s), with the constant term of the step
-// coefficient adjusted accordingly (table columns c,d).  This keeps full relative precision near the
-// poles, where x = cos(theta) rounds away the information about theta: there the recurrence sits at its double root (step coefficient
-// 2 - (l theta)^2-ish) and an ABSOLUTE error eps in the coefficient grows like l^2 eps -- 4e-13 of the map rms on the rings next to the poles at
-// lmax 240, 3e-12 at lmax 600 (tests/test_grid_fuzz.py found it), against 1e-14 elsewhere.  The form is exact algebra for every ring but cancels
-// towards the equator (a (1 - sin^2) + b: the spin-0 equator ring of a wave forced into it went from 4e-14 to 7e-13 at lmax 240), so a wave takes it
-// only if its MOST EQUATORIAL ring still has cos^2 > 0.1 (theta < 71.5 deg: at most one digit of the coefficient).  Until round 5 the bound was 1/2:
-// a wave spans 256-512 ring pairs, so grids below 1024-2048 rings -- and the CC-grid detour of the synthesis up to lmax ~2000 -- never ran their
-// polar rings in this form; with 0.1 that shrinks to 644-1288 rings (below which l^2 eps stays under ~4e-12).
-#ifndef PXS_POLAR_COS2
-#define PXS_POLAR_COS2 0.1
-#endif
-__device__ __forceinline__ bool leg_wave_polar(const LegK& a, int wv, int K) {
-	const int last = min((wv+1)*K*64, a.npairs) - 1;   // most equatorial pair of the wave (wave-uniform; pairs are ordered pole first)
-	const double c = a.cth[last];
-	return c*c > PXS_POLAR_COS2;
-}
 
-// make a VGPR copy of a wave-uniform value once, so that v_fma_f64 can take it as the addend next to
-// an SGPR multiplicand (gfx950 allows one scalar source per VALU op; without this the compiler
-// re-materialises the constant for every use with two v_mov_b32)
-#ifdef PXS_HOST_SIM
-#define PXS_VCOPY(dst, src) double dst = (src)
-#else
-#define PXS_VCOPY(dst, src) double dst; asm("v_mov_b64 %0, %1" : "=v"(dst) : "s"(src))
-#endif
-
-// (An L2 prefetch of the coefficient streams via global_load_lds into an LDS sink was tried to hide SMEM
-// miss latency and measured SLOWER on MI355X: leg_syn 10.8 -> 12.4 ms at config 2; removed.)
-
-#ifdef PXS_HOST_SIM
-#define PXS_UNIFORM_INT(x) (x)
-#define PXS_UNIFORM_LONG(x) (x)
-#else
-#define PXS_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
-// (a wave-uniform table offset that the compiler keeps in VGPRs turns every coefficient row load of the loops below into a per-lane
-// global_load: seen when the seed stores entered the kernels -- leg_syn 101 -> 123 ms at config 3)
-#define PXS_UNIFORM_LONG(x) ((long)(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long)(x) >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long)(x))))
-#endif
-// Recurrence seeds.  Phase A (recurrence only, no accumulation, until the first lane of the wave reaches scale 0) is the same
-// for every transform on a plan: ~18 % of the steps of a live (wave, m) at a third of the cost of an accumulating step, i.e.
-// ~5 % of the Legendre time, plus the sin^m start values.  The first launch on a ring set records the state it ends in, later
-// launches load it: K x 20 bytes (spin 0) or K x 40 bytes (spin s) per lane.
-#define S0_SEEDED_PHASE_A \
-	if (a.seed_mode == 2) { \
-		const double* sd = a.seed_d + ((long)m*a.nwave + wv)*(2*K*64); const int* si = a.seed_i + ((long)m*a.nwave + wv)*((K+1)*64); \
-		k = PXS_UNIFORM_INT(si[K*64]); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { lam1[s] = sd[s*64 + lane]; lam2[s] = sd[(K+s)*64 + lane]; sc[s] = si[s*64 + lane]; } \
-	} else { \
-		S0_PHASE_A \
-		if (a.seed_mode == 1) { \
-			double* sd = a.seed_d + ((long)m*a.nwave + wv)*(2*K*64); int* si = a.seed_i + ((long)m*a.nwave + wv)*((K+1)*64); \
-			_Pragma("unroll") for (int s = 0; s < K; s++) { sd[s*64 + lane] = lam1[s]; sd[(K+s)*64 + lane] = lam2[s]; si[s*64 + lane] = sc[s]; } \
-			if (lane == 0) si[K*64] = k; \
-		} \
-	}
-#define SPIN_SEEDED_PHASE_A \
-	if (a.seed_mode == 2) { \
-		const double* sd = a.seed_d + ((long)m*a.nwave + wv)*(4*K*64); const int* si = a.seed_i + ((long)m*a.nwave + wv)*((2*K+1)*64); \
-		j = PXS_UNIFORM_INT(si[2*K*64]); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			S.gp1[s] = sd[s*64 + lane]; S.gp2[s] = sd[(K+s)*64 + lane]; S.gm1[s] = sd[(2*K+s)*64 + lane]; S.gm2[s] = sd[(3*K+s)*64 + lane]; \
-			S.scp[s] = si[s*64 + lane]; S.scm[s] = si[(K+s)*64 + lane]; } \
-	} else { \
-		SPIN_PHASE_A \
-		if (a.seed_mode == 1) { \
-			double* sd = a.seed_d + ((long)m*a.nwave + wv)*(4*K*64); int* si = a.seed_i + ((long)m*a.nwave + wv)*((2*K+1)*64); \
-			_Pragma("unroll") for (int s = 0; s < K; s++) { \
-				sd[s*64 + lane] = S.gp1[s]; sd[(K+s)*64 + lane] = S.gp2[s]; sd[(2*K+s)*64 + lane] = S.gm1[s]; sd[(3*K+s)*64 + lane] = S.gm2[s]; \
-				si[s*64 + lane] = S.scp[s]; si[(K+s)*64 + lane] = S.scm[s]; } \
-			if (lane == 0) si[2*K*64] = j; \
-		} \
-	}
-
-// Phase A of the spin-0 kernels: no lane of the wave has reached scale 0 yet, so nothing is
-// accumulated.  Four recurrence steps per iteration with the four coefficient rows fetched together;
-// the rescale / activity test runs once per 4 steps (a chain grows by < 2^60 in 4 steps, far from
-// overflow at 2^1024, and entering the accumulating phases a few steps late only drops terms < 2^-340).
-#define S0_PHASE_A \
-	while (k + 4 <= nk) { \
-		bool act = false; \
-		_Pragma("unroll") for (int s = 0; s < K; s++) act |= (sc[s] == 0 && lam2[s] != 0.0); \
-		if (__any(act)) break; \
-		const double4_t q0 = LDC(coef, k), q1 = LDC(coef, k+1), q2 = LDC(coef, k+2), q3 = LDC(coef, k+3); \
-		const double b0 = polar ? q0.c : q0.b, b1 = polar ? q1.c : q1.b, b2 = polar ? q2.c : q2.b, b3 = polar ? q3.c : q3.b; \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			lam1[s] = fma(fma(q0.a, csq[s], b0), lam2[s], lam1[s]); \
-			lam2[s] = fma(fma(q1.a, csq[s], b1), lam1[s], lam2[s]); \
-			lam1[s] = fma(fma(q2.a, csq[s], b2), lam2[s], lam1[s]); \
-			lam2[s] = fma(fma(q3.a, csq[s], b3), lam1[s], lam2[s]); \
-			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) { lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL; sc[s]++; } \
-		} \
-		k += 4; \
-	}
-
-// Phase B history: it used to be a per-step loop with per-lane gating (cndmask) and a rescale test in every step:
-// 207 instructions per step for leg_ana_spin<6> against 97 per step in the fast loop, ~18 % of the kernel time in a
-// phase that covers ~8 % of the steps.  (Rejected before that: merging the gated steps into the fast pair loop behind
-// a wave-uniform `if (pend)`: leg_syn 118 -> 172 ms at config 3; a branch-free pair-wise gated loop: VGPRs 124 -> 192.)
-// Now phase B runs the ungated fast steps and only tests / rescales every 4 steps, see the kernels.
-// two fast steps of the spin-0 synthesis (lam1/lam2 swap roles)
-#define S0_SYN_PAIR(c0, c1, a0, a1) { \
-	PXS_VCOPY(vb0, polar ? c0.c : c0.b); \
-	PXS_VCOPY(vb1, polar ? c1.c : c1.b); \
-	_Pragma("unroll") for (int s = 0; s < K; s++) { \
-		p1r[s] = fma(lam2[s], a0.a, p1r[s]); p1i[s] = fma(lam2[s], a0.b, p1i[s]); \
-		p2r[s] = fma(lam2[s], a0.c, p2r[s]); p2i[s] = fma(lam2[s], a0.d, p2i[s]); \
-		lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]); \
-	} \
-	_Pragma("unroll") for (int s = 0; s < K; s++) { \
-		p1r[s] = fma(lam1[s], a1.a, p1r[s]); p1i[s] = fma(lam1[s], a1.b, p1i[s]); \
-		p2r[s] = fma(lam1[s], a1.c, p2r[s]); p2i[s] = fma(lam1[s], a1.d, p2i[s]); \
-		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
-	} }
-
-// K = 4 is asked to fit 7 waves per SIMD (72 instead of 74 VGPRs, no spills): the synthesis kernels are short of waves, not of
-// registers per wave (pinned to 2 / 3 / 4 waves per SIMD leg_syn_spin<3> takes 1.51 / 1.29 / 1.0 of its time): C4 leg_syn 126.3 -> 121.9 ms
-template<int K> __global__ __launch_bounds__(64, (K == 4 ? 7 : 1)) void leg_syn_s0(const LegK a)
-{
-	const int lane = threadIdx.x; int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int nk = (a.lmax - m)/2 + 1;
-	const double4_t* __restrict__ coef = a.coef + row0;
-	const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt + (long)bb*a.almt_bs) + row0;
-	double x[K], csq[K], lam1[K], lam2[K], p1r[K], p1i[K], p2r[K], p2i[K];
-	int sc[K], rn[K], rs[K];
-	bool alive_any = false;
-	const bool polar = leg_wave_polar(a, wv, K);
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
-		x[s] = valid ? a.cth[p] : 0.0;
-		const double sth = valid ? a.sth[p] : 0.0;
-		csq[s] = polar ? -sth*sth : x[s]*x[s];
-		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
-		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
-		if (alive && a.seed_mode != 2) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
-		p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0;
-		alive_any |= alive;
-	}
-	int k = 0;
-	if (__any(alive_any)) {
-		// phase A: nobody at scale 0 yet -> recurrence only, 4 steps per check (S0_PHASE_A)
-		S0_SEEDED_PHASE_A
-		k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
-		PXS_COUNT(0, (long)(nk - k)*K*6 + (a.seed_mode != 2 ? (long)k*K*2 : 0L));
-		// phase B: some lanes are still below scale 0.  The steps are the plain fast steps (no per-lane gating); every
-		// 4 steps the lanes below scale 0 are rescaled.  Such a lane accumulates scaled-up garbage meanwhile; its sums are
-		// reset when it reaches scale 0 (its true terms before that are < 2^-340 of the final value).
-		while (k + 1 < nk) {
-			bool pend = false;
-#pragma unroll
-			for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
-			if (!__any(pend)) break;
-			for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
-				const double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1), a0 = LDC(at, k), a1 = LDC(at, k+1);
-				S0_SYN_PAIR(c0, c1, a0, a1)
-			}
-#pragma unroll
-			for (int s = 0; s < K; s++)
-				if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) {
-					lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL;
-					if (++sc[s] == 0) p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0;
-				}
-		}
-#pragma unroll
-		for (int s = 0; s < K; s++) if (sc[s] < 0) { p1r[s] = p1i[s] = p2r[s] = p2i[s] = 0; lam1[s] = lam2[s] = 0; }   // never reached scale 0
-		// phase C: fast loop, two steps per iteration (lam1/lam2 swap roles, no register moves),
-		// coefficients of the next iteration prefetched with scalar loads (tables are padded by 2 rows)
-		double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1), a0 = LDC(at, k), a1 = LDC(at, k+1);
-#ifndef PXS_NO_PHASEC_UNROLL
-		// two pairs per iteration on alternating row sets: the prefetched rows are consumed where they landed (the single-pair loop
-		// rotated them with 8-16 s_mov_b64 per pair; SALU was 27-45 % of the VALU count, profiles/r04_leg_sq_counters_c3.txt)
-		while (k + 3 < nk) {
-			double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3), m0 = LDC(at, k+2), m1 = LDC(at, k+3);
-			S0_SYN_PAIR(c0, c1, a0, a1)
-			k += 2;
-			c0 = LDC(coef, k+2); c1 = LDC(coef, k+3); a0 = LDC(at, k+2); a1 = LDC(at, k+3);
-			S0_SYN_PAIR(n0, n1, m0, m1)
-			k += 2;
-		}
-#endif
-		for (; k + 1 < nk; k += 2) {
-			const double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3), m0 = LDC(at, k+2), m1 = LDC(at, k+3);
-			S0_SYN_PAIR(c0, c1, a0, a1)
-			c0 = n0; c1 = n1; a0 = m0; a1 = m1;
-		}
-		if (k < nk) {
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				p1r[s] = fma(lam2[s], a0.a, p1r[s]); p1i[s] = fma(lam2[s], a0.b, p1i[s]);
-				p2r[s] = fma(lam2[s], a0.c, p2r[s]); p2i[s] = fma(lam2[s], a0.d, p2i[s]);
-			}
-		}
-	}
-	double2* __restrict__ out = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
-#pragma unroll
-	for (int s = 0; s < K; s++) {      // ring indices and cos(theta) are re-read here rather than kept in registers through the loops
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		const int rn_ = valid ? a.ring_n[p] : -1, rs_ = valid ? a.ring_s[p] : -1;
-		const double x_ = valid ? a.cth[p] : 0.0;
-		if (rn_ >= 0) out[rn_] = make_double2(p1r[s] + x_*p2r[s], p1i[s] + x_*p2i[s]);
-		if (rs_ >= 0) out[rs_] = make_double2(p1r[s] - x_*p2r[s], p1i[s] - x_*p2i[s]);
-	}
-}
-
-// Workgroups are ONE wave: lanes run in lockstep and a wave's LDS operations execute in order, so
-// cross-lane visibility of the LDS tile only needs the LDS counter drained -- not an s_barrier, whose
-// compiler-inserted s_waitcnt vmcnt(0) would also wait for the (slow, fire-and-forget) global store
-// of the previous flush.
-#ifdef PXS_HOST_SIM
-#define PXS_WAVE_LDS_SYNC() __syncthreads()
-#elif defined(PXS_LDS_NOWAIT)
-#define PXS_WAVE_LDS_SYNC() asm volatile("" ::: "memory")
-#else
-#define PXS_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
-// The sums over the rings of a wave (4 values per recurrence step) are collected for LEG_FSTEPS steps in an LDS tile and
-// flushed together: output j = 4*step + row of the tile is then owned by lane j, which adds up its partial sums and
-// contributes ONE value to a contiguous 512-byte store (or atomic add).  Measured on MI355X at config 3 (leg_ana per round
-// trip, same box): no reduction at all 105.5 ms, lane swaps + LDS writes +22.7 ms, and the former flush (every 4 steps, 4
-// lanes per output, two shuffles, 128-byte stores) +14 ms; this flush +3.3 ms.  What remains is the lane-swap stage: 6 swaps,
-// 3 adds and a ds_write per step next to 48 FMAs, every one of them a 4-cycle VALU issue for a wave64 (10/58 = the measured
-// share).  More ring pairs per lane would amortise it, but the kernels sit at the 3-waves-per-SIMD VGPR line already.
-#define LEG_FSTEPS 16
-#ifdef PXS_HOST_SIM
-// simulator path: every lane writes its 4 sums, lane j adds row j over the 64 lanes
-#define LEG_RED_STRIDE 66
-#define LEG_RED_DOUBLES (4*LEG_FSTEPS*LEG_RED_STRIDE)
-__device__ __forceinline__ double leg_flush_sum(const double* red, int lane) {
-	const double* r = red + lane*LEG_RED_STRIDE;
-	double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-	for (int i = 0; i < 64; i += 4) { s0 += r[i]; s1 += r[i+1]; s2 += r[i+2]; s3 += r[i+3]; }
-	return (s0 + s1) + (s2 + s3);
-}
-__device__ __forceinline__ int leg_flush_col(int lane) { return lane; }
-#define LEG_RED_PUT(kk, t0, t1, t2, t3) \
-	red[((kk)*4+0)*LEG_RED_STRIDE + lane] = t0; red[((kk)*4+1)*LEG_RED_STRIDE + lane] = t1; \
-	red[((kk)*4+2)*LEG_RED_STRIDE + lane] = t2; red[((kk)*4+3)*LEG_RED_STRIDE + lane] = t3;
-#else
-// MI355X path: reduce-scatter across lanes with the gfx950 lane-swap instructions.  Stage 1
-// (v_permlane32_swap on the pairs (t0,t1), (t2,t3)) leaves sum(t0|t2) in lanes 0-31 and sum(t1|t3) in
-// lanes 32-63; stage 2 (v_permlane16_swap) leaves ONE value per lane, already summed over the 4 lanes
-// {l, l+16, l+32, l+48}: the four 16-lane rows of the wave hold t0, t2, t1, t3.  One ds_write_b64 per step (4x fewer
-// LDS bytes than transposing all partial sums; the LDS write port was the limiter); row r of step kk goes to
-// red[(4 kk + r)*18 .. +16], so that lane j = 4 kk + r reads its 16 partial sums as 8 aligned 16-byte words.
-// (Tried and rejected: v_mfma_f64_4x4x4 with B = 1 as a lane adder: correct, but 8 dependent f64 MFMAs per step made the
-// kernel matrix-pipe bound.  Round 3, with the lane layout from tools/mfma_probe.hip -- A at lane 16k+4b+i, B at 16k+4b+j, D at
-// 16i+4b+j -- and B_r = [j == r]: four MFMAs accumulate the four sums of a step into ONE register, 4 issues + a ds_write instead
-// of 9 VALU ops + a ds_write, 160 / 168 VGPRs: leg_ana_spin<4> 105.9 -> 112.9 ms, leg_ana_s0<8> 26.9 -> 31.0 ms at config 3: the
-// f64 MFMA shares the FMA pipe's throughput on MI355X, it does not add to it. transposing all four sums through LDS: 145.1 against 142.1 ms.)
-#define LEG_RED_STRIDE 18
-#define LEG_RED_DOUBLES (4*LEG_FSTEPS*LEG_RED_STRIDE)
-__device__ __forceinline__ void leg_swap32(double& a, double& b) {
-	const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-	const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-	const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-	a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
-}
-__device__ __forceinline__ void leg_swap16(double& a, double& b) {
-	const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-	const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-	const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-	a = __hiloint2double(r1[0], r0[0]); b = __hiloint2double(r1[1], r0[1]);
-}
-__device__ __forceinline__ double leg_flush_sum(const double* red, int lane) {
-	const double2* r = reinterpret_cast<const double2*>(red + lane*LEG_RED_STRIDE);
-	// two rounds of 4 loads, not unrolled: all 16 values at once cost 16-20 more VGPRs at the point where every chain is live
-	// (leg_ana_s0<8> 174 VGPRs = 2 waves per SIMD instead of 3)
-	double sum = 0;
-#pragma unroll 1
-	for (int h = 0; h < 8; h += 4) {
-		const double2 a = r[h], b = r[h+1], c = r[h+2], d = r[h+3];
-		sum += ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
-	}
-	return sum;
-}
-// lane j = 4 kk + r holds row r of step kk: rows are t0, t2, t1, t3
-__device__ __forceinline__ int leg_flush_col(int lane) { const int r = lane & 3; return (lane & ~3) | ((r == 1) ? 2 : (r == 2) ? 1 : r); }
-#ifdef PXS_EXP_NORED
-#define LEG_RED_PUT(kk, t0, t1, t2, t3) { asm volatile("" :: "v"(t0), "v"(t1), "v"(t2), "v"(t3)); }     // timing experiment (wrong results)
-#else
-#define LEG_RED_PUT(kk, t0, t1, t2, t3) { \
-	double a_ = t0, b_ = t1, c_ = t2, d_ = t3; \
-	leg_swap32(a_, b_); leg_swap32(c_, d_); \
-	double u_ = a_ + b_, v_ = c_ + d_; \
-	leg_swap16(u_, v_); \
-	red[((kk)*4 + (lane >> 4))*LEG_RED_STRIDE + (lane & 15)] = u_ + v_; }
-#endif
-#endif
-// nkk steps of the tile -> dst[4 step + c] (c = 0..3: the sums t0..t3 of the step).  atomic: several waves add into the same
-// rows (dst pre-zeroed); otherwise dst belongs to this wave alone
-__device__ __forceinline__ void leg_flush(double* red, double* __restrict__ dst, int lane, int nkk, int atomic) {
-#if defined(PXS_EXP_NORED) || defined(PXS_EXP_NOFLUSH)
-	return;      // timing experiments (wrong results)
-#endif
-	PXS_WAVE_LDS_SYNC();
-	if (lane < 4*nkk) {
-		const double sum = leg_flush_sum(red, lane);
-		double* q = dst + leg_flush_col(lane);
-#ifdef PXS_HOST_SIM
-		if (atomic) atomicAdd(q, sum); else *q = sum;
-#else
-		if (atomic) unsafeAtomicAdd(q, sum); else *q = sum;
-#endif
-	}
-	PXS_WAVE_LDS_SYNC();
-}
-
-// two fast steps of the spin-0 analysis: 2 x 4 lane sums into the LDS reduction tile, flush every 4 steps
-#define S0_ANA_PAIR(c0, c1) { \
-	PXS_VCOPY(vb0, polar ? c0.c : c0.b); \
-	PXS_VCOPY(vb1, polar ? c1.c : c1.b); \
-	double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0; \
-	_Pragma("unroll") for (int s = 0; s < K; s++) { \
-		t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3); \
-		lam1[s] = fma(fma(c0.a, csq[s], vb0), lam2[s], lam1[s]); \
-	} \
-	_Pragma("unroll") for (int s = 0; s < K; s++) { \
-		u0 = fma(lam1[s], d1r[s], u0); u1 = fma(lam1[s], d1i[s], u1); u2 = fma(lam1[s], d2r[s], u2); u3 = fma(lam1[s], d2i[s], u3); \
-		lam2[s] = fma(fma(c1.a, csq[s], vb1), lam1[s], lam2[s]); \
-	} \
-	/* steps come in aligned pairs (phase A advances by 4, phases B and C by 2): kk is even here */ \
-	LEG_RED_PUT(kk, t0, t1, t2, t3) \
-	LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
-	kk += 2; \
-	if (kk == LEG_FSTEPS) { leg_flush(red, pout + 4*kbase, lane, LEG_FSTEPS, a.atomic); kk = 0; kbase = k+2; } }
-
-template<int K> __global__ __launch_bounds__(64) void leg_ana_s0(const LegK a)
-{
-	PXS_SHARED(double, red);
-	const int lane = threadIdx.x; int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int nk = (a.lmax - m)/2 + 1;
-	const double4_t* __restrict__ coef = a.coef + row0;
-	double* __restrict__ pout = a.part + (long)bb*a.mom_bs + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
-	const double2* __restrict__ in = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
-	double csq[K], lam1[K], lam2[K], d1r[K], d1i[K], d2r[K], d2i[K];
-	int sc[K];
-	bool alive_any = false;
-	const bool polar = leg_wave_polar(a, wv, K);
-	// ring data of slot s: sum and (difference x cos theta) of the north and south ring
-	auto load_data = [&](int s) {
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		const int rn = valid ? a.ring_n[p] : -1, rs = valid ? a.ring_s[p] : -1;
-		const double x = valid ? a.cth[p] : 0.0;
-		const double2 vn = rn >= 0 ? in[rn] : make_double2(0, 0);
-		const double2 vs = rs >= 0 ? in[rs] : make_double2(0, 0);
-		d1r[s] = vn.x + vs.x; d1i[s] = vn.y + vs.y;
-		d2r[s] = (vn.x - vs.x)*x; d2i[s] = (vn.y - vs.y)*x;
-	};
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		const double x = valid ? a.cth[p] : 0.0;
-		const double sth = valid ? a.sth[p] : 0.0;
-		csq[s] = polar ? -sth*sth : x*x;
-		const bool alive = valid && ((double)m <= a.lmax*sth + a.ofs);
-		lam1[s] = 0; lam2[s] = 0; sc[s] = 0;
-		if (alive && a.seed_mode != 2) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[s], sc[s]); }
-		// a lane below scale 0 keeps zero data until it gets there, so that it can run the ungated steps
-		d1r[s] = d1i[s] = d2r[s] = d2i[s] = 0;
-		alive_any |= alive;
-	}
-	if (!__any(alive_any)) return;      // partial buffer is pre-zeroed
-	int k = 0;
-	S0_SEEDED_PHASE_A
-	k = PXS_UNIFORM_INT(k); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
-	PXS_COUNT(1, (long)(nk - k)*K*6 + (a.seed_mode != 2 ? (long)k*K*2 : 0L));
-	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = k + 1;      // rows before k are not written (reduce_partials skips them)
-	// ring data of the lanes that start at scale 0 or reached it during phase A (rings without signal have lam = 0)
-#pragma unroll
-	for (int s = 0; s < K; s++) if (sc[s] == 0) load_data(s);
-	int kk = 0, kbase = k;
-	// phase B: plain fast steps; every 4 steps the lanes below scale 0 are rescaled, and a lane that reaches scale 0
-	// fetches its ring data (its true terms before that are < 2^-340 of the result)
-	while (k + 1 < nk) {
-		bool pend = false;
-#pragma unroll
-		for (int s = 0; s < K; s++) pend |= (sc[s] < 0);
-		if (!__any(pend)) break;
-		for (int it = 0; it < 2 && k + 1 < nk; it++, k += 2) {
-			const double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1);
-			S0_ANA_PAIR(c0, c1)
-		}
-#pragma unroll
-		for (int s = 0; s < K; s++)
-			if (sc[s] < 0 && fabs(lam2[s]) > SC_BIG) {
-				lam1[s] *= SC_SMALL; lam2[s] *= SC_SMALL;
-				if (++sc[s] == 0) load_data(s);
-			}
-	}
-	// phase C: every lane at scale 0 (or without data): next coefficients prefetched with scalar loads
-	double4_t c0 = LDC(coef, k), c1 = LDC(coef, k+1);
-#ifndef PXS_NO_PHASEC_UNROLL
-	while (k + 3 < nk) {      // (two pairs per iteration on alternating row sets, see leg_syn_s0)
-		double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3);
-		S0_ANA_PAIR(c0, c1)
-		k += 2;
-		c0 = LDC(coef, k+2); c1 = LDC(coef, k+3);
-		S0_ANA_PAIR(n0, n1)
-		k += 2;
-	}
-#endif
-	for (; k + 1 < nk; k += 2) {
-		const double4_t n0 = LDC(coef, k+2), n1 = LDC(coef, k+3);
-		S0_ANA_PAIR(c0, c1)
-		c0 = n0; c1 = n1;
-	}
-	if (k < nk) {
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-		for (int s = 0; s < K; s++) { t0 = fma(lam2[s], d1r[s], t0); t1 = fma(lam2[s], d1i[s], t1); t2 = fma(lam2[s], d2r[s], t2); t3 = fma(lam2[s], d2i[s], t3); }
-		LEG_RED_PUT(kk, t0, t1, t2, t3)
-		kk++;
-	}
-	if (kk > 0) leg_flush(red, pout + 4*kbase, lane, kk, a.atomic);
-}
-
-
-// ---- batched spin-0 analysis as an FP64-MFMA GEMM (round 5) -----------------------------------------------------------------------
-// For the maps of a batched call the per-m problem is  mom[k][map, c] = sum_ring p_k(ring) D[ring][map, c]  with the SAME p_k(ring) for
-// every map (c = the four real right-hand sides of leg_ana_s0: re / im of the ring-pair sum, re / im of the difference x cos theta):
-// the ring axis is the K dimension of v_mfma_f64_16x16x4_f64, M = 16 consecutive recurrence steps, N = 16 = 4 maps x 4 sides.
-// The reference loops over the maps, one ducc0 call each (pixell/curvedsky.py:1038-1046); here a wave runs ONE Ishioka recurrence per
-// ring pair (lane = ring pair, phases A / B as in leg_ana_s0; a lane below scale 0 contributes p = 0), parks 16 steps of it in a
-// [16][64] LDS tile and issues 16 MFMAs per tile and group of 4 maps against B operands (the ring data, 16 x 2 VGPRs per group) that
-// stay in registers for the whole l loop.  What the VALU form pays per map -- the recurrence (2 of 6 FMAs), the 64-lane
-// reduce-scatter (10 of ~58 VALU per step) and the three-VGPR-operand FMA rate -- is paid once per 4 NG maps or not at all.
-//  * Workgroup = 8 waves over 512 consecutive ring pairs, wave w the pairs [64 w, 64 w + 64): polar waves join at the tile where their
-//    first lane reaches scale 0.  Tiles are aligned to multiples of 16 steps of the m; every wave adds its 16 x 16 accumulators
-//    into an LDS tile (ds_add_f64) and after ONE barrier per tile the waves share out the flush: one global_atomic_add_f64 per
-//    (chunk of 512 pairs, row, map) -- the count of leg_ana_s0<8>.
-//  * Recurrence lane L is MFMA slot (kk, q) = (L >> 4, L & 15): the P row is written as 64 consecutive doubles and lane (i, kk)
-//    reads its 16 A operands P[i][16 kk + q] from rows of 65 doubles -- conflict-free for ds_read_b64 and ds_read2_b64 alike.
-//  * The ring data reach the B registers through the LDS: the 512 threads read the rows leg[map][m][ring] of 4 maps coalesced (one
-//    ring pair per thread), park (sum, difference x cos) as 16 doubles per pair (17-double entries: lane (j, kk) of MFMA q then reads
-//    entry 64 w + 16 kk + q, double j, conflict-free), and every lane picks its 16 operands.  (First form: per-lane gathers straight
-//    from global memory -- 16 % of the kernel's wave time, tools/mm_time.sh.)
-//  * Step coefficients come from a compact table (a, b) resp. (a, a + b) per step (LegTables::coef2), the 16 steps of the NEXT tile
-//    requested with four s_load_dwordx16 before the MFMAs of the current one (first form: the 32-byte rows of the VALU kernels,
-//    requested and awaited group by group -- four scalar-load round trips per tile, 38 % of the wave time).
-#define MM_PSTRIDE 65
-#define MM_WAVES 8
-#define MM_ESTRIDE 17
-#ifdef PXS_HOST_SIM
-struct mm_acc { double v[4]; double& operator[](int i) { return v[i]; } };
-static inline mm_acc mm_mfma(double av, double bv, mm_acc c) {      // D[4r + lane/16][lane%16] += sum_kk A[i][kk] B[kk][j], A at lane i + 16 kk, B at lane j + 16 kk
-	pxsim::BlockCtx* cx = pxsim::t_ctx; const int w = pxsim::wave_id(), l = pxsim::lane_id();
-	uint64_t* s = cx->wslot->data() + (size_t)w*128;
-	memcpy(&s[l], &av, 8); memcpy(&s[64 + l], &bv, 8); cx->wbar[w]->wait();
-	for (int r = 0; r < 4; r++) {
-		const int i = 4*r + (l >> 4), j = l & 15;
-		double sum = c.v[r];
-		for (int kk = 0; kk < 4; kk++) { double x, y; memcpy(&x, &s[i + 16*kk], 8); memcpy(&y, &s[64 + j + 16*kk], 8); sum = fma(x, y, sum); }
-		c.v[r] = sum;
-	}
-	cx->wbar[w]->wait();
-	return c;
-}
-static inline void mm_lds_add(double* p, double v) { atomicAdd(p, v); }
-#define MM_WAVE_SYNC() pxsim::t_ctx->wbar[pxsim::wave_id()]->wait()
-#else
-typedef double mm_acc __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ mm_acc mm_mfma(double av, double bv, mm_acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0); }
-#ifdef PXS_LAB_NOLDSADD
-__device__ __forceinline__ void mm_lds_add(double* p, double v) { *p = v; }      // timing experiment (wrong results)
-#else
-__device__ __forceinline__ void mm_lds_add(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#endif
-#define MM_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
-// lab build (-DPXS_LAB_MMTIME): shader-clock time of the phases of leg_ana_s0_mm, summed over the waves (tools/mm_time.sh)
-#if defined(PXS_LAB_MMTIME) && !defined(PXS_HOST_SIM)
-__device__ unsigned long long mm_prof[16];
-#define MM_T0 long long tprev_ = clock64(); unsigned long long tacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define MM_TICK(i) { const long long tn_ = clock64(); tacc_[i] += (unsigned long long)(tn_ - tprev_); tprev_ = tn_; }
-#define MM_TDUMP if (lane == 0) { for (int i_ = 0; i_ < 14; i_++) atomicAdd(&mm_prof[i_], tacc_[i_]); atomicAdd(&mm_prof[15], 1ull); }
-#else
-#define MM_T0
-#define MM_TICK(i)
-#define MM_TDUMP
-#endif
-// step coefficient a x^2 + b' with both a and b' wave-uniform: gfx950 takes one scalar source per VALU op, so b' is copied to a VGPR
-// right at its use (left to the compiler, the copies of all 16 steps of a tile were made early and lived in 64 VGPRs: spills)
-__device__ __forceinline__ double mm_coef(double ca, double x2, double cb) { PXS_VCOPY(vb_, cb); return fma(ca, x2, vb_); }
-// LDS: [W][16][MM_PSTRIDE] P tiles + [2][4 NG][64] reduction tiles (the staging area of the prologue, 64 W entries of MM_ESTRIDE doubles, lies over both)
-__host__ __device__ constexpr int mm_lds_doubles(int NG, int W) { return W*16*MM_PSTRIDE + 2*NG*4*64 > 64*W*MM_ESTRIDE ? W*16*MM_PSTRIDE + 2*NG*4*64 : 64*W*MM_ESTRIDE; }
-static inline size_t mm_ana_lds(int NG, int W) { return sizeof(double)*(size_t)mm_lds_doubles(NG, W) + 16; }
 
 // compact step table: (a, b) or (a, a + b) of the rows of LegTables::coef; 32 rows of padding (a tile reads 16 steps whatever nk is)
 __global__ __launch_bounds__(256) void coef2_kernel(const double4_t* __restrict__ coef, long nrows, double2* __restrict__ c2, double2* __restrict__ c2p) {
@@ -835,1016 +229,6 @@ __global__ __launch_bounds__(256) void coef2_kernel(const double4_t* __restrict_
 	else { c2[i] = make_double2(0, 0); c2p[i] = make_double2(0, 0); }
 }
 
-template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_s0_mm(const LegK a)
-{
-	PXS_SHARED(double, sh);
-	constexpr int K = 1;
-	MM_T0
-	double* __restrict__ ptile = sh;                              // [W][16][MM_PSTRIDE]
-	double* __restrict__ red = sh + W*16*MM_PSTRIDE;              // [2][4 NG][64]: the accumulators of a tile summed over the waves
-	int* __restrict__ s_kmin = reinterpret_cast<int*>(sh + mm_lds_doubles(NG, W));
-	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6);
-	int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int nk = (a.lmax - m)/2 + 1;
-	const double4_t* __restrict__ coef = a.coef + row0;
-	const int pbase = wv*64*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64*(w + 1), a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();      // (per wave: its own 64 pairs, its own coefficient stream)
-	double csq[K], lam1[K], lam2[K]; int sc[K];
-	bool alive;
-	{
-		const int p = pbase + tid;      // pair of this recurrence lane: wave w owns the pairs [64 w, 64 w + 64) of the chunk
-		const bool valid = p < a.npairs;
-		const double x = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0;
-		csq[0] = polar ? -sth*sth : x*x;
-		alive = valid && ((double)m <= a.lmax*sth + a.ofs);
-		lam1[0] = 0; lam2[0] = 0; sc[0] = 0;
-		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[0], sc[0]); }
-	}
-	if (tid == 0) *s_kmin = nk;
-	__syncthreads();
-	MM_TICK(0)
-	// phase A, per wave: recurrence only until the first lane of the wave is at scale 0; kw = the first step this wave contributes to
-	int k = 0;
-	const bool wave_alive = __any(alive);
-	if (wave_alive) { S0_PHASE_A }
-	const int kw = wave_alive ? PXS_UNIFORM_INT(k) : nk + 16;
-	MM_TICK(1)
-	if (lane == 0) atomicMin(s_kmin, kw);
-	__syncthreads();
-	const int kmin = PXS_UNIFORM_INT(*s_kmin);
-	MM_TICK(2)
-	if (kmin >= nk) { MM_TDUMP return; }      // (workgroup-uniform) no ring of this chunk carries signal at this m
-	// B operands through the LDS: thread = ring pair, 4 maps per round
-	double breg[NG][16];
-	{
-		const int p = pbase + tid;
-		const bool ok = p < a.npairs;
-		const int rn = ok ? a.ring_n[p] : -1, rs = ok ? a.ring_s[p] : -1;
-		const double x = ok ? a.cth[p] : 0.0;
-		MM_TICK(8)
-		double* __restrict__ ent = sh + tid*MM_ESTRIDE;
-		const double* __restrict__ rd = sh + (64*w + 16*(lane >> 4))*MM_ESTRIDE + (lane & 15);
-#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			double2 vn[4], vs[4];
-#pragma unroll
-			for (int mm = 0; mm < 4; mm++) {
-				const int map = (bb*NG + g)*4 + mm;
-				const double2* __restrict__ in = a.leg + (long)map*a.leg_bs + (long)m*a.ld;
-				const bool okm = map < a.nmaps;
-				vn[mm] = (okm && rn >= 0) ? in[rn] : make_double2(0, 0); vs[mm] = (okm && rs >= 0) ? in[rs] : make_double2(0, 0);
-			}
-			MM_TICK(9)
-			if (g > 0) __syncthreads();      // the reads of the previous round
-#pragma unroll
-			for (int mm = 0; mm < 4; mm++) {
-				ent[4*mm + 0] = vn[mm].x + vs[mm].x; ent[4*mm + 1] = vn[mm].y + vs[mm].y;
-				ent[4*mm + 2] = (vn[mm].x - vs[mm].x)*x; ent[4*mm + 3] = (vn[mm].y - vs[mm].y)*x;
-			}
-			__syncthreads();
-			MM_TICK(10)
-#pragma unroll
-			for (int q = 0; q < 16; q++) breg[g][q] = rd[q*MM_ESTRIDE];
-			MM_WAVE_SYNC();
-			MM_TICK(11)
-		}
-		__syncthreads();
-		for (int i = tid; i < 2*NG*4*64; i += 64*W) red[i] = 0.0;
-		__syncthreads();
-	}
-	MM_TICK(3)
-	const double* __restrict__ tab = reinterpret_cast<const double*>(polar ? a.coef2p : a.coef2) + 2*row0;      // (a, b') of step k at tab[2 k]
-	bool pend = __any(sc[0] < 0);
-	double* __restrict__ pmine = ptile + w*16*MM_PSTRIDE;
-	const double* __restrict__ pread = pmine + (lane & 15)*MM_PSTRIDE + 16*(lane >> 4);
-	double cf[32]; int cf_tile = -1;      // coefficients of the 16 steps of tile cf_tile, requested a tile ahead
-	long ntile = 0;
-	// flush of tile tf (after the barrier that ends it): register r of group g holds rows 4 r + lane / 16 of the tile, column lane % 16 =
-	// 4 (map in the group) + side.  It is issued behind the MFMAs of the NEXT tile (the two reduction tiles alternate), off the path
-	// from the barrier to that tile's recurrence.
-	auto mm_flush = [&](int tf) {
-		double* __restrict__ redf = red + (tf & 1)*NG*4*64;
-		for (int c = w; c < 4*NG; c += W) {
-			const int g = c >> 2, r = c & 3;
-			double* rp = redf + c*64 + lane;
-			const double v = *rp; *rp = 0.0;
-			const int krow = 16*tf + 4*r + (lane >> 4), map = (bb*NG + g)*4 + ((lane & 15) >> 2);
-			if (krow < nk && map < a.nmaps) {
-				double* dst = a.mom + (long)map*a.mom_bs + 4*(row0 + krow) + (lane & 3);
-#ifdef PXS_HOST_SIM
-				atomicAdd(dst, v);
-#elif defined(PXS_LAB_NOATOM)
-				if (v == 12345.678) *dst = v;      // timing experiment (wrong results)
-#else
-				unsafeAtomicAdd(dst, v);
-#endif
-			}
-		}
-	};
-	int tlast = -1;
-	for (int t = kmin >> 4; 16*t < nk; t++) {
-		const int k0 = 16*t;
-		double* __restrict__ redt = red + (t & 1)*NG*4*64;
-		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
-			ntile++;
-			if (cf_tile != t) {
-#pragma unroll
-				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*k0 + i);
-			}
-#pragma unroll
-			for (int q4 = 0; q4 < 4; q4++) {
-				const int kq = k0 + 4*q4;
-				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-				if (kq >= kw && kq < nk) {
-					p0 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 0], csq[0], cf[8*q4 + 1]), lam2[0], lam1[0]);
-					p1 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 2], csq[0], cf[8*q4 + 3]), lam1[0], lam2[0]);
-					p2 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 4], csq[0], cf[8*q4 + 5]), lam2[0], lam1[0]);
-					p3 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 6], csq[0], cf[8*q4 + 7]), lam1[0], lam2[0]);
-					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
-						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
-						pend = __any(sc[0] < 0);
-					}
-					// rows beyond the last step of this m stay out of the sums (their table rows belong to the next m)
-					if (kq + 1 >= nk) p1 = 0.0;
-					if (kq + 2 >= nk) p2 = 0.0;
-					if (kq + 3 >= nk) p3 = 0.0;
-				}
-				pmine[(4*q4 + 0)*MM_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MM_PSTRIDE + lane] = p1;
-				pmine[(4*q4 + 2)*MM_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MM_PSTRIDE + lane] = p3;
-			}
-			MM_WAVE_SYNC();
-			MM_TICK(4)
-			double av[4];
-#pragma unroll
-			for (int q = 0; q < 4; q++) av[q] = pread[q];
-			MM_WAVE_SYNC();
-			if (k0 + 16 < nk) {      // the rows of the next tile, on their way during the MFMAs (requested after the first A operands have landed)
-#pragma unroll
-				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
-				cf_tile = t + 1;
-			}
-			mm_acc acc[NG];
-#pragma unroll
-			for (int g = 0; g < NG; g++) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
-#pragma unroll
-			for (int q = 0; q < 16; q++) {
-				const double aq = q < 4 ? av[q] : pread[q];
-#pragma unroll
-				for (int g = 0; g < NG; g++) acc[g] = mm_mfma(aq, breg[g][q], acc[g]);
-			}
-			if (tlast >= 0) { mm_flush(tlast); tlast = -1; }
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) mm_lds_add(redt + (g*4 + r)*64 + lane, acc[g][r]);
-			MM_TICK(5)
-		}
-		if (tlast >= 0) mm_flush(tlast);
-		tlast = t;
-		__syncthreads();
-		MM_TICK(6)
-	}
-	if (tlast >= 0) mm_flush(tlast);
-	MM_TDUMP
-	PXS_COUNT(1, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
-}
-
-
-// ---- batched spin-0 synthesis as an FP64-MFMA GEMM (round 5) ----------------------------------------------------------------------
-// The transpose of leg_ana_s0_mm: leg[ring][map, c] = sum_k p_k(ring) almt[k][map, c], c = the four real columns of alm_pre_s0 (even
-// part re / im, odd part re / im).  M = 16 ring pairs, N = 16 = 4 maps x 4 columns, K = recurrence steps: the accumulators
-// (64 ring pairs x 16 columns per group of 4 maps = 4 x 8 VGPRs) stay in registers for the whole l loop, one wave per workgroup
-// and NO cross-wave step at all (every wave owns its rings).  A operands: lane (i, kk) of MFMA (rb, q) takes step q + 4 kk of ring
-// pair 16 rb + i from the wave's [16][68] P tile (the same tile and recurrence as the analysis; rows of 68 doubles: the four steps of
-// an MFMA lie 4 rows = 32 banks apart); B operands: the pre-scaled alm rows of the tile, one double per lane and MFMA step-quad,
-// loaded a tile ahead (the 32 bytes per step and map the VALU kernel takes through the scalar cache).  At the end a lane holds one
-// column of one ring pair: the quad (even re, even im, odd re, odd im) is combined across lanes into the north and south ring values.
-#define MMS_PSTRIDE 68
-static inline size_t mm_syn_lds() { return sizeof(double)*16*MMS_PSTRIDE; }
-#ifdef PXS_HOST_SIM
-#define MMS_XOR2(v) __shfl_xor((v), 2)
-#else
-__device__ __forceinline__ double mms_xor2(double v) {      // value of lane ^ 2 (quad permute [2, 3, 0, 1])
-	const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4e, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4e, 0xf, 0xf, true);
-	return __hiloint2double(hi, lo);
-}
-#define MMS_XOR2(v) mms_xor2(v)
-#endif
-
-template<int NG> __global__ __launch_bounds__(64, 4) void leg_syn_s0_mm(const LegK a)
-{
-	PXS_SHARED(double, pmine);      // [16][MMS_PSTRIDE]
-	constexpr int K = 1;
-	const int lane = threadIdx.x;
-	int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int nk = (a.lmax - m)/2 + 1;
-	const double4_t* __restrict__ coef = a.coef + row0;
-	const int pbase = wv*64;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 64, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
-	double csq[K], lam1[K], lam2[K]; int sc[K];
-	bool alive;
-	{
-		const int p = pbase + lane;
-		const bool valid = p < a.npairs;
-		const double x = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0;
-		csq[0] = polar ? -sth*sth : x*x;
-		alive = valid && ((double)m <= a.lmax*sth + a.ofs);
-		lam1[0] = 0; lam2[0] = 0; sc[0] = 0;
-		if (alive) { double mt; int e; pow_scaled(sth, m, mt, e); to_scaled(mt, e, lam2[0], sc[0]); }
-	}
-	mm_acc acc[NG][4];
-#pragma unroll
-	for (int g = 0; g < NG; g++)
-#pragma unroll
-		for (int rb = 0; rb < 4; rb++) { acc[g][rb][0] = 0; acc[g][rb][1] = 0; acc[g][rb][2] = 0; acc[g][rb][3] = 0; }
-	long ntile = 0;
-	// phase A: recurrence only until the first lane of the wave is at scale 0 (a wave without a live ring skips the loop below)
-	int k = 0;
-	const bool wave_alive = __any(alive);
-	if (wave_alive) { S0_PHASE_A }
-	const int kw = PXS_UNIFORM_INT(wave_alive ? k : nk + 16);      // (explicitly wave-uniform: left as a select, the loop below was compiled as divergent and the prefetched coefficient rows went to VGPRs)
-	coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
-	{
-		const double* __restrict__ tab = reinterpret_cast<const double*>(polar ? a.coef2p : a.coef2) + 2*row0;      // (a, b') of step k at tab[2 k]
-		// B operand of MFMA step-quad q: lane (j, kk) holds column j & 3 of map 4 (bb NG + g) + (j >> 2) at step q + 4 kk of the tile
-		const int jcol = lane & 15, kk4 = lane >> 4;
-		const double* bsrc[NG]; bool bok[NG];
-#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			const int map = (bb*NG + g)*4 + (jcol >> 2);
-			bok[g] = map < a.nmaps;
-			bsrc[g] = a.almt + (long)(bok[g] ? map : 0)*a.almt_bs + 4*row0 + (jcol & 3) + 16*kk4;
-		}
-		auto load_b = [&](int k0, double (*b)[4]) {
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int q = 0; q < 4; q++) b[g][q] = (bok[g] && k0 + q + 4*kk4 < nk) ? bsrc[g][4L*(k0 + q)] : 0.0;
-		};
-		bool pend = __any(sc[0] < 0);
-		const double* __restrict__ pread = pmine + 4*(lane >> 4)*MMS_PSTRIDE + (lane & 15);
-		double cf[32];      // coefficients of the 16 steps of the tile, requested a tile ahead (every tile from the wave's first one on is run)
-		double bcur[NG][4], bnxt[NG][4];
-		load_b(16*(kw >> 4), bcur);
-		if (kw < nk) {
-#pragma unroll
-			for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 32L*(kw >> 4) + i);
-		}
-		for (int t = kw >> 4; 16*t < nk; t++) {
-			const int k0 = 16*t;
-			ntile++;
-#pragma unroll
-			for (int q4 = 0; q4 < 4; q4++) {
-				const int kq = k0 + 4*q4;
-				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-				if (kq >= kw && kq < nk) {
-					p0 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 0], csq[0], cf[8*q4 + 1]), lam2[0], lam1[0]);
-					p1 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 2], csq[0], cf[8*q4 + 3]), lam1[0], lam2[0]);
-					p2 = lam2[0]; lam1[0] = fma(mm_coef(cf[8*q4 + 4], csq[0], cf[8*q4 + 5]), lam2[0], lam1[0]);
-					p3 = lam1[0]; lam2[0] = fma(mm_coef(cf[8*q4 + 6], csq[0], cf[8*q4 + 7]), lam1[0], lam2[0]);
-					if (pend) {      // phase B: lanes below scale 0 contribute nothing yet; rescale them every 4 steps
-						if (sc[0] < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(lam2[0]) > SC_BIG) { lam1[0] *= SC_SMALL; lam2[0] *= SC_SMALL; sc[0]++; } }
-						pend = __any(sc[0] < 0);
-					}
-					if (kq + 1 >= nk) p1 = 0.0;
-					if (kq + 2 >= nk) p2 = 0.0;
-					if (kq + 3 >= nk) p3 = 0.0;
-				}
-				pmine[(4*q4 + 0)*MMS_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MMS_PSTRIDE + lane] = p1;
-				pmine[(4*q4 + 2)*MMS_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MMS_PSTRIDE + lane] = p3;
-			}
-			MM_WAVE_SYNC();
-			double av[4];
-#pragma unroll
-			for (int rb = 0; rb < 4; rb++) av[rb] = pread[16*rb];
-			MM_WAVE_SYNC();
-			if (k0 + 16 < nk) {      // the rows of the next tile (coefficients and pre-scaled alm), on their way during the MFMAs
-#pragma unroll
-				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
-				load_b(k0 + 16, bnxt);
-			}
-#pragma unroll
-			for (int q = 0; q < 4; q++)
-#pragma unroll
-				for (int rb = 0; rb < 4; rb++) {
-					const double aq = q == 0 ? av[rb] : pread[q*MMS_PSTRIDE + 16*rb];
-#pragma unroll
-					for (int g = 0; g < NG; g++) acc[g][rb] = mm_mfma(aq, bcur[g][q], acc[g][rb]);
-				}
-			MM_WAVE_SYNC();      // the A operands are out of the tile before the next one is written
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int q = 0; q < 4; q++) bcur[g][q] = bnxt[g][q];
-		}
-	}
-	// register r of acc[g][rb] at lane (i4 = lane / 16, j = lane % 16): ring pair 16 rb + 4 r + i4, column j = 4 (map in the group) + c
-	const int c = lane & 3;
-#pragma unroll
-	for (int g = 0; g < NG; g++) {
-		const int map = (bb*NG + g)*4 + ((lane & 15) >> 2);
-		double* __restrict__ out = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + (long)m*a.ld) + (c & 1);
-#pragma unroll
-		for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const int p = pbase + 16*rb + 4*r + (lane >> 4);
-				const bool valid = p < a.npairs && map < a.nmaps;
-				const double v = acc[g][rb][r], o = MMS_XOR2(v);
-				const double x = valid ? a.cth[p] : 0.0;
-				// c = 0, 1: north ring, even + x odd; c = 2, 3: south ring, even - x odd (this lane holds the odd part)
-				const double val = c < 2 ? fma(x, o, v) : fma(-x, v, o);
-				const int ring = valid ? (c < 2 ? a.ring_n[p] : a.ring_s[p]) : -1;
-				if (ring >= 0) out[2*ring] = val;
-			}
-	}
-	PXS_COUNT(0, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
-}
-
-// ---------------------------------------------------------------------------------
-// spin-s kernels.  rows l = l0..lmax.  chains G+ (spin +s) and G- (spin -s) of the NORTH ring;
-// south ring: F+_S = (-1)^(l+m) F-_N, F-_S = (-1)^(l+m) F+_N.
-// G_{l+1} = (a x +- b) G_l - G_{l-1}; in polar waves x -> u = -2 sin^2(theta/2), +-b -> a +- b.
-// ---------------------------------------------------------------------------------
-template<int K> struct SpinState {
-	double x[K], gp1[K], gp2[K], gm1[K], gm2[K];
-	int scp[K], scm[K];
-};
-
-template<int K> __device__ __forceinline__ bool spin_init(const LegK& a, int wv, int lane, int m, SpinState<K>& S, int* rn, int* rs, bool polar) {
-	const int s_ = a.spin;
-	bool alive_any = false;
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		const int p = (wv*K + s)*64 + lane;
-		const bool valid = p < a.npairs;
-		rn[s] = valid ? a.ring_n[p] : -1; rs[s] = valid ? a.ring_s[p] : -1;
-		const double cth = valid ? a.cth[p] : 0.0;
-		const double sth = valid ? a.sth[p] : 0.0;
-		const double shh = valid ? a.sh2[p] : 0.0;
-		S.x[s] = polar ? -2.0*shh*shh : cth;
-		// libsharp's m-limit generalised to spin: rings with m beyond it carry nothing up to lmax
-		const double t1 = a.lmax*sth + a.ofs;
-		const double b = -2.0*s_*fabs(cth);
-		const double c = (double)s_*s_ - t1*t1;
-		const double discr = b*b - 4*c;
-		const double mlim = discr <= 0 ? a.lmax : fmin((double)a.lmax, 0.5*(-b + sqrt(discr)));
-		const bool alive = valid && ((double)m <= mlim + 0.5);
-		S.gp1[s] = S.gm1[s] = 0; S.gp2[s] = S.gm2[s] = 0; S.scp[s] = S.scm[s] = 0;
-		if (alive && a.seed_mode != 2) {
-			const double sh = shh, ch = a.ch2[p];
-			double m1, m2; int e1, e2;
-			if (m >= s_) {
-				pow_scaled(sh, m + s_, m1, e1); pow_scaled(ch, m - s_, m2, e2);
-				double mt = m1*m2; int e = e1 + e2 + m; frexp_norm(mt, e); to_scaled(mt, e, S.gp2[s], S.scp[s]);
-				pow_scaled(sh, m - s_, m1, e1); pow_scaled(ch, m + s_, m2, e2);
-				mt = m1*m2; e = e1 + e2 + m; frexp_norm(mt, e); to_scaled(mt, e, S.gm2[s], S.scm[s]);
-			} else {
-				pow_scaled(sh, s_ + m, m1, e1); pow_scaled(ch, s_ - m, m2, e2);
-				double mt = m1*m2; int e = e1 + e2; frexp_norm(mt, e); to_scaled(mt, e, S.gp2[s], S.scp[s]);
-				pow_scaled(sh, s_ - m, m1, e1); pow_scaled(ch, s_ + m, m2, e2);
-				mt = m1*m2; e = e1 + e2; frexp_norm(mt, e); to_scaled(mt, e, S.gm2[s], S.scm[s]);
-				if ((s_ - m) & 1) S.gm2[s] = -S.gm2[s];
-			}
-		}
-		alive_any |= alive;
-	}
-	return alive_any;
-}
-
-// phase A of the spin kernels (see S0_PHASE_A): 4 steps per rescale / activity test; sgn is unchanged by 4 steps
-#define SPIN_PHASE_A \
-	while (j + 4 <= nl) { \
-		bool act = false; \
-		_Pragma("unroll") for (int s = 0; s < K; s++) act |= (S.scp[s] == 0 && S.gp2[s] != 0.0) || (S.scm[s] == 0 && S.gm2[s] != 0.0); \
-		if (__any(act)) break; \
-		const double4_t q0 = LDC(coef, j), q1 = LDC(coef, j+1), q2 = LDC(coef, j+2), q3 = LDC(coef, j+3); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			double ax; \
-			ax = q0.a*S.x[s]; S.gp1[s] = fma(ax + (polar ? q0.c : q0.b), S.gp2[s], -S.gp1[s]); S.gm1[s] = fma(ax + (polar ? q0.d : -q0.b), S.gm2[s], -S.gm1[s]); \
-			ax = q1.a*S.x[s]; S.gp2[s] = fma(ax + (polar ? q1.c : q1.b), S.gp1[s], -S.gp2[s]); S.gm2[s] = fma(ax + (polar ? q1.d : -q1.b), S.gm1[s], -S.gm2[s]); \
-			ax = q2.a*S.x[s]; S.gp1[s] = fma(ax + (polar ? q2.c : q2.b), S.gp2[s], -S.gp1[s]); S.gm1[s] = fma(ax + (polar ? q2.d : -q2.b), S.gm2[s], -S.gm1[s]); \
-			ax = q3.a*S.x[s]; S.gp2[s] = fma(ax + (polar ? q3.c : q3.b), S.gp1[s], -S.gp2[s]); S.gm2[s] = fma(ax + (polar ? q3.d : -q3.b), S.gm1[s], -S.gm2[s]); \
-			if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; } \
-			if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; } \
-		} \
-		j += 4; \
-	}
-
-// (step coefficient a x +- b as one FMA with the additive constant copied to a VGPR once per step -- gfx950 allows one
-// scalar source per VALU op -- instead of a multiply shared by two adds: 12 + 2/K instead of 13 VALU ops per ring pair and l)
-// two fast steps of the spin synthesis (G1/G2 swap roles).  The south-ring sums take (-1)^(l+m) a: they are
-// accumulated with sign +1 on even steps and -1 on odd steps and multiplied by the sign of the first step at the end.
-#define SPIN_SYN_PAIR(f0, f1, a0, a1) { \
-	{ \
-		const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b; \
-		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			const double gp = S.gp2[s], gm = S.gm2[s]; \
-			pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]); \
-			mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]); \
-			qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]); \
-			nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]); \
-			S.gp1[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp1[s]); S.gm1[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm1[s]); \
-		} \
-	} \
-	{ \
-		const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b; \
-		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			const double gp = S.gp1[s], gm = S.gm1[s]; \
-			pnr[s] = fma(gp, a1.a, pnr[s]); pni[s] = fma(gp, a1.b, pni[s]); \
-			mnr[s] = fma(gm, a1.c, mnr[s]); mni[s] = fma(gm, a1.d, mni[s]); \
-			qsr[s] = fma(-gm, a1.a, qsr[s]); qsi[s] = fma(-gm, a1.b, qsi[s]); \
-			nsr[s] = fma(-gp, a1.c, nsr[s]); nsi[s] = fma(-gp, a1.d, nsi[s]); \
-			S.gp2[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp2[s]); S.gm2[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm2[s]); \
-		} \
-	} }
-
-// (leg_syn_spin<3> must stay below 128 VGPRs = 4 waves per SIMD; computing the lane as threadIdx.x & 63 for multi-wave
-// workgroups once pushed it to 132 = 3 waves and leg_syn from 120 to 151 ms at config 3 -- keep an eye on that cliff.)
-// (leg_syn_spin<3> held to 96 VGPRs = 5 waves per SIMD by __launch_bounds__: 20 bytes of spills, 102.0 -> 100.1 ms at C3: inside the noise, not kept)
-template<int K> __global__ __launch_bounds__(64) void leg_syn_spin(const LegK a)
-{
-	const int lane = threadIdx.x; int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const int l0 = max(m, a.spin);
-	const int nl = a.lmax - l0 + 1;
-	double2* __restrict__ outq = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
-	double2* __restrict__ outu = a.leg + (long)bb*a.leg_bs + ((long)a.nm + m)*a.ld;
-	SpinState<K> S; int rn[K], rs[K];
-	// north: P = sum G+ a+, M = sum G- a-;  south (before the sign): qs = sum +-G- a+, ns = sum +-G+ a-
-	double pnr[K], pni[K], mnr[K], mni[K], qsr[K], qsi[K], nsr[K], nsi[K];
-#pragma unroll
-	for (int s = 0; s < K; s++) pnr[s] = pni[s] = mnr[s] = mni[s] = qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
-	const bool polar = leg_wave_polar(a, wv, K);
-	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
-	double sg0 = 1.0;
-	if (nl > 0 && __any(alive_any)) {
-		const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-		const double4_t* __restrict__ coef = a.coef + row0;
-		const double4_t* __restrict__ at = reinterpret_cast<const double4_t*>(a.almt + (long)bb*a.almt_bs) + row0;
-		int j = 0;
-		SPIN_SEEDED_PHASE_A
-		j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
-		PXS_COUNT(0, (long)(nl - j)*K*12 + (a.seed_mode != 2 ? (long)j*K*4 : 0L));
-		sg0 = ((l0 + j + m) & 1) ? -1.0 : 1.0;      // (-1)^(l+m) of the first accumulated step; pairs of steps keep the parity
-		// phase B: plain fast steps; every 4 steps the chains below scale 0 are rescaled.  A lane's sums hold scaled-up
-		// garbage until both of its chains are at scale 0, when they are reset (true terms before that: < 2^-340 of the result)
-		while (j + 1 < nl) {
-			bool pend = false;
-#pragma unroll
-			for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
-			if (!__any(pend)) break;
-			for (int it = 0; it < 2 && j + 1 < nl; it++, j += 2) {
-				const double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1), a0 = LDC(at, j), a1 = LDC(at, j+1);
-				SPIN_SYN_PAIR(f0, f1, a0, a1)
-			}
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				const bool was = (S.scp[s] < 0) || (S.scm[s] < 0);
-				if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
-				if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
-				if (was && S.scp[s] == 0 && S.scm[s] == 0) pnr[s] = pni[s] = mnr[s] = mni[s] = qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
-			}
-		}
-#pragma unroll
-		for (int s = 0; s < K; s++)
-			if (S.scp[s] < 0 || S.scm[s] < 0) {      // never reached scale 0
-				pnr[s] = pni[s] = mnr[s] = mni[s] = qsr[s] = qsi[s] = nsr[s] = nsi[s] = 0;
-				S.gp1[s] = S.gp2[s] = S.gm1[s] = S.gm2[s] = 0;
-			}
-		// phase C: fast loop, next coefficients prefetched
-		double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1), a0 = LDC(at, j), a1 = LDC(at, j+1);
-#ifndef PXS_NO_PHASEC_UNROLL
-		while (j + 3 < nl) {      // (two pairs per iteration on alternating row sets, see leg_syn_s0)
-			double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3), m0 = LDC(at, j+2), m1 = LDC(at, j+3);
-			SPIN_SYN_PAIR(f0, f1, a0, a1)
-			j += 2;
-			f0 = LDC(coef, j+2); f1 = LDC(coef, j+3); a0 = LDC(at, j+2); a1 = LDC(at, j+3);
-			SPIN_SYN_PAIR(n0, n1, m0, m1)
-			j += 2;
-		}
-#endif
-		for (; j + 1 < nl; j += 2) {
-			const double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3), m0 = LDC(at, j+2), m1 = LDC(at, j+3);
-			SPIN_SYN_PAIR(f0, f1, a0, a1)
-			f0 = n0; f1 = n1; a0 = m0; a1 = m1;
-		}
-		if (j < nl) {
-#pragma unroll
-			for (int s = 0; s < K; s++) {
-				const double gp = S.gp2[s], gm = S.gm2[s];
-				pnr[s] = fma(gp, a0.a, pnr[s]); pni[s] = fma(gp, a0.b, pni[s]);
-				mnr[s] = fma(gm, a0.c, mnr[s]); mni[s] = fma(gm, a0.d, mni[s]);
-				qsr[s] = fma(gm, a0.a, qsr[s]); qsi[s] = fma(gm, a0.b, qsi[s]);
-				nsr[s] = fma(gp, a0.c, nsr[s]); nsi[s] = fma(gp, a0.d, nsi[s]);
-			}
-		}
-	}
-	// Q = (P+M)/2, U = -i (P-M)/2.  The ring indices are re-read here rather than kept in registers through the loops.
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-		const int p = (wv*K + s)*64 + lane;
-		const int rn_ = p < a.npairs ? a.ring_n[p] : -1, rs_ = p < a.npairs ? a.ring_s[p] : -1;
-		if (rn_ >= 0) {
-			outq[rn_] = make_double2(0.5*(pnr[s] + mnr[s]), 0.5*(pni[s] + mni[s]));
-			outu[rn_] = make_double2(0.5*(pni[s] - mni[s]), -0.5*(pnr[s] - mnr[s]));
-		}
-		if (rs_ >= 0) {
-			const double psr = sg0*qsr[s], psi = sg0*qsi[s], msr = sg0*nsr[s], msi = sg0*nsi[s];
-			outq[rs_] = make_double2(0.5*(psr + msr), 0.5*(psi + msi));
-			outu[rs_] = make_double2(0.5*(psi - msi), -0.5*(psr - msr));
-		}
-	}
-}
-
-// two fast steps of the spin analysis; mu+ = G+ T+_N + sgn G- T+_S, mu- = G- T-_N + sgn G+ T-_S with the sign of the
-// first step already folded into the south-ring data (even steps +, odd steps -)
-#define SPIN_ANA_PAIR(f0, f1) { \
-	double t0 = 0, t1 = 0, t2 = 0, t3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0; \
-	{ \
-		const double ca = f0.a, c1 = polar ? f0.c : f0.b, c2 = polar ? f0.d : -f0.b; \
-		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			const double gp = S.gp2[s], gm = S.gm2[s]; \
-			t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0); \
-			t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1); \
-			t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2); \
-			t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3); \
-			S.gp1[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp1[s]); S.gm1[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm1[s]); \
-		} \
-	} \
-	{ \
-		const double ca = f1.a, c1 = polar ? f1.c : f1.b, c2 = polar ? f1.d : -f1.b; \
-		PXS_VCOPY(v1, c1); PXS_VCOPY(v2, c2); \
-		_Pragma("unroll") for (int s = 0; s < K; s++) { \
-			const double gp = S.gp1[s], gm = S.gm1[s]; \
-			u0 = fma(gp, tpnr[s], u0); u0 = fma(-gm, tpsr[s], u0); \
-			u1 = fma(gp, tpni[s], u1); u1 = fma(-gm, tpsi[s], u1); \
-			u2 = fma(gm, tmnr[s], u2); u2 = fma(-gp, tmsr[s], u2); \
-			u3 = fma(gm, tmni[s], u3); u3 = fma(-gp, tmsi[s], u3); \
-			S.gp2[s] = fma(fma(ca, S.x[s], v1), gp, -S.gp2[s]); S.gm2[s] = fma(fma(ca, S.x[s], v2), gm, -S.gm2[s]); \
-		} \
-	} \
-	/* steps come in aligned pairs: kk is even here */ \
-	LEG_RED_PUT(kk, t0, t1, t2, t3) \
-	LEG_RED_PUT(kk+1, u0, u1, u2, u3) \
-	kk += 2; \
-	if (kk == LEG_FSTEPS) { leg_flush(red, pout + 4*jbase, lane, LEG_FSTEPS, a.atomic); kk = 0; jbase = j+2; } }
-
-template<int K> __global__ __launch_bounds__(64) void leg_ana_spin(const LegK a)
-{
-	PXS_SHARED(double, red);
-	const int lane = threadIdx.x; int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const int l0 = max(m, a.spin);
-	const int nl = a.lmax - l0 + 1;
-	if (nl <= 0) return;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const double4_t* __restrict__ coef = a.coef + row0;
-	double* __restrict__ pout = a.part + (long)bb*a.mom_bs + ((long)wv*a.rows_chunk + (row0 - a.rowbase))*4;
-	const double2* __restrict__ inq = a.leg + (long)bb*a.leg_bs + (long)m*a.ld;
-	const double2* __restrict__ inu = a.leg + (long)bb*a.leg_bs + ((long)a.nm + m)*a.ld;
-	SpinState<K> S; int rn[K], rs[K];
-	const bool polar = leg_wave_polar(a, wv, K);
-	const bool alive_any = spin_init<K>(a, wv, lane, m, S, rn, rs, polar);
-	if (!__any(alive_any)) return;
-	// T+ = Q + iU, T- = Q - iU for north and south rings; the south values carry (-1)^(l+m) of the first accumulated
-	// step (phase A advances in multiples of 4, so that is the sign at l0).  A lane whose chains are still below scale 0
-	// keeps zero data until both get there (phase B), so that it can run the ungated steps.
-	const double sgn0 = ((l0 + m) & 1) ? -1.0 : 1.0;
-	double tpnr[K], tpni[K], tmnr[K], tmni[K], tpsr[K], tpsi[K], tmsr[K], tmsi[K];
-	auto load_data = [&](int s) {
-		// ring indices are re-read here rather than kept in registers through the loops (the kernel sits at the 256-VGPR line)
-		const int p = (wv*K + s)*64 + lane;
-		const int rn_ = p < a.npairs ? a.ring_n[p] : -1, rs_ = p < a.npairs ? a.ring_s[p] : -1;
-		double2 q = rn_ >= 0 ? inq[rn_] : make_double2(0, 0), u = rn_ >= 0 ? inu[rn_] : make_double2(0, 0);
-		tpnr[s] = q.x - u.y; tpni[s] = q.y + u.x; tmnr[s] = q.x + u.y; tmni[s] = q.y - u.x;
-		q = rs_ >= 0 ? inq[rs_] : make_double2(0, 0); u = rs_ >= 0 ? inu[rs_] : make_double2(0, 0);
-		tpsr[s] = sgn0*(q.x - u.y); tpsi[s] = sgn0*(q.y + u.x); tmsr[s] = sgn0*(q.x + u.y); tmsi[s] = sgn0*(q.y - u.x);
-	};
-#pragma unroll
-	for (int s = 0; s < K; s++) tpnr[s] = tpni[s] = tmnr[s] = tmni[s] = tpsr[s] = tpsi[s] = tmsr[s] = tmsi[s] = 0;
-	int j = 0;
-	SPIN_SEEDED_PHASE_A
-	j = PXS_UNIFORM_INT(j); coef = (const double4_t*)PXS_UNIFORM_LONG((long)coef);
-	PXS_COUNT(1, (long)(nl - j)*K*12 + (a.seed_mode != 2 ? (long)j*K*4 : 0L));
-	if (lane == 0 && !a.atomic) a.first[wv*a.nmc + (m - a.m0)] = j + 1;      // rows before j are not written (reduce_partials skips them)
-	// ring data of the lanes whose chains start at scale 0 or both reached it during phase A
-#pragma unroll
-	for (int s = 0; s < K; s++) if (S.scp[s] == 0 && S.scm[s] == 0) load_data(s);
-	int kk = 0, jbase = j;
-	// phase B: plain fast steps; every 4 steps the chains below scale 0 are rescaled, and a lane whose two chains
-	// have both reached scale 0 fetches its ring data (true terms before that: < 2^-340 of the result)
-	while (j + 1 < nl) {
-		bool pend = false;
-#pragma unroll
-		for (int s = 0; s < K; s++) pend |= (S.scp[s] < 0) || (S.scm[s] < 0);
-		if (!__any(pend)) break;
-		for (int it = 0; it < 2 && j + 1 < nl; it++, j += 2) {
-			const double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1);
-			SPIN_ANA_PAIR(f0, f1)
-		}
-#pragma unroll
-		for (int s = 0; s < K; s++) {
-			const bool was = (S.scp[s] < 0) || (S.scm[s] < 0);
-			if (S.scp[s] < 0 && fabs(S.gp2[s]) > SC_BIG) { S.gp1[s] *= SC_SMALL; S.gp2[s] *= SC_SMALL; S.scp[s]++; }
-			if (S.scm[s] < 0 && fabs(S.gm2[s]) > SC_BIG) { S.gm1[s] *= SC_SMALL; S.gm2[s] *= SC_SMALL; S.scm[s]++; }
-			if (was && S.scp[s] == 0 && S.scm[s] == 0) load_data(s);
-		}
-	}
-	// phase C: next coefficients prefetched
-	double4_t f0 = LDC(coef, j), f1 = LDC(coef, j+1);
-#ifndef PXS_NO_PHASEC_UNROLL
-	while (j + 3 < nl) {      // (two pairs per iteration on alternating row sets, see leg_syn_s0)
-		double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3);
-		SPIN_ANA_PAIR(f0, f1)
-		j += 2;
-		f0 = LDC(coef, j+2); f1 = LDC(coef, j+3);
-		SPIN_ANA_PAIR(n0, n1)
-		j += 2;
-	}
-#endif
-	for (; j + 1 < nl; j += 2) {
-		const double4_t n0 = LDC(coef, j+2), n1 = LDC(coef, j+3);
-		SPIN_ANA_PAIR(f0, f1)
-		f0 = n0; f1 = n1;
-	}
-	if (j < nl) {
-		double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-		for (int s = 0; s < K; s++) {
-			const double gp = S.gp2[s], gm = S.gm2[s];
-			t0 = fma(gp, tpnr[s], t0); t0 = fma(gm, tpsr[s], t0);
-			t1 = fma(gp, tpni[s], t1); t1 = fma(gm, tpsi[s], t1);
-			t2 = fma(gm, tmnr[s], t2); t2 = fma(gp, tmsr[s], t2);
-			t3 = fma(gm, tmni[s], t3); t3 = fma(gp, tmsi[s], t3);
-		}
-		LEG_RED_PUT(kk, t0, t1, t2, t3)
-		kk++;
-	}
-	if (kk > 0) leg_flush(red, pout + 4*jbase, lane, kk, a.atomic);
-}
-
-
-// ---- batched spin-s analysis as an FP64-MFMA GEMM (round 5) -----------------------------------------------------------------------
-// Stacks of T/Q/U maps (Monte-Carlo polarisation sims): the Q/U pairs of 4 or more maps in one call.  Per m
-//   mu+[l][map] = sum_ring G+_l T+_N + sgn_l G-_l T+_S,   mu-[l][map] = sum_ring G-_l T-_N + sgn_l G+_l T-_S,   sgn_l = (-1)^(l + m)
-// (leg_ana_spin) with the SAME G+ / G- for every map.  One chain per HALF-WAVE: lanes 0-31 of a wave run G+ of 32 ring pairs, lanes 32-63 G- of the
-// same pairs, and the G- lanes park sgn_l G-.  With B = (T+_N re, im, T-_S re, im) on the G+ slots and (T+_S re, im, T-_N re, im) on the G- slots ONE
-// GEMM over the 64 slots gives (mu+, sgn_l mu-): the sign of the last two columns is a function of the row and is applied at the flush.  That makes the
-// kernel the shape of leg_ana_s0_mm -- one P tile per wave, 8 waves over 256 ring pairs, 8 maps per workgroup, four waves per SIMD.  (First form: both
-// chains in every lane, two P tiles per wave, two accumulators: the LDS held two waves per SIMD and the f64 MFMA, which needs several issuing waves for
-// its rate, ran the Q/U analysis of 16 maps in 111 ms against the VALU kernel's 123.)
-// one chain of leg_ana_spin's pair of recurrences: G_{l+1} = (a x + c) G_l - G_{l-1}, c = +-b (polar waves: a +- b with x = -2 sin^2(theta / 2))
-struct SpinChain { double x, g1, g2, sgl, pa; int sc; };
-__device__ __forceinline__ bool spin_chain_init(const LegK& a, int p, int m, int half, bool polar, SpinChain& C) {
-	const int s_ = a.spin;
-	const bool valid = p < a.npairs;
-	const double cth = valid ? a.cth[p] : 0.0, sth = valid ? a.sth[p] : 0.0, shh = valid ? a.sh2[p] : 0.0;
-	C.x = polar ? -2.0*shh*shh : cth; C.sgl = half ? -1.0 : 1.0; C.pa = polar ? 1.0 : 0.0;
-	const double t1 = a.lmax*sth + a.ofs, b = -2.0*s_*fabs(cth), c = (double)s_*s_ - t1*t1, discr = b*b - 4*c;      // (libsharp's m-limit generalised to spin, as spin_init)
-	const double mlim = discr <= 0 ? a.lmax : fmin((double)a.lmax, 0.5*(-b + sqrt(discr)));
-	const bool alive = valid && ((double)m <= mlim + 0.5);
-	C.g1 = 0; C.g2 = 0; C.sc = 0;
-	if (alive) {
-		const double sh = shh, ch = a.ch2[p];
-		double m1, m2; int e1, e2;
-		// exponents of sin(theta/2), cos(theta/2) of the start value: G+ (m + s, m - s) / G- (m - s, m + s) for m >= s, (s + m, s - m) / (s - m, s + m) below
-		const int es = m >= s_ ? (half ? m - s_ : m + s_) : (half ? s_ - m : s_ + m), ec = m >= s_ ? (half ? m + s_ : m - s_) : (half ? s_ + m : s_ - m);
-		pow_scaled(sh, es, m1, e1); pow_scaled(ch, ec, m2, e2);
-		double mt = m1*m2; int e = e1 + e2 + (m >= s_ ? m : 0); frexp_norm(mt, e); to_scaled(mt, e, C.g2, C.sc);
-		if (m < s_ && half && ((s_ - m) & 1)) C.g2 = -C.g2;
-	}
-	return alive;
-}
-// coefficient of a step from the row (a, b): a x + (polar ? a : 0) +- b
-__device__ __forceinline__ double spin_chain_coef(const SpinChain& C, double ca, double cb) { return fma(ca, C.x, fma(C.sgl, cb, C.pa*ca)); }
-
-template<int NG, int W> __global__ __launch_bounds__(64*W, 4) void leg_ana_spin_mm(const LegK a)
-{
-	PXS_SHARED(double, sh);
-	double* __restrict__ ptile = sh;                              // [W][16][MM_PSTRIDE]
-	double* __restrict__ red = sh + W*16*MM_PSTRIDE;              // [2][4 NG][64]
-	int* __restrict__ s_kmin = reinterpret_cast<int*>(sh + mm_lds_doubles(NG, W));
-	const int tid = threadIdx.x, lane = tid & 63, w = PXS_UNIFORM_INT(tid >> 6), half = lane >> 5;
-	int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const int l0 = max(m, a.spin);
-	const int nl = a.lmax - l0 + 1;
-	if (nl <= 0) return;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int pbase = wv*32*W;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 32*(w + 1), a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();      // (per wave)
-	const int pmine_ = pbase + 32*w + (lane & 31);       // ring pair of this lane's chain
-	SpinChain C;
-	const bool alive = spin_chain_init(a, pmine_, m, half, polar, C);
-	const double* __restrict__ tab = reinterpret_cast<const double*>(a.coef2) + 2*row0;      // (a, b) of step k at tab[2 k]
-	if (tid == 0) *s_kmin = nl;
-	__syncthreads();
-	// phase A, per wave: recurrence only until the first lane of the wave is at scale 0
-	int k = 0;
-	const bool wave_alive = __any(alive);
-	if (wave_alive) {
-		while (k + 4 <= nl) {
-			if (__any(C.sc == 0 && C.g2 != 0.0)) break;
-			double cq[8];
-#pragma unroll
-			for (int i = 0; i < 8; i++) cq[i] = LDCD(tab, 2L*k + i);
-			C.g1 = fma(spin_chain_coef(C, cq[0], cq[1]), C.g2, -C.g1);
-			C.g2 = fma(spin_chain_coef(C, cq[2], cq[3]), C.g1, -C.g2);
-			C.g1 = fma(spin_chain_coef(C, cq[4], cq[5]), C.g2, -C.g1);
-			C.g2 = fma(spin_chain_coef(C, cq[6], cq[7]), C.g1, -C.g2);
-			if (C.sc < 0 && fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; }
-			k += 4;
-		}
-	}
-	const int kw = PXS_UNIFORM_INT(wave_alive ? k : nl + 16);
-	if (lane == 0) atomicMin(s_kmin, kw);
-	__syncthreads();
-	const int kmin = PXS_UNIFORM_INT(*s_kmin);
-	if (kmin >= nl) return;      // (workgroup-uniform) no ring of this chunk carries signal at this m
-	// B operands through the LDS: thread = slot (chain of a ring pair), 4 maps per round: G+ slots (T+_N re, im, T-_S re, im), G- slots (T+_S re, im, T-_N re, im)
-	double breg[NG][16];
-	{
-		const bool ok = pmine_ < a.npairs;
-		const int rn = ok ? a.ring_n[pmine_] : -1, rs = ok ? a.ring_s[pmine_] : -1;
-		double* __restrict__ ent = sh + tid*MM_ESTRIDE;
-		const double* __restrict__ rd = sh + (64*w + 16*(lane >> 4))*MM_ESTRIDE + (lane & 15);
-#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			double2 qn[4], un[4], qs[4], us[4];
-#pragma unroll
-			for (int mm = 0; mm < 4; mm++) {
-				const int map = (bb*NG + g)*4 + mm;
-				const double2* __restrict__ inq = a.leg + (long)map*a.leg_bs + (long)m*a.ld;
-				const double2* __restrict__ inu = a.leg + (long)map*a.leg_bs + ((long)a.nm + m)*a.ld;
-				const bool okm = map < a.nmaps;
-				qn[mm] = (okm && rn >= 0) ? inq[rn] : make_double2(0, 0); un[mm] = (okm && rn >= 0) ? inu[rn] : make_double2(0, 0);
-				qs[mm] = (okm && rs >= 0) ? inq[rs] : make_double2(0, 0); us[mm] = (okm && rs >= 0) ? inu[rs] : make_double2(0, 0);
-			}
-			if (g > 0) __syncthreads();      // the reads of the previous round
-#pragma unroll
-			for (int mm = 0; mm < 4; mm++) {
-				// T+ = Q + iU, T- = Q - iU
-				const double tpn_r = qn[mm].x - un[mm].y, tpn_i = qn[mm].y + un[mm].x, tmn_r = qn[mm].x + un[mm].y, tmn_i = qn[mm].y - un[mm].x;
-				const double tps_r = qs[mm].x - us[mm].y, tps_i = qs[mm].y + us[mm].x, tms_r = qs[mm].x + us[mm].y, tms_i = qs[mm].y - us[mm].x;
-				ent[4*mm + 0] = half ? tps_r : tpn_r; ent[4*mm + 1] = half ? tps_i : tpn_i;
-				ent[4*mm + 2] = half ? tmn_r : tms_r; ent[4*mm + 3] = half ? tmn_i : tms_i;
-			}
-			__syncthreads();
-#pragma unroll
-			for (int q = 0; q < 16; q++) breg[g][q] = rd[q*MM_ESTRIDE];
-		}
-		__syncthreads();
-		for (int i = tid; i < 2*NG*4*64; i += 64*W) red[i] = 0.0;
-		__syncthreads();
-	}
-	bool pend = __any(C.sc < 0);
-	double* __restrict__ pmine = ptile + w*16*MM_PSTRIDE;
-	const double* __restrict__ pread = pmine + (lane & 15)*MM_PSTRIDE + 16*(lane >> 4);
-	double cf[32];      // (a, b) of the 16 steps of a tile, requested a tile ahead
-	int cf_tile = -1;
-	long ntile = 0;
-	auto mm_flush = [&](int tf) {      // rows 4 r + lane / 16 of tile tf, column lane % 16 = 4 (map in the group) + c; c >= 2 (mu-): x sgn of the row
-		double* __restrict__ redf = red + (tf & 1)*NG*4*64;
-		for (int cidx = w; cidx < 4*NG; cidx += W) {
-			const int g = cidx >> 2, r = cidx & 3;
-			double* rp = redf + cidx*64 + lane;
-			double v = *rp; *rp = 0.0;
-			const int krow = 16*tf + 4*r + (lane >> 4), map = (bb*NG + g)*4 + ((lane & 15) >> 2), c = lane & 3;
-			if (krow < nl && map < a.nmaps) {
-				if (c >= 2 && ((l0 + krow + m) & 1)) v = -v;
-				double* dst = a.mom + (long)map*a.mom_bs + 4*(row0 + krow) + c;
-#ifdef PXS_HOST_SIM
-				atomicAdd(dst, v);
-#else
-				unsafeAtomicAdd(dst, v);
-#endif
-			}
-		}
-	};
-	int tlast = -1;
-	for (int t = kmin >> 4; 16*t < nl; t++) {
-		const int k0 = 16*t;
-		double* __restrict__ redt = red + (t & 1)*NG*4*64;
-		if (k0 + 16 > kw) {      // (wave-uniform) this wave has steps in the tile
-			ntile++;
-			if (cf_tile != t) {
-#pragma unroll
-				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*k0 + i);
-			}
-#pragma unroll
-			for (int q4 = 0; q4 < 4; q4++) {
-				const int kq = k0 + 4*q4;
-				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-				if (kq >= kw && kq < nl) {
-					p0 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 0], cf[8*q4 + 1]), C.g2, -C.g1);
-					p1 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 2], cf[8*q4 + 3]), C.g1, -C.g2);
-					p2 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 4], cf[8*q4 + 5]), C.g2, -C.g1);
-					p3 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 6], cf[8*q4 + 7]), C.g1, -C.g2);
-					if (pend) {      // phase B: a chain below scale 0 contributes nothing yet; rescale it every 4 steps
-						if (C.sc < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; } }
-						pend = __any(C.sc < 0);
-					}
-					// the G- lanes park sgn_l G-: the sign of the first row of the group, alternating
-					const double se = (half && ((l0 + kq + m) & 1)) ? -1.0 : 1.0, so = half ? -se : 1.0;
-					p0 *= se; p1 *= so; p2 *= se; p3 *= so;
-					if (kq + 1 >= nl) p1 = 0.0;
-					if (kq + 2 >= nl) p2 = 0.0;
-					if (kq + 3 >= nl) p3 = 0.0;
-				}
-				pmine[(4*q4 + 0)*MM_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MM_PSTRIDE + lane] = p1;
-				pmine[(4*q4 + 2)*MM_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MM_PSTRIDE + lane] = p3;
-			}
-			MM_WAVE_SYNC();
-			double av[4];
-#pragma unroll
-			for (int q = 0; q < 4; q++) av[q] = pread[q];
-			MM_WAVE_SYNC();
-			if (k0 + 16 < nl) {
-#pragma unroll
-				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
-				cf_tile = t + 1;
-			}
-			mm_acc acc[NG];
-#pragma unroll
-			for (int g = 0; g < NG; g++) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
-#pragma unroll
-			for (int q = 0; q < 16; q++) {
-				const double aq = q < 4 ? av[q] : pread[q];
-#pragma unroll
-				for (int g = 0; g < NG; g++) acc[g] = mm_mfma(aq, breg[g][q], acc[g]);
-			}
-			if (tlast >= 0) { mm_flush(tlast); tlast = -1; }
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) mm_lds_add(redt + (g*4 + r)*64 + lane, acc[g][r]);
-		}
-		if (tlast >= 0) mm_flush(tlast);
-		tlast = t;
-		__syncthreads();
-	}
-	if (tlast >= 0) mm_flush(tlast);
-	PXS_COUNT(1, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
-}
-
-// ---- batched spin-s synthesis as an FP64-MFMA GEMM (round 5) ----------------------------------------------------------------------
-// The transpose of leg_ana_spin_mm (cf. leg_syn_spin): north  P = sum_l G+ a+, M = sum_l G- a-;  south  P' = sum_l sgn_l G- a+, M' = sum_l sgn_l G+ a-.
-// One chain per half-wave as in the analysis: the 64 rows of a wave's accumulators are the G+ slots of 32 ring pairs (row blocks 0, 1) and their
-// G- slots (row blocks 2, 3); the G- lanes park sgn_l G-, and with B = (a+, sgn_l a-) -- ONE B for all rows -- the G+ rows come out as (P, M') and the G-
-// rows as (P', M).  The shape of leg_syn_s0_mm: one P tile, 4 x 8 accumulator VGPRs per group of 4 maps, one wave per workgroup, no cross-wave step.
-template<int NG> __global__ __launch_bounds__(64, 4) void leg_syn_spin_mm(const LegK a)
-{
-	PXS_SHARED(double, pmine);      // [16][MMS_PSTRIDE]
-	const int lane = threadIdx.x, half = lane >> 5;
-	int wv, m, bb;
-	if (!leg_block(a, wv, m, bb)) return;
-	const int l0 = max(m, a.spin);
-	const int nl = a.lmax - l0 + 1;
-	const long row0 = PXS_UNIFORM_LONG(a.row[m]);
-	const int pbase = wv*32;
-	const bool polar = [&] { const double c = a.cth[min(pbase + 32, a.npairs) - 1]; return c*c > PXS_POLAR_COS2; }();
-	SpinChain C;
-	const bool alive = spin_chain_init(a, pbase + (lane & 31), m, half, polar, C);
-	mm_acc acc[NG][4];
-#pragma unroll
-	for (int g = 0; g < NG; g++)
-#pragma unroll
-		for (int rb = 0; rb < 4; rb++) { acc[g][rb][0] = 0; acc[g][rb][1] = 0; acc[g][rb][2] = 0; acc[g][rb][3] = 0; }
-	long ntile = 0;
-	const double* __restrict__ tab = reinterpret_cast<const double*>(a.coef2) + 2*row0;      // (a, b) of step k at tab[2 k]
-	// phase A: recurrence only until the first lane of the wave is at scale 0 (a wave without a live ring skips the loop below)
-	int k = 0;
-	const bool wave_alive = nl > 0 && __any(alive);
-	if (wave_alive) {
-		while (k + 4 <= nl) {
-			if (__any(C.sc == 0 && C.g2 != 0.0)) break;
-			double cq[8];
-#pragma unroll
-			for (int i = 0; i < 8; i++) cq[i] = LDCD(tab, 2L*k + i);
-			C.g1 = fma(spin_chain_coef(C, cq[0], cq[1]), C.g2, -C.g1);
-			C.g2 = fma(spin_chain_coef(C, cq[2], cq[3]), C.g1, -C.g2);
-			C.g1 = fma(spin_chain_coef(C, cq[4], cq[5]), C.g2, -C.g1);
-			C.g2 = fma(spin_chain_coef(C, cq[6], cq[7]), C.g1, -C.g2);
-			if (C.sc < 0 && fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; }
-			k += 4;
-		}
-	}
-	const int kw = PXS_UNIFORM_INT(wave_alive ? k : max(nl, 0) + 16);
-	{
-		// B operand of MFMA step-quad q: lane (j, kk) holds column j & 3 of map 4 (bb NG + g) + (j >> 2) at step q + 4 kk of the tile: (a+ re, a+ im, sgn a- re, sgn a- im)
-		const int jcol = lane & 15, kk4 = lane >> 4, cc = jcol & 3;
-		const double* bsrc[NG]; bool bok[NG];
-#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			const int map = (bb*NG + g)*4 + (jcol >> 2);
-			bok[g] = map < a.nmaps;
-			bsrc[g] = a.almt + (long)(bok[g] ? map : 0)*a.almt_bs + 4*row0 + cc + 16*kk4;
-		}
-		auto load_b = [&](int k0, double (*b)[4]) {
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const int row = k0 + q + 4*kk4;
-					const double v = (bok[g] && row < nl) ? bsrc[g][4L*(k0 + q)] : 0.0;
-					b[g][q] = (cc >= 2 && ((l0 + row + m) & 1)) ? -v : v;
-				}
-		};
-		bool pend = __any(C.sc < 0);
-		const double* __restrict__ pread = pmine + 4*(lane >> 4)*MMS_PSTRIDE + (lane & 15);
-		double cf[32];      // (a, b) of the 16 steps of the tile, requested a tile ahead (every tile from the wave's first one on is run)
-		double bcur[NG][4], bnxt[NG][4];
-		load_b(16*(kw >> 4), bcur);
-		if (kw < nl) {
-#pragma unroll
-			for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 32L*(kw >> 4) + i);
-		}
-		for (int t = kw >> 4; 16*t < nl; t++) {
-			const int k0 = 16*t;
-			ntile++;
-#pragma unroll
-			for (int q4 = 0; q4 < 4; q4++) {
-				const int kq = k0 + 4*q4;
-				double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-				if (kq >= kw && kq < nl) {
-					p0 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 0], cf[8*q4 + 1]), C.g2, -C.g1);
-					p1 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 2], cf[8*q4 + 3]), C.g1, -C.g2);
-					p2 = C.g2; C.g1 = fma(spin_chain_coef(C, cf[8*q4 + 4], cf[8*q4 + 5]), C.g2, -C.g1);
-					p3 = C.g1; C.g2 = fma(spin_chain_coef(C, cf[8*q4 + 6], cf[8*q4 + 7]), C.g1, -C.g2);
-					if (pend) {
-						if (C.sc < 0) { p0 = p1 = p2 = p3 = 0.0; if (fabs(C.g2) > SC_BIG) { C.g1 *= SC_SMALL; C.g2 *= SC_SMALL; C.sc++; } }
-						pend = __any(C.sc < 0);
-					}
-					const double se = (half && ((l0 + kq + m) & 1)) ? -1.0 : 1.0, so = half ? -se : 1.0;      // the G- lanes park sgn_l G-
-					p0 *= se; p1 *= so; p2 *= se; p3 *= so;
-					if (kq + 1 >= nl) p1 = 0.0;
-					if (kq + 2 >= nl) p2 = 0.0;
-					if (kq + 3 >= nl) p3 = 0.0;
-				}
-				pmine[(4*q4 + 0)*MMS_PSTRIDE + lane] = p0; pmine[(4*q4 + 1)*MMS_PSTRIDE + lane] = p1;
-				pmine[(4*q4 + 2)*MMS_PSTRIDE + lane] = p2; pmine[(4*q4 + 3)*MMS_PSTRIDE + lane] = p3;
-			}
-			MM_WAVE_SYNC();
-			double av[4];
-#pragma unroll
-			for (int rb = 0; rb < 4; rb++) av[rb] = pread[16*rb];
-			MM_WAVE_SYNC();
-			if (k0 + 16 < nl) {      // the rows of the next tile (coefficients and pre-scaled alm), on their way during the MFMAs
-#pragma unroll
-				for (int i = 0; i < 32; i++) cf[i] = LDCD(tab, 2L*(k0 + 16) + i);
-				load_b(k0 + 16, bnxt);
-			}
-#pragma unroll
-			for (int q = 0; q < 4; q++)
-#pragma unroll
-				for (int rb = 0; rb < 4; rb++) {
-					const double aq = q == 0 ? av[rb] : pread[q*MMS_PSTRIDE + 16*rb];
-#pragma unroll
-					for (int g = 0; g < NG; g++) acc[g][rb] = mm_mfma(aq, bcur[g][q], acc[g][rb]);
-				}
-			MM_WAVE_SYNC();      // the A operands are out of the tile before the next one is written
-#pragma unroll
-			for (int g = 0; g < NG; g++)
-#pragma unroll
-				for (int q = 0; q < 4; q++) bcur[g][q] = bnxt[g][q];
-		}
-	}
-	// register r of acc[g][rb] at lane (i4 = lane / 16, jc = lane % 16): slot 16 rb + 4 r + i4 (rb < 2: G+ of ring pair 16 rb + 4 r + i4, rb >= 2: G- of pair
-	// 16 (rb - 2) + 4 r + i4), column 4 (map in the group) + c.  G+ rows: c = 0, 1: P re / im (north); 2, 3: M' re / im (south).  G- rows: c = 0, 1: P' re / im
-	// (south); 2, 3: M re / im (north).  Q = (P + M) / 2, U = -i (P - M) / 2: lanes c < 2 write the north ring, lanes c >= 2 the south ring; even c the
-	// real part of Q and the imaginary part of U, odd c the other two.
-	const int c = lane & 3;
-#pragma unroll
-	for (int g = 0; g < NG; g++) {
-		const int map = (bb*NG + g)*4 + ((lane & 15) >> 2);
-		double* __restrict__ outq = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + (long)m*a.ld);
-		double* __restrict__ outu = reinterpret_cast<double*>(a.leg + (long)(map < a.nmaps ? map : 0)*a.leg_bs + ((long)a.nm + m)*a.ld);
-#pragma unroll
-		for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const int p = pbase + 16*rb + 4*r + (lane >> 4);
-				const bool valid = p < a.npairs && map < a.nmaps;
-				const double own = acc[g][rb][r], oth = MMS_XOR2(acc[g][rb + 2][r]);
-				const double P = c < 2 ? own : oth, M = c < 2 ? oth : own;
-				const double sum = 0.5*(P + M), dif = 0.5*(P - M);
-				const int ring = valid ? (c < 2 ? a.ring_n[p] : a.ring_s[p]) : -1;
-				if (ring >= 0) {
-					if (c & 1) { outq[2*ring + 1] = sum; outu[2*ring] = dif; }
-					else       { outq[2*ring] = sum; outu[2*ring + 1] = -dif; }
-				}
-			}
-	}
-	PXS_COUNT(0, ntile*(NG*256L + 32L) + (wave_alive ? (long)kw*2 : 0L));
-}
 
 // ---------------------------------------------------------------------------------
 // host side
@@ -2253,20 +637,8 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 		a.almt += (size_t)b0*a.almt_bs;
 		LegWork::Seeds* sb = seeds_for(wk, rs, tb, 0, K, a); seeds_wait(sb, st);
 		if (prof) prof->begin(st, 0);
-		if (tb.spin == 0) {
-			// (ring pairs per lane the product's rules select: 4 and 2; lab builds -- PXS_K_* -- compile the others too)
-#ifdef PXS_LAB
-			if (K == 8)      hipLaunchKernelGGL(leg_syn_s0<8>, leg_grid(a), dim3(64), 0, st, a); else
-#endif
-			if (K == 2) hipLaunchKernelGGL(leg_syn_s0<2>, leg_grid(a), dim3(64), 0, st, a);
-			else             hipLaunchKernelGGL(leg_syn_s0<4>, leg_grid(a), dim3(64), 0, st, a);
-		} else {
-#ifdef PXS_LAB
-			if (K == 4)      hipLaunchKernelGGL(leg_syn_spin<4>, leg_grid(a), dim3(64), 0, st, a); else
-#endif
-			if (K == 3) hipLaunchKernelGGL(leg_syn_spin<3>, leg_grid(a), dim3(64), 0, st, a);
-			else             hipLaunchKernelGGL(leg_syn_spin<2>, leg_grid(a), dim3(64), 0, st, a);
-		}
+		if (tb.spin == 0) launch_leg_syn_s0(K, leg_grid(a), st, a);
+		else              launch_leg_syn_spin(K, leg_grid(a), st, a);
 		if (prof) prof->end(st, 0);
 		seeds_written(sb, st);
 	};
@@ -2281,8 +653,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 			LegK a = make_legk(rs, tb, wk, leg + (size_t)m0*leg_bstride, ld, 1, ngroups, leg_bstride);
 			a.almt += (size_t)m0*a.almt_bs; a.nmaps = nmaps; a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 			if (prof) prof->begin(st, 0);
-			if (ng == 2) hipLaunchKernelGGL(leg_syn_s0_mm<2>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
-			else         hipLaunchKernelGGL(leg_syn_s0_mm<1>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
+			launch_leg_syn_s0_mm(ng, leg_grid(a), st, a);
 			if (prof) prof->end(st, 0);
 		};
 		static const int ngmax = lab_k("PXS_SYN_MM_NG", 2, 1, 2);      // groups of 4 maps per wave (tuning)
@@ -2303,8 +674,7 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 			a.almt += (size_t)m0*a.almt_bs; a.nmaps = nmaps; a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 			PXS_REQUIRE((long)8*((a.nm + 7)/8)*a.nwave*ngroups < (1L << 31), "internal: Legendre grid too large for one launch");
 			if (prof) prof->begin(st, 0);
-			if (ng == 2) hipLaunchKernelGGL(leg_syn_spin_mm<2>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
-			else         hipLaunchKernelGGL(leg_syn_spin_mm<1>, leg_grid(a), dim3(64), mm_syn_lds(), st, a);
+			launch_leg_syn_spin_mm(ng, leg_grid(a), st, a);
 			if (prof) prof->end(st, 0);
 		};
 		const int gmax = std::max(1, leg_max_batch(rs, tb, 1)/2), r = nmm % 8, n8 = nmm - r;
@@ -2322,19 +692,6 @@ void leg_synthesis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWo
 // takes 4-map workgroups, a single left-over map the VALU kernel.  Summation order differs from the single-map kernel: a batched
 // call equals its single-map calls to rounding (1e-13), not bit for bit.
 static int ana_mm_min() { static int v = [] { const char* e = getenv("PXS_ANA_MM_MIN"); const int x = e ? atoi(e) : 4; return x <= 0 ? (1 << 30) : std::max(2, x); }(); return v; }
-template<int NG, int W> static void mm_launch1(dim3 grid, hipStream_t st, const LegK& a) {
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_s0_mm<NG, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
-	hipLaunchKernelGGL((leg_ana_s0_mm<NG, W>), grid, dim3(64*W), mm_ana_lds(NG, W), st, a);
-#if defined(PXS_LAB_MMTIME) && !defined(PXS_HOST_SIM)
-	{	unsigned long long h[16]; PXS_HIP(hipStreamSynchronize(st)); PXS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(mm_prof), sizeof(h)));
-		static const char* nm_[14] = {"init", "phaseA", "kmin_barrier", "B_final_barriers", "P_phase", "mfma+ds_add", "barrier", "flush", "B_index", "B_data_loads", "B_lds_write+barrier", "B_lds_read", "-", "-"};
-		double tot = 0; for (int i = 0; i < 14; i++) tot += (double)h[i];
-		fprintf(stderr, "[mm_prof] waves %llu, cycles per wave %.0f:", h[15], tot/std::max(1.0, (double)h[15]));
-		for (int i = 0; i < 12; i++) fprintf(stderr, " %s %.1f%%", nm_[i], 100.0*h[i]/tot);
-		fprintf(stderr, "\n"); memset(h, 0, sizeof(h)); PXS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mm_prof), h, sizeof(h))); }
-#endif
-}
-template<int W> static void mm_launch(int ng, dim3 grid, hipStream_t st, const LegK& a) { if (ng == 2) mm_launch1<2, W>(grid, st, a); else mm_launch1<1, W>(grid, st, a); }
 static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWork& wk,
                   const double2* leg, void* alm, int alm_dtype, long alm_cstride, const uint64_t* d_mstart, long lstride,
                   LegProfile* prof, long ld, int nb, long alm_bstride, long leg_bstride)
@@ -2354,14 +711,7 @@ static void leg_analysis_mm(hipStream_t st, const RingSet& rs, const LegTables& 
 		a.mom = wk.mom.as<double>() + (size_t)b0*a.mom_bs; a.part = a.mom; a.atomic = 1; a.nmaps = nmaps;
 		a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 		if (prof) prof->begin(st, 1);
-		const dim3 grid = leg_grid(a);
-#ifdef PXS_LAB      /* (lab builds: other workgroup sizes, PXS_ANA_MM_W; measured at C4: 2 waves 95 ms, 4: 78, 8: 77, 16: 82 per 64 maps) */
-		if (W == 16)     mm_launch<16>(ng, grid, st, a);
-		else if (W == 4) mm_launch<4>(ng, grid, st, a);
-		else if (W == 2) mm_launch<2>(ng, grid, st, a);
-		else
-#endif
-		mm_launch<8>(ng, grid, st, a);
+		launch_leg_ana_s0_mm(ng, W, leg_grid(a), st, a);
 		if (prof) prof->end(st, 1);
 	};
 	const int gmax = std::max(1, leg_max_batch(rs, tb, W));      // groups one launch can take (grid limit)
@@ -2390,8 +740,6 @@ static void leg_analysis_spin_mm(hipStream_t st, const RingSet& rs, const LegTab
 	wk.mom.ensure(sizeof(double)*(size_t)n4*nmm);
 	PXS_HIP(hipMemsetAsync(wk.mom.p, 0, sizeof(double)*(size_t)n4*nmm, st));
 	ensure_coef2(st, tb);
-	static const bool once = [] { (void)hipFuncSetAttribute((const void*)leg_ana_spin_mm<2, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
-		(void)hipFuncSetAttribute((const void*)leg_ana_spin_mm<1, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); return true; }(); (void)once;
 	auto launch = [&](int b0, int nmaps, int ng) {
 		const int per = 4*ng, ngroups = (nmaps + per - 1)/per;
 		// (a workgroup covers 32 W ring pairs: nwave of the block mapping counts those)
@@ -2400,8 +748,7 @@ static void leg_analysis_spin_mm(hipStream_t st, const RingSet& rs, const LegTab
 		a.mom = wk.mom.as<double>() + (size_t)b0*a.mom_bs; a.part = a.mom; a.atomic = 1; a.nmaps = nmaps;
 		a.coef2 = tb.d_coef2.as<double2>(); a.coef2p = tb.d_coef2p.as<double2>();
 		if (prof) prof->begin(st, 1);
-		if (ng == 2) hipLaunchKernelGGL((leg_ana_spin_mm<2, W>), leg_grid(a), dim3(64*W), mm_ana_lds(2, W), st, a);
-		else         hipLaunchKernelGGL((leg_ana_spin_mm<1, W>), leg_grid(a), dim3(64*W), mm_ana_lds(1, W), st, a);
+		launch_leg_ana_spin_mm(ng, leg_grid(a), st, a);
 		if (prof) prof->end(st, 1);
 	};
 	const int gmax = std::max(1, leg_max_batch(rs, tb, 2)), r = nmm % 8, n8 = nmm - r;
@@ -2487,22 +834,8 @@ void leg_analysis(hipStream_t st, const RingSet& rs, const LegTables& tb, LegWor
 		}
 		if (prof) prof->begin(st, 1);
 		const dim3 grid = leg_grid(a);
-		if (tb.spin == 0) {
-#ifdef PXS_LAB
-			if (K == 12)     hipLaunchKernelGGL(leg_ana_s0<12>, grid, dim3(64), sh, st, a); else
-#endif
-			if (K == 8) hipLaunchKernelGGL(leg_ana_s0<8>, grid, dim3(64), sh, st, a);
-			else if (K == 2) hipLaunchKernelGGL(leg_ana_s0<2>, grid, dim3(64), sh, st, a);
-			else             hipLaunchKernelGGL(leg_ana_s0<4>, grid, dim3(64), sh, st, a);
-		} else {
-#ifdef PXS_LAB
-			if (K >= 6)      hipLaunchKernelGGL(leg_ana_spin<6>, grid, dim3(64), sh, st, a);
-			else if (K == 5) hipLaunchKernelGGL(leg_ana_spin<5>, grid, dim3(64), sh, st, a); else
-#endif
-			if (K >= 4) hipLaunchKernelGGL(leg_ana_spin<4>, grid, dim3(64), sh, st, a);
-			else if (K == 3) hipLaunchKernelGGL(leg_ana_spin<3>, grid, dim3(64), sh, st, a);
-			else             hipLaunchKernelGGL(leg_ana_spin<2>, grid, dim3(64), sh, st, a);
-		}
+		if (tb.spin == 0) launch_leg_ana_s0(K, grid, sh, st, a);
+		else              launch_leg_ana_spin(K, grid, sh, st, a);
 		if (prof) prof->end(st, 1);
 		if (atomic) continue;
 		const long maxrow = tb.row[m0+1] - tb.row[m0];       // rows per m shrink with m

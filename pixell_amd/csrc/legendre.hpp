@@ -1,4 +1,4 @@
-// Legendre stage of the SHT on gfx950 (alm <-> leg[m][ring]); see legendre.hip.
+// Legendre stage of the SHT on gfx950 (alm <-> leg[m][ring]); see legendre.hip (host side, design notes), leg_s0.hip / leg_spin.hip (kernels), legendre_dev.hpp.
 #pragma once
 #include <map>
 #include <tuple>
@@ -46,7 +46,7 @@ struct LegWork {     // scratch owned by the SHT plan
 	DevBuf part;     // [nwave][nrows][4] doubles (analysis partial moments)
 	DevBuf mom;      // [nrows][4] reduced moments
 	DevBuf first;    // [nwave][m chunk] int: 1 + first row a wave wrote for that m (0: the wave had no live ring and wrote nothing)
-	// recurrence seeds (legendre.hip, S0_SEEDED_PHASE_A): one set per (ring set, spin, direction, K), recorded by the first launch
+	// recurrence seeds (legendre_dev.hpp, S0_SEEDED_PHASE_A): one set per (ring set, spin, direction, K), recorded by the first launch
 	struct Seeds { DevBuf d, i; bool ready = false, refused = false; hipEvent_t written = nullptr; hipStream_t wstream = nullptr;
 	               ~Seeds() { if (written) (void)hipEventDestroy(written); } };
 	std::map<std::tuple<const void*, int, int, int>, Seeds> seeds;

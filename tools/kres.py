@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """kernel resource usage of one .hip file (VGPRs, SGPRs, scratch, LDS, occupancy per kernel) from hipcc's
--Rpass-analysis=kernel-resource-usage.  usage: tools/kres.py pixell_amd/csrc/legendre.hip [extra hipcc flags]"""
+-Rpass-analysis=kernel-resource-usage.  usage: tools/kres.py pixell_amd/csrc/leg_s0.hip [extra hipcc flags]"""
 import subprocess, sys, re
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]+sys.argv[2:]
