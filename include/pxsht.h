@@ -174,6 +174,10 @@ int pxm_rotate_queb(int ny, int nx, const double* d_ly, const double* d_lx, int 
 int pxm_ps2d(int64_t n, const void* a, const void* b, int dtype, void* out, int out_dtype, int device, void* stream);
 int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsize, int nbin,
              const void* map, int dtype, double* d_sum, double* d_lsum, double* d_hit, int device, void* stream);
+/* binning by a per-pixel bin table (enmap.rbin, enmap.py:2512-2524; enmap.lbin with a transform of |l|, :2526-2531; both through _bin_helper
+ * :2533-2556): ADDS map[i] (f32 | f64, n contiguous pixels) to d_sum[d_bin[i]] for 0 <= d_bin[i] < nbin; d_bin: DEVICE int32[n], made by the host
+ * from the geometry alone; the caller zeroes d_sum (DEVICE f64[nbin]) */
+int pxm_bin_index(int64_t n, const int32_t* d_bin, int nbin, const void* map, int dtype, double* d_sum, int device, void* stream);
 /* data[i] *= vec[(i / inner) % n] on a contiguous complex array of `total` elements; d_vec: DEVICE complex128[n]
  * (the per-axis phase ramps of pixell.fft.shift, fft.py:347-368) */
 int pxm_mul_axis(int64_t total, int64_t n, int64_t inner, void* data, int dtype, const void* d_vec, int device, void* stream);

@@ -39,18 +39,19 @@ def _declare(lib):
 	lib.pxm_rotate_queb.argtypes = [i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
 	lib.pxm_ps2d.argtypes = [i64, vp, vp, i32, vp, i32, i32, vp]
 	lib.pxm_lbin.argtypes = [i32, i32, vp, vp, f64, i32, vp, i32, vp, vp, vp, i32, vp]
+	lib.pxm_bin_index.argtypes = [i64, vp, i32, vp, i32, vp, i32, vp]
 	lib.pxm_mul_axis.argtypes = [i64, i64, i64, vp, i32, vp, i32, vp]
 	lib.pxf_fft_nd.argtypes = [i32, vp, vp, vp, i32, vp, i32, i32, dbl, i32, i32, vp, vp, i32, vp]
 	lib.pxf_fft_supported.argtypes = [i64]
 	lib.pxf_fft_good_size.argtypes = [i64]; lib.pxf_fft_good_size.restype = i64
 	for name in ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_synthesis", "pxs_analysis", "pxs_gridweights",
-			"pxs_grid_maxlmax", "pxs_plan_info", "pxs_plan_option", "pxs_plan_query", "pxf_fft_nd", "pxf_fft_supported", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxs_debug_chain", "pxs_memory", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]:
+			"pxs_grid_maxlmax", "pxs_plan_info", "pxs_plan_option", "pxs_plan_query", "pxf_fft_nd", "pxf_fft_supported", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxs_debug_chain", "pxs_memory", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_bin_index", "pxm_mul_axis"]:
 		getattr(lib, name).restype = i32
 	return lib
 
 EXPORTS = ["pxs_plan_rings", "pxs_plan_grid2d", "pxs_plan_destroy", "pxs_synthesis", "pxs_analysis",
 	"pxs_gridweights", "pxs_grid_maxlmax", "pxs_plan_info", "pxs_plan_option", "pxs_plan_query", "pxf_fft_nd", "pxf_fft_supported",
-	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxs_debug_chain", "pxs_memory", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_mul_axis"]
+	"pxf_fft_good_size", "pxs_last_error", "pxs_version", "pxs_profile", "pxs_profile_read", "pxs_profile_flops", "pxs_debug_theta_plan", "pxs_debug_chain", "pxs_memory", "pxa_alm2cl", "pxa_lmatmul", "pxm_rotate_queb", "pxm_ps2d", "pxm_lbin", "pxm_bin_index", "pxm_mul_axis"]
 
 def lib_path():
 	# PIXELL_AMD_LIB: another build of the same library (kernel A/B experiments, tools/build_variants.sh, tools/gpu_v2lab.sh, tools/gpu_leg_ab.sh)

@@ -121,6 +121,48 @@ __global__ __launch_bounds__(256) void lbin_kernel(int ny, int nx, const double*
 	}
 }
 
+// sum[bin[i]] += map[i] for 0 <= bin[i] < nbin: binning by a per-pixel bin table (enmap.rbin, and enmap.lbin with a transform of |l|: there the bin of a
+// pixel is a geometry table the host makes once, enmap.py:2512-2556 _bin_helper).  A block takes 4096 consecutive pixels, collects them in an LDS histogram of
+// the LBIN_LDS bins from its smallest one on and adds that to the global sums; pixels further out add to the global sums themselves.
+#define BIN_PER_THREAD 16
+__global__ __launch_bounds__(256) void bin_index_kernel(long n, const int* __restrict__ bin, int nbin, const void* __restrict__ map, int dtype, double* __restrict__ osum)
+{
+	PXS_SHARED(double, hist);          // [LBIN_LDS] sums; then one int: the block's smallest bin
+	int* bmin = reinterpret_cast<int*>(hist + LBIN_LDS);
+	const int tid = threadIdx.x;
+	const long i0 = (long)blockIdx.x*256*BIN_PER_THREAD;
+	for (int k = tid; k < LBIN_LDS; k += 256) hist[k] = 0.0;
+	if (tid == 0) *bmin = 0x7fffffff;
+	__syncthreads();
+	int b[BIN_PER_THREAD];
+	int lo = 0x7fffffff;
+#pragma unroll
+	for (int jj = 0; jj < BIN_PER_THREAD; jj++) {
+		const long i = i0 + (long)jj*256 + tid;
+		int v = i < n ? bin[i] : -1;
+		if (v >= nbin) v = -1;
+		b[jj] = v;
+		if (v >= 0 && v < lo) lo = v;
+	}
+	if (lo != 0x7fffffff) atomicMin(bmin, lo);
+	__syncthreads();
+	const int base = *bmin;
+#pragma unroll
+	for (int jj = 0; jj < BIN_PER_THREAD; jj++) {
+		if (b[jj] < 0) continue;
+		const long i = i0 + (long)jj*256 + tid;
+		const double v = dtype == PX_F32 ? (double)((const float*)map)[i] : ((const double*)map)[i];
+		const int k = b[jj] - base;
+		if (k < LBIN_LDS) PXS_ATOMIC_ADD(hist + k, v); else PXS_ATOMIC_ADD(osum + b[jj], v);
+	}
+	__syncthreads();
+	for (int k = tid; k < LBIN_LDS; k += 256) {
+		const long bb = (long)base + k;
+		if (bb >= nbin) break;
+		if (hist[k] != 0.0) PXS_ATOMIC_ADD(osum + bb, hist[k]);
+	}
+}
+
 // data[i] *= vec[(i / inner) % n]: multiply along one axis of a contiguous complex array (fft.shift's phase ramps, fft.py:347-368)
 __global__ __launch_bounds__(256) void mul_axis_kernel(long total, long n, long inner, void* __restrict__ data, int dtype, const double2* __restrict__ vec)
 {
@@ -175,6 +217,18 @@ int pxm_lbin(int ny, int nx, const double* d_ly, const double* d_lx, double bsiz
 	PXS_HIP(hipSetDevice(device));
 	if (nbin > 0) hipLaunchKernelGGL(lbin_kernel, dim3((nx + LBIN_TILE - 1)/LBIN_TILE, (ny + LBIN_TILE - 1)/LBIN_TILE), dim3(256), sizeof(double)*3*LBIN_LDS + 16, (hipStream_t)stream, ny, nx, d_ly, d_lx, bsize, nbin,
 		map, dtype, d_lsum ? 1 : 0, d_sum, d_lsum, d_hit);
+	PXS_HIP(hipGetLastError());
+	PXS_CATCH
+}
+
+int pxm_bin_index(int64_t n, const int32_t* d_bin, int nbin, const void* map, int dtype, double* d_sum, int device, void* stream)
+{
+	PXS_TRY
+	PXS_REQUIRE(n >= 0 && nbin >= 0 && (n == 0 || (d_bin && map)) && (nbin == 0 || d_sum), "pxm_bin_index: bad arguments");
+	PXS_REQUIRE(dtype == PX_F32 || dtype == PX_F64, "pxm_bin_index: map must be float32 or float64");
+	PXS_HIP(hipSetDevice(device));
+	if (n > 0 && nbin > 0) hipLaunchKernelGGL(bin_index_kernel, dim3((unsigned)((n + 256*BIN_PER_THREAD - 1)/(256*BIN_PER_THREAD))), dim3(256), sizeof(double)*LBIN_LDS + 16, (hipStream_t)stream,
+		(long)n, (const int*)d_bin, nbin, map, dtype, d_sum);
 	PXS_HIP(hipGetLastError());
 	PXS_CATCH
 }

@@ -354,7 +354,12 @@ _lbin_cache = {}
 def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=None):
 	"""radial binning of a real fourier-space map in |l| (enmap.lbin / _bin_helper, enmap.py:2526-2556): returns b(l), l"""
 	from . import sht
-	if lop is not None: raise NotImplementedError("lbin: lop is not supported by the accelerated path")
+	if lop is not None:
+		# a transform of |l| (e.g. a logarithm): the bin of a pixel is no longer floor(|l| / bsize) of the kernel above but a table of the geometry,
+		# made here as the reference makes it (the default bin width comes from the TRANSFORMED |l|, enmap.py:2528-2530)
+		l = np.asarray(lop(np.asarray(modlmap(map.shape, map.wcs))))
+		if bsize is None: bsize = min(abs(l[0, 1]), abs(l[1, 0]))
+		return _bin_helper(map, l, bsize*brel, return_nhit=return_nhit, return_bins=return_bins)
 	gkey = _geo_key(map.shape, map.wcs)
 	with _cache_lock:
 		geo = _lbin_cache.get((gkey, bsize, brel)) if gkey is not None else None
@@ -400,8 +405,93 @@ def lbin(map, bsize=None, brel=1.0, return_nhit=False, return_bins=False, lop=No
 	if return_nhit: return mout, orads, nhit.astype(int)
 	return mout, orads
 
+def _bin_helper(map, r, bsize, return_nhit=False, return_bins=False):
+	"""means of the map over the bins floor(r / bsize) of a per-pixel coordinate r[ny,nx] (enmap._bin_helper, enmap.py:2533-2556): the bin table,
+	the pixel counts and the mean coordinate of every bin are functions of the geometry (host); the sums over the map run on the GPU (pxm_bin_index)"""
+	from . import sht
+	r = np.asarray(r, float)
+	n = int(np.max(r/bsize))
+	rinds = np.floor(r/bsize).reshape(-1).astype(np.int64)
+	nhit = np.bincount(rinds, minlength=n)[:n]
+	with np.errstate(invalid="ignore", divide="ignore"): orads = np.bincount(rinds, weights=r.reshape(-1), minlength=n)[:n]/nhit
+	dev_map, was_host = _to_device(map)
+	d = _data(dev_map)
+	if sht._np_dtype(d) not in (np.dtype(np.float32), np.dtype(np.float64)): raise ValueError("binning needs a real map")
+	if hasattr(d, "contiguous"): d = d.contiguous()
+	ny, nx = d.shape[-2:]; npre = int(np.prod(d.shape[:-2], dtype=int))
+	if rinds.size != ny*nx: raise ValueError("binning: the coordinate map does not have the map's pixel shape")
+	tab = np.where((rinds >= 0) & (rinds < n), rinds, -1).astype(np.int32)
+	if hasattr(d, "data_ptr"):
+		torch = _torch()
+		dtab = torch.as_tensor(tab, device=d.device); acc = torch.zeros((npre, max(n, 1)), dtype=torch.float64, device=d.device)
+	else: dtab = tab; acc = np.zeros((npre, max(n, 1)))
+	lib = sht._lib.load(); dev = sht.device_index(); st = sht.current_stream()
+	esz = sht._np_dtype(d).itemsize
+	for i in range(npre):
+		sht._lib.check(lib.pxm_bin_index(ny*nx, _ptr(dtab), n, _ptr(d)+i*ny*nx*esz, sht._DT[sht._np_dtype(d)], _ptr(acc)+i*max(n, 1)*8, dev, st))
+	acc = acc.cpu().numpy() if hasattr(acc, "data_ptr") else acc
+	with np.errstate(invalid="ignore", divide="ignore"): mout = (acc[:, :n]/nhit).reshape(tuple(d.shape[:-2])+(n,))
+	if return_bins:
+		edges = np.arange(len(orads)+1)*bsize
+		orads = np.array([orads, edges[:-1], edges[1:]])
+	if return_nhit: return mout, orads, nhit
+	return mout, orads
+
+def posaxes(shape, wcs):
+	"""(dec[ny], ra[nx]) of the pixel centres of a separable geometry, radians (enmap.posaxes)"""
+	if not wcsutils.is_separable(wcs): raise NotImplementedError("posaxes: only separable cylindrical geometries")
+	dec = pix2sky(shape, wcs, [np.arange(shape[-2]), np.zeros(shape[-2])])[0]
+	ra  = pix2sky(shape, wcs, [np.zeros(shape[-1]), np.arange(shape[-1])])[1]
+	return dec, ra
+
+def center(shape, wcs):
+	"""[dec, ra] of the middle of the pixel grid (enmap.center, enmap.py:1254-1256)"""
+	return pix2sky(shape, wcs, (np.array(shape[-2:])-1)/2.0)
+
+def modrmap(shape, wcs, ref="center"):
+	"""angular distance of every pixel centre from ref = [dec, ra] (radians; "center": the middle of the map) as a host ndmap: geometry only
+	(enmap.modrmap, enmap.py:1263-1273, with utils.angdist's Vincenty form, stable at small and at large separations)"""
+	if isinstance(ref, str):
+		if ref != "center": raise ValueError(ref)
+		ref = center(shape, wcs)
+	ref = np.asarray(ref, float)
+	dec, ra = posaxes(shape, wcs)
+	dra = (ra-ref[1])[None, :]
+	sd, cd = np.sin(dec)[:, None], np.cos(dec)[:, None]
+	sr, cr = np.sin(ref[0]), np.cos(ref[0])
+	y = np.hypot(cr*np.sin(dra), cd*sr-sd*cr*np.cos(dra))
+	x = sd*sr+cd*cr*np.cos(dra)
+	return ndmap(np.arctan2(y, x), wcs)
+
+def shift(map, off, inplace=False, keepwcs=False):
+	"""cyclic shift of the pixels: (i, j) -> (i + off[0], j + off[1]) (enmap.shift, enmap.py:3277-3290); unless keepwcs the reference pixel moves along"""
+	off = np.atleast_1d(off).astype(int)
+	axes = tuple(range(-len(off), 0))
+	if isinstance(map, dmap):
+		t = _torch().roll(map.tensor, tuple(int(o) for o in off), axes)
+		if inplace: map.tensor.copy_(t); res = map
+		else: res = dmap(t, map.wcs)
+	else:
+		t = np.roll(np.asarray(map), tuple(int(o) for o in off), axes)
+		if inplace: map[...] = t; res = map
+		else: res = ndmap(t, map.wcs)
+	if not keepwcs:
+		w = res.wcs.deepcopy(); w.wcs.crpix = np.array(w.wcs.crpix, float); w.wcs.crpix[:len(off)] += off[::-1]; res.wcs = w
+	return res
+
+def rbin(map, center=[0, 0], bsize=None, brel=1.0, return_nhit=False, return_bins=False, rop=None):
+	"""mean of the map in rings of width bsize (default: the smaller pixel pitch) around center = [dec, ra]: b(r)[..., nbin], r[nbin]
+	(enmap.rbin, enmap.py:2512-2524)"""
+	r = np.asarray(modrmap(map.shape, map.wcs, ref=center))
+	if rop: r = np.asarray(rop(r))
+	if bsize is None: bsize = np.min(extent(map.shape, map.wcs)/np.array(map.shape[-2:]))
+	return _bin_helper(map, r, bsize*brel, return_nhit=return_nhit, return_bins=return_bins)
+
 for _cls in (ndmap, dmap):
 	_cls.extent   = lambda self, **kw: extent(self.shape, self.wcs, **kw)
+	_cls.modrmap  = lambda self, **kw: modrmap(self.shape, self.wcs, **kw)
+	_cls.rbin     = lambda self, *a, **kw: rbin(self, *a, **kw)
+	_cls.pix2sky  = lambda self, pix: pix2sky(self.shape, self.wcs, pix)
 	_cls.laxes    = lambda self, **kw: laxes(self.shape, self.wcs, **kw)
 	_cls.lmap     = lambda self, **kw: lmap(self.shape, self.wcs, **kw)
 	_cls.modlmap  = lambda self, **kw: modlmap(self.shape, self.wcs, **kw)

@@ -4,8 +4,8 @@ The method set and semantics of pixell's uharm.UHT (pixell/uharm.py:8-182) for t
 path: map2harm / harm2map and their adjoints, quad_weights, lprof2hprof, hmul, harm2powspec, sum_hprof / mean_hprof.  In "flat"
 mode the harmonic representation is a complex map of the 2-D FFT bins (enmap.map2harm, normalize="phys"); in "curved" mode it is
 an alm array.  The profile transforms (rprof2hprof, hprof2rprof: 1-D Legendre transforms of beams) run in curved mode as m = 0
-transforms on one-pixel rings; their flat-mode versions, hrand in flat mode and hprof_rpow in flat mode are host-side helpers of the
-reference outside this path and raise NotImplementedError.
+transforms on one-pixel rings, in flat mode through the 2-D FFT of the painted profile and ring means of its inverse (enmap.rbin); hrand in flat
+mode raises, as the reference's does for every input.
 Maps may be numpy ndmaps (staged) or enmap.dmap (device resident, nothing leaves HBM).
 The stock pixell.uharm.UHT itself also runs on this backend unchanged through the integration routes of INTEGRATION.md
 (pixell.curvedsky over pixell_amd.sht, pixell.fft.engines["hip"]); this class is for callers that keep their data on the GPU."""
@@ -108,7 +108,9 @@ class UHT:
 		return enmap.dmap(res, harm.wcs) if dev else enmap.ndmap(res, getattr(harm, "wcs", self.wcs))
 	def hrand(self, hprof):
 		if self.mode == "curved": return curvedsky.rand_alm(hprof, lmax=self.lmax)
-		raise NotImplementedError("hrand in flat mode (enmap.rand_gauss_harm) is outside the accelerated path")
+		# (the reference's flat branch -- map_mul(multi_pow(hprof / pixsize, 0.5), rand_gauss_harm(shape, wcs)), uharm.py:166-170 -- raises for EVERY hprof: multi_pow
+		# needs [ncomp, ncomp, ny, nx], map_mul's matrix product then needs a noise map with a component axis, and the noise is drawn as [ny, nx])
+		raise NotImplementedError("hrand in flat mode: the reference's own flat-mode hrand raises for every input (uharm.py:166-170)")
 	def harm2powspec(self, harm, harm2=None, patch=False):
 		"""pseudo (cross) power spectrum as a harmonic profile; patch: divide the curved-sky spectrum by fsky"""
 		if self.mode == "flat": return enmap.calc_ps2d(harm, harm2)
@@ -119,16 +121,38 @@ class UHT:
 		return np.sum(hprof*self.nper, (-2, -1) if self.mode == "flat" else -1)
 	def mean_hprof(self, hprof): return self.sum_hprof(hprof)/self.ntot
 	def rprof2hprof(self, br, r):
-		"""radial profile br[..., nr] at radii r -> harmonic profile (curved: a function of l up to lmax; uharm.py:127-132)"""
+		"""radial profile br[..., nr] at radii r -> harmonic profile (uharm.py:127-132).  curved: a function of l up to lmax; flat: the real part of
+		the 2-D FFT of the profile painted around pixel (0, 0) of the patch, times the pixel area, so that l = 0 holds the integral of the profile
+		(profile2harm_flat_2d, uharm.py:230-245)"""
 		if self.mode == "curved": return curvedsky.profile2harm(br, r, lmax=self.lmax)
-		raise NotImplementedError("rprof2hprof in flat mode (profile2harm_flat_2d) is a host-side helper outside the accelerated path")
+		br, r = np.asarray(br), np.asarray(r)
+		cpix = np.array(self.shape)//2-1
+		cpos = enmap.pix2sky(self.shape, self.wcs, cpix)
+		rmap = np.roll(np.asarray(enmap.modrmap(self.shape, self.wcs, cpos)), tuple(-cpix), (-2, -1))           # distance from the pixel that ends up at (0, 0)
+		flat = br.reshape(-1, br.shape[-1])
+		bmap = np.stack([np.interp(rmap, r, row, right=0) for row in flat]).reshape(br.shape[:-1]+self.shape)
+		harm = enmap.fft(enmap.ndmap(bmap, self.wcs), normalize=False)
+		return enmap.ndmap(np.asarray(harm).real*enmap.pixsize(self.shape, self.wcs), self.wcs)
 	def hprof2rprof(self, harm, r):
+		"""the inverse: harmonic profile -> radial profile at radii r (flat: harm2profile_flat_2d, uharm.py:247-258: inverse FFT, the centre moved to
+		the middle of the patch, means over rings of one pixel pitch around it, interpolated to r; zero beyond the last ring)"""
 		if self.mode == "curved": return curvedsky.harm2profile(harm, r)
-		raise NotImplementedError("hprof2rprof in flat mode (harm2profile_flat_2d) is a host-side helper outside the accelerated path")
+		h = enmap.ndmap(np.asarray(harm)+0j, self.wcs)
+		bmap = np.asarray(enmap.ifft(h, normalize=False)).real/(enmap.pixsize(self.shape, self.wcs)*self.npix)
+		cpix = np.array(self.shape)//2-1
+		cpos = enmap.pix2sky(self.shape, self.wcs, cpix)
+		bmap = enmap.shift(enmap.ndmap(bmap, self.wcs), cpix, keepwcs=True)
+		wbr, wr = enmap.rbin(bmap, center=cpos)
+		if r is None: return wbr, r
+		flat = wbr.reshape(-1, wbr.shape[-1])
+		return np.stack([np.interp(r, wr, row, right=0) for row in flat]).reshape(wbr.shape[:-1]+np.shape(r))
 	def hprof_rpow(self, hprof, power):
 		"""the harmonic profile of (the real-space profile of hprof)**power: map2harm(harm2map(hprof)**power) for profiles
-		(uharm.py:191-207).  curved: the profile is sampled at a tenth of the beam's 1/e^(1/2) scale out to 20 of them"""
-		if self.mode != "curved": raise NotImplementedError("hprof_rpow in flat mode is a host-side helper outside the accelerated path")
+		(uharm.py:191-207).  curved: the profile is sampled at a tenth of the beam's 1/e^(1/2) scale out to 20 of them; flat: through the maps"""
+		if self.mode != "curved":
+			norm = self.area**0.5
+			m = self.harm2map(enmap.ndmap(np.asarray(hprof)/norm+0j, self.wcs))
+			return self.map2harm(m**power)*norm
 		hprof = np.asarray(hprof)
 		scale = 1/max(1, np.where(hprof > np.max(hprof)*np.exp(-0.5))[0][-1])
 		r = np.arange(0, 20*scale, scale/10)
