@@ -14,6 +14,12 @@
 #include <vector>
 #include <mutex>
 #include <condition_variable>
+#include <functional>
+#include <atomic>
+#include <climits>
+#include <unistd.h>
+#include <sys/syscall.h>
+#include <linux/futex.h>
 #include <algorithm>
 
 struct double2 { double x, y; };
@@ -64,19 +70,60 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 #define __restrict__
 
 namespace pxsim {
+// How the lanes of a workgroup run.  Default: FIBERS -- the lanes of a block are user-level contexts on ONE OS thread that hand over to each other at
+// barriers and wave rendezvous (a barrier of 64 - 1024 lanes is a few microseconds instead of that many sleeps and wake-ups in the kernel: the test suite spent
+// 6x its user time in futex calls), and the blocks of a grid are shared out over a few worker threads.  PXS_SIM_THREADS=1: one OS thread per lane, as before
+// (real preemption between lanes; kept for cross-checks).
+void fiber_yield();
+bool fiber_mode();
 struct Barrier {
-	std::mutex m; std::condition_variable cv; int n, count = 0; unsigned gen = 0;
+	int n; std::atomic<int> count{0}; std::atomic<uint32_t> gen{0};
 	explicit Barrier(int n_) : n(n_) {}
-	void wait() { std::unique_lock<std::mutex> l(m); unsigned g = gen; if (++count == n) { count = 0; gen++; cv.notify_all(); } else cv.wait(l, [&] { return g != gen; }); }
+	void wait() {
+		const uint32_t g = gen.load(std::memory_order_acquire);
+		if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+			count.store(0, std::memory_order_relaxed); gen.store(g + 1, std::memory_order_release);
+			if (!fiber_mode()) syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+		} else if (fiber_mode()) {
+			while (gen.load(std::memory_order_relaxed) == g) fiber_yield();
+		} else {
+			while (gen.load(std::memory_order_acquire) == g) syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen), FUTEX_WAIT_PRIVATE, g, nullptr, nullptr, 0);
+		}
+	}
 };
 struct BlockCtx {
 	char* shared; Barrier* bar; std::vector<Barrier*> wbar; std::vector<uint64_t>* wslot; int nthreads;
 };
 extern thread_local uint3_ t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local BlockCtx* t_ctx;
+// runs body() once per lane of one block on the calling OS thread, lanes as fibers (hostsim.cpp)
+void run_block_fibers(int nt, dim3 block, const std::function<void()>& body);
+int sim_workers();
 template<class F> void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
 	const int nt = block.x*block.y*block.z;
 	const int nw = (nt + 63)/64;
+	if (fiber_mode() && nt > 1) {
+		const long nblk = (long)grid.x*grid.y*grid.z;
+		const int W = (int)std::max<long>(1, std::min<long>(sim_workers(), nblk));
+		const std::function<void()> fn = [&] { body(); };
+		auto worker = [&](int w) {
+			std::vector<char> sh(shmem + 64);
+			Barrier bar(nt);
+			std::vector<Barrier*> wb; for (int k = 0; k < nw; k++) wb.push_back(new Barrier(std::min(64, nt - 64*k)));
+			std::vector<uint64_t> slots((size_t)nw*64*2);
+			BlockCtx ctx{sh.data(), &bar, wb, &slots, nt};
+			t_ctx = &ctx; t_blockDim = {block.x, block.y, block.z}; t_gridDim = {grid.x, grid.y, grid.z};
+			for (long b = w; b < nblk; b += W) {
+				t_blockIdx = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x*grid.y))};
+				run_block_fibers(nt, block, fn);
+			}
+			for (auto x : wb) delete x;
+			t_ctx = nullptr;
+		};
+		if (W == 1) worker(0);
+		else { std::vector<std::thread> th; for (int w = 0; w < W; w++) th.emplace_back(worker, w); for (auto& x : th) x.join(); }
+		return;
+	}
 	std::vector<char> sh(shmem + 64);
 	Barrier bar(nt);
 	std::vector<Barrier*> wb; for (int w = 0; w < nw; w++) wb.push_back(new Barrier(std::min(64, nt - 64*w)));
