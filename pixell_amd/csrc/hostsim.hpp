@@ -1,7 +1,7 @@
 // TEST-ONLY host simulator of the tiny subset of HIP the kernels in this directory use.
 // Compiling the *same* .hip sources with g++ -DPXS_HOST_SIM gives libpxsht_hostsim.so, in which
-// every workgroup is executed by one OS thread per lane (barriers and wave shuffles are real
-// rendezvous).  It exists so that the index arithmetic of the kernels can be unit-tested in
+// every workgroup is executed lane by lane -- each lane its own execution context (a fiber; one OS thread per lane with
+// PXS_SIM_THREADS=1), barriers and wave shuffles real rendezvous between them.  It exists so that the index arithmetic of the kernels can be unit-tested in
 // the GPU-less container (tests/ -m "not gpu"); it is never built by __graft_entry__.build(),
 // never loaded by the product loader, and is orders of magnitude too slow to be a fallback.
 #pragma once

@@ -302,7 +302,7 @@ template<class CFG> static LineEntry entry_of() {
 // runs the stage chains.  Per grid: to_cc (with the middle circle M = 2 N_cc of the default analysis) and from_cc_adjoint (without).
 //   5400 rings x lmax 4000 (BASELINE C2 / C4): N = 10 800, N_cc = 2 good_size_complex(4001) = 8064, M = 16 128: 1024 threads x <= 21 points
 #ifdef PXS_HOST_SIM
-// (the simulator runs one OS thread per lane: 64-thread workgroups on a grid of 360 rings, lmax 250 -- every feature of the large
+// (the simulator runs every lane as its own context: 64-thread workgroups on a grid of 360 rings, lmax 250 -- every feature of the large
 // configuration at a fifteenth of its size: 2 and 3 butterflies per thread, radix 7, M > N)
 using CfgSimA = LineCfg<64, RfSeq<12, 10, 6>, RfSeq<7, 9, 16>, RfSeq<16, 9, 7>, RfSeq<12, 7, 6>>;
 using CfgSimB = LineCfg<64, RfSeq<12, 10, 6>, RfSeq<>, RfSeq<>, RfSeq<12, 7, 6>>;

@@ -1,5 +1,5 @@
 """TEST-ONLY: compile pixell_amd/csrc/*.hip with g++ -DPXS_HOST_SIM into libpxsht_hostsim.so so the
-kernels' index logic can be exercised without a GPU (one OS thread per lane).  Never used by the
+kernels' index logic can be exercised without a GPU (every lane its own fiber, or OS thread with PXS_SIM_THREADS=1).  Never used by the
 product path; see pixell_amd/csrc/hostsim.hpp."""
 import os, subprocess, glob
 HERE = os.path.dirname(os.path.abspath(__file__))
