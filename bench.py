@@ -6,7 +6,7 @@ float64 data.  Inputs are synthetic band-limited Gaussian maps made on the GPU b
 
   --config c3 (default)  3x(21600x43200) T/Q/U, lmax 10000: the configuration the metric is quoted on.  With N > 1 every
                          rank transforms its own map (weak scaling, no data-path collective) and the alm of each step are
-                         all-gathered over RCCL on a side stream, overlapped with the synthesis.
+                         all-gathered over RCCL on a side stream, overlapped with the synthesis and the next step's analysis (two alm buffers).
   --config c4            BASELINE config 4: 64 independent 1x(5400x10800) maps, lmax 4000, sharded contiguously over the
                          ranks (strong scaling: 64/N maps per GPU, one batched call per direction), RCCL all-gather of the alm.
   --config c5            BASELINE config 5: 100 Gaussian realisations at lmax 6000 on 10800x21600, sharded over the ranks; per
@@ -461,14 +461,23 @@ def run_sht(args, ctx):
 		seen = [None]*world; dist.all_gather_object(seen, (rank, torch.cuda.get_device_name(local)))
 		ranks_seen = len({r for r, _ in seen})
 
+	# N > 1: the alm of a step go out on the side stream while its synthesis AND the next step's analysis run: two alm buffers take turns, and a step
+	# only waits for the gather that read ITS buffer two steps ago (one buffer made every step wait for its own gather before the next analysis could
+	# overwrite the alm: at 8 ranks the 7 GB a rank receives take longer than the synthesis of its 8 maps)
+	alm_pp = [alm_out, torch.zeros_like(alm_out)] if gather is not None else [alm_out]
+	gathered_ev = [None]*len(alm_pp); nstep = [0]
 	def step():
-		curvedsky.map2alm(dmap, alm=alm_out, spin=cfg["spin"], ainfo=ainfo)
+		b = nstep[0] % len(alm_pp); nstep[0] += 1
+		a = alm_pp[b]
+		if gathered_ev[b] is not None: torch.cuda.current_stream().wait_event(gathered_ev[b])
+		curvedsky.map2alm(dmap, alm=a, spin=cfg["spin"], ainfo=ainfo)
 		if gather is not None:
 			ev = torch.cuda.Event(); ev.record()
 			side.wait_event(ev)
-			with torch.cuda.stream(side): gather.run(alm_out, side)
-		curvedsky.alm2map(alm_out, dmap, spin=cfg["spin"], ainfo=ainfo)
-		if gather is not None: torch.cuda.current_stream().wait_stream(side)   # alm_out is rewritten by the next step
+			with torch.cuda.stream(side):
+				gather.run(a, side)
+				gathered_ev[b] = torch.cuda.Event(); gathered_ev[b].record(side)
+		curvedsky.alm2map(a, dmap, spin=cfg["spin"], ainfo=ainfo)
 
 	for _ in range(args.warmup): step()
 	torch.cuda.synchronize()
@@ -604,7 +613,7 @@ def run_sht(args, ctx):
 				res["cpu_baseline"] = cpu_baseline(dict(cfg, ncomp=ncomp))
 			except Exception as e:   # the baseline must never take the GPU number down with it
 				log("cpu_baseline failed: %r" % (e,)); res["cpu_baseline"] = None
-	del dmap, alm_out
+	del dmap, alm_out, alm_pp, gather
 	return res
 
 
