@@ -48,7 +48,12 @@ void dev_free(void* p, size_t n) {
 	std::lock_guard<std::mutex> g(a.mu);
 	a.live -= std::min(a.live, n);
 	if (n >= Arena::MINB && a.pooled + n <= a.cap) {
+		// (the device the block lives on, not the thread's current one: a plan may be destroyed from a thread that has another device selected)
 		int dev = 0; (void)hipGetDevice(&dev);
+#ifndef PXS_HOST_SIM
+		hipPointerAttribute_t at;
+		if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device; else (void)hipGetLastError();
+#endif
 		a.pool.emplace(n, std::make_pair(p, dev)); a.pooled += n;
 		return;
 	}

@@ -15,6 +15,7 @@
 #include "regfft_dev.hpp"
 #include <algorithm>
 #include <map>
+#include <utility>
 #include <memory>
 #include <vector>
 
@@ -129,7 +130,7 @@ using RingC4 = RingCfg<1024, 4000, RfSeq<16, 15, 15, 3>>;
 static const RingEntry RING_CONFIGS[] = { ring_entry<RingC4>() };
 #endif
 
-struct RingLineState { std::map<long, DevBuf> tw; int ncu = 0; };
+struct RingLineState { std::map<std::pair<int, long>, DevBuf> tw; std::map<int, int> ncu; };      // twiddle tables and CU counts per (device, ring length)
 static std::mutex g_ring_mu;
 static RingLineState& ring_state() { static RingLineState s; return s; }
 
@@ -167,7 +168,11 @@ static void ring_tables(const RingEntry* e, const double2*& tw, int& ncu)
 {
 	{	std::lock_guard<std::mutex> g(g_ring_mu);
 		RingLineState& s = ring_state();
-		DevBuf& b = s.tw[e->X];
+		int dev = 0;
+#ifndef PXS_HOST_SIM
+		PXS_HIP(hipGetDevice(&dev));
+#endif
+		DevBuf& b = s.tw[std::make_pair(dev, e->X)];
 		if (!b.p) {
 			std::vector<double2> t((size_t)e->ntw, make_double2(1, 0));
 			const long double tpi = 6.283185307179586476925286766559L;
@@ -176,15 +181,15 @@ static void ring_tables(const RingEntry* e, const double2*& tw, int& ncu)
 			b = upload(t);
 		}
 		tw = b.as<double2>();
-		if (s.ncu == 0) {
+		int& n = s.ncu[dev];
+		if (n == 0) {
 #ifdef PXS_HOST_SIM
-			s.ncu = 2;
+			n = 2;
 #else
-			int dev = 0; PXS_HIP(hipGetDevice(&dev));
-			hipDeviceProp_t pr; PXS_HIP(hipGetDeviceProperties(&pr, dev)); s.ncu = std::max(1, pr.multiProcessorCount);
+			hipDeviceProp_t pr; PXS_HIP(hipGetDeviceProperties(&pr, dev)); n = std::max(1, pr.multiProcessorCount);
 #endif
 		}
-		ncu = s.ncu;
+		ncu = n;
 	}
 }
 
