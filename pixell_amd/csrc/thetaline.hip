@@ -394,7 +394,8 @@ bool FftChain::line_analysis(hipStream_t st, const ThetaPlan& tp, bool has_mid, 
 	a.ntask = (int)ntask;
 	a.out = leg_cc; a.ld = ldcc; a.ocstride = (long)nm*ldcc; a.w = w; a.scale = 1.0;
 	const long per_cu = std::max<long>(1, std::min<long>(2048/e->nt, (long)(160*1024)/(long)e->lds));
-	const long nwg = std::min<long>(ntask, (long)tl_->ncu*per_cu);
+	long nwg = std::min<long>(ntask, (long)tl_->ncu*per_cu);
+	if (const char* ev = lab_getenv("PXS_TL_NWG")) nwg = std::max<long>(1, std::min<long>(nwg, atol(ev)));      // (lab builds: fewer workgroups, to see a line's phases without the other CUs' traffic)
 #ifdef PXS_LAB_TL_TIME
 	static DevBuf prof(16*sizeof(unsigned long long));
 	PXS_HIP(hipMemsetAsync(prof.p, 0, prof.bytes, st)); a.prof = prof.as<unsigned long long>();
