@@ -30,10 +30,10 @@ def run_pair(nt, nph, lmax, spin, nb, monkeypatch, seed=3, mmax=None):
 	assert np.abs(out["0"][0]).max() > 0 and np.abs(out["0"][1]).max() > 0
 
 @pytest.mark.hostsim
-@pytest.mark.parametrize("spin,nb", [(0, 1), (1, 1)])      # (mmax = 24: 25 columns, the last pair has one member; spin 1: the odd column first)
-def test_line_engine_hostsim(monkeypatch, spin, nb):
+@pytest.mark.parametrize("spin,nb,mmax", [(0, 1, 24), (1, 1, 24), (2, 1, 250), (0, 3, 250)])      # (mmax = 24: 25 columns, the last pair has one member; spin 1: the odd column first)
+def test_line_engine_hostsim(monkeypatch, spin, nb, mmax):
 	assert _lib.is_hostsim()
-	run_pair(360, 720, 250, spin, nb, monkeypatch, mmax=24)
+	run_pair(360, 720, 250, spin, nb, monkeypatch, mmax=mmax)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("spin,nb", [(0, 1), (2, 1), (0, 3)])
@@ -62,6 +62,29 @@ def run_ring_pair(nt, nph, lmax, spin, monkeypatch, dtype=np.float64, flip=(Fals
 def test_ring_line_hostsim(monkeypatch):
 	run_ring_pair(360, 720, 250, 0, monkeypatch, mmax=60)      # (odd ring-pair handling: 360 rings = 180 pairs; 720 pixels = the simulator's configuration)
 	run_ring_pair(181, 720, 200, 2, monkeypatch, mmax=40)      # an odd number of rings: the last pair has one ring
+	run_ring_pair(360, 720, 250, 2, monkeypatch, dtype=np.float32, flip=(True, False))      # float32 maps, rows stored south to north
+	run_ring_pair(360, 720, 250, 0, monkeypatch, flip=(False, True))                        # pixels stored east to west
+
+def run_band(ny_full, nx, lmax, dec_cut_deg, monkeypatch):
+	"""a declination band through the curvedsky interface (method "cyl": explicit rings): alm2map with the ring engine and with the chain"""
+	from pixell_amd import curvedsky, enmap
+	shape, wcs = enmap.band_geometry(np.deg2rad(dec_cut_deg), shape=None, res=np.pi/ny_full)
+	assert shape[-1] == nx
+	rng = np.random.default_rng(8)
+	ainfo = curvedsky.alm_info(lmax)
+	alm = rng.standard_normal((3, ainfo.nelem)) + 1j*rng.standard_normal((3, ainfo.nelem)); alm[:, :lmax + 1] = alm[:, :lmax + 1].real
+	out = {}
+	for line in ("1", "0"):
+		monkeypatch.setenv("PXS_RING_LINE", line)
+		sht.clear_plans()
+		out[line] = np.array(curvedsky.alm2map(alm, enmap.zeros((3,) + tuple(shape[-2:]), wcs), spin=[0, 2], ainfo=ainfo))
+	scale = np.abs(out["0"]).max()
+	assert scale > 0 and np.abs(out["1"] - out["0"]).max() < 1e-13*scale
+
+@pytest.mark.hostsim
+def test_ring_line_band_hostsim(monkeypatch): run_band(360, 720, 200, 20.0, monkeypatch)
+@pytest.mark.gpu
+def test_ring_line_band_gpu(monkeypatch): run_band(5400, 10800, 3000, 15.0, monkeypatch)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("spin,dtype,flip", [(0, np.float64, (False, False)), (2, np.float64, (True, True)), (0, np.float32, (False, True))])
