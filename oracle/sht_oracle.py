@@ -474,7 +474,7 @@ def _fine_cc_nodes(lmax, fine_cc):
 	nf = Ncc+1
 	return Ncc, np.pi*np.arange(nf)/Ncc, get_gridweights("CC", nf)/(2*np.pi)
 
-def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=0.0,
+def analysis_2d(*, map, spin, lmax, geometry, alm=None, mmax=None, mstart=None, phi0=0.0,
 		nthreads=0, lstride=1, weights=False, fine_cc=True):
 	"""ducc0.sht.experimental.analysis_2d (curvedsky.py:1032-1046).
 	fine_cc=True (default) or an N_cc (the product's analysis="ducc0"): ducc0's own route for the CC / F1 / MW / MWflip grids as
@@ -497,6 +497,8 @@ def analysis_2d(*, alm, map, spin, lmax, geometry, mmax=None, mstart=None, phi0=
 	if mstart is None: mstart = _tri_mstart(lmax, mmax)
 	if lmax > grid_maxlmax(geometry, nt):
 		raise ValueError("too few rings for analysis up to requested lmax")
+	if alm is None:      # (ducc0 allocates the output when it is not given: curvedsky.py:573 relies on it)
+		alm = np.zeros((nc, _nelem_default(lmax, mmax, mstart, lstride)), np.complex64 if map.dtype == np.float32 else np.complex128)
 	if fine_cc is True and geometry == "CC" and nt >= 2*lmax+2: weights = True
 	if geometry in ("DH", "F2") or weights:
 		w = get_gridweights(geometry, nt)/nph

@@ -1,8 +1,8 @@
 """Drop-in for the spherical-harmonic-transform API of pixell/curvedsky.py on MI355X.
 
 Same function names, argument meaning and error behaviour as the reference for the `2d` and
-`cyl` methods (curvedsky.py:83-302, 756-1086, 1170-1446); the `general` method, healpix rings and
-rotate_alm are outside the accelerated path and raise NotImplementedError.
+`cyl` methods and the healpix / profile helpers (curvedsky.py:83-302, 312-403, 510-580, 756-1086, 1170-1446); the `general` method
+(non-cylindrical pixelisations) and rotate_alm are outside the accelerated path and raise NotImplementedError (prof2alm: without the rotation).
 
 Differences that matter for speed, not for results:
   * the flipped / padded copies of map2buffer / buffer2map (curvedsky.py:1384-1411) are not
@@ -625,6 +625,29 @@ def harm2profile(bl, r):
 	for I in nditer(bl.shape[:-1]):
 		out[I] = sht.synthesis(alm=np.ascontiguousarray(alm[I][None], dtype=np.complex128), **kw)[0]
 	return out
+
+def prof2alm(profile, dir=[0, np.pi/2], spin=0, geometry="CC", nthread=None, norot=False):
+	"""alm of a 1-D profile[..., n] sampled on the rings of `geometry` (an azimuthally symmetric field around the pole): one m = 0 analysis_2d of the
+	profile as a map one pixel wide, band limit get_ducc_maxlmax(geometry, n) (curvedsky.prof2alm, curvedsky.py:556-580).  norot: the m = 0 layout
+	as it is; otherwise expanded to the full triangular layout.  The reference then rotates the pole to dir = [ra, dec] with ducc0.sht.rotate_alm
+	(out of this path's scope): only the default direction -- the pole itself, the identity rotation -- is accepted."""
+	profile = np.asarray(profile)
+	lmax = get_ducc_maxlmax(geometry, profile.shape[-1])
+	iainfo = alm_info(lmax=lmax, mmax=0)
+	oainfo = alm_info(lmax=lmax, mmax=lmax if not norot else 0)
+	if not norot and not (float(dir[0]) == 0.0 and float(dir[1]) == np.pi/2):
+		raise NotImplementedError("prof2alm: rotating the profile to dir needs rotate_alm, which is outside the accelerated path")
+	ctype = complex_dtype(profile.dtype)
+	oalm = np.zeros(profile.shape[:-1]+(oainfo.nelem,), ctype)
+	pre = profile.shape[:-1]
+	jobs = [(0, (None,))] if len(pre) == 0 else [(s, Ipre+(slice(i1, i2),)) for Ipre in nditer(pre[:-1]) for s, i1, i2 in enmap.spin_helper(spin, pre[-1])]
+	for s, I in jobs:
+		prof = np.ascontiguousarray(profile[I][..., None])
+		alm = np.zeros(prof.shape[:-2]+(iainfo.nelem,), ctype)
+		sht.analysis_2d(alm=alm, map=prof, spin=int(s), lmax=lmax, mmax=0, geometry=geometry)
+		if not norot: alm = transfer_alm(iainfo, alm, oainfo)
+		oalm[I] = alm
+	return oalm
 
 # ---------------------------------------------------------------------------------------
 # alm post-processing either side of the transforms (SURVEY 8 f1): almxfl, alm2cl, rand_alm.

@@ -396,3 +396,21 @@ def test_host_array_route_gpu(monkeypatch):
 	ax_d = torch.zeros((1, ainfo.nelem), dtype=torch.complex64, device="cuda"); curvedsky.alm2map_adjoint(enmap.dmap(torch.from_numpy(x).cuda(), wcs), alm=ax_d, spin=[0], ainfo=ainfo)
 	assert np.array_equal(ax_h, ax_d.cpu().numpy())
 	sht.clear_plans(); torch.cuda.empty_cache()
+
+def prof2alm_body(golden_dir):
+	"""curvedsky.prof2alm (curvedsky.py:556-580) without the rotation: the m = 0 alm of the reference (tests/golden/make_prof2alm.py), their
+	expansion to the full layout for the default direction (the identity rotation), NotImplementedError for any other"""
+	d = np.load(os.path.join(golden_dir, "prof2alm.npz"))
+	a = curvedsky.prof2alm(d["prof_cc"], norot=True)
+	assert a.shape == d["alm_cc"].shape and np.abs(a-d["alm_cc"]).max() < 1e-12*np.abs(d["alm_cc"]).max()
+	b = curvedsky.prof2alm(d["prof_f1"], spin=[0, 2], geometry="F1", norot=True)
+	assert b.shape == d["alm_f1"].shape and np.abs(b-d["alm_f1"]).max() < 1e-12*np.abs(d["alm_f1"]).max()
+	full = curvedsky.prof2alm(d["prof_cc"])
+	lmax = d["alm_cc"].shape[-1]-1
+	assert full.shape == ((lmax+1)*(lmax+2)//2,) and np.array_equal(full[:lmax+1], a) and not full[lmax+1:].any()
+	with pytest.raises(NotImplementedError): curvedsky.prof2alm(d["prof_cc"], dir=[0.3, 0.2])
+
+@pytest.mark.hostsim
+def test_prof2alm_hostsim(golden_dir): prof2alm_body(golden_dir)
+@pytest.mark.gpu
+def test_prof2alm_gpu(golden_dir): prof2alm_body(golden_dir)
