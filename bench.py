@@ -548,7 +548,8 @@ def run_sht(args, ctx):
 		kernel_ms_per_step=round(dom_ms_per_step, 3),
 		launches_per_step=prof[dom][1]//max(args.steps, 1), R_algorithmic=R_alg, R_actual_syn=R_syn, R_actual_ana=R_ana)
 	roof["sustained"] = sustained_note(roof["frac_hw_both"])
-	roof.update(measured_traffic(args.config, [dom]))
+	full_workload = not batched or ntot == cfg["nbatch_total"]      # (the committed counter passes are of the full configuration: a share of the batch has no profile)
+	if full_workload: roof.update(measured_traffic(args.config, [dom]))
 	# ---- the HBM-bound family: ring FFTs + theta resampling (fused chains, csrc/fftchain.hip) ----
 	chain_ms = (prof["ring_fft"][0]+prof["resample"][0])/args.steps
 	chain_bytes = 2*chain_alg_bytes(cfg, R_ana, nmaps)           # both directions
@@ -556,7 +557,8 @@ def run_sht(args, ctx):
 		achieved=round(chain_bytes/(chain_ms*1e-3)/1e9, 1) if chain_ms > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
 		algorithmic_bytes_per_step=chain_bytes, kernel_ms_per_step=round(chain_ms, 3))
 	chain["frac"] = round(chain["achieved"]/HBM_PEAK_GBS, 4)
-	chain.update(measured_traffic(args.config, ["chain_kernel", "theta_line_kernel", "ring_line_kernel", "transpose", "fft_lds", "split_pair", "unpack", "fold"]))
+	if full_workload: chain.update(measured_traffic(args.config, ["chain_kernel", "theta_line_kernel", "ring_line_kernel", "transpose", "fft_lds", "split_pair", "unpack", "fold"]))
+	else: chain["traffic"] = None
 	map_bytes = ncomp_all*ny*nx*8; alm_bytes = ncomp_all*nalm(lmax)*16
 	tot_bytes = (ntot*ncomp*(ny*nx*8+nalm(lmax)*16)) if batched else world*(map_bytes+alm_bytes)
 	hbm_gbs = 2*tot_bytes/(ms_step*1e-3)/1e9
@@ -626,8 +628,8 @@ def compact_leg(res):
 	out["workload"] = res["config"]["workload"]
 	if "ms_per_realisation" in res: out.update(ms_per_realisation=res["ms_per_realisation"], stage_ms_per_realisation=res["stage_ms_per_realisation"], roundtrip_rms_error=res["checks"]["roundtrip_rms_error"], realisations_per_call=res["config"]["realisations_per_call"])
 	r = res["roofline"]
-	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_convention_exceeds_peak", "frac_hw", "frac_hw_both", "frac_definition", "sustained", "kernel_ms_per_step", "kernel_ms_per_realisation") if k in r}
-	if "fft_chain" in res: out["fft_chain"] = {k: res["fft_chain"][k] for k in ("bound", "achieved", "unit", "frac", "kernel_ms_per_step")}
+	out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_convention_exceeds_peak", "frac_hw", "frac_hw_both", "frac_definition", "sustained", "kernel_ms_per_step", "kernel_ms_per_realisation", "traffic", "traffic_unit", "traffic_source") if k in r}
+	if "fft_chain" in res: out["fft_chain"] = {k: res["fft_chain"][k] for k in ("bound", "achieved", "unit", "frac", "kernel_ms_per_step", "algorithmic_bytes_per_step", "traffic", "traffic_source") if k in res["fft_chain"]}
 	if "fft" in res and res["fft"] and "frac" in res["fft"]: out["fft"] = res["fft"]
 	return out
 
